@@ -1,0 +1,287 @@
+"""Pins the CPU oracle against every known-answer vector, snapshot and fixture the
+reference's own tests hold for the hot path.  CPU only."""
+import gzip
+import hashlib
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, read_golden
+from oracle import oracle as orc
+
+
+# ---- scan preprocess: ref src/scan.rs:130-181 --------------------------------------------
+
+def _scan(data, expected):
+    sb = orc.ScanBuffer()
+    sb.process(bytes(data), expected)
+    return sb.processed_scan_data(), list(np.frombuffer(sb.start_positions(), dtype=np.uint32))
+
+
+def test_scan_kat_identity():
+    out, starts = _scan([0x12, 0x34, 0x56, 0x78], 1)
+    assert out == bytes([0x12, 0x34, 0x56, 0x78]) and starts == [0]
+
+
+def test_scan_kat_only_markers():
+    out, starts = _scan([0xFF, 0xD0, 0xFF, 0xD0], 3)
+    assert out == b"" and starts == [0, 0, 0]
+
+
+def test_scan_kat_stuffing_and_rst():
+    out, starts = _scan([0xFF, 0x00, 0x44, 0x55, 0xFF, 0xD0, 0x34], 2)
+    assert out == bytes([0xFF, 0x44, 0x55, 0x00, 0x34, 0, 0, 0]) and starts == [0, 1]
+
+
+def test_scan_kat_expanding_output():
+    out, starts = _scan([0x11, 0xFF, 0xD0, 0x11, 0xFF, 0xD0, 0x11], 3)
+    assert out == bytes([0x11, 0, 0, 0, 0x11, 0, 0, 0, 0x11, 0, 0, 0]) and starts == [0, 1, 2]
+
+
+def test_scan_kat_too_many_rst_markers():
+    sb = orc.ScanBuffer()
+    with pytest.raises(orc.OracleError) as e:
+        sb.process(bytes([0x11, 0xFF, 0xD0, 0x11, 0xFF, 0xD0, 0x11]), 1)
+    assert str(e.value) == "restart interval count mismatch: counted 3, expected 1"
+
+
+def test_scan_dat_interval_count():
+    # ref benches/bench.rs:18 -- process(scan.dat, 42876) must succeed
+    data = read_golden("scan", "scan.dat")
+    assert len(data) == 496464
+    sb = orc.ScanBuffer()
+    sb.process(data, 42876)
+    starts = np.frombuffer(sb.start_positions(), dtype=np.uint32)
+    assert starts.size == 42876 and starts[0] == 0 and np.all(np.diff(starts.astype(np.int64)) >= 0)
+    with pytest.raises(orc.OracleError):
+        orc.ScanBuffer().process(data, 42875)
+
+
+# ---- Huffman LUT: ref src/huffman.rs:355-548 ------------------------------------------------
+
+def test_tablegen_luma_dc_snapshot():
+    assert orc.Table(default=0).debug() + "\n" == read_golden("huffman", "luma_dc.txt").decode()
+
+
+def test_tablegen_luma_ac_snapshot():
+    assert orc.Table(default=1).debug() + "\n" == read_golden("huffman", "luma_ac.txt").decode()
+
+
+def test_default_tables_l2_blocks():
+    # 1+5+1+6 L2 blocks (6656 B) for the four Annex-K tables
+    assert [orc.Table(default=i).l2_len() // 256 for i in range(4)] == [1, 5, 1, 6]
+
+
+def test_malformed_tables_rejected():
+    with pytest.raises(orc.OracleError):
+        orc.Table([3] + [0] * 15, [1, 2, 3])          # three 1-bit codes
+    with pytest.raises(orc.OracleError):
+        orc.Table([2, 0, 0, 0, 0, 0, 0, 0, 1] + [0] * 7, [1, 2, 3])  # 9-bit code under a full prefix
+
+
+# ---- bit reader: ref src/bits.rs:69-141 ---------------------------------------------------
+
+def test_bitstream_kat():
+    bs = orc.BitStream([0b01010101_00000001_11110000_01110011, 0b00001111, 0b10000000])
+    assert bs.peek(2) == 0b01
+    assert bs.peek(0) == 0
+    assert bs.peek(4) == 0b0111
+    bs.consume(0)
+    assert bs.peek(8) == 0b01110011
+    bs.consume(0)
+    bs.consume(2)
+    assert bs.peek(2) == 0b11
+    assert bs.peek(0) == 0
+    bs.consume(0)
+    assert bs.peek(6) == 0b110011
+    assert bs.peek(26) == 0b110011_11110000_00000001_0101
+    assert bs.peek(22) == 0b110011_11110000_00000001
+    bs.consume(22)
+    bs.refill()
+    assert bs.peek(0) == 0
+    assert bs.peek(8) == 0b01010101
+    assert bs.peek(16) == 0b01010101_00001111
+    bs.consume(16)
+    bs.refill()
+    assert bs.peek(24) == 0
+    bs.consume(24)
+    bs.refill()
+    assert bs.peek(1) == 1
+    assert bs.peek(0) == 0
+    bs.consume(0)
+    assert bs.peek(1) == 1
+    assert bs.peek(0) == 0
+
+
+def test_decode_kat_diff_45():
+    scan = bytes([0xEB, 0x77, 0x62, 0x80, 0x01, 0x05, 0x87, 0xAF, 0x22, 0x80, 0x3F, 0xFF])
+    bs = orc.BitStream(np.frombuffer(scan, dtype="<u4"))
+    table = orc.Table([0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0], list(range(12)))
+    dccat = bs.huffdecode(table)
+    diff = bs.peek(dccat)
+    bs.consume(dccat)
+    assert orc.huff_extend(diff, dccat) == 45
+
+
+def test_huff_extend_shift_wrap():
+    # WGSL shift counts are modulo 32 (quirk list): t = 0 -> vt = 1 << 31
+    assert orc.huff_extend(0, 0) == 0
+    assert orc.huff_extend(5, 4) == -10
+    assert orc.huff_extend(8, 4) == 8
+
+
+# ---- parser: ref src/file/tests.rs:69-175 ----------------------------------------------------
+
+def _parser_cases():
+    d = os.path.join(GOLDEN, "parser")
+    return sorted(f[:-4] for f in os.listdir(d) if f.endswith(".jpg"))
+
+
+@pytest.mark.parametrize("stem", _parser_cases())
+def test_parser_reftests(stem):
+    jpg = read_golden("parser", stem + ".jpg")
+    p = os.path.join(GOLDEN, "parser", stem + ".log")
+    expect = gzip.open(p + ".gz").read() if os.path.exists(p + ".gz") else open(p, "rb").read()
+    assert orc.parser_dump(jpg) == expect.decode("latin-1")
+
+
+def test_parser_all_16_present():
+    assert len(_parser_cases()) == 16
+
+
+def test_parser_inline_empty():
+    e = "error: reached end of data while decoding JPEG stream\n"
+    assert orc.parser_dump(bytes([0xFF])) == e
+    assert orc.parser_dump(bytes([0xFF, 0xD8])) == e
+    assert orc.parser_dump(bytes([0xFF, 0xD8, 0xFF, 0xD9])) == ""
+    assert orc.parser_dump(bytes([0xFF, 0xD8, 0xFF, 0xD9, 0xFF])) == "1 trailing bytes: [ff]\n"
+
+
+def test_parser_inline_app():
+    assert orc.parser_dump(bytes([0xFF, 0xD8, 0xFF, 0xE0, 0x00, 0x02, 0xFF, 0xD9])) == \
+        "0002 [FF E0] APP { n: 0, kind: None } []\n"
+    assert orc.parser_dump(bytes([0xFF, 0xD8, 0xFF, 0xE0, 0x00, 0x04, 0x00, 0x00, 0xFF, 0xD9])) == \
+        "0002 [FF E0] APP { n: 0, kind: None } [0, 0]\n"
+    assert orc.parser_dump(bytes([0xFF, 0xD8, 0xFF, 0xE0, 0x00, 0x04, 0x00, 0x00,
+                                  0xFF, 0xDD, 0x00, 0x04, 0x00, 0x0F, 0xFF, 0xD9])) == \
+        "0002 [FF E0] APP { n: 0, kind: None } [0, 0]\n0008 [FF DD] DRI { Ri: 15 }\n"
+
+
+# ---- ImageData validation: ref src/lib.rs:622-793 -----------------------------------------
+
+def test_image_mjpeg_geometry():
+    img = orc.ImageData(read_golden("parser", "mjpeg.jpg"))
+    assert (img.width(), img.height(), img.parallelism()) == (960, 720, 540)
+    md = np.frombuffer(img.metadata(), dtype=np.uint32)
+    assert md[256] == 10 and md[273] == 60 and list(md[274:278]) == [2, 1, 4, 32]
+    # no DHT in the file -> the four Annex-K tables (1+5+1+6 blocks of 512 B)
+    assert len(img.l2()) == 6656
+    # components: {v,h,q,dc,ac}: Y uses tables 0/1, Cb/Cr use 2/3
+    assert list(md[257:272]) == [1, 2, 0, 0, 1, 1, 1, 1, 2, 3, 1, 1, 1, 2, 3]
+
+
+@pytest.mark.parametrize("stem,msg", [
+    ("16bit-qtables", "invalid quantization table precision Pq=1 (only 0 is allowed)"),
+    ("non-interleaved-mcu", "not a baseline JPEG (SOF=SOF2)"),
+    ("progressive3", "not a baseline JPEG (SOF=SOF2)"),
+    ("grayscale_square", "frame with 1 components not supported (only 3 components are supported)"),
+    ("rgb", "invalid sampling factors 1x1 for Y component (expected 2x1)"),
+    ("restarts", "invalid sampling factors 1x1 for Y component (expected 2x1)"),
+    ("extraneous-data", "invalid sampling factors 2x2 for Y component (expected 2x1)"),
+])
+def test_image_rejections(stem, msg):
+    with pytest.raises(orc.OracleError) as e:
+        orc.ImageData(read_golden("parser", stem + ".jpg"))
+    assert str(e.value) == msg
+
+
+def test_image_not_jpeg():
+    with pytest.raises(orc.OracleError) as e:
+        orc.ImageData(b"\x89PNG\r\n")
+    assert str(e.value) == "JPEG image does not start with SOI marker"
+    with pytest.raises(orc.OracleError) as e:
+        orc.ImageData(bytes([0xFF, 0xD8, 0xFF, 0xD9]))
+    assert str(e.value) == "missing SOS/SOI marker"
+
+
+# ---- GPU reftest restated on the CPU: ref src/tests.rs:18-135 --------------------------------
+
+def _read_png_rgb(data):
+    """Minimal 8-bit RGB, non-interlaced PNG reader (the reference uses the png crate)."""
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, w = 8, b"", None
+    while pos < len(data):
+        n = int.from_bytes(data[pos:pos + 4], "big")
+        typ = data[pos + 4:pos + 8]
+        body = data[pos + 8:pos + 8 + n]
+        pos += 12 + n
+        if typ == b"IHDR":
+            w, h = int.from_bytes(body[0:4], "big"), int.from_bytes(body[4:8], "big")
+            assert body[8] == 8 and body[9] == 2 and body[12] == 0
+        elif typ == b"IDAT":
+            idat += body
+    raw = zlib.decompress(idat)
+    out = np.zeros((h, w * 3), dtype=np.uint8)
+    prev = np.zeros(w * 3, dtype=np.int32)
+    stride = 1 + w * 3
+    for y in range(h):
+        ft = raw[y * stride]
+        line = np.frombuffer(raw[y * stride + 1:(y + 1) * stride], dtype=np.uint8).astype(np.int32)
+        cur = np.zeros(w * 3, dtype=np.int32)
+        for i in range(w * 3):
+            a = cur[i - 3] if i >= 3 else 0
+            b = prev[i]
+            c = prev[i - 3] if i >= 3 else 0
+            if ft == 0:
+                p = 0
+            elif ft == 1:
+                p = a
+            elif ft == 2:
+                p = b
+            elif ft == 3:
+                p = (a + b) // 2
+            else:
+                pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                p = a if pa <= pb and pa <= pc else (b if pb <= pc else c)
+            cur[i] = (line[i] + p) & 255
+        out[y] = cur
+        prev = cur
+    return out.reshape(h, w, 3)
+
+
+@pytest.mark.parametrize("name", ["64x8-Ri-1.jpg", "64x8-Ri-2.jpg"])
+def test_reftest_422_within_tolerance(name):
+    ref = _read_png_rgb(read_golden("refs", "64x8.png"))
+    img = orc.ImageData(read_golden("refs", name))
+    assert (img.width(), img.height()) == (ref.shape[1], ref.shape[0])
+    rgba = img.decode()
+    diff = np.abs(rgba[:, :, :3].astype(np.int32) - ref.astype(np.int32))
+    assert diff.max() <= 3  # ABS_TOLERANCE, src/tests.rs:18
+    assert np.all(rgba[:, :, 3] == 255)
+
+
+def test_reftest_ri1_equals_ri2():
+    a = orc.ImageData(read_golden("refs", "64x8-Ri-1.jpg")).decode()
+    b = orc.ImageData(read_golden("refs", "64x8-Ri-2.jpg")).decode()
+    assert np.array_equal(a, b)
+
+
+def test_reftest_444_rejected():
+    # ref src/tests.rs:137-142: the 4:4:4 fixture is #[ignore]d, ImageData rejects it
+    with pytest.raises(orc.OracleError) as e:
+        orc.ImageData(read_golden("refs", "64x8-Hi1-Vi1.jpg"))
+    assert "invalid sampling factors 1x1 for Y component" in str(e.value)
+
+
+def test_cross_check_against_survey_probe_hashes():
+    """SURVEY.md section 8c records SHA-256 values from an independent NumPy emulation
+    of the WGSL semantics; two independent restatements must agree."""
+    a = orc.ImageData(read_golden("refs", "64x8-Ri-1.jpg")).decode()
+    assert hashlib.sha256(a.tobytes()).hexdigest() == \
+        "30d5ae4c2ae877f80b33d923736c97f164e424ab7bb21bb23a26d0c707a944c6"
+    m = orc.ImageData(read_golden("parser", "mjpeg.jpg")).decode()
+    assert m.shape == (720, 960, 4)
+    assert hashlib.sha256(m.tobytes()).hexdigest() == \
+        "502b1b9c9a0401b20a04c3220710ae6c6c8a1068719a58018739b258602f9905"
