@@ -1,0 +1,295 @@
+"""compeg_amd -- host-side mirror of the reference's public API over the C ABI of
+libcompeg_hip.so (hand-written gfx950 kernels).
+
+Same names, argument meaning and error behaviour as SludgePhD/Compeg's Rust
+crate (src/lib.rs), so tests read like the reference's own:
+
+    gpu = Gpu.open()
+    decoder = Decoder(gpu)
+    data = ImageData(jpeg_bytes)          # raises compeg_amd.Error like ImageData::new -> Err
+    op = decoder.decode_blocking(data)
+    rgba = decoder.read_texture(data.width(), data.height())
+
+Everything that computes runs in the native library; this package only moves
+handles around.  There is no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import (E_COUNT_MISMATCH, E_HIP, E_INVALID_ARG, E_MALFORMED, E_UNSUPPORTED, L1_BYTES,
+                   LIB_PATH, METADATA_BYTES, Error, check, lib)
+
+__all__ = ["Gpu", "Decoder", "DecodeOp", "ImageData", "ScanBuffer", "Batch", "Texture", "Error",
+           "version", "LIB_PATH"]
+
+
+def version():
+    return lib.compeg_version().decode()
+
+
+def _host_view(data):
+    a = data if isinstance(data, np.ndarray) else np.frombuffer(data, dtype=np.uint8)
+    return np.ascontiguousarray(a)
+
+
+class Gpu:
+    """An open handle to one MI355X (ref: `Gpu`, src/lib.rs:64-270)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def open(cls, device=-1):
+        """ref: Gpu::open (src/lib.rs:78-102)."""
+        h = C.c_void_p()
+        check(lib.compeg_gpu_open(device, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_stream(cls, device, hip_stream):
+        """`Gpu::from_wgpu` analogue (src/lib.rs:105): adopt a caller-owned HIP stream
+        (an int / pointer value, e.g. torch.cuda.current_stream().cuda_stream)."""
+        h = C.c_void_p()
+        check(lib.compeg_gpu_from_stream(device, C.c_void_p(hip_stream), C.byref(h)))
+        return cls(h)
+
+    def device(self):
+        return lib.compeg_gpu_device(self._h)
+
+    def name(self):
+        return lib.compeg_gpu_name(self._h).decode()
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.compeg_gpu_release(self._h)
+            self._h = None
+
+
+class ImageData:
+    """A parsed JPEG (ref: `ImageData`, src/lib.rs:576-851)."""
+
+    def __init__(self, jpeg, copy=True):
+        self._h = None
+        self._keep = _host_view(jpeg)
+        h = C.c_void_p()
+        check(lib.compeg_image_parse(self._keep.ctypes.data, self._keep.nbytes, 1 if copy else 0, C.byref(h)))
+        self._h = h
+        if copy:
+            self._keep = None
+
+    new = classmethod(lambda cls, jpeg: cls(jpeg))
+
+    def width(self):
+        return lib.compeg_image_width(self._h)
+
+    def height(self):
+        return lib.compeg_image_height(self._h)
+
+    def parallelism(self):
+        return lib.compeg_image_parallelism(self._h)
+
+    # what the reference uploads for this image (src/lib.rs:397-407)
+    def metadata(self):
+        return C.string_at(lib.compeg_image_metadata(self._h), METADATA_BYTES)
+
+    def huffman_l1(self):
+        return C.string_at(lib.compeg_image_huffman_l1(self._h), L1_BYTES)
+
+    def huffman_l2(self):
+        n = C.c_size_t()
+        p = lib.compeg_image_huffman_l2(self._h, C.byref(n))
+        return C.string_at(p, n.value) if n.value else b""
+
+    def scan_range(self):
+        o, n = C.c_size_t(), C.c_size_t()
+        lib.compeg_image_scan_range(self._h, C.byref(o), C.byref(n))
+        return o.value, n.value
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.compeg_image_free(self._h)
+            self._h = None
+
+
+class ScanBuffer:
+    """ref: `ScanBuffer` (src/scan.rs:15-77; bench-only re-export, src/lib.rs:44-46)."""
+
+    def __init__(self):
+        self._h = C.c_void_p(lib.compeg_scanbuffer_new())
+
+    def process(self, scan_data, expected_restart_intervals):
+        a = _host_view(scan_data)
+        check(lib.compeg_scanbuffer_process(self._h, a.ctypes.data, a.nbytes, expected_restart_intervals))
+
+    def _get(self, fn):
+        n = C.c_size_t()
+        p = fn(self._h, C.byref(n))
+        return C.string_at(p, n.value) if n.value else b""
+
+    def processed_scan_data(self):
+        return self._get(lib.compeg_scanbuffer_data)
+
+    def start_positions(self):
+        return self._get(lib.compeg_scanbuffer_start_positions)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.compeg_scanbuffer_free(self._h)
+            self._h = None
+
+
+class Texture:
+    """Device-resident RGBA8 output (the role of wgpu::Texture in the reference).
+    Exposes __cuda_array_interface__ so torch / cupy can wrap it without a copy."""
+
+    def __init__(self, ptr, width, height, pitch, owner=None, owned=False):
+        self.ptr, self.width, self.height, self.pitch = ptr, width, height, pitch
+        self._owner, self._owned = owner, owned
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": (self.height, self.width, 4), "typestr": "|u1", "data": (self.ptr, False),
+                "strides": (self.pitch, 4, 1), "version": 3}
+
+    def __del__(self):
+        if getattr(self, "_owned", False) and self.ptr:
+            lib.compeg_device_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+
+class DecodeOp:
+    """ref: `DecodeOp` (src/lib.rs:541-574)."""
+
+    def __init__(self, handle, decoder):
+        self._h, self._decoder = handle, decoder
+
+    def wait(self):
+        check(lib.compeg_op_wait(self._h))
+
+    def texture(self):
+        return self._decoder.texture()
+
+    def texture_changed(self):
+        return bool(lib.compeg_op_texture_changed(self._h))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.compeg_op_free(self._h)
+            self._h = None
+
+
+class Decoder:
+    """A GPU JPEG decode context (ref: `Decoder`, src/lib.rs:273-529).  One thread at a time."""
+
+    def __init__(self, gpu):
+        self._gpu = gpu
+        h = C.c_void_p()
+        check(lib.compeg_decoder_new(gpu._h, C.byref(h)))
+        self._h = h
+
+    new = classmethod(lambda cls, gpu: cls(gpu))
+
+    def enqueue(self, data, hip_stream=0):
+        """ref: Decoder::enqueue (src/lib.rs:385).  Returns texture_changed."""
+        changed = C.c_int()
+        check(lib.compeg_decoder_enqueue(self._h, data._h, C.c_void_p(hip_stream), C.byref(changed)))
+        return bool(changed.value)
+
+    def start_decode(self, data):
+        op = C.c_void_p()
+        check(lib.compeg_decoder_start_decode(self._h, data._h, C.byref(op)))
+        return DecodeOp(op, self)
+
+    def decode_blocking(self, data):
+        op = C.c_void_p()
+        check(lib.compeg_decoder_decode_blocking(self._h, data._h, C.byref(op)))
+        return DecodeOp(op, self)
+
+    def last_warning(self):
+        return lib.compeg_decoder_last_warning(self._h).decode()
+
+    def texture(self):
+        p, w, h, pitch = C.c_void_p(), C.c_uint32(), C.c_uint32(), C.c_size_t()
+        check(lib.compeg_decoder_output(self._h, C.byref(p), C.byref(w), C.byref(h), C.byref(pitch)))
+        return Texture(p.value, w.value, h.value, pitch.value, owner=self)
+
+    def into_texture(self):
+        p, w, h, pitch = C.c_void_p(), C.c_uint32(), C.c_uint32(), C.c_size_t()
+        check(lib.compeg_decoder_take_output(self._h, C.byref(p), C.byref(w), C.byref(h), C.byref(pitch)))
+        self._h = None
+        return Texture(p.value, w.value, h.value, pitch.value, owned=True)
+
+    def read_texture(self, width, height):
+        """Tightly packed host copy of the WxH corner (what src/tests.rs:52-84 does)."""
+        out = np.empty((height, width, 4), dtype=np.uint8)
+        check(lib.compeg_decoder_read_output(self._h, out.ctypes.data, width, height))
+        return out
+
+    def read_coefficients(self, total_dus):
+        out = np.empty(total_dus * 32, dtype=np.int32)
+        check(lib.compeg_decoder_read_coefficients(self._h, out.ctypes.data, out.size))
+        return out
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.compeg_decoder_free(self._h)
+            self._h = None
+
+
+class Batch:
+    """Extension (not in the reference): many independent images per launch sequence."""
+
+    def __init__(self, gpu):
+        self._gpu = gpu
+        h = C.c_void_p()
+        check(lib.compeg_batch_new(gpu._h, C.byref(h)))
+        self._h = h
+        self._images = []
+
+    def upload(self, images, host_threads=0):
+        self._images = list(images)
+        arr = (C.c_void_p * len(self._images))(*[im._h for im in self._images])
+        check(lib.compeg_batch_upload(self._h, arr, len(self._images), host_threads))
+
+    def set_chunk(self, images_per_launch):
+        check(lib.compeg_batch_set_chunk(self._h, images_per_launch))
+
+    def decode(self, hip_stream=0):
+        check(lib.compeg_batch_decode(self._h, C.c_void_p(hip_stream)))
+
+    def wait(self):
+        check(lib.compeg_batch_wait(self._h))
+
+    def count(self):
+        return lib.compeg_batch_count(self._h)
+
+    def output(self, index):
+        p, w, h, pitch = C.c_void_p(), C.c_uint32(), C.c_uint32(), C.c_size_t()
+        check(lib.compeg_batch_output(self._h, index, C.byref(p), C.byref(w), C.byref(h), C.byref(pitch)))
+        return Texture(p.value, w.value, h.value, pitch.value, owner=self)
+
+    def read_output(self, index):
+        t = self.output(index)
+        out = np.empty((t.height, t.width, 4), dtype=np.uint8)
+        check(lib.compeg_batch_read_output(self._h, index, out.ctypes.data))
+        return out
+
+    def algorithmic_bytes(self):
+        return lib.compeg_batch_algorithmic_bytes(self._h)
+
+    def pixels(self):
+        return lib.compeg_batch_pixels(self._h)
+
+    def last_timing(self):
+        """(total_ms, huffman_ms, idct_composite_ms) of the latest decode, from HIP events
+        recorded on the stream the kernels ran on."""
+        total = C.c_float()
+        stages = (C.c_float * 2)()
+        check(lib.compeg_batch_last_timing(self._h, C.byref(total), stages))
+        return total.value, stages[0], stages[1]
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.compeg_batch_free(self._h)
+            self._h = None

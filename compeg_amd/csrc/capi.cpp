@@ -1,0 +1,600 @@
+// extern "C" surface of libcompeg_hip (include/compeg_hip.h).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "compeg_hip.h"
+#include "runtime.h"
+
+using namespace compeg;
+
+struct compeg_image {
+    ImageData *data;
+};
+
+struct compeg_scanbuffer {
+    ScanBuffer buf;
+};
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(const Status &s)
+{
+    g_error = s.message;
+    return s.code;
+}
+
+int fail(int code, const char *msg)
+{
+    g_error = msg;
+    return code;
+}
+
+int ok()
+{
+    return COMPEG_OK;
+}
+
+// Runs body(), turning C++ exceptions (allocation failure) into an error code
+// so that nothing propagates across the C boundary.
+template <class F>
+int guarded(F &&body)
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return fail(COMPEG_E_HIP, "out of host memory");
+    } catch (const std::exception &e) {
+        return fail(COMPEG_E_INVALID_ARG, e.what());
+    }
+}
+
+int open_gpu(int device, hipStream_t stream, bool adopt, compeg_gpu **out)
+{
+    if (!out)
+        return fail(COMPEG_E_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(COMPEG_E_HIP, "no HIP device available (libcompeg_hip needs a gfx950 GPU; "
+                                  "there is no CPU fallback)");
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess)
+            device = 0;
+    }
+    if (device >= ndev)
+        return fail(COMPEG_E_INVALID_ARG, "HIP device index out of range");
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess)
+        return fail(hip_status(e, "hipGetDeviceProperties"));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        std::string m = std::string("device is ") + prop.gcnArchName +
+                        ", but libcompeg_hip carries gfx950 (MI355X) code objects only";
+        return fail(COMPEG_E_HIP, m.c_str());
+    }
+    e = hipSetDevice(device);
+    if (e != hipSuccess)
+        return fail(hip_status(e, "hipSetDevice"));
+    compeg_gpu *g = new compeg_gpu();
+    g->device = device;
+    g->name = prop.name;
+    if (adopt) {
+        g->stream = stream;
+        g->owns_stream = false;
+    } else {
+        e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete g;
+            return fail(hip_status(e, "hipStreamCreate"));
+        }
+        g->owns_stream = true;
+    }
+    *out = g;
+    return ok();
+}
+
+} // namespace
+
+extern "C" {
+
+const char *compeg_last_error(void)
+{
+    return g_error.c_str();
+}
+
+const char *compeg_version(void)
+{
+    return "compeg-hip 0.1.0 (gfx950)";
+}
+
+int compeg_gpu_open(int device, compeg_gpu **out)
+{
+    return guarded([&] { return open_gpu(device, nullptr, false, out); });
+}
+
+int compeg_gpu_from_stream(int device, void *hip_stream, compeg_gpu **out)
+{
+    return guarded([&] { return open_gpu(device, static_cast<hipStream_t>(hip_stream), true, out); });
+}
+
+void compeg_gpu_retain(compeg_gpu *gpu)
+{
+    if (gpu)
+        gpu->refs.fetch_add(1, std::memory_order_relaxed);
+}
+
+void compeg_gpu_release(compeg_gpu *gpu)
+{
+    if (!gpu)
+        return;
+    if (gpu->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+        if (gpu->owns_stream && gpu->stream) {
+            (void)hipSetDevice(gpu->device);
+            (void)hipStreamSynchronize(gpu->stream);
+            (void)hipStreamDestroy(gpu->stream);
+        }
+        delete gpu;
+    }
+}
+
+int compeg_gpu_device(const compeg_gpu *gpu)
+{
+    return gpu ? gpu->device : -1;
+}
+
+const char *compeg_gpu_name(const compeg_gpu *gpu)
+{
+    return gpu ? gpu->name.c_str() : "";
+}
+
+/* ---- ImageData ------------------------------------------------------------ */
+
+int compeg_image_parse(const uint8_t *jpeg, size_t len, int copy, compeg_image **out)
+{
+    return guarded([&] {
+        if (!out)
+            return fail(COMPEG_E_INVALID_ARG, "out is NULL");
+        *out = nullptr;
+        ImageData *d = nullptr;
+        Status s = ImageData::parse(jpeg, len, copy != 0, &d);
+        if (!s.ok())
+            return fail(s);
+        *out = new compeg_image{d};
+        return ok();
+    });
+}
+
+void compeg_image_free(compeg_image *img)
+{
+    if (img) {
+        delete img->data;
+        delete img;
+    }
+}
+
+uint32_t compeg_image_width(const compeg_image *img)
+{
+    return img ? img->data->width : 0;
+}
+
+uint32_t compeg_image_height(const compeg_image *img)
+{
+    return img ? img->data->height : 0;
+}
+
+uint32_t compeg_image_parallelism(const compeg_image *img)
+{
+    return img ? img->data->metadata.total_restart_intervals : 0;
+}
+
+const uint8_t *compeg_image_metadata(const compeg_image *img)
+{
+    return img ? reinterpret_cast<const uint8_t *>(&img->data->metadata) : nullptr;
+}
+
+const uint8_t *compeg_image_huffman_l1(const compeg_image *img)
+{
+    return img ? reinterpret_cast<const uint8_t *>(img->data->l1) : nullptr;
+}
+
+const uint8_t *compeg_image_huffman_l2(const compeg_image *img, size_t *nbytes)
+{
+    if (nbytes)
+        *nbytes = img ? img->data->l2.size() * 2 : 0;
+    return img ? reinterpret_cast<const uint8_t *>(img->data->l2.data()) : nullptr;
+}
+
+void compeg_image_scan_range(const compeg_image *img, size_t *offset, size_t *len)
+{
+    if (offset)
+        *offset = img ? img->data->scan_offset : 0;
+    if (len)
+        *len = img ? img->data->scan_len : 0;
+}
+
+/* ---- ScanBuffer ----------------------------------------------------------- */
+
+compeg_scanbuffer *compeg_scanbuffer_new(void)
+{
+    try {
+        return new compeg_scanbuffer();
+    } catch (...) {
+        return nullptr;
+    }
+}
+
+void compeg_scanbuffer_free(compeg_scanbuffer *sb)
+{
+    delete sb;
+}
+
+int compeg_scanbuffer_process(compeg_scanbuffer *sb, const uint8_t *scan, size_t len,
+                              uint32_t expected_restart_intervals)
+{
+    return guarded([&] {
+        if (!sb || (!scan && len))
+            return fail(COMPEG_E_INVALID_ARG, "NULL argument");
+        Status s = sb->buf.process(scan, len, expected_restart_intervals);
+        return s.ok() ? ok() : fail(s);
+    });
+}
+
+const uint8_t *compeg_scanbuffer_data(const compeg_scanbuffer *sb, size_t *nbytes)
+{
+    if (nbytes)
+        *nbytes = sb ? sb->buf.data_bytes() : 0;
+    return sb ? sb->buf.data() : nullptr;
+}
+
+const uint8_t *compeg_scanbuffer_start_positions(const compeg_scanbuffer *sb, size_t *nbytes)
+{
+    if (nbytes)
+        *nbytes = sb ? sb->buf.nstarts() * 4 : 0;
+    return sb ? reinterpret_cast<const uint8_t *>(sb->buf.starts()) : nullptr;
+}
+
+/* ---- Decoder -------------------------------------------------------------- */
+
+int compeg_decoder_new(compeg_gpu *gpu, compeg_decoder **out)
+{
+    return guarded([&] {
+        if (!gpu || !out)
+            return fail(COMPEG_E_INVALID_ARG, "NULL argument");
+        hipError_t e = hipSetDevice(gpu->device);
+        if (e != hipSuccess)
+            return fail(hip_status(e, "hipSetDevice"));
+        compeg_decoder *d = new compeg_decoder();
+        compeg_gpu_retain(gpu);
+        d->gpu = gpu;
+        *out = d;
+        return ok();
+    });
+}
+
+void compeg_decoder_free(compeg_decoder *dec)
+{
+    if (dec) {
+        (void)hipSetDevice(dec->gpu->device);
+        delete dec;
+    }
+}
+
+int compeg_decoder_enqueue(compeg_decoder *dec, const compeg_image *img, void *hip_stream,
+                           int *texture_changed)
+{
+    return guarded([&] {
+        if (!dec || !img)
+            return fail(COMPEG_E_INVALID_ARG, "NULL argument");
+        bool changed = false;
+        Status s = dec->enqueue(*img->data, static_cast<hipStream_t>(hip_stream), &changed);
+        if (texture_changed)
+            *texture_changed = changed ? 1 : 0;
+        return s.ok() ? ok() : fail(s);
+    });
+}
+
+int compeg_decoder_start_decode(compeg_decoder *dec, const compeg_image *img, compeg_op **op)
+{
+    return guarded([&] {
+        if (!dec || !img || !op)
+            return fail(COMPEG_E_INVALID_ARG, "NULL argument");
+        *op = nullptr;
+        bool changed = false;
+        Status s = dec->enqueue(*img->data, dec->gpu->stream, &changed);
+        if (!s.ok())
+            return fail(s);
+        compeg_op *o = new compeg_op();
+        o->device = dec->gpu->device;
+        o->texture_changed = changed;
+        hipError_t e = hipEventCreateWithFlags(&o->done, hipEventDisableTiming);
+        if (e == hipSuccess)
+            e = hipEventRecord(o->done, dec->gpu->stream);
+        if (e != hipSuccess) {
+            compeg_op_free(o);
+            return fail(hip_status(e, "hipEventRecord"));
+        }
+        *op = o;
+        return ok();
+    });
+}
+
+int compeg_decoder_decode_blocking(compeg_decoder *dec, const compeg_image *img, compeg_op **op)
+{
+    int rc = compeg_decoder_start_decode(dec, img, op);
+    if (rc != COMPEG_OK)
+        return rc;
+    return compeg_op_wait(*op);
+}
+
+const char *compeg_decoder_last_warning(const compeg_decoder *dec)
+{
+    return dec ? dec->warning.c_str() : "";
+}
+
+int compeg_op_wait(compeg_op *op)
+{
+    if (!op)
+        return fail(COMPEG_E_INVALID_ARG, "op is NULL");
+    hipError_t e = hipEventSynchronize(op->done);
+    return e == hipSuccess ? ok() : fail(hip_status(e, "hipEventSynchronize"));
+}
+
+int compeg_op_texture_changed(const compeg_op *op)
+{
+    return op && op->texture_changed ? 1 : 0;
+}
+
+void compeg_op_free(compeg_op *op)
+{
+    if (op) {
+        if (op->done)
+            (void)hipEventDestroy(op->done);
+        delete op;
+    }
+}
+
+int compeg_decoder_output(const compeg_decoder *dec, void **device_ptr, uint32_t *width,
+                          uint32_t *height, size_t *pitch_bytes)
+{
+    if (!dec)
+        return fail(COMPEG_E_INVALID_ARG, "dec is NULL");
+    if (device_ptr)
+        *device_ptr = dec->out.ptr;
+    if (width)
+        *width = dec->out_w;
+    if (height)
+        *height = dec->out_h;
+    if (pitch_bytes)
+        *pitch_bytes = dec->out_pitch;
+    return ok();
+}
+
+int compeg_decoder_take_output(compeg_decoder *dec, void **device_ptr, uint32_t *width,
+                               uint32_t *height, size_t *pitch_bytes)
+{
+    if (!dec || !device_ptr)
+        return fail(COMPEG_E_INVALID_ARG, "NULL argument");
+    (void)hipSetDevice(dec->gpu->device);
+    hipError_t e = hipStreamSynchronize(dec->last_stream);
+    if (e != hipSuccess)
+        return fail(hip_status(e, "hipStreamSynchronize"));
+    compeg_decoder_output(dec, nullptr, width, height, pitch_bytes);
+    *device_ptr = dec->out.release();
+    delete dec;
+    return ok();
+}
+
+void compeg_device_free(void *device_ptr)
+{
+    if (device_ptr)
+        (void)hipFree(device_ptr);
+}
+
+int compeg_decoder_read_output(compeg_decoder *dec, uint8_t *host_rgba, uint32_t width,
+                               uint32_t height)
+{
+    return guarded([&] {
+        if (!dec || !host_rgba)
+            return fail(COMPEG_E_INVALID_ARG, "NULL argument");
+        if (width > dec->out_w || height > dec->out_h)
+            return fail(COMPEG_E_INVALID_ARG, "requested area exceeds the output");
+        (void)hipSetDevice(dec->gpu->device);
+        hipError_t e = hipStreamSynchronize(dec->last_stream);
+        if (e == hipSuccess && width && height)
+            e = hipMemcpy2D(host_rgba, size_t(width) * 4, dec->out.ptr, dec->out_pitch,
+                            size_t(width) * 4, height, hipMemcpyDeviceToHost);
+        return e == hipSuccess ? ok() : fail(hip_status(e, "read_output"));
+    });
+}
+
+int compeg_decoder_read_coefficients(compeg_decoder *dec, int32_t *host, size_t count)
+{
+    return guarded([&] {
+        if (!dec || !host || !dec->have_last)
+            return fail(COMPEG_E_INVALID_ARG, "no decode to read back");
+        const Metadata &md = dec->last_md;
+        const size_t dus =
+            size_t(md.total_restart_intervals) * md.restart_interval * md.dus_per_mcu;
+        if (count < dus * kRetained)
+            return fail(COMPEG_E_INVALID_ARG, "coefficient buffer too small");
+        (void)hipSetDevice(dec->gpu->device);
+        hipError_t e = hipStreamSynchronize(dec->last_stream);
+        if (e != hipSuccess)
+            return fail(hip_status(e, "hipStreamSynchronize"));
+        std::vector<int16_t> ac(dus * kRetained);
+        std::vector<int32_t> dc(dus);
+        if (dus) {
+            e = hipMemcpy(ac.data(), dec->ac.ptr, ac.size() * 2, hipMemcpyDeviceToHost);
+            if (e == hipSuccess)
+                e = hipMemcpy(dc.data(), dec->dc.ptr, dc.size() * 4, hipMemcpyDeviceToHost);
+            if (e != hipSuccess)
+                return fail(hip_status(e, "hipMemcpy"));
+        }
+        // component of every data unit inside an MCU, in scan order
+        uint32_t comp_of[kMaxDusPerMcu] = {0};
+        uint32_t k = 0;
+        for (uint32_t c = 0; c < 3; c++)
+            for (uint32_t i = 0; i < md.components[c].hsample * md.components[c].vsample &&
+                                 k < uint32_t(kMaxDusPerMcu);
+                 i++)
+                comp_of[k++] = c;
+        for (size_t du = 0; du < dus; du++) {
+            const uint32_t *q = md.qtables[md.components[comp_of[du % md.dus_per_mcu]].qtable & 3];
+            host[du * kRetained] = dc[du];
+            for (int z = 1; z < kRetained; z++)
+                host[du * kRetained + z] = int32_t(uint32_t(int32_t(ac[du * kRetained + z])) * q[z]);
+        }
+        return ok();
+    });
+}
+
+/* ---- Batch ---------------------------------------------------------------- */
+
+int compeg_batch_new(compeg_gpu *gpu, compeg_batch **out)
+{
+    return guarded([&] {
+        if (!gpu || !out)
+            return fail(COMPEG_E_INVALID_ARG, "NULL argument");
+        compeg_batch *b = new compeg_batch();
+        compeg_gpu_retain(gpu);
+        b->gpu = gpu;
+        *out = b;
+        return ok();
+    });
+}
+
+void compeg_batch_free(compeg_batch *batch)
+{
+    if (batch) {
+        (void)hipSetDevice(batch->gpu->device);
+        delete batch;
+    }
+}
+
+int compeg_batch_upload(compeg_batch *batch, const compeg_image *const *images, size_t count,
+                        int host_threads)
+{
+    return guarded([&] {
+        if (!batch || (!images && count))
+            return fail(COMPEG_E_INVALID_ARG, "NULL argument");
+        std::vector<const ImageData *> ptrs(count);
+        for (size_t i = 0; i < count; i++) {
+            if (!images[i])
+                return fail(COMPEG_E_INVALID_ARG, "NULL image in batch");
+            ptrs[i] = images[i]->data;
+        }
+        Status s = batch->upload(ptrs.data(), count, host_threads);
+        return s.ok() ? ok() : fail(s);
+    });
+}
+
+int compeg_batch_decode(compeg_batch *batch, void *hip_stream)
+{
+    return guarded([&] {
+        if (!batch)
+            return fail(COMPEG_E_INVALID_ARG, "batch is NULL");
+        hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : batch->gpu->stream;
+        Status s = batch->decode(st);
+        return s.ok() ? ok() : fail(s);
+    });
+}
+
+int compeg_batch_wait(compeg_batch *batch)
+{
+    if (!batch)
+        return fail(COMPEG_E_INVALID_ARG, "batch is NULL");
+    (void)hipSetDevice(batch->gpu->device);
+    hipError_t e = hipStreamSynchronize(batch->last_stream ? batch->last_stream : batch->gpu->stream);
+    return e == hipSuccess ? ok() : fail(hip_status(e, "hipStreamSynchronize"));
+}
+
+size_t compeg_batch_count(const compeg_batch *batch)
+{
+    return batch ? batch->count : 0;
+}
+
+int compeg_batch_set_chunk(compeg_batch *batch, uint32_t images_per_launch)
+{
+    if (!batch)
+        return fail(COMPEG_E_INVALID_ARG, "batch is NULL");
+    batch->chunk = images_per_launch;
+    return ok();
+}
+
+int compeg_batch_output(const compeg_batch *batch, size_t index, void **device_ptr, uint32_t *width,
+                        uint32_t *height, size_t *pitch_bytes)
+{
+    if (!batch || index >= batch->count)
+        return fail(COMPEG_E_INVALID_ARG, "batch index out of range");
+    const ImageDesc &d = batch->descs[index];
+    if (device_ptr)
+        *device_ptr = d.out;
+    if (width)
+        *width = d.out_w;
+    if (height)
+        *height = d.out_h;
+    if (pitch_bytes)
+        *pitch_bytes = d.out_pitch;
+    return ok();
+}
+
+int compeg_batch_read_output(compeg_batch *batch, size_t index, uint8_t *host_rgba)
+{
+    return guarded([&] {
+        if (!batch || index >= batch->count || !host_rgba)
+            return fail(COMPEG_E_INVALID_ARG, "bad argument");
+        int rc = compeg_batch_wait(batch);
+        if (rc != COMPEG_OK)
+            return rc;
+        const ImageDesc &d = batch->descs[index];
+        const size_t bytes = size_t(d.out_pitch) * d.out_h;
+        hipError_t e = bytes ? hipMemcpy(host_rgba, d.out, bytes, hipMemcpyDeviceToHost) : hipSuccess;
+        return e == hipSuccess ? ok() : fail(hip_status(e, "hipMemcpy"));
+    });
+}
+
+uint64_t compeg_batch_algorithmic_bytes(const compeg_batch *batch)
+{
+    return batch ? batch->algorithmic_bytes : 0;
+}
+
+uint64_t compeg_batch_pixels(const compeg_batch *batch)
+{
+    return batch ? batch->pixels : 0;
+}
+
+int compeg_batch_last_timing(compeg_batch *batch, float *total_ms, float stage_ms[2])
+{
+    return guarded([&] {
+        if (!batch || !batch->timed)
+            return fail(COMPEG_E_INVALID_ARG, "no timed decode");
+        (void)hipSetDevice(batch->gpu->device);
+        hipError_t e = hipEventSynchronize(batch->ev[2]);
+        float t = 0, a = 0, b = 0;
+        if (e == hipSuccess)
+            e = hipEventElapsedTime(&t, batch->ev[0], batch->ev[2]);
+        const bool split = !batch->chunk || batch->chunk >= batch->count;
+        if (e == hipSuccess && split) {
+            e = hipEventElapsedTime(&a, batch->ev[0], batch->ev[1]);
+            if (e == hipSuccess)
+                e = hipEventElapsedTime(&b, batch->ev[1], batch->ev[2]);
+        }
+        if (e != hipSuccess)
+            return fail(hip_status(e, "hipEventElapsedTime"));
+        if (total_ms)
+            *total_ms = t;
+        if (stage_ms) {
+            stage_ms[0] = a;
+            stage_ms[1] = b;
+        }
+        return ok();
+    });
+}
+
+} // extern "C"

@@ -1,0 +1,66 @@
+// Plain-data types shared by the host runtime and the gfx950 kernels.
+#pragma once
+
+#include <cstdint>
+
+namespace compeg {
+
+constexpr int kWave = 64;              // CDNA wavefront
+constexpr int kRetained = 32;          // zig-zag positions kept per data unit (metadata.rs:43)
+constexpr int kMaxDusPerMcu = 6;
+
+// LDS slot of one lane's data unit while it is being decoded: 32 int16 in
+// zig-zag order, padded to 80 bytes so that the 16-byte flush reads of a
+// 16-lane group fall on 16 distinct 4-bank groups.
+constexpr int kDuSlotBytes = 80;
+
+// Everything the kernels need to know about one image.  Lives in device
+// memory (one array entry per image of a batch); all pointers are device
+// pointers.  Filled by the host from the reference-format Metadata block.
+struct ImageDesc {
+    // inputs, in the reference's upload format (lib.rs:397-407)
+    const uint32_t *words;  // preprocessed scan, little-endian packed bytes
+    const uint32_t *starts; // word index of every restart interval
+    const uint16_t *l1;     // 4 x 256 entries
+    const uint16_t *l2;     // l2_entries entries
+    uint32_t nwords;
+    uint32_t nstarts;
+    uint32_t l2_entries;
+    // geometry
+    uint32_t total_intervals;
+    uint32_t restart_interval; // MCUs per interval
+    uint32_t dus_per_mcu;
+    uint32_t width_mcus;
+    uint32_t mcu_w, mcu_h; // pixels
+    uint32_t total_dus;
+    // per data unit inside an MCU: component index, 2 bits each
+    uint32_t comp_of_du;
+    // per component: L1 table index for DC / AC codes, DC quantiser
+    uint32_t dc_table[3];
+    uint32_t ac_table[3];
+    uint32_t dc_quant[3];
+    uint32_t hsample[3], vsample[3]; // sampling factors (composite stage)
+    uint32_t du_base[3];             // first data unit of the component inside an MCU
+    // quantisation tables as floats, zig-zag order, one row per component
+    float quant[3][kRetained];
+    // intermediates: quantised AC levels (slot 0 unused) and dequantised DC
+    int16_t *ac;  // [total_dus][32]
+    int32_t *dc;  // [total_dus]
+    // output
+    uint8_t *out; // RGBA8
+    uint32_t out_w, out_h;
+    uint32_t out_pitch; // bytes
+    // launch bookkeeping for batched grids
+    uint32_t first_huff_block; // block index of this image's first huffman block
+    uint32_t first_idct_block;
+};
+
+// How the huffman kernel's dynamic LDS is carved (bytes).
+struct HuffLdsPlan {
+    uint32_t l2_entries_in_lds; // L2 entries staged (rest read from global)
+    uint32_t window_words;      // per-wave scan window
+    uint32_t waves_per_block;
+    uint32_t total_bytes;
+};
+
+} // namespace compeg

@@ -1,0 +1,154 @@
+// gfx950 kernels of libcompeg_hip.
+//
+//   huffman_kernel        replaces src/huffman.wgsl (one lane per restart
+//                         interval, like the reference, but with the LUTs,
+//                         the compressed stream and the data unit being
+//                         decoded all resident in LDS)
+//   idct_composite_kernel replaces both passes of src/dct.wgsl: IDCT,
+//                         4:2:2 chroma replication and YCbCr->RGBA in one
+//                         kernel; decoded samples never leave the CU.
+//
+// No MFMA: there is no dense contraction anywhere on this path (both kernels
+// are bounded by HBM traffic / serial entropy decoding).
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "kernels_body.h"
+
+namespace compeg {
+
+// LDS layout (dynamic, 16-byte aligned carve-outs):
+//   [L1: 5*256 u16][L2: l2_in_lds u16][per wave: window_words u32 | 64 DU slots]
+__global__ void __launch_bounds__(256)
+huffman_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const ImageDesc &d = descs[blockIdx.y];
+    const uint32_t first_interval = blockIdx.x * blockDim.x;
+    if (first_interval >= d.total_intervals)
+        return; // uniform for the whole block
+
+    uint16_t *l1 = reinterpret_cast<uint16_t *>(smem);
+    uint16_t *l2 = l1 + kL1Entries;
+    const uint32_t wave_area = align16(window_words * 4u) + kWave * kDuSlotBytes;
+    uint8_t *wave_base = smem + align16((kL1Entries + l2_in_lds) * 2u);
+
+    stage_luts(d, l1, l2, l2_in_lds, threadIdx.x, blockDim.x);
+
+    const uint32_t wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    uint32_t *win = reinterpret_cast<uint32_t *>(wave_base + wave * wave_area);
+    uint8_t *slots = reinterpret_cast<uint8_t *>(win) + align16(window_words * 4u);
+
+    const uint32_t wave_first = first_interval + wave * kWave;
+    uint32_t win_base = 0, win_len = 0;
+    if (wave_first < d.total_intervals) {
+        wave_window(d, wave_first, window_words, win_base, win_len);
+        stage_window(d, win, win_base, win_len, lane);
+    }
+    __syncthreads();
+
+    const uint32_t interval = wave_first + lane;
+    if (interval >= d.total_intervals)
+        return;
+
+    HuffShared s;
+    s.l1 = l1;
+    s.l2 = l2;
+    s.l2_staged = umin(l2_in_lds, d.l2_entries);
+    s.win = win;
+    s.win_base = win_base;
+    s.win_len = win_len;
+    s.du_slots = slots;
+    huff_decode_interval(d, s, interval, lane);
+}
+
+// One lane per data unit for the IDCT, then the same lanes regroup (through
+// LDS) so that every wave-wide store writes 16 MCUs x 64 contiguous bytes.
+__global__ void __launch_bounds__(256)
+idct_composite_kernel(const ImageDesc *__restrict__ descs)
+{
+    __shared__ float quant[3 * kRetained];
+    __shared__ uint32_t px[4 * kWave * kPxSlotWords];
+
+    const ImageDesc &d = descs[blockIdx.y];
+    const uint32_t first_du = blockIdx.x * blockDim.x;
+    if (first_du >= d.total_dus)
+        return;
+    if (threadIdx.x < 3 * kRetained)
+        quant[threadIdx.x] = d.quant[threadIdx.x / kRetained][threadIdx.x % kRetained];
+    __syncthreads();
+
+    const uint32_t wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    uint32_t *wave_px = px + wave * kWave * kPxSlotWords;
+    const uint32_t du = first_du + threadIdx.x;
+    if (du < d.total_dus) {
+        const uint32_t k = du % d.dus_per_mcu;
+        const uint32_t comp = (d.comp_of_du >> (2u * k)) & 3u;
+        // 64-byte record, four 16-byte loads
+        Vec4u rec[4];
+        const Vec4u *src = reinterpret_cast<const Vec4u *>(d.ac + size_t(du) * kRetained);
+        rec[0] = src[0];
+        rec[1] = src[1];
+        rec[2] = src[2];
+        rec[3] = src[3];
+        uint32_t out[16];
+        idct_data_unit(reinterpret_cast<const int16_t *>(rec), d.dc[du], quant + comp * kRetained, out);
+        uint32_t *slot = wave_px + lane * kPxSlotWords;
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            slot[i] = out[i];
+    }
+    __syncthreads();
+
+    const uint32_t total_mcus = d.total_dus / d.dus_per_mcu;
+    const uint32_t first_mcu = (first_du + wave * kWave) / 4u; // 4:2:2: 4 data units per MCU
+    composite_422(d, wave_px, first_mcu, total_mcus, lane);
+}
+
+HuffLdsPlan plan_huffman(uint32_t max_intervals, uint32_t images, uint32_t max_l2,
+                         uint32_t avg_words_per_interval)
+{
+    HuffLdsPlan p;
+    // One wave per workgroup while the whole launch has few waves (a single
+    // 4K frame with DRI=4 is only 254 waves for 256 CUs): every wave then
+    // gets its own CU.  Four waves per workgroup once the chip is
+    // oversubscribed, to amortise LUT staging.
+    const uint64_t total_waves = uint64_t((max_intervals + kWave - 1) / kWave) * images;
+    p.waves_per_block = total_waves <= 2048 ? 1u : 4u;
+    p.l2_entries_in_lds = max_l2 < 8192u ? (max_l2 + 1u) & ~1u : 8192u;
+    // window: 1.5x the average footprint of 64 intervals, 2..16 KB
+    uint32_t w = avg_words_per_interval * kWave * 3u / 2u + 8u;
+    if (w < 512u)
+        w = 512u;
+    if (w > 4096u)
+        w = 4096u;
+    p.window_words = (w + 3u) & ~3u;
+    const uint32_t tables = (((kL1Entries + p.l2_entries_in_lds) * 2u) + 15u) & ~15u;
+    const uint32_t wave_area = ((p.window_words * 4u + 15u) & ~15u) + kWave * kDuSlotBytes;
+    p.total_bytes = tables + p.waves_per_block * wave_area;
+    return p;
+}
+
+hipError_t launch_huffman(const ImageDesc *descs, uint32_t images, uint32_t max_intervals,
+                          const HuffLdsPlan &plan, hipStream_t stream)
+{
+    if (images == 0 || max_intervals == 0)
+        return hipSuccess;
+    const uint32_t threads = plan.waves_per_block * kWave;
+    dim3 grid((max_intervals + threads - 1) / threads, images, 1);
+    hipLaunchKernelGGL(huffman_kernel, grid, dim3(threads), plan.total_bytes, stream, descs,
+                       plan.l2_entries_in_lds, plan.window_words);
+    return hipGetLastError();
+}
+
+hipError_t launch_idct_composite(const ImageDesc *descs, uint32_t images, uint32_t max_dus,
+                                 hipStream_t stream)
+{
+    if (images == 0 || max_dus == 0)
+        return hipSuccess;
+    dim3 grid((max_dus + 255) / 256, images, 1);
+    hipLaunchKernelGGL(idct_composite_kernel, grid, dim3(256), 0, stream, descs);
+    return hipGetLastError();
+}
+
+} // namespace compeg

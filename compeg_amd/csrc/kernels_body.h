@@ -1,0 +1,458 @@
+// Per-lane bodies of the gfx950 kernels.
+//
+// The functions here are what one lane executes between two workgroup
+// barriers; kernels.hip wraps them in __global__ entry points.  They are kept
+// free of HIP-only intrinsics so that tests/emul can compile the very same
+// code with g++ under ASan/UBSan and run the lanes one after another (GPU
+// sanitizers are not available on the target pool).
+//
+// Arithmetic contract (bit-exact with the reference's WGSL):
+//   - bit reader: u32 arithmetic wraps, shift counts are taken modulo 32
+//     (src/huffman.wgsl:35-79), including the reference's behaviour when the
+//     buffer underflows at a DC code (quirk Q1);
+//   - ZRL advances 17 positions (Q2); only zig-zag positions < 32 are kept (Q3);
+//   - IDCT: every operation is an individually rounded f32 operation in the
+//     reference's order (src/dct.wgsl:73-201) -- this file must be compiled
+//     with -ffp-contract=off;
+//   - colour conversion: integer, arithmetic shifts (src/dct.wgsl:323-334).
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+
+#include "device_types.h"
+
+#if defined(__HIPCC__)
+#define CG_DEV __device__ __forceinline__
+#else
+#define CG_DEV static inline
+#endif
+
+namespace compeg {
+
+struct alignas(16) Vec4u {
+    uint32_t x, y, z, w;
+};
+
+// ---------------------------------------------------------------------------
+// Huffman / RLE decode, one lane per restart interval
+// ---------------------------------------------------------------------------
+
+// Views into the workgroup's LDS.
+struct HuffShared {
+    const uint16_t *l1;   // 5 x 256 entries; table 4 is all-zero (out-of-range selector)
+    const uint16_t *l2;   // first l2_staged entries of the image's L2 LUT
+    uint32_t l2_staged;
+    const uint32_t *win;  // this wave's scan window, already byte-swapped to MSB-first
+    uint32_t win_base;    // word index of win[0]
+    uint32_t win_len;
+    uint8_t *du_slots;    // this wave's 64 data-unit slots (kDuSlotBytes each)
+};
+
+CG_DEV uint32_t bswap32(uint32_t w)
+{
+    return (w << 24) | ((w & 0xff00u) << 8) | ((w >> 8) & 0xff00u) | (w >> 24);
+}
+
+struct BitReader {
+    uint32_t cur, nxt, left, next_word;
+};
+
+// One 32-bit word of the interval's stream, MSB-first.  Words beyond the
+// preprocessed data read as zero (the reference relies on WebGPU's robust
+// buffer access there).
+CG_DEV uint32_t fetch_word(const ImageDesc &d, const HuffShared &s, uint32_t idx)
+{
+    const uint32_t rel = idx - s.win_base;
+    if (rel < s.win_len)
+        return s.win[rel];
+    return idx < d.nwords ? bswap32(d.words[idx]) : 0u;
+}
+
+CG_DEV void refill(BitReader &b, const ImageDesc &d, const HuffShared &s)
+{
+    if (b.left < 32u) {
+        const uint32_t w = fetch_word(d, s, b.next_word);
+        b.next_word += 1u;
+        b.cur |= w >> (b.left & 31u);
+        b.nxt = (w << 1) << ((31u - b.left) & 31u);
+        b.left += 32u;
+    }
+}
+
+CG_DEV void consume(BitReader &b, uint32_t n)
+{
+    b.cur = (b.cur << (n & 31u)) | ((b.nxt >> 1) >> ((31u - n) & 31u));
+    b.nxt <<= (n & 31u);
+    b.left -= n;
+}
+
+CG_DEV uint32_t peek(const BitReader &b, uint32_t n)
+{
+    return (b.cur >> 1) >> ((31u - n) & 31u);
+}
+
+CG_DEV int32_t huff_extend(int32_t v, uint32_t t)
+{
+    const int32_t vt = int32_t(1u << ((t - 1u) & 31u));
+    const uint32_t ext = uint32_t(v) + (0xffffffffu << (t & 31u)) + 1u;
+    return v < vt ? int32_t(ext) : v;
+}
+
+CG_DEV void zero_slot(uint8_t *slot)
+{
+    const Vec4u z = {0, 0, 0, 0};
+    Vec4u *p = reinterpret_cast<Vec4u *>(slot);
+    p[0] = z;
+    p[1] = z;
+    p[2] = z;
+    p[3] = z;
+}
+
+constexpr uint32_t kL1Entries = 5 * 256; // 4 tables + the all-zero table
+
+CG_DEV uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
+CG_DEV uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+// Workgroup prologue, thread `tid` of `nthreads`: copies the image's LUTs
+// into LDS with 4-byte accesses (both tables are 4-byte aligned and padded).
+CG_DEV void stage_luts(const ImageDesc &d, uint16_t *l1, uint16_t *l2, uint32_t l2_in_lds,
+                       uint32_t tid, uint32_t nthreads)
+{
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(d.l1);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(l1);
+    for (uint32_t i = tid; i < 4 * 128; i += nthreads)
+        dst[i] = src[i];
+    for (uint32_t i = tid; i < 128; i += nthreads)
+        dst[4 * 128 + i] = 0u;
+    const uint32_t n2 = umin(l2_in_lds, d.l2_entries);
+    const uint32_t *src2 = reinterpret_cast<const uint32_t *>(d.l2);
+    uint32_t *dst2 = reinterpret_cast<uint32_t *>(l2);
+    for (uint32_t i = tid; i < (n2 + 1) / 2; i += nthreads)
+        dst2[i] = src2[i];
+}
+
+// The scan window of the wave whose first interval is `wave_first`: the
+// contiguous words of its 64 intervals plus the reader's two-word look-ahead,
+// cut to the LDS budget.
+CG_DEV void wave_window(const ImageDesc &d, uint32_t wave_first, uint32_t window_words,
+                        uint32_t &base, uint32_t &len)
+{
+    base = wave_first < d.nstarts ? d.starts[wave_first] : 0u;
+    const uint32_t after = wave_first + kWave;
+    uint32_t end = (after < d.total_intervals && after < d.nstarts) ? d.starts[after] : d.nwords;
+    end = umin(umin(end, d.nwords) + 2u, d.nwords);
+    base = umin(base, d.nwords);
+    len = end > base ? umin(end - base, window_words) : 0u;
+}
+
+CG_DEV void stage_window(const ImageDesc &d, uint32_t *win, uint32_t base, uint32_t len,
+                         uint32_t lane)
+{
+    for (uint32_t i = lane; i < len; i += kWave)
+        win[i] = bswap32(d.words[base + i]);
+}
+
+// Decodes restart interval `interval` of image d.  Quantised AC levels go
+// through the lane's LDS slot and leave as one 64-byte record per data unit;
+// the dequantised DC goes straight to d.dc.
+CG_DEV void huff_decode_interval(const ImageDesc &d, const HuffShared &s, uint32_t interval,
+                                 uint32_t lane)
+{
+    uint8_t *slot = s.du_slots + lane * kDuSlotBytes;
+    int16_t *slot16 = reinterpret_cast<int16_t *>(slot);
+    zero_slot(slot);
+
+    BitReader b;
+    b.next_word = interval < d.nstarts ? d.starts[interval] : 0u;
+    b.cur = b.nxt = b.left = 0u;
+    refill(b, d, s);
+
+    int32_t pred0 = 0, pred1 = 0, pred2 = 0;
+    const uint32_t dpm = d.dus_per_mcu;
+    const uint32_t du_count = d.restart_interval * dpm;
+    uint32_t du_global = interval * du_count;
+    uint32_t du_local = 0;
+    uint32_t k = 0; // data unit inside the MCU
+    uint32_t comp = d.comp_of_du & 3u;
+    uint32_t dc_off = d.dc_table[0] * 256u, ac_off = d.ac_table[0] * 256u;
+    if (comp == 1u) {
+        dc_off = d.dc_table[1] * 256u;
+        ac_off = d.ac_table[1] * 256u;
+    } else if (comp == 2u) {
+        dc_off = d.dc_table[2] * 256u;
+        ac_off = d.ac_table[2] * 256u;
+    }
+    uint32_t pos = 0; // 0: the next symbol is the DC code; 1..63: AC position
+
+    while (du_local < du_count) {
+        const bool is_dc = pos == 0u;
+        if (!is_dc)
+            refill(b, d, s); // no refill in front of a DC code (quirk Q1)
+
+        // two-level LUT lookup on the next 16 bits (src/huffman.wgsl:85-113)
+        const uint32_t code = b.cur >> 16;
+        uint32_t e = s.l1[(is_dc ? dc_off : ac_off) + (code >> 8)];
+        if (e & 0x8000u) {
+            const uint32_t idx = (e & 0x7fffu) + (code & 0xffu);
+            e = idx < s.l2_staged ? s.l2[idx] : (idx < d.l2_entries ? d.l2[idx] : 0u);
+        }
+        consume(b, e >> 8);
+        const uint32_t sym = e & 0xffu;
+
+        // magnitude bits: category for DC, low nibble for AC (0 for EOB / ZRL)
+        const uint32_t nbits = is_dc ? sym : (sym & 15u);
+        const int32_t raw = int32_t(peek(b, nbits));
+        consume(b, nbits);
+        const int32_t val = huff_extend(raw, nbits);
+
+        bool du_done = false;
+        if (is_dc) {
+            int32_t p = comp == 0u ? pred0 : (comp == 1u ? pred1 : pred2);
+            p = int32_t(uint32_t(p) + uint32_t(val)); // dccat == 0 gives val == 0
+            if (comp == 0u)
+                pred0 = p;
+            else if (comp == 1u)
+                pred1 = p;
+            else
+                pred2 = p;
+            const uint32_t q0 = comp == 0u ? d.dc_quant[0] : (comp == 1u ? d.dc_quant[1] : d.dc_quant[2]);
+            d.dc[du_global] = int32_t(uint32_t(p) * q0);
+            pos = 1u;
+        } else if (sym == 0u) {
+            du_done = true; // EOB
+        } else {
+            const uint32_t p = pos + (sym >> 4);
+            const bool zrl = sym == 0xf0u;
+            if (!zrl && p < uint32_t(kRetained))
+                slot16[p] = int16_t(val);
+            pos = p + (zrl ? 2u : 1u); // ZRL skips 17 in total (quirk Q2)
+            du_done = pos >= 64u;
+        }
+
+        if (du_done) {
+            // 64-byte record out, slot cleared for the next data unit
+            Vec4u *src = reinterpret_cast<Vec4u *>(slot);
+            Vec4u *dst = reinterpret_cast<Vec4u *>(d.ac + size_t(du_global) * kRetained);
+            dst[0] = src[0];
+            dst[1] = src[1];
+            dst[2] = src[2];
+            dst[3] = src[3];
+            zero_slot(slot);
+
+            du_local++;
+            du_global++;
+            pos = 0u;
+            k = k + 1u == dpm ? 0u : k + 1u;
+            comp = (d.comp_of_du >> (2u * k)) & 3u;
+            dc_off = (comp == 0u ? d.dc_table[0] : (comp == 1u ? d.dc_table[1] : d.dc_table[2])) * 256u;
+            ac_off = (comp == 0u ? d.ac_table[0] : (comp == 1u ? d.ac_table[1] : d.ac_table[2])) * 256u;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Inverse DCT of one data unit, entirely in one lane's registers
+// ---------------------------------------------------------------------------
+
+// f32 nearest to the reference's WGSL literals (src/dct.wgsl:24-27)
+#define CG_S0 ((float)1.0)
+#define CG_S1 ((float)1.387039845)
+#define CG_S2 ((float)1.306562965)
+#define CG_S3 ((float)1.175875602)
+#define CG_S4 ((float)1.0)
+#define CG_S5 ((float)0.785694958)
+#define CG_S6 ((float)0.541196100)
+#define CG_S7 ((float)0.275899379)
+#define CG_C1414 ((float)1.414213562)
+#define CG_C1847 ((float)1.847759065)
+#define CG_C1082 ((float)1.082392200)
+#define CG_C2613 ((float)2.613125930)
+
+CG_DEV float aan_scale(int i)
+{
+    switch (i) {
+    case 0: return CG_S0;
+    case 1: return CG_S1;
+    case 2: return CG_S2;
+    case 3: return CG_S3;
+    case 4: return CG_S4;
+    case 5: return CG_S5;
+    case 6: return CG_S6;
+    default: return CG_S7;
+    }
+}
+
+// natural (row-major) index -> zig-zag position (src/dct.wgsl:29-38)
+CG_DEV int zigzag_of(int natural)
+{
+    constexpr int8_t t[64] = {0,  1,  5,  6,  14, 15, 27, 28, 2,  4,  7,  13, 16, 26, 29, 42,
+                              3,  8,  12, 17, 25, 30, 41, 43, 9,  11, 18, 24, 31, 40, 44, 53,
+                              10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60,
+                              21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
+    return t[natural];
+}
+
+// One 8-point AAN pass over v[0], v[stride], ... (libjpeg-turbo jidctflt
+// structure as used by the reference).  `bias` is added to the DC input
+// (128.5 in the row pass).
+template <int STRIDE, bool ROW_PASS>
+CG_DEV void aan_1d(float *v)
+{
+    float in0 = v[0 * STRIDE], in1 = v[1 * STRIDE], in2 = v[2 * STRIDE], in3 = v[3 * STRIDE];
+    float in4 = v[4 * STRIDE], in5 = v[5 * STRIDE], in6 = v[6 * STRIDE], in7 = v[7 * STRIDE];
+    if (ROW_PASS) {
+        in0 = in0 + 128.5f;
+    } else {
+        in0 = in0 * 0.125f;
+        in1 = in1 * 0.125f;
+        in2 = in2 * 0.125f;
+        in3 = in3 * 0.125f;
+        in4 = in4 * 0.125f;
+        in5 = in5 * 0.125f;
+        in6 = in6 * 0.125f;
+        in7 = in7 * 0.125f;
+    }
+    // even part
+    const float tmp10 = in0 + in4, tmp11 = in0 - in4;
+    const float tmp13 = in2 + in6;
+    const float tmp12 = (in2 - in6) * CG_C1414 - tmp13;
+    const float e0 = tmp10 + tmp13, e3 = tmp10 - tmp13;
+    const float e1 = tmp11 + tmp12, e2 = tmp11 - tmp12;
+    // odd part
+    const float z13 = in5 + in3, z10 = in5 - in3;
+    const float z11 = in1 + in7, z12 = in1 - in7;
+    const float o7 = z11 + z13;
+    const float t11 = (z11 - z13) * CG_C1414;
+    const float z5 = (z10 + z12) * CG_C1847;
+    const float t10 = z5 - z12 * CG_C1082;
+    const float t12 = z5 - z10 * CG_C2613;
+    const float o6 = t12 - o7;
+    const float o5 = t11 - o6;
+    const float o4 = t10 - o5;
+
+    v[0 * STRIDE] = e0 + o7;
+    v[7 * STRIDE] = e0 - o7;
+    v[1 * STRIDE] = e1 + o6;
+    v[6 * STRIDE] = e1 - o6;
+    v[2 * STRIDE] = e2 + o5;
+    v[5 * STRIDE] = e2 - o5;
+    v[3 * STRIDE] = e3 + o4;
+    v[4 * STRIDE] = e3 - o4;
+}
+
+CG_DEV uint32_t sample_u8(float f)
+{
+    // clamp(f, 0, 255) = min(max(f, 0), 255), then truncation (dct.wgsl:174-197)
+    float m = f > 0.0f ? f : 0.0f;
+    m = m < 255.0f ? m : 255.0f;
+    return uint32_t(m);
+}
+
+// quant: this component's 32 quantiser values as floats (zig-zag order).
+// px[2*y], px[2*y+1]: the 8 samples of row y, sample 0 in the low byte --
+// the reference's packed pixel format (dct.wgsl:187-201).
+CG_DEV void idct_data_unit(const int16_t *ac, int32_t dc, const float *quant, uint32_t px[16])
+{
+    float v[64];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const int z = zigzag_of(r * 8 + c);
+            const float mul = aan_scale(r) * aan_scale(c);
+            float x = 0.0f;
+            if (z == 0) {
+                x = static_cast<float>(dc) * mul; // already dequantised with i32 wrap by the decoder
+            } else if (z < kRetained) {
+                // level * q is exact in f32 (|level| < 2^15, q < 2^8), so this
+                // equals f32(i32(level * q)) of the reference
+                const float level = static_cast<float>(static_cast<int32_t>(ac[z]));
+                x = (level * quant[z]) * mul;
+            }
+            v[r * 8 + c] = x;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; c++)
+        aan_1d<8, false>(v + c);
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+        aan_1d<1, true>(v + r * 8);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        px[2 * r + 0] = sample_u8(v[r * 8 + 0]) | sample_u8(v[r * 8 + 1]) << 8 |
+                        sample_u8(v[r * 8 + 2]) << 16 | sample_u8(v[r * 8 + 3]) << 24;
+        px[2 * r + 1] = sample_u8(v[r * 8 + 4]) | sample_u8(v[r * 8 + 5]) << 8 |
+                        sample_u8(v[r * 8 + 6]) << 16 | sample_u8(v[r * 8 + 7]) << 24;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Composite: 4:2:2 chroma replication + YCbCr -> RGBA8
+// ---------------------------------------------------------------------------
+
+constexpr int kPxSlotWords = 17; // 16 words of samples + 1 pad (LDS banks)
+
+CG_DEV uint32_t ycbcr_to_rgba(uint32_t y_, uint32_t cb_, uint32_t cr_)
+{
+    const int32_t y = int32_t(y_), cb = int32_t(cb_) - 128, cr = int32_t(cr_) - 128;
+    int32_t r = y + ((45 * cr) >> 5);
+    int32_t g = y - ((11 * cb + 23 * cr) >> 5);
+    int32_t b = y + ((113 * cb) >> 6);
+    r = r < 0 ? 0 : (r > 255 ? 255 : r);
+    g = g < 0 ? 0 : (g > 255 ? 255 : g);
+    b = b < 0 ? 0 : (b > 255 ? 255 : b);
+    return uint32_t(r) | uint32_t(g) << 8 | uint32_t(b) << 16 | 0xff000000u;
+}
+
+// Lane `j` of a wave composites pixel columns 4*(j%4) .. +3 of MCU
+// `mcu = first_mcu + j/4` (4:2:2: MCU = 16x8 pixels, data units Y0 Y1 Cb Cr)
+// for all 8 rows, so that one wave-wide 16-byte store covers 16 MCUs x 64 B
+// of one pixel row.  px_slots: the wave's 64 sample slots in LDS, slot i =
+// data unit (first_mcu*4 + i).
+CG_DEV void composite_422(const ImageDesc &d, const uint32_t *px_slots, uint32_t first_mcu,
+                          uint32_t total_mcus, uint32_t j)
+{
+    const uint32_t m = j >> 2, quarter = j & 3u;
+    const uint32_t mcu = first_mcu + m;
+    if (mcu >= total_mcus)
+        return;
+    const uint32_t mx = mcu % d.width_mcus, my = mcu / d.width_mcus;
+    const uint32_t x0 = mx * 16u + quarter * 4u;
+    if (x0 >= d.out_w)
+        return;
+    const uint32_t *ydu = px_slots + (m * 4u + (quarter >> 1)) * kPxSlotWords;
+    const uint32_t *cbdu = px_slots + (m * 4u + 2u) * kPxSlotWords;
+    const uint32_t *crdu = px_slots + (m * 4u + 3u) * kPxSlotWords;
+    const uint32_t cshift = (quarter & 1u) * 16u; // chroma samples 2*quarter, 2*quarter+1
+#pragma unroll
+    for (uint32_t row = 0; row < 8; row++) {
+        const uint32_t y = my * 8u + row;
+        if (y >= d.out_h)
+            break;
+        const uint32_t yw = ydu[row * 2u + (quarter & 1u)];
+        const uint32_t cbw = cbdu[row * 2u + (quarter >> 1)] >> cshift;
+        const uint32_t crw = crdu[row * 2u + (quarter >> 1)] >> cshift;
+        Vec4u o;
+        o.x = ycbcr_to_rgba(yw & 0xffu, cbw & 0xffu, crw & 0xffu);
+        o.y = ycbcr_to_rgba((yw >> 8) & 0xffu, cbw & 0xffu, crw & 0xffu);
+        o.z = ycbcr_to_rgba((yw >> 16) & 0xffu, (cbw >> 8) & 0xffu, (crw >> 8) & 0xffu);
+        o.w = ycbcr_to_rgba(yw >> 24, (cbw >> 8) & 0xffu, (crw >> 8) & 0xffu);
+        uint8_t *p = d.out + size_t(y) * d.out_pitch + size_t(x0) * 4u;
+        if (x0 + 3u < d.out_w && (d.out_pitch & 15u) == 0u) {
+            *reinterpret_cast<Vec4u *>(p) = o;
+        } else {
+            uint32_t *q = reinterpret_cast<uint32_t *>(p);
+            q[0] = o.x;
+            if (x0 + 1u < d.out_w)
+                q[1] = o.y;
+            if (x0 + 2u < d.out_w)
+                q[2] = o.z;
+            if (x0 + 3u < d.out_w)
+                q[3] = o.w;
+        }
+    }
+}
+
+} // namespace compeg

@@ -1,0 +1,355 @@
+// See runtime.h.
+#include "runtime.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+
+namespace compeg {
+
+Status hip_status(hipError_t e, const char *what)
+{
+    if (e == hipSuccess)
+        return Status{};
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    return Status::error(COMPEG_E_HIP, buf);
+}
+
+#define CG_HIP(expr)                                                                               \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return hip_status(e_, #expr);                                                          \
+    } while (0)
+
+#define CG_TRY(expr)                                                                               \
+    do {                                                                                           \
+        Status s_ = (expr);                                                                        \
+        if (!s_.ok())                                                                              \
+            return s_;                                                                             \
+    } while (0)
+
+DeviceBuffer::~DeviceBuffer()
+{
+    if (ptr)
+        (void)hipFree(ptr);
+}
+
+Status DeviceBuffer::reserve(size_t bytes, bool *reallocated)
+{
+    if (reallocated)
+        *reallocated = false;
+    if (bytes <= capacity && ptr)
+        return Status{};
+    if (bytes == 0)
+        bytes = 256;
+    if (ptr) {
+        CG_HIP(hipFree(ptr)); // waits for work that may still use the old block
+        ptr = nullptr;
+        capacity = 0;
+    }
+    CG_HIP(hipMalloc(&ptr, bytes));
+    capacity = bytes;
+    if (reallocated)
+        *reallocated = true;
+    return Status{};
+}
+
+void *DeviceBuffer::release()
+{
+    void *p = ptr;
+    ptr = nullptr;
+    capacity = 0;
+    return p;
+}
+
+PinnedBuffer::~PinnedBuffer()
+{
+    if (ptr)
+        (void)hipHostFree(ptr);
+}
+
+Status PinnedBuffer::reserve(size_t bytes)
+{
+    if (bytes <= capacity && ptr)
+        return Status{};
+    if (ptr) {
+        CG_HIP(hipHostFree(ptr));
+        ptr = nullptr;
+        capacity = 0;
+    }
+    bytes = std::max<size_t>(bytes + bytes / 4, 64 * 1024);
+    CG_HIP(hipHostMalloc(&ptr, bytes, hipHostMallocDefault));
+    capacity = bytes;
+    return Status{};
+}
+
+namespace {
+
+void *pinned_alloc(size_t n)
+{
+    void *p = nullptr;
+    return hipHostMalloc(&p, n, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+}
+
+void pinned_free(void *p) { (void)hipHostFree(p); }
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+} // namespace
+} // namespace compeg
+
+using namespace compeg;
+
+compeg_decoder::compeg_decoder() : scan(pinned_alloc, pinned_free) {}
+
+compeg_decoder::~compeg_decoder()
+{
+    if (last_stream || upload_pending)
+        (void)hipStreamSynchronize(last_stream);
+    if (upload_done)
+        (void)hipEventDestroy(upload_done);
+    if (gpu)
+        compeg_gpu_release(gpu);
+}
+
+// Counterpart of Decoder::enqueue (src/lib.rs:385-477).
+Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *changed)
+{
+    CG_HIP(hipSetDevice(gpu->device));
+    warning.clear();
+
+    // DynamicTexture::reserve (dynamic.rs:214-248): recreate at exactly the
+    // requested size when either dimension is too small.
+    bool realloc_out = false;
+    if (img.width > out_w || img.height > out_h || !out.ptr) {
+        const size_t pitch = align_up(size_t(img.width) * 4, 16);
+        // never shrink the allocation itself, only the logical extent
+        CG_TRY(out.reserve(std::max<size_t>(pitch * img.height, 256)));
+        out_w = img.width;
+        out_h = img.height;
+        out_pitch = pitch;
+        realloc_out = true;
+    }
+    if (changed)
+        *changed = realloc_out;
+
+    if (!upload_done)
+        CG_HIP(hipEventCreateWithFlags(&upload_done, hipEventDisableTiming));
+    if (upload_pending) {
+        CG_HIP(hipEventSynchronize(upload_done));
+        upload_pending = false;
+    }
+
+    const Metadata &md = img.metadata;
+    Status pre = scan.process(img.scan_data(), img.scan_len, md.total_restart_intervals);
+    if (!pre.ok()) {
+        if (pre.code != COMPEG_E_COUNT_MISMATCH)
+            return pre;
+        warning = pre.message; // the reference drops this error (lib.rs:391-394)
+    }
+
+    const uint32_t total_dus = img.total_dus();
+    const size_t l2_bytes = align_up(img.l2.size() * 2, 4);
+    const size_t blob_bytes = align_up(sizeof(ImageDesc), 256) + COMPEG_HUFFMAN_L1_BYTES + l2_bytes;
+    CG_TRY(host_blob.reserve(blob_bytes));
+    CG_TRY(dev_blob.reserve(blob_bytes));
+    CG_TRY(words.reserve(scan.nwords() * 4 + 16));
+    CG_TRY(starts.reserve(scan.nstarts() * 4 + 16));
+    CG_TRY(ac.reserve(size_t(total_dus) * kRetained * 2 + 64));
+    CG_TRY(dc.reserve(size_t(total_dus) * 4 + 64));
+
+    uint8_t *hb = static_cast<uint8_t *>(host_blob.ptr);
+    uint8_t *db = static_cast<uint8_t *>(dev_blob.ptr);
+    const size_t l1_off = align_up(sizeof(ImageDesc), 256), l2_off = l1_off + COMPEG_HUFFMAN_L1_BYTES;
+    ImageDesc &d = *reinterpret_cast<ImageDesc *>(hb);
+    fill_desc(img, d);
+    d.words = static_cast<const uint32_t *>(words.ptr);
+    d.starts = static_cast<const uint32_t *>(starts.ptr);
+    d.nwords = uint32_t(scan.nwords());
+    d.nstarts = uint32_t(scan.nstarts());
+    d.l1 = reinterpret_cast<const uint16_t *>(db + l1_off);
+    d.l2 = reinterpret_cast<const uint16_t *>(db + l2_off);
+    d.ac = static_cast<int16_t *>(ac.ptr);
+    d.dc = static_cast<int32_t *>(dc.ptr);
+    d.out = static_cast<uint8_t *>(out.ptr);
+    d.out_w = out_w;
+    d.out_h = out_h;
+    d.out_pitch = uint32_t(out_pitch);
+    memcpy(hb + l1_off, img.l1, COMPEG_HUFFMAN_L1_BYTES);
+    if (!img.l2.empty())
+        memcpy(hb + l2_off, img.l2.data(), img.l2.size() * 2);
+
+    CG_HIP(hipMemcpyAsync(db, hb, blob_bytes, hipMemcpyHostToDevice, stream));
+    if (scan.nstarts())
+        CG_HIP(hipMemcpyAsync(starts.ptr, scan.starts(), scan.nstarts() * 4, hipMemcpyHostToDevice,
+                              stream));
+    if (scan.nwords())
+        CG_HIP(hipMemcpyAsync(words.ptr, scan.words(), scan.nwords() * 4, hipMemcpyHostToDevice,
+                              stream));
+    CG_HIP(hipEventRecord(upload_done, stream));
+    upload_pending = true;
+    last_stream = stream;
+    last_md = md;
+    have_last = true;
+
+    if (total_dus == 0)
+        return Status{};
+    const uint32_t avg_words =
+        md.total_restart_intervals ? uint32_t(scan.nwords() / md.total_restart_intervals) + 1 : 1;
+    const HuffLdsPlan plan =
+        plan_huffman(md.total_restart_intervals, 1, uint32_t(img.l2.size()), avg_words);
+    CG_HIP(launch_huffman(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals,
+                          plan, stream));
+    CG_HIP(launch_idct_composite(reinterpret_cast<const ImageDesc *>(db), 1, total_dus, stream));
+    return Status{};
+}
+
+compeg_batch::~compeg_batch()
+{
+    (void)hipStreamSynchronize(last_stream);
+    for (hipEvent_t e : ev)
+        if (e)
+            (void)hipEventDestroy(e);
+    if (gpu)
+        compeg_gpu_release(gpu);
+}
+
+Status compeg_batch::upload(const ImageData *const *images, size_t n, int threads)
+{
+    CG_HIP(hipSetDevice(gpu->device));
+    CG_HIP(hipStreamSynchronize(last_stream));
+    count = 0;
+    if (n > 65535)
+        return Status::error(COMPEG_E_INVALID_ARG, "at most 65535 images per batch");
+
+    // host front-end: preprocess every scan (independent, so spread over threads)
+    std::vector<ScanBuffer> scans(n);
+    std::vector<Status> results(n);
+    unsigned nthreads = threads > 0 ? unsigned(threads) : std::max(1u, std::thread::hardware_concurrency());
+    nthreads = unsigned(std::min<size_t>(nthreads, std::max<size_t>(n, 1)));
+    auto work = [&](unsigned t) {
+        for (size_t i = t; i < n; i += nthreads)
+            results[i] = scans[i].process(images[i]->scan_data(), images[i]->scan_len,
+                                          images[i]->metadata.total_restart_intervals);
+    };
+    if (nthreads <= 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nthreads; t++)
+            pool.emplace_back(work, t);
+        for (auto &th : pool)
+            th.join();
+    }
+    for (size_t i = 0; i < n; i++)
+        if (!results[i].ok() && results[i].code != COMPEG_E_COUNT_MISMATCH)
+            return results[i];
+
+    // lay out one input arena: per image [L1][L2][starts][words], 256-byte aligned
+    descs.assign(n, ImageDesc{});
+    out_offset.assign(n, 0);
+    std::vector<size_t> in_off(n);
+    size_t in_total = 0, ac_total = 0, dc_total = 0, out_total = 0;
+    max_intervals = max_dus = max_l2 = 0;
+    algorithmic_bytes = pixels = 0;
+    uint64_t words_sum = 0, intervals_sum = 0;
+    for (size_t i = 0; i < n; i++) {
+        const ImageData &img = *images[i];
+        in_off[i] = in_total;
+        in_total += align_up(COMPEG_HUFFMAN_L1_BYTES + align_up(img.l2.size() * 2, 4) +
+                                 scans[i].nstarts() * 4 + scans[i].nwords() * 4 + 16,
+                             256);
+        out_offset[i] = out_total;
+        out_total += align_up(size_t(img.width) * 4 * img.height, 256);
+        ac_total += size_t(img.total_dus()) * kRetained * 2;
+        dc_total += size_t(img.total_dus()) * 4;
+        max_intervals = std::max(max_intervals, img.metadata.total_restart_intervals);
+        max_dus = std::max(max_dus, img.total_dus());
+        max_l2 = std::max<uint32_t>(max_l2, uint32_t(img.l2.size()));
+        words_sum += scans[i].nwords();
+        intervals_sum += img.metadata.total_restart_intervals;
+        algorithmic_bytes += 4ull * scans[i].nwords() + 4ull * img.metadata.total_restart_intervals +
+                             COMPEG_METADATA_BYTES + COMPEG_HUFFMAN_L1_BYTES + img.l2.size() * 2 +
+                             4ull * img.width * img.height;
+        pixels += uint64_t(img.width) * img.height;
+    }
+    avg_words = intervals_sum ? uint32_t(words_sum / intervals_sum) + 1 : 1;
+
+    CG_TRY(inputs.reserve(in_total + 256));
+    CG_TRY(ac.reserve(ac_total + 256));
+    CG_TRY(dc.reserve(dc_total + 256));
+    CG_TRY(out.reserve(out_total + 256));
+    CG_TRY(dev_descs.reserve(n * sizeof(ImageDesc) + 256));
+
+    PinnedBuffer stage;
+    CG_TRY(stage.reserve(in_total + 256));
+    uint8_t *hs = static_cast<uint8_t *>(stage.ptr);
+    uint8_t *di = static_cast<uint8_t *>(inputs.ptr);
+    size_t ac_at = 0, dc_at = 0;
+    for (size_t i = 0; i < n; i++) {
+        const ImageData &img = *images[i];
+        ImageDesc &d = descs[i];
+        fill_desc(img, d);
+        size_t o = in_off[i];
+        memcpy(hs + o, img.l1, COMPEG_HUFFMAN_L1_BYTES);
+        d.l1 = reinterpret_cast<const uint16_t *>(di + o);
+        o += COMPEG_HUFFMAN_L1_BYTES;
+        if (!img.l2.empty())
+            memcpy(hs + o, img.l2.data(), img.l2.size() * 2);
+        d.l2 = reinterpret_cast<const uint16_t *>(di + o);
+        o += align_up(img.l2.size() * 2, 4);
+        if (scans[i].nstarts())
+            memcpy(hs + o, scans[i].starts(), scans[i].nstarts() * 4);
+        d.starts = reinterpret_cast<const uint32_t *>(di + o);
+        d.nstarts = uint32_t(scans[i].nstarts());
+        o += scans[i].nstarts() * 4;
+        if (scans[i].nwords())
+            memcpy(hs + o, scans[i].words(), scans[i].nwords() * 4);
+        d.words = reinterpret_cast<const uint32_t *>(di + o);
+        d.nwords = uint32_t(scans[i].nwords());
+        d.ac = reinterpret_cast<int16_t *>(static_cast<uint8_t *>(ac.ptr) + ac_at);
+        d.dc = reinterpret_cast<int32_t *>(static_cast<uint8_t *>(dc.ptr) + dc_at);
+        ac_at += size_t(img.total_dus()) * kRetained * 2;
+        dc_at += size_t(img.total_dus()) * 4;
+        d.out = static_cast<uint8_t *>(out.ptr) + out_offset[i];
+        d.out_w = img.width;
+        d.out_h = img.height;
+        d.out_pitch = img.width * 4;
+    }
+    CG_HIP(hipMemcpy(inputs.ptr, hs, in_total, hipMemcpyHostToDevice));
+    CG_HIP(hipMemcpy(dev_descs.ptr, descs.data(), n * sizeof(ImageDesc), hipMemcpyHostToDevice));
+    count = n;
+    timed = false;
+    return Status{};
+}
+
+Status compeg_batch::decode(hipStream_t stream)
+{
+    if (count == 0)
+        return Status{};
+    CG_HIP(hipSetDevice(gpu->device));
+    for (hipEvent_t &e : ev)
+        if (!e)
+            CG_HIP(hipEventCreate(&e));
+    const ImageDesc *dd = static_cast<const ImageDesc *>(dev_descs.ptr);
+    const uint32_t n = uint32_t(count);
+    const uint32_t step = chunk ? std::min(chunk, n) : n;
+    CG_HIP(hipEventRecord(ev[0], stream));
+    for (uint32_t at = 0; at < n; at += step) {
+        const uint32_t m = std::min(step, n - at);
+        const HuffLdsPlan plan = plan_huffman(max_intervals, m, max_l2, avg_words);
+        CG_HIP(launch_huffman(dd + at, m, max_intervals, plan, stream));
+        if (step == n)
+            CG_HIP(hipEventRecord(ev[1], stream));
+        CG_HIP(launch_idct_composite(dd + at, m, max_dus, stream));
+    }
+    CG_HIP(hipEventRecord(ev[2], stream));
+    timed = true;
+    last_stream = stream;
+    return Status{};
+}

@@ -1,0 +1,99 @@
+// Device-side resource management and decode orchestration of libcompeg_hip:
+// the counterpart of the reference's Gpu / Decoder / DecodeOp
+// (src/lib.rs:64-574) and of its grow-only DynamicBuffer / DynamicTexture
+// (src/dynamic.rs:11-79,166-257).  Bind groups have no equivalent: kernel
+// arguments are plain device pointers.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <atomic>
+#include <string>
+#include <vector>
+
+#include "device_types.h"
+#include "front.h"
+#include "kernels.h"
+#include "scan.h"
+
+namespace compeg {
+
+Status hip_status(hipError_t e, const char *what);
+
+// Grow-only device allocation; contents are not preserved across growth
+// (every user rewrites the buffer in full before reading it).
+struct DeviceBuffer {
+    void *ptr = nullptr;
+    size_t capacity = 0;
+    ~DeviceBuffer();
+    DeviceBuffer() = default;
+    DeviceBuffer(const DeviceBuffer &) = delete;
+    DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+    Status reserve(size_t bytes, bool *reallocated = nullptr);
+    void *release();
+};
+
+struct PinnedBuffer {
+    void *ptr = nullptr;
+    size_t capacity = 0;
+    ~PinnedBuffer();
+    Status reserve(size_t bytes);
+};
+
+// Fills the kernel-facing descriptor from the reference-format metadata.
+// Pointers are left for the caller to set.
+void fill_desc(const ImageData &img, ImageDesc &d);
+
+} // namespace compeg
+
+struct compeg_gpu {
+    std::atomic<int> refs{1};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    std::string name;
+};
+
+struct compeg_op {
+    hipEvent_t done = nullptr;
+    int device = 0;
+    bool texture_changed = false;
+};
+
+struct compeg_decoder {
+    compeg_gpu *gpu = nullptr;
+    compeg::ScanBuffer scan;
+    compeg::PinnedBuffer host_blob;   // ImageDesc + L1 + L2 for the next upload
+    compeg::DeviceBuffer dev_blob, words, starts, ac, dc, out;
+    uint32_t out_w = 0, out_h = 0;
+    size_t out_pitch = 0;
+    hipEvent_t upload_done = nullptr; // host staging may be rewritten after this
+    bool upload_pending = false;
+    hipStream_t last_stream = nullptr;
+    std::string warning;
+    // what read_coefficients needs to rebuild the reference's buffer
+    compeg::Metadata last_md{};
+    bool have_last = false;
+
+    compeg_decoder();
+    ~compeg_decoder();
+    compeg::Status enqueue(const compeg::ImageData &img, hipStream_t stream, bool *changed);
+};
+
+struct compeg_batch {
+    compeg_gpu *gpu = nullptr;
+    size_t count = 0;
+    std::vector<compeg::ImageDesc> descs; // host copy (device pointers inside)
+    compeg::DeviceBuffer dev_descs, inputs, ac, dc, out;
+    std::vector<size_t> out_offset;
+    uint32_t max_intervals = 0, max_dus = 0, max_l2 = 0, avg_words = 0;
+    uint64_t algorithmic_bytes = 0, pixels = 0;
+    uint32_t chunk = 0; // images per launch pair, 0 = all
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    bool timed = false;
+    hipStream_t last_stream = nullptr;
+
+    ~compeg_batch();
+    compeg::Status upload(const compeg::ImageData *const *images, size_t n, int threads);
+    compeg::Status decode(hipStream_t stream);
+};

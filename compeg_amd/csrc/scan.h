@@ -1,0 +1,53 @@
+// Host scan preprocessor: strips RSTn markers and FF 00 stuffing from the
+// entropy-coded segment, aligns every restart interval to a 32-bit word and
+// records each interval's word offset.  Byte-identical to the reference's
+// ScanBuffer::process on a fresh buffer (src/scan.rs:33-128).
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+
+#include "front.h"
+
+namespace compeg {
+
+// Grow-only byte arena; the decoder plugs in pinned host memory so that the
+// preprocessed scan can be DMA'd without a bounce copy.
+struct HostArena {
+    using AllocFn = void *(*)(size_t);
+    using FreeFn = void (*)(void *);
+    uint8_t *data = nullptr;
+    size_t capacity = 0;
+    AllocFn alloc_fn;
+    FreeFn free_fn;
+
+    HostArena(AllocFn a, FreeFn f) : alloc_fn(a), free_fn(f) {}
+    HostArena();
+    ~HostArena();
+    HostArena(const HostArena &) = delete;
+    HostArena &operator=(const HostArena &) = delete;
+    bool reserve(size_t bytes); // contents are not preserved
+};
+
+class ScanBuffer {
+  public:
+    ScanBuffer() = default;
+    ScanBuffer(HostArena::AllocFn a, HostArena::FreeFn f) : words_(a, f), starts_(a, f) {}
+
+    // COMPEG_E_COUNT_MISMATCH leaves the truncated result in place, like the
+    // reference (scan.rs:55-63).
+    Status process(const uint8_t *scan, size_t len, uint32_t expected_intervals);
+
+    const uint8_t *data() const { return words_.data; }
+    size_t data_bytes() const { return nwords_ * 4; }
+    const uint32_t *words() const { return reinterpret_cast<const uint32_t *>(words_.data); }
+    size_t nwords() const { return nwords_; }
+    const uint32_t *starts() const { return reinterpret_cast<const uint32_t *>(starts_.data); }
+    size_t nstarts() const { return nstarts_; }
+
+  private:
+    HostArena words_, starts_;
+    size_t nwords_ = 0, nstarts_ = 0;
+};
+
+} // namespace compeg

@@ -1,0 +1,196 @@
+/*
+ * compeg_hip.h -- C ABI of libcompeg_hip.so: an MI355X-native (gfx950) decoder
+ * for baseline 8-bit YCbCr 4:2:2 restart-interval JPEGs.
+ *
+ * The entry points are what a Rust `compeg`-shaped crate binds in place of the
+ * reference's wgpu-backed implementation.  Each group cites the reference
+ * interface it replaces (paths relative to SludgePhD/Compeg, v0.5.0).
+ * INTEGRATION.md shows the Rust side.
+ *
+ * Conventions
+ *   - every fallible call returns COMPEG_OK (0) or a negative COMPEG_E_* code;
+ *     the message is available from compeg_last_error() (thread-local).  Texts
+ *     equal the reference's error strings where it has one (src/lib.rs:622-793,
+ *     src/file.rs:21-25,43-45,281-283,345-347, src/scan.rs:58-63).
+ *   - nothing in this library aborts the process; inputs on which the
+ *     reference panics (src/lib.rs:784-785 division by zero, src/huffman.rs
+ *     asserts, src/file.rs:316,331-335 slicing) return COMPEG_E_MALFORMED.
+ *   - objects are not internally synchronised: one thread at a time per
+ *     decoder / scan buffer (the reference's `&mut self`), any number of
+ *     decoders per compeg_gpu (the reference's `Arc<Gpu>`).
+ *   - `hip_stream` arguments are `hipStream_t` passed as `void*` (NULL = the
+ *     default stream) so that the header needs no HIP include.
+ */
+#ifndef COMPEG_HIP_H
+#define COMPEG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default) /* the library itself is built -fvisibility=hidden */
+#endif
+
+#define COMPEG_OK 0
+#define COMPEG_E_INVALID_ARG (-1) /* NULL handle, bad size ...                       */
+#define COMPEG_E_UNSUPPORTED (-2) /* well-formed JPEG outside the supported subset   */
+#define COMPEG_E_MALFORMED (-3)   /* broken stream (incl. inputs the reference panics on) */
+#define COMPEG_E_COUNT_MISMATCH (-4) /* restart-interval count mismatch (scan.rs:58-63) */
+#define COMPEG_E_HIP (-5)         /* HIP runtime failure, no usable gfx950 device    */
+
+/* Size of the uniform block shared by all kernels (src/metadata.rs:21-41). */
+#define COMPEG_METADATA_BYTES 1112
+#define COMPEG_HUFFMAN_L1_BYTES 2048
+
+typedef struct compeg_gpu compeg_gpu;
+typedef struct compeg_decoder compeg_decoder;
+typedef struct compeg_image compeg_image;
+typedef struct compeg_scanbuffer compeg_scanbuffer;
+typedef struct compeg_op compeg_op;
+typedef struct compeg_batch compeg_batch;
+
+/* Last error message of the calling thread ("" if none). */
+const char *compeg_last_error(void);
+/* Library version string, e.g. "compeg-hip 0.1.0 (gfx950)". */
+const char *compeg_version(void);
+
+/* ---- Gpu: src/lib.rs:64-270 (`Gpu::open`, `Gpu::from_wgpu`) -------------- */
+
+/* Opens HIP device `device` (-1 = current device) and loads the gfx950 code
+ * object.  The handle is reference-counted and immutable, i.e. shareable
+ * between threads like `Arc<Gpu>`. */
+int compeg_gpu_open(int device, compeg_gpu **out);
+/* `from_wgpu` analogue: adopt a caller-owned stream as the queue that
+ * start_decode / decode_blocking submit to. */
+int compeg_gpu_from_stream(int device, void *hip_stream, compeg_gpu **out);
+void compeg_gpu_retain(compeg_gpu *gpu);
+void compeg_gpu_release(compeg_gpu *gpu);
+int compeg_gpu_device(const compeg_gpu *gpu);
+/* Human-readable device name ("AMD Instinct MI355X ..."), valid while gpu lives. */
+const char *compeg_gpu_name(const compeg_gpu *gpu);
+
+/* ---- ImageData: src/lib.rs:576-851 ---------------------------------------- */
+
+/* Parses and validates a JPEG (`ImageData::new`).  copy != 0 keeps a private
+ * copy of the bytes (Cow::Owned); copy == 0 borrows them (Cow::Borrowed): the
+ * caller keeps `jpeg` alive and unchanged while the image is in use. */
+int compeg_image_parse(const uint8_t *jpeg, size_t len, int copy, compeg_image **out);
+void compeg_image_free(compeg_image *img);
+uint32_t compeg_image_width(const compeg_image *img);       /* lib.rs:828-831 */
+uint32_t compeg_image_height(const compeg_image *img);      /* lib.rs:834-837 */
+uint32_t compeg_image_parallelism(const compeg_image *img); /* lib.rs:838-846 */
+/* What the reference uploads per image (src/lib.rs:397-407), exposed so that a
+ * binding's tests can compare them byte for byte: the 1112-byte Metadata
+ * block, the 2048-byte L1 LUT, the L2 LUT, and the location of the
+ * entropy-coded segment inside the JPEG. */
+const uint8_t *compeg_image_metadata(const compeg_image *img);
+const uint8_t *compeg_image_huffman_l1(const compeg_image *img);
+const uint8_t *compeg_image_huffman_l2(const compeg_image *img, size_t *nbytes);
+void compeg_image_scan_range(const compeg_image *img, size_t *offset, size_t *len);
+
+/* ---- ScanBuffer: src/scan.rs:15-77 (doc-hidden re-export, lib.rs:44-46) ---- */
+
+compeg_scanbuffer *compeg_scanbuffer_new(void);
+void compeg_scanbuffer_free(compeg_scanbuffer *sb);
+/* `ScanBuffer::process`.  On COMPEG_E_COUNT_MISMATCH the buffers still hold
+ * the (truncated) result, as in the reference. */
+int compeg_scanbuffer_process(compeg_scanbuffer *sb, const uint8_t *scan, size_t len,
+                              uint32_t expected_restart_intervals);
+/* `processed_scan_data()` / `start_positions()`: valid until the next process(). */
+const uint8_t *compeg_scanbuffer_data(const compeg_scanbuffer *sb, size_t *nbytes);
+const uint8_t *compeg_scanbuffer_start_positions(const compeg_scanbuffer *sb, size_t *nbytes);
+
+/* ---- Decoder / DecodeOp: src/lib.rs:273-574 ------------------------------- */
+
+int compeg_decoder_new(compeg_gpu *gpu, compeg_decoder **out); /* Decoder::new */
+void compeg_decoder_free(compeg_decoder *dec);
+
+/* `Decoder::enqueue(&ImageData, &mut CommandEncoder) -> bool` (lib.rs:385):
+ * preprocess on the host, upload, and record the decode on `hip_stream` (the
+ * command-encoder analogue) without waiting.  *texture_changed (optional) is
+ * set to 1 when the output buffer was reallocated (always on the first call).
+ * Like the reference, a restart-interval count mismatch does not stop the
+ * decode (lib.rs:391-394 drops that error); it is reported through
+ * compeg_decoder_last_warning(). */
+int compeg_decoder_enqueue(compeg_decoder *dec, const compeg_image *img, void *hip_stream,
+                           int *texture_changed);
+/* `start_decode` (lib.rs:483-499): enqueue on the gpu's own stream + submit. */
+int compeg_decoder_start_decode(compeg_decoder *dec, const compeg_image *img, compeg_op **op);
+/* `decode_blocking` (lib.rs:508-529): start_decode + wait. */
+int compeg_decoder_decode_blocking(compeg_decoder *dec, const compeg_image *img, compeg_op **op);
+const char *compeg_decoder_last_warning(const compeg_decoder *dec);
+
+/* `DecodeOp` (lib.rs:541-574).  compeg_op_wait replaces polling the
+ * SubmissionIndex.  Ops are freed by the caller. */
+int compeg_op_wait(compeg_op *op);
+int compeg_op_texture_changed(const compeg_op *op);
+void compeg_op_free(compeg_op *op);
+
+/* `Decoder::texture()` (lib.rs:372-374): the device-resident RGBA8 output,
+ * row-major, bytes R,G,B,255, `pitch` bytes per row.  Like the reference's
+ * texture it never shrinks, so width/height may exceed the last image; only
+ * the image's own WxH corner is defined.  The pointer stays valid until the
+ * next decode that reallocates (texture_changed) or the decoder is freed. */
+int compeg_decoder_output(const compeg_decoder *dec, void **device_ptr, uint32_t *width,
+                          uint32_t *height, size_t *pitch_bytes);
+/* `Decoder::into_texture()` (lib.rs:380-383): transfers ownership of the
+ * output allocation to the caller (release it with compeg_device_free) and
+ * frees the decoder. */
+int compeg_decoder_take_output(compeg_decoder *dec, void **device_ptr, uint32_t *width,
+                               uint32_t *height, size_t *pitch_bytes);
+void compeg_device_free(void *device_ptr);
+/* Test-harness helper (src/tests.rs:52-84 does copy_texture_to_buffer):
+ * waits for the decoder's pending work and copies the WxH corner to host
+ * memory, tightly packed (4*width bytes per row). */
+int compeg_decoder_read_output(compeg_decoder *dec, uint8_t *host_rgba, uint32_t width,
+                               uint32_t height);
+/* Debug read-back (role of DownloadBuffer, src/dynamic.rs:81-163): the
+ * coefficient buffer as the reference's huffman pass leaves it,
+ * int32[total_dus*32] at du*32 + zigzag_pos, dequantised. */
+int compeg_decoder_read_coefficients(compeg_decoder *dec, int32_t *host_coefficients,
+                                     size_t count);
+
+/* ---- Batch (extension; not in the reference) -------------------------------
+ * Decodes many independent images with one launch sequence: the images'
+ * preprocessed scans and tables are made resident in HBM once
+ * (compeg_batch_upload), after which every compeg_batch_decode is pure device
+ * work.  Outputs are tightly packed RGBA8 images (pitch = 4*width) in one
+ * device allocation. */
+int compeg_batch_new(compeg_gpu *gpu, compeg_batch **out);
+void compeg_batch_free(compeg_batch *batch);
+/* Host front-end for all images (preprocess, may use `host_threads` threads,
+ * 0 = one per core) + upload; replaces any previous content. */
+int compeg_batch_upload(compeg_batch *batch, const compeg_image *const *images, size_t count,
+                        int host_threads);
+/* Records the decode of every uploaded image on hip_stream (NULL = the gpu's
+ * stream) and returns without waiting. */
+int compeg_batch_decode(compeg_batch *batch, void *hip_stream);
+/* Images per kernel-launch pair (0 = the whole batch in one pair, the default).
+ * Smaller chunks keep the coefficient intermediates cache-resident. */
+int compeg_batch_set_chunk(compeg_batch *batch, uint32_t images_per_launch);
+int compeg_batch_wait(compeg_batch *batch);
+size_t compeg_batch_count(const compeg_batch *batch);
+/* Device pointer / geometry of image `index`'s output. */
+int compeg_batch_output(const compeg_batch *batch, size_t index, void **device_ptr,
+                        uint32_t *width, uint32_t *height, size_t *pitch_bytes);
+int compeg_batch_read_output(compeg_batch *batch, size_t index, uint8_t *host_rgba);
+/* Algorithmic bytes of the uploaded batch as SURVEY.md 8(d) defines them:
+ * 4*scan_words + 4*intervals + 1112 + 2048 + L2 bytes + 4*W*H per image. */
+uint64_t compeg_batch_algorithmic_bytes(const compeg_batch *batch);
+uint64_t compeg_batch_pixels(const compeg_batch *batch);
+/* Kernel-level timing of the most recent compeg_batch_decode, measured with
+ * HIP events recorded on the stream the kernels ran on: total milliseconds
+ * and (optional) per-stage milliseconds [huffman, idct+composite].  Waits for
+ * that decode to finish. */
+int compeg_batch_last_timing(compeg_batch *batch, float *total_ms, float stage_ms[2]);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
+#ifdef __cplusplus
+}
+#endif
+#endif /* COMPEG_HIP_H */

@@ -1,0 +1,182 @@
+// Host-side emulation of the gfx950 kernels for sanitizer runs (TEST ONLY).
+//
+// Compiles compeg_amd/csrc/kernels_body.h -- the code the GPU lanes execute --
+// with g++ under ASan/UBSan and runs the lanes of every workgroup one after
+// another, with a heap block standing in for LDS.  GPU AddressSanitizer is not
+// available on the target pool, so this is where out-of-bounds LDS/global
+// accesses and undefined shifts in the kernel bodies get caught.  It is not a
+// fallback: nothing in compeg_amd loads this library.
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../compeg_amd/csrc/device_types.h"
+#include "../../compeg_amd/csrc/front.h"
+#include "../../compeg_amd/csrc/kernels_body.h"
+#include "../../compeg_amd/csrc/scan.h"
+
+namespace compeg {
+void fill_desc(const ImageData &img, ImageDesc &d);
+}
+using namespace compeg;
+
+extern "C" __attribute__((visibility("default")))
+int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, uint32_t tex_h,
+                int16_t *ac_out, int32_t *dc_out, uint32_t waves_per_block, uint32_t window_words,
+                uint32_t l2_in_lds, char *err, size_t errlen)
+{
+    ImageData *img = nullptr;
+    Status s = ImageData::parse(jpeg, len, false, &img);
+    if (!s.ok()) {
+        snprintf(err, errlen, "%s", s.message.c_str());
+        return s.code;
+    }
+    ScanBuffer scan;
+    Status pre = scan.process(img->scan_data(), img->scan_len, img->metadata.total_restart_intervals);
+    if (!pre.ok() && pre.code != COMPEG_E_COUNT_MISMATCH) {
+        delete img;
+        return pre.code;
+    }
+    ImageDesc d;
+    fill_desc(*img, d);
+    // exact-size heap copies so that ASan sees every overrun
+    std::vector<uint32_t> words(scan.words(), scan.words() + scan.nwords());
+    std::vector<uint32_t> starts(scan.starts(), scan.starts() + scan.nstarts());
+    std::vector<uint16_t> l1(img->l1, img->l1 + 1024), l2(img->l2);
+    std::vector<int16_t> ac(size_t(d.total_dus) * kRetained);
+    std::vector<int32_t> dc(d.total_dus);
+    d.words = words.data();
+    d.starts = starts.data();
+    d.nwords = uint32_t(words.size());
+    d.nstarts = uint32_t(starts.size());
+    d.l1 = l1.data();
+    d.l2 = l2.data();
+    d.ac = ac.data();
+    d.dc = dc.data();
+    d.out = rgba;
+    d.out_w = tex_w;
+    d.out_h = tex_h;
+    d.out_pitch = tex_w * 4;
+
+    // ---- huffman_kernel ----
+    l2_in_lds &= ~1u;
+    const uint32_t threads = waves_per_block * kWave;
+    const uint32_t wave_area = align16(window_words * 4u) + kWave * kDuSlotBytes;
+    const uint32_t lds_bytes = align16((kL1Entries + l2_in_lds) * 2u) + waves_per_block * wave_area;
+    for (uint32_t first = 0; first < d.total_intervals; first += threads) {
+        uint8_t *smem = static_cast<uint8_t *>(aligned_alloc(16, align16(lds_bytes)));
+        memset(smem, 0xa5, lds_bytes); // LDS is not zero-initialised
+        uint16_t *sl1 = reinterpret_cast<uint16_t *>(smem);
+        uint16_t *sl2 = sl1 + kL1Entries;
+        uint8_t *wave_base = smem + align16((kL1Entries + l2_in_lds) * 2u);
+        for (uint32_t tid = 0; tid < threads; tid++)
+            stage_luts(d, sl1, sl2, l2_in_lds, tid, threads);
+        for (uint32_t wave = 0; wave < waves_per_block; wave++) {
+            uint32_t *win = reinterpret_cast<uint32_t *>(wave_base + wave * wave_area);
+            uint8_t *slots = reinterpret_cast<uint8_t *>(win) + align16(window_words * 4u);
+            const uint32_t wave_first = first + wave * kWave;
+            if (wave_first >= d.total_intervals)
+                continue;
+            uint32_t wb = 0, wl = 0;
+            wave_window(d, wave_first, window_words, wb, wl);
+            for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
+                stage_window(d, win, wb, wl, lane);
+            HuffShared sh{sl1, sl2, umin(l2_in_lds, d.l2_entries), win, wb, wl, slots};
+            for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
+                if (wave_first + lane < d.total_intervals)
+                    huff_decode_interval(d, sh, wave_first + lane, lane);
+        }
+        free(smem);
+    }
+    if (ac_out)
+        memcpy(ac_out, ac.data(), ac.size() * 2);
+    if (dc_out)
+        memcpy(dc_out, dc.data(), dc.size() * 4);
+
+    // ---- idct_composite_kernel ----
+    const uint32_t total_mcus = d.dus_per_mcu ? d.total_dus / d.dus_per_mcu : 0;
+    for (uint32_t first_du = 0; first_du < d.total_dus; first_du += 256) {
+        std::vector<float> quant(3 * kRetained);
+        for (uint32_t t = 0; t < 3 * kRetained; t++)
+            quant[t] = d.quant[t / kRetained][t % kRetained];
+        std::vector<uint32_t> px(4 * kWave * kPxSlotWords, 0xa5a5a5a5u);
+        for (uint32_t tid = 0; tid < 256; tid++) {
+            const uint32_t du = first_du + tid;
+            if (du >= d.total_dus)
+                continue;
+            const uint32_t comp = (d.comp_of_du >> (2u * (du % d.dus_per_mcu))) & 3u;
+            alignas(16) int16_t rec[kRetained];
+            memcpy(rec, d.ac + size_t(du) * kRetained, sizeof rec);
+            uint32_t out[16];
+            idct_data_unit(rec, d.dc[du], quant.data() + comp * kRetained, out);
+            memcpy(px.data() + size_t(tid / kWave) * kWave * kPxSlotWords + (tid % kWave) * kPxSlotWords,
+                   out, sizeof out);
+        }
+        for (uint32_t tid = 0; tid < 256; tid++) {
+            const uint32_t wave = tid / kWave, lane = tid % kWave;
+            composite_422(d, px.data() + size_t(wave) * kWave * kPxSlotWords,
+                          (first_du + wave * kWave) / 4u, total_mcus, lane);
+        }
+    }
+    delete img;
+    return 0;
+}
+
+// emul_runner in.jpg out.rgba out.ac out.dc waves_per_block window_words l2_in_lds [tex_w tex_h]
+int main(int argc, char **argv)
+{
+    if (argc < 8) {
+        fprintf(stderr, "usage: %s in.jpg out.rgba out.ac out.dc waves window_words l2_in_lds [tex_w tex_h]\n", argv[0]);
+        return 2;
+    }
+    FILE *f = fopen(argv[1], "rb");
+    if (!f)
+        return 2;
+    std::vector<uint8_t> jpeg;
+    uint8_t buf[65536];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0)
+        jpeg.insert(jpeg.end(), buf, buf + n);
+    fclose(f);
+    // exact-size copy: reads past the end of the file are caught by ASan
+    uint8_t *exact = static_cast<uint8_t *>(malloc(jpeg.size() ? jpeg.size() : 1));
+    memcpy(exact, jpeg.data(), jpeg.size());
+
+    ImageData *probe = nullptr;
+    Status s = ImageData::parse(exact, jpeg.size(), false, &probe);
+    if (!s.ok()) {
+        printf("error: %s\n", s.message.c_str());
+        free(exact);
+        return 1;
+    }
+    uint32_t tex_w = argc > 9 ? uint32_t(atoi(argv[8])) : probe->width;
+    uint32_t tex_h = argc > 9 ? uint32_t(atoi(argv[9])) : probe->height;
+    const uint32_t dus = probe->total_dus();
+    delete probe;
+    std::vector<uint8_t> rgba(size_t(tex_w) * tex_h * 4, 0);
+    std::vector<int16_t> ac(size_t(dus) * kRetained);
+    std::vector<int32_t> dc(dus);
+    char err[256] = "";
+    int rc = emul_decode(exact, jpeg.size(), rgba.data(), tex_w, tex_h, ac.data(), dc.data(),
+                         uint32_t(atoi(argv[5])), uint32_t(atoi(argv[6])), uint32_t(atoi(argv[7])),
+                         err, sizeof err);
+    free(exact);
+    if (rc != 0) {
+        printf("error: %s\n", err);
+        return 1;
+    }
+    auto dump = [](const char *path, const void *p, size_t bytes) {
+        FILE *o = fopen(path, "wb");
+        if (o) {
+            fwrite(p, 1, bytes, o);
+            fclose(o);
+        }
+    };
+    dump(argv[2], rgba.data(), rgba.size());
+    dump(argv[3], ac.data(), ac.size() * 2);
+    dump(argv[4], dc.data(), dc.size() * 4);
+    printf("ok %u %u %u\n", tex_w, tex_h, dus);
+    return 0;
+}
