@@ -281,13 +281,13 @@ class Batch:
     def pixels(self):
         return lib.compeg_batch_pixels(self._h)
 
-    def last_timing(self):
-        """(total_ms, huffman_ms, idct_composite_ms) of the latest decode, from HIP events
-        recorded on the stream the kernels ran on."""
-        total = C.c_float()
-        stages = (C.c_float * 2)()
-        check(lib.compeg_batch_last_timing(self._h, C.byref(total), stages))
-        return total.value, stages[0], stages[1]
+    def timing(self, reset=True):
+        """(decodes, total_ms, huffman_ms, idct_composite_ms) summed over the decodes since the
+        last upload/reset, from HIP events recorded on the stream the kernels ran on."""
+        n, total = C.c_uint32(), C.c_double()
+        stages = (C.c_double * 2)()
+        check(lib.compeg_batch_timing(self._h, 1 if reset else 0, C.byref(n), C.byref(total), stages))
+        return n.value, total.value, stages[0], stages[1]
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -77,7 +77,7 @@ def _load():
         "compeg_batch_read_output": (i, [vp, sz, vp]),
         "compeg_batch_algorithmic_bytes": (C.c_uint64, [vp]),
         "compeg_batch_pixels": (C.c_uint64, [vp]),
-        "compeg_batch_last_timing": (i, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+        "compeg_batch_timing": (i, [vp, i, pu32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here = header/library mismatch: fail loudly

@@ -83,7 +83,7 @@ int open_gpu(int device, hipStream_t stream, bool adopt, compeg_gpu **out)
         return fail(hip_status(e, "hipSetDevice"));
     compeg_gpu *g = new compeg_gpu();
     g->device = device;
-    g->name = prop.name;
+    g->name = prop.name[0] ? std::string(prop.name) + " (" + prop.gcnArchName + ")" : std::string(prop.gcnArchName);
     if (adopt) {
         g->stream = stream;
         g->owns_stream = false;
@@ -569,30 +569,42 @@ uint64_t compeg_batch_pixels(const compeg_batch *batch)
     return batch ? batch->pixels : 0;
 }
 
-int compeg_batch_last_timing(compeg_batch *batch, float *total_ms, float stage_ms[2])
+int compeg_batch_timing(compeg_batch *batch, int reset, uint32_t *decodes, double *total_ms,
+                        double stage_ms[2])
 {
     return guarded([&] {
-        if (!batch || !batch->timed)
-            return fail(COMPEG_E_INVALID_ARG, "no timed decode");
+        if (!batch)
+            return fail(COMPEG_E_INVALID_ARG, "batch is NULL");
         (void)hipSetDevice(batch->gpu->device);
-        hipError_t e = hipEventSynchronize(batch->ev[2]);
-        float t = 0, a = 0, b = 0;
-        if (e == hipSuccess)
-            e = hipEventElapsedTime(&t, batch->ev[0], batch->ev[2]);
+        double t = 0, a = 0, b = 0;
         const bool split = !batch->chunk || batch->chunk >= batch->count;
-        if (e == hipSuccess && split) {
-            e = hipEventElapsedTime(&a, batch->ev[0], batch->ev[1]);
+        for (size_t i = 0; i < batch->decodes_timed; i++) {
+            hipEvent_t *ev = batch->events.data() + i * 3;
+            hipError_t e = hipEventSynchronize(ev[2]);
+            float x = 0, y = 0, z = 0;
             if (e == hipSuccess)
-                e = hipEventElapsedTime(&b, batch->ev[1], batch->ev[2]);
+                e = hipEventElapsedTime(&x, ev[0], ev[2]);
+            if (e == hipSuccess && split) {
+                e = hipEventElapsedTime(&y, ev[0], ev[1]);
+                if (e == hipSuccess)
+                    e = hipEventElapsedTime(&z, ev[1], ev[2]);
+            }
+            if (e != hipSuccess)
+                return fail(hip_status(e, "hipEventElapsedTime"));
+            t += x;
+            a += y;
+            b += z;
         }
-        if (e != hipSuccess)
-            return fail(hip_status(e, "hipEventElapsedTime"));
+        if (decodes)
+            *decodes = uint32_t(batch->decodes_timed);
         if (total_ms)
             *total_ms = t;
         if (stage_ms) {
             stage_ms[0] = a;
             stage_ms[1] = b;
         }
+        if (reset)
+            batch->decodes_timed = 0;
         return ok();
     });
 }

@@ -129,7 +129,12 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     if (img.width > out_w || img.height > out_h || !out.ptr) {
         const size_t pitch = align_up(size_t(img.width) * 4, 16);
         // never shrink the allocation itself, only the logical extent
-        CG_TRY(out.reserve(std::max<size_t>(pitch * img.height, 256)));
+        bool fresh = false;
+        CG_TRY(out.reserve(std::max<size_t>(pitch * img.height, 256), &fresh));
+        // wgpu zero-initialises new textures; texels no MCU covers (a truncated
+        // last restart interval, lib.rs:785) therefore read as 0 in the reference
+        if (fresh)
+            CG_HIP(hipMemsetAsync(out.ptr, 0, out.capacity, stream));
         out_w = img.width;
         out_h = img.height;
         out_pitch = pitch;
@@ -212,9 +217,8 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
 compeg_batch::~compeg_batch()
 {
     (void)hipStreamSynchronize(last_stream);
-    for (hipEvent_t e : ev)
-        if (e)
-            (void)hipEventDestroy(e);
+    for (hipEvent_t e : events)
+        (void)hipEventDestroy(e);
     if (gpu)
         compeg_gpu_release(gpu);
 }
@@ -284,6 +288,7 @@ Status compeg_batch::upload(const ImageData *const *images, size_t n, int thread
     CG_TRY(ac.reserve(ac_total + 256));
     CG_TRY(dc.reserve(dc_total + 256));
     CG_TRY(out.reserve(out_total + 256));
+    CG_HIP(hipMemset(out.ptr, 0, out.capacity));
     CG_TRY(dev_descs.reserve(n * sizeof(ImageDesc) + 256));
 
     PinnedBuffer stage;
@@ -324,7 +329,7 @@ Status compeg_batch::upload(const ImageData *const *images, size_t n, int thread
     CG_HIP(hipMemcpy(inputs.ptr, hs, in_total, hipMemcpyHostToDevice));
     CG_HIP(hipMemcpy(dev_descs.ptr, descs.data(), n * sizeof(ImageDesc), hipMemcpyHostToDevice));
     count = n;
-    timed = false;
+    decodes_timed = 0;
     return Status{};
 }
 
@@ -333,23 +338,34 @@ Status compeg_batch::decode(hipStream_t stream)
     if (count == 0)
         return Status{};
     CG_HIP(hipSetDevice(gpu->device));
-    for (hipEvent_t &e : ev)
-        if (!e)
+    constexpr size_t kMaxTimed = 4096;
+    const bool timing = decodes_timed < kMaxTimed;
+    hipEvent_t *ev = nullptr;
+    if (timing) {
+        while (events.size() < (decodes_timed + 1) * 3) {
+            hipEvent_t e;
             CG_HIP(hipEventCreate(&e));
+            events.push_back(e);
+        }
+        ev = events.data() + decodes_timed * 3;
+    }
     const ImageDesc *dd = static_cast<const ImageDesc *>(dev_descs.ptr);
     const uint32_t n = uint32_t(count);
     const uint32_t step = chunk ? std::min(chunk, n) : n;
-    CG_HIP(hipEventRecord(ev[0], stream));
+    if (timing)
+        CG_HIP(hipEventRecord(ev[0], stream));
     for (uint32_t at = 0; at < n; at += step) {
         const uint32_t m = std::min(step, n - at);
         const HuffLdsPlan plan = plan_huffman(max_intervals, m, max_l2, avg_words);
         CG_HIP(launch_huffman(dd + at, m, max_intervals, plan, stream));
-        if (step == n)
-            CG_HIP(hipEventRecord(ev[1], stream));
+        if (timing && at == 0)
+            CG_HIP(hipEventRecord(ev[1], stream)); // stage split is exact for unchunked decodes
         CG_HIP(launch_idct_composite(dd + at, m, max_dus, stream));
     }
-    CG_HIP(hipEventRecord(ev[2], stream));
-    timed = true;
+    if (timing) {
+        CG_HIP(hipEventRecord(ev[2], stream));
+        decodes_timed++;
+    }
     last_stream = stream;
     return Status{};
 }

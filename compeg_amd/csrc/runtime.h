@@ -89,8 +89,10 @@ struct compeg_batch {
     uint32_t max_intervals = 0, max_dus = 0, max_l2 = 0, avg_words = 0;
     uint64_t algorithmic_bytes = 0, pixels = 0;
     uint32_t chunk = 0; // images per launch pair, 0 = all
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-    bool timed = false;
+    // one event triple per decode since the last upload / timing reset:
+    // [start, after huffman, end], recorded on the decode's own stream
+    std::vector<hipEvent_t> events;
+    size_t decodes_timed = 0;
     hipStream_t last_stream = nullptr;
 
     ~compeg_batch();

@@ -181,11 +181,14 @@ int compeg_batch_read_output(compeg_batch *batch, size_t index, uint8_t *host_rg
  * 4*scan_words + 4*intervals + 1112 + 2048 + L2 bytes + 4*W*H per image. */
 uint64_t compeg_batch_algorithmic_bytes(const compeg_batch *batch);
 uint64_t compeg_batch_pixels(const compeg_batch *batch);
-/* Kernel-level timing of the most recent compeg_batch_decode, measured with
- * HIP events recorded on the stream the kernels ran on: total milliseconds
- * and (optional) per-stage milliseconds [huffman, idct+composite].  Waits for
- * that decode to finish. */
-int compeg_batch_last_timing(compeg_batch *batch, float *total_ms, float stage_ms[2]);
+/* Kernel-level timing of every compeg_batch_decode since the last upload or
+ * reset (at most 4096 are kept), measured with HIP events recorded on the
+ * stream the kernels ran on: number of decodes, summed total milliseconds and
+ * (for unchunked decodes) summed per-stage milliseconds
+ * [huffman, idct+composite].  Waits for those decodes to finish; reset != 0
+ * then starts a new measurement. */
+int compeg_batch_timing(compeg_batch *batch, int reset, uint32_t *decodes, double *total_ms,
+                        double stage_ms[2]);
 
 #if defined(__GNUC__)
 #pragma GCC visibility pop

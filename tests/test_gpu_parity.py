@@ -39,7 +39,7 @@ def _assert_equal(got, want):
 
 
 def test_native_library_is_loaded(ca, gpu):
-    assert "MI355" in gpu.name() or "gfx950" in gpu.name() or gpu.name()
+    assert "gfx950" in gpu.name()
     maps = open("/proc/self/maps").read()
     assert "libcompeg_hip.so" in maps
 
@@ -87,7 +87,6 @@ def test_synthetic_parity(ca, gpu, w, h, kind, q, ri, seed):
     got_coef = dec.read_coefficients(ref.total_dus())
     assert np.array_equal(got_coef, coef), "huffman stage differs from the oracle"
     _assert_equal(got, want)
-    assert np.all(got[:, :, 3] == 255)
 
 
 def test_no_dht_and_jfif_variants(ca, gpu):
@@ -174,8 +173,8 @@ def test_batch_matches_single_decodes(ca, gpu):
     assert batch.count() == len(jpegs)
     for i, j in enumerate(jpegs):
         _assert_equal(batch.read_output(i), orc.ImageData(j).decode())
-    total, huff, idct = batch.last_timing()
-    assert total > 0 and huff > 0 and idct > 0
+    n, total, huff, idct = batch.timing()
+    assert n == 1 and total > 0 and huff > 0 and idct > 0
     # chunked launches give the same pixels
     batch.set_chunk(2)
     batch.decode()

@@ -170,36 +170,36 @@ static void encode_block(bitw *w, const int16_t zz[64], int *pred, const enc_tab
         put_bits(w, ac->code[0], ac->len[0]);
 }
 
-static double COS[8][8];
+static float COSF[8][8];
 static int cos_ready = 0;
 
-static void fdct_quant(const float in[64], const uint8_t q[64], int16_t zz[64])
+static void init_cos(void)
 {
-    if (!cos_ready) {
-        for (int u = 0; u < 8; u++)
-            for (int x = 0; x < 8; x++)
-                COS[u][x] = cos((2 * x + 1) * u * M_PI / 16.0) * (u == 0 ? sqrt(0.125) : 0.5);
-        cos_ready = 1;
-    }
-    double tmp[64], outp[64];
+    for (int u = 0; u < 8; u++)
+        for (int x = 0; x < 8; x++)
+            COSF[u][x] = (float)(cos((2 * x + 1) * u * M_PI / 16.0) * (u == 0 ? sqrt(0.125) : 0.5));
+    cos_ready = 1;
+}
+
+static void fdct_quant(const float in[64], const float rq[64], int16_t zz[64])
+{
+    float tmp[64], outp[64];
     for (int y = 0; y < 8; y++)
         for (int u = 0; u < 8; u++) {
-            double s = 0;
+            float s = 0;
             for (int x = 0; x < 8; x++)
-                s += in[y * 8 + x] * COS[u][x];
+                s += in[y * 8 + x] * COSF[u][x];
             tmp[y * 8 + u] = s;
         }
     for (int v = 0; v < 8; v++)
         for (int u = 0; u < 8; u++) {
-            double s = 0;
+            float s = 0;
             for (int y = 0; y < 8; y++)
-                s += tmp[y * 8 + u] * COS[v][y];
+                s += tmp[y * 8 + u] * COSF[v][y];
             outp[v * 8 + u] = s;
         }
-    for (int k = 0; k < 64; k++) {
-        double c = outp[ZZ[k]] / q[k]; /* q is kept in zig-zag order */
-        zz[k] = (int16_t)lrint(c);
-    }
+    for (int k = 0; k < 64; k++)
+        zz[k] = (int16_t)lrintf(outp[ZZ[k]] * rq[k]); /* rq = 1/q, zig-zag order */
 }
 
 static void scale_qtable(const uint8_t base[64], int quality, uint8_t out_zz[64])
@@ -229,8 +229,15 @@ size_t synth_encode(const uint8_t *rgb, int w, int h, int quality, int hs, int v
                     unsigned flags, uint8_t *out, size_t cap)
 {
     uint8_t ql[64], qc[64];
+    float rql[64], rqc[64];
     scale_qtable(Q_LUMA, quality, ql);
     scale_qtable(Q_CHROMA, quality, qc);
+    for (int k = 0; k < 64; k++) {
+        rql[k] = 1.0f / (float)ql[k];
+        rqc[k] = 1.0f / (float)qc[k];
+    }
+    if (!cos_ready)
+        init_cos();
     enc_table dcl, dcc, acl, acc;
     make_enc_table(&dcl, DC_L_BITS, DC_VALS);
     make_enc_table(&dcc, DC_C_BITS, DC_VALS);
@@ -341,7 +348,7 @@ size_t synth_encode(const uint8_t *rgb, int w, int h, int quality, int hs, int v
                     for (int y = 0; y < 8; y++)
                         for (int x = 0; x < 8; x++)
                             blk[y * 8 + x] = Y[(v * 8 + y) * mw + u * 8 + x];
-                    fdct_quant(blk, ql, zz);
+                    fdct_quant(blk, rql, zz);
                     encode_block(bw, zz, &pred[0], &dcl, &acl);
                 }
             for (int c = 0; c < 2; c++) {
@@ -354,7 +361,7 @@ size_t synth_encode(const uint8_t *rgb, int w, int h, int quality, int hs, int v
                                 s += src[(y * vs + dy) * mw + x * hs + dx];
                         blk[y * 8 + x] = s / (float)(hs * vs);
                     }
-                fdct_quant(blk, qc, zz);
+                fdct_quant(blk, rqc, zz);
                 encode_block(bw, zz, &pred[1 + c], &dcc, &acc);
             }
         }
@@ -395,24 +402,43 @@ void synth_fill(uint8_t *rgb, int w, int h, uint64_t seed, int kind, int noise)
             ph[c][k] = (double)(splitmix(&s) % 1000) / 1000.0 * 6.283185307;
             amp[c][k] = 20.0 + (double)(splitmix(&s) % 25);
         }
-    for (int y = 0; y < h; y++)
+    /* sin(a + b) = sin a cos b + cos a sin b with a = fx*x + ph, b = fy*y */
+    float *sx = (float *)malloc(sizeof(float) * 18 * (size_t)(w > 0 ? w : 1));
+    float *cx = sx + 9 * (size_t)(w > 0 ? w : 1);
+    if (kind == 0)
+        for (int c = 0; c < 3; c++)
+            for (int k = 0; k < 3; k++)
+                for (int x = 0; x < w; x++) {
+                    sx[(size_t)(c * 3 + k) * w + x] = (float)(amp[c][k] * sin(fx[c][k] * x + ph[c][k]));
+                    cx[(size_t)(c * 3 + k) * w + x] = (float)(amp[c][k] * cos(fx[c][k] * x + ph[c][k]));
+                }
+    for (int y = 0; y < h; y++) {
+        float sy[9], cy[9];
+        for (int c = 0; c < 3; c++)
+            for (int k = 0; k < 3; k++) {
+                sy[c * 3 + k] = (float)sin(fy[c][k] * y);
+                cy[c * 3 + k] = (float)cos(fy[c][k] * y);
+            }
         for (int x = 0; x < w; x++) {
             uint8_t *p = rgb + ((size_t)y * w + x) * 3;
             uint64_t r = splitmix(&s);
             for (int c = 0; c < 3; c++) {
-                double v;
+                float v;
                 if (kind == 1) {
-                    v = (double)((r >> (c * 8)) & 255);
+                    v = (float)((r >> (c * 8)) & 255);
                 } else if (kind == 2) {
-                    v = ((r >> 40) % 997 == 0) ? (double)((r >> (c * 8)) & 255) : 128.0;
+                    v = ((r >> 40) % 997 == 0) ? (float)((r >> (c * 8)) & 255) : 128.0f;
                 } else {
-                    v = 128.0;
+                    v = 128.0f;
                     for (int k = 0; k < 3; k++)
-                        v += amp[c][k] * sin(fx[c][k] * x + fy[c][k] * y + ph[c][k]);
+                        v += sx[(size_t)(c * 3 + k) * w + x] * cy[c * 3 + k] +
+                             cx[(size_t)(c * 3 + k) * w + x] * sy[c * 3 + k];
                     if (noise > 0)
-                        v += (double)((int)((r >> (c * 16)) % (unsigned)(2 * noise + 1)) - noise);
+                        v += (float)((int)((r >> (c * 16)) % (unsigned)(2 * noise + 1)) - noise);
                 }
                 p[c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : (int)v));
             }
         }
+    }
+    free(sx);
 }
