@@ -429,6 +429,17 @@ int compeg_decoder_read_coefficients(compeg_decoder *dec, int32_t *host, size_t 
             return fail(hip_status(e, "hipStreamSynchronize"));
         std::vector<int16_t> ac(dus * kRetained);
         std::vector<int32_t> dc(dus);
+        if (dus && !dec->coefficients_valid) {
+            // the fused kernel keeps coefficients on chip: rerun the entropy
+            // stage alone into the scratch buffers for this debug read-back
+            e = launch_huffman(static_cast<const ImageDesc *>(dec->dev_blob.ptr), 1,
+                               md.total_restart_intervals, dec->last_plan, dec->last_stream);
+            if (e == hipSuccess)
+                e = hipStreamSynchronize(dec->last_stream);
+            if (e != hipSuccess)
+                return fail(hip_status(e, "huffman_kernel (coefficient read-back)"));
+            dec->coefficients_valid = true;
+        }
         if (dus) {
             e = hipMemcpy(ac.data(), dec->ac.ptr, ac.size() * 2, hipMemcpyDeviceToHost);
             if (e == hipSuccess)

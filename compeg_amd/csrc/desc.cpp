@@ -9,6 +9,7 @@
 namespace compeg {
 
 void fill_desc(const ImageData &img, ImageDesc &d);
+uint32_t max_wave_span(const uint32_t *starts, size_t nstarts, size_t nwords, uint32_t intervals);
 
 void fill_desc(const ImageData &img, ImageDesc &d)
 {
@@ -38,6 +39,20 @@ void fill_desc(const ImageData &img, ImageDesc &d)
         for (int z = 0; z < kRetained; z++)
             d.quant[c][z] = float(md.qtables[cm.qtable & 3][z]);
     }
+}
+
+
+uint32_t max_wave_span(const uint32_t *starts, size_t nstarts, size_t nwords, uint32_t intervals)
+{
+    uint32_t best = 0;
+    for (size_t first = 0; first < intervals; first += kWave) {
+        const uint64_t lo = first < nstarts ? starts[first] : 0;
+        const size_t after = first + kWave;
+        const uint64_t hi = (after < intervals && after < nstarts) ? starts[after] : nwords;
+        if (hi > lo && hi - lo > best)
+            best = uint32_t(hi - lo > 0xffffffffu ? 0xffffffffu : hi - lo);
+    }
+    return best;
 }
 
 } // namespace compeg

@@ -9,14 +9,19 @@ namespace compeg {
 
 // Chooses workgroup shape and LDS carve-up for a decode of `images` images
 // whose largest image has `max_intervals` restart intervals and `max_l2`
-// L2 entries; avg_words_per_interval sizes the per-wave scan window.
+// L2 entries; max_wave_words (largest scan span of 64 consecutive intervals)
+// sizes the per-wave scan window.
 HuffLdsPlan plan_huffman(uint32_t max_intervals, uint32_t images, uint32_t max_l2,
-                         uint32_t avg_words_per_interval);
+                         uint32_t max_wave_words);
+// Largest word span covered by any group of 64 consecutive restart intervals.
+uint32_t max_wave_span(const uint32_t *starts, size_t nstarts, size_t nwords, uint32_t intervals);
 
 // descs: device array of `images` descriptors.  Grid = (blocks for the
 // largest image, images); blocks past an image's own extent exit at once.
 hipError_t launch_huffman(const ImageDesc *descs, uint32_t images, uint32_t max_intervals,
                           const HuffLdsPlan &plan, hipStream_t stream);
+hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t max_intervals,
+                            const HuffLdsPlan &plan, hipStream_t stream);
 hipError_t launch_idct_composite(const ImageDesc *descs, uint32_t images, uint32_t max_dus,
                                  hipStream_t stream);
 

@@ -12,8 +12,8 @@
 // are bounded by HBM traffic / serial entropy decoding).
 #include <hip/hip_runtime.h>
 
-#include "kernels.h"
 #include "kernels_body.h"
+#include "kernels.h"
 
 namespace compeg {
 
@@ -62,6 +62,52 @@ huffman_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t
     huff_decode_interval(d, s, interval, lane);
 }
 
+// Fused path: same prologue as huffman_kernel, then every lane runs the whole
+// decode of its interval (entropy decode -> IDCT -> composite), so neither
+// coefficients nor samples ever touch HBM.
+__global__ void __launch_bounds__(256, 2)
+decode_fused_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const ImageDesc &d = descs[blockIdx.y];
+    const uint32_t first_interval = blockIdx.x * blockDim.x;
+    if (first_interval >= d.total_intervals)
+        return;
+
+    uint16_t *l1 = reinterpret_cast<uint16_t *>(smem);
+    uint16_t *l2 = l1 + kL1Entries;
+    const uint32_t wave_area = align16(window_words * 4u) + kWave * kDuSlotBytes;
+    uint8_t *wave_base = smem + align16((kL1Entries + l2_in_lds) * 2u);
+
+    stage_luts(d, l1, l2, l2_in_lds, threadIdx.x, blockDim.x);
+
+    const uint32_t wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    uint32_t *win = reinterpret_cast<uint32_t *>(wave_base + wave * wave_area);
+    uint8_t *slots = reinterpret_cast<uint8_t *>(win) + align16(window_words * 4u);
+
+    const uint32_t wave_first = first_interval + wave * kWave;
+    uint32_t win_base = 0, win_len = 0;
+    if (wave_first < d.total_intervals) {
+        wave_window(d, wave_first, window_words, win_base, win_len);
+        stage_window(d, win, win_base, win_len, lane);
+    }
+    __syncthreads();
+
+    const uint32_t interval = wave_first + lane;
+    if (interval >= d.total_intervals)
+        return;
+
+    HuffShared s;
+    s.l1 = l1;
+    s.l2 = l2;
+    s.l2_staged = umin(l2_in_lds, d.l2_entries);
+    s.win = win;
+    s.win_base = win_base;
+    s.win_len = win_len;
+    s.du_slots = slots;
+    decode_interval_fused_422(d, s, interval, lane);
+}
+
 // One lane per data unit for the IDCT, then the same lanes regroup (through
 // LDS) so that every wave-wide store writes 16 MCUs x 64 contiguous bytes.
 __global__ void __launch_bounds__(256)
@@ -86,13 +132,13 @@ idct_composite_kernel(const ImageDesc *__restrict__ descs)
         const uint32_t comp = (d.comp_of_du >> (2u * k)) & 3u;
         // 64-byte record, four 16-byte loads
         Vec4u rec[4];
-        const Vec4u *src = reinterpret_cast<const Vec4u *>(d.ac + size_t(du) * kRetained);
+        auto *src = CG_GLOBAL(const Vec4u, reinterpret_cast<const Vec4u *>(d.ac + size_t(du) * kRetained));
         rec[0] = src[0];
         rec[1] = src[1];
         rec[2] = src[2];
         rec[3] = src[3];
         uint32_t out[16];
-        idct_data_unit(reinterpret_cast<const int16_t *>(rec), d.dc[du], quant + comp * kRetained, out);
+        idct_data_unit(reinterpret_cast<const int16_t *>(rec), CG_GLOBAL(const int32_t, d.dc)[du], quant + comp * kRetained, out);
         uint32_t *slot = wave_px + lane * kPxSlotWords;
 #pragma unroll
         for (int i = 0; i < 16; i++)
@@ -106,7 +152,7 @@ idct_composite_kernel(const ImageDesc *__restrict__ descs)
 }
 
 HuffLdsPlan plan_huffman(uint32_t max_intervals, uint32_t images, uint32_t max_l2,
-                         uint32_t avg_words_per_interval)
+                         uint32_t max_wave_words)
 {
     HuffLdsPlan p;
     // One wave per workgroup while the whole launch has few waves (a single
@@ -116,12 +162,14 @@ HuffLdsPlan plan_huffman(uint32_t max_intervals, uint32_t images, uint32_t max_l
     const uint64_t total_waves = uint64_t((max_intervals + kWave - 1) / kWave) * images;
     p.waves_per_block = total_waves <= 2048 ? 1u : 4u;
     p.l2_entries_in_lds = max_l2 < 8192u ? (max_l2 + 1u) & ~1u : 8192u;
-    // window: 1.5x the average footprint of 64 intervals, 2..16 KB
-    uint32_t w = avg_words_per_interval * kWave * 3u / 2u + 8u;
-    if (w < 512u)
-        w = 512u;
-    if (w > 4096u)
-        w = 4096u;
+    // window: the largest word span of any wave's 64 intervals (the host knows
+    // every start offset) plus the per-data-unit slack, capped at 24 KB;
+    // waves that need more fall back to global reads for the excess
+    uint32_t w = max_wave_words + kDuWordSlack + 4u;
+    if (w < 256u)
+        w = 256u;
+    if (w > 6144u)
+        w = 6144u;
     p.window_words = (w + 3u) & ~3u;
     const uint32_t tables = (((kL1Entries + p.l2_entries_in_lds) * 2u) + 15u) & ~15u;
     const uint32_t wave_area = ((p.window_words * 4u + 15u) & ~15u) + kWave * kDuSlotBytes;
@@ -137,6 +185,18 @@ hipError_t launch_huffman(const ImageDesc *descs, uint32_t images, uint32_t max_
     const uint32_t threads = plan.waves_per_block * kWave;
     dim3 grid((max_intervals + threads - 1) / threads, images, 1);
     hipLaunchKernelGGL(huffman_kernel, grid, dim3(threads), plan.total_bytes, stream, descs,
+                       plan.l2_entries_in_lds, plan.window_words);
+    return hipGetLastError();
+}
+
+hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t max_intervals,
+                            const HuffLdsPlan &plan, hipStream_t stream)
+{
+    if (images == 0 || max_intervals == 0)
+        return hipSuccess;
+    const uint32_t threads = plan.waves_per_block * kWave;
+    dim3 grid((max_intervals + threads - 1) / threads, images, 1);
+    hipLaunchKernelGGL(decode_fused_422_kernel, grid, dim3(threads), plan.total_bytes, stream, descs,
                        plan.l2_entries_in_lds, plan.window_words);
     return hipGetLastError();
 }

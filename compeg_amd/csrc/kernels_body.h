@@ -28,6 +28,20 @@
 #define CG_DEV static inline
 #endif
 
+// Pointers that reach a kernel through the in-memory ImageDesc have no
+// provable address space, and hipcc then emits flat_load / flat_store (slower,
+// and they tie up the LDS wait counter as well).  CG_GLOBAL(T, p) states that
+// p is a global-memory pointer; on the host it is a plain pointer.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CG_GLOBAL(T, p) (reinterpret_cast<__attribute__((address_space(1))) T *>(reinterpret_cast<uintptr_t>(p)))
+// keeps a wave-uniform value in a scalar register instead of re-loading it
+// from the descriptor inside hot loops
+#define CG_PIN_SCALAR(x) asm volatile("" : "+s"(x))
+#else
+#define CG_GLOBAL(T, p) (p)
+#define CG_PIN_SCALAR(x) (void)(x)
+#endif
+
 namespace compeg {
 
 struct alignas(16) Vec4u {
@@ -66,7 +80,7 @@ CG_DEV uint32_t fetch_word(const ImageDesc &d, const HuffShared &s, uint32_t idx
     const uint32_t rel = idx - s.win_base;
     if (rel < s.win_len)
         return s.win[rel];
-    return idx < d.nwords ? bswap32(d.words[idx]) : 0u;
+    return idx < d.nwords ? bswap32(CG_GLOBAL(const uint32_t, d.words)[idx]) : 0u;
 }
 
 CG_DEV void refill(BitReader &b, const ImageDesc &d, const HuffShared &s)
@@ -110,26 +124,42 @@ CG_DEV void zero_slot(uint8_t *slot)
 }
 
 constexpr uint32_t kL1Entries = 5 * 256; // 4 tables + the all-zero table
+// How far one data unit can advance the reader: at most 63 symbols of at
+// most 31 bits, one refill per symbol, plus the word kept in flight.
+constexpr uint32_t kDuWordSlack = 66;
 
 CG_DEV uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
 CG_DEV uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
 // Workgroup prologue, thread `tid` of `nthreads`: copies the image's LUTs
 // into LDS with 4-byte accesses (both tables are 4-byte aligned and padded).
+CG_DEV void copy_words_to_lds(uint32_t *dst, const uint32_t *src_, uint32_t n, uint32_t tid,
+                              uint32_t nthreads)
+{
+    auto *src = CG_GLOBAL(const uint32_t, src_);
+    uint32_t i = tid;
+    for (; i + 3u * nthreads < n; i += 4u * nthreads) {
+        const uint32_t a = src[i], b = src[i + nthreads], c = src[i + 2u * nthreads],
+                       e = src[i + 3u * nthreads];
+        dst[i] = a;
+        dst[i + nthreads] = b;
+        dst[i + 2u * nthreads] = c;
+        dst[i + 3u * nthreads] = e;
+    }
+    for (; i < n; i += nthreads)
+        dst[i] = src[i];
+}
+
 CG_DEV void stage_luts(const ImageDesc &d, uint16_t *l1, uint16_t *l2, uint32_t l2_in_lds,
                        uint32_t tid, uint32_t nthreads)
 {
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(d.l1);
     uint32_t *dst = reinterpret_cast<uint32_t *>(l1);
-    for (uint32_t i = tid; i < 4 * 128; i += nthreads)
-        dst[i] = src[i];
+    copy_words_to_lds(dst, reinterpret_cast<const uint32_t *>(d.l1), 4 * 128, tid, nthreads);
     for (uint32_t i = tid; i < 128; i += nthreads)
         dst[4 * 128 + i] = 0u;
     const uint32_t n2 = umin(l2_in_lds, d.l2_entries);
-    const uint32_t *src2 = reinterpret_cast<const uint32_t *>(d.l2);
-    uint32_t *dst2 = reinterpret_cast<uint32_t *>(l2);
-    for (uint32_t i = tid; i < (n2 + 1) / 2; i += nthreads)
-        dst2[i] = src2[i];
+    copy_words_to_lds(reinterpret_cast<uint32_t *>(l2), reinterpret_cast<const uint32_t *>(d.l2),
+                      (n2 + 1) / 2, tid, nthreads);
 }
 
 // The scan window of the wave whose first interval is `wave_first`: the
@@ -138,10 +168,12 @@ CG_DEV void stage_luts(const ImageDesc &d, uint16_t *l1, uint16_t *l2, uint32_t 
 CG_DEV void wave_window(const ImageDesc &d, uint32_t wave_first, uint32_t window_words,
                         uint32_t &base, uint32_t &len)
 {
-    base = wave_first < d.nstarts ? d.starts[wave_first] : 0u;
+    base = wave_first < d.nstarts ? CG_GLOBAL(const uint32_t, d.starts)[wave_first] : 0u;
     const uint32_t after = wave_first + kWave;
-    uint32_t end = (after < d.total_intervals && after < d.nstarts) ? d.starts[after] : d.nwords;
-    end = umin(umin(end, d.nwords) + 2u, d.nwords);
+    uint32_t end = (after < d.total_intervals && after < d.nstarts) ? CG_GLOBAL(const uint32_t, d.starts)[after] : d.nwords;
+    // the slack lets the last intervals of the wave pass decode_ac's in-window
+    // test; positions past the end of the scan are staged as zeros
+    end = umin(end, d.nwords) + kDuWordSlack;
     base = umin(base, d.nwords);
     len = end > base ? umin(end - base, window_words) : 0u;
 }
@@ -149,8 +181,22 @@ CG_DEV void wave_window(const ImageDesc &d, uint32_t wave_first, uint32_t window
 CG_DEV void stage_window(const ImageDesc &d, uint32_t *win, uint32_t base, uint32_t len,
                          uint32_t lane)
 {
-    for (uint32_t i = lane; i < len; i += kWave)
-        win[i] = bswap32(d.words[base + i]);
+    // eight independent loads in flight per lane before the first LDS write
+    // (a plain load/store loop serialises on every load's latency)
+    uint32_t i = lane;
+    for (; i + 7u * kWave < len; i += 8u * kWave) {
+        uint32_t w[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            w[j] = base + i + uint32_t(j) * kWave < d.nwords
+                       ? CG_GLOBAL(const uint32_t, d.words)[base + i + uint32_t(j) * kWave]
+                       : 0u;
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            win[i + uint32_t(j) * kWave] = bswap32(w[j]);
+    }
+    for (; i < len; i += kWave)
+        win[i] = base + i < d.nwords ? bswap32(CG_GLOBAL(const uint32_t, d.words)[base + i]) : 0u;
 }
 
 // Decodes restart interval `interval` of image d.  Quantised AC levels go
@@ -164,7 +210,7 @@ CG_DEV void huff_decode_interval(const ImageDesc &d, const HuffShared &s, uint32
     zero_slot(slot);
 
     BitReader b;
-    b.next_word = interval < d.nstarts ? d.starts[interval] : 0u;
+    b.next_word = interval < d.nstarts ? CG_GLOBAL(const uint32_t, d.starts)[interval] : 0u;
     b.cur = b.nxt = b.left = 0u;
     refill(b, d, s);
 
@@ -195,7 +241,7 @@ CG_DEV void huff_decode_interval(const ImageDesc &d, const HuffShared &s, uint32
         uint32_t e = s.l1[(is_dc ? dc_off : ac_off) + (code >> 8)];
         if (e & 0x8000u) {
             const uint32_t idx = (e & 0x7fffu) + (code & 0xffu);
-            e = idx < s.l2_staged ? s.l2[idx] : (idx < d.l2_entries ? d.l2[idx] : 0u);
+            e = idx < s.l2_staged ? s.l2[idx] : (idx < d.l2_entries ? CG_GLOBAL(const uint16_t, d.l2)[idx] : 0u);
         }
         consume(b, e >> 8);
         const uint32_t sym = e & 0xffu;
@@ -217,7 +263,7 @@ CG_DEV void huff_decode_interval(const ImageDesc &d, const HuffShared &s, uint32
             else
                 pred2 = p;
             const uint32_t q0 = comp == 0u ? d.dc_quant[0] : (comp == 1u ? d.dc_quant[1] : d.dc_quant[2]);
-            d.dc[du_global] = int32_t(uint32_t(p) * q0);
+            CG_GLOBAL(int32_t, d.dc)[du_global] = int32_t(uint32_t(p) * q0);
             pos = 1u;
         } else if (sym == 0u) {
             du_done = true; // EOB
@@ -233,7 +279,7 @@ CG_DEV void huff_decode_interval(const ImageDesc &d, const HuffShared &s, uint32
         if (du_done) {
             // 64-byte record out, slot cleared for the next data unit
             Vec4u *src = reinterpret_cast<Vec4u *>(slot);
-            Vec4u *dst = reinterpret_cast<Vec4u *>(d.ac + size_t(du_global) * kRetained);
+            auto *dst = CG_GLOBAL(Vec4u, reinterpret_cast<Vec4u *>(d.ac + size_t(du_global) * kRetained));
             dst[0] = src[0];
             dst[1] = src[1];
             dst[2] = src[2];
@@ -389,6 +435,146 @@ CG_DEV void idct_data_unit(const int16_t *ac, int32_t dc, const float *quant, ui
 }
 
 // ---------------------------------------------------------------------------
+// Fused path: one lane decodes, transforms and composites its own MCUs
+// ---------------------------------------------------------------------------
+
+// Bit reader with the next stream word already in flight: the LDS (or global)
+// read issued at one refill is consumed at the next, so its latency hides
+// behind the symbols in between.  State and arithmetic are those of the
+// reference reader (cur / nxt / left), only the fetch is hoisted.
+struct PrefetchReader {
+    BitReader b;
+    uint32_t pre; // == word[b.next_word], MSB-first
+};
+
+// FAST: the caller has checked that every word this data unit can touch lies
+// inside the LDS window and that the whole L2 LUT is staged, so the loop body
+// contains LDS accesses only.  Otherwise words outside the window (window cut
+// short by the LDS budget, or a hostile start offset) and L2 entries beyond the
+// staged part come from global memory; words past the end of the scan read as
+// zero (the reference relies on robust buffer access there).
+template <bool FAST>
+CG_DEV uint32_t fetch_word_pf(const ImageDesc &d, const HuffShared &s, uint32_t idx)
+{
+    const uint32_t rel = idx - s.win_base;
+    if (FAST)
+        return s.win[rel];
+    uint32_t w = s.win[rel < s.win_len ? rel : 0u];
+    if (rel >= s.win_len)
+        w = idx < d.nwords ? bswap32(CG_GLOBAL(const uint32_t, d.words)[idx]) : 0u;
+    return w;
+}
+
+CG_DEV void reader_init(PrefetchReader &r, const ImageDesc &d, const HuffShared &s, uint32_t start)
+{
+    r.b.next_word = start;
+    r.b.cur = r.b.nxt = r.b.left = 0u;
+    r.pre = fetch_word_pf<false>(d, s, start);
+}
+
+// Branch-free form of the reference refill (src/huffman.wgsl:52-67): the
+// updates are selected on `left < 32`, and the next word is (re)read every
+// time -- when nothing was consumed it is the same word again.
+template <bool FAST>
+CG_DEV void reader_refill(PrefetchReader &r, const ImageDesc &d, const HuffShared &s)
+{
+    const bool need = r.b.left < 32u;
+    const uint32_t w = r.pre, sh = r.b.left & 31u;
+    r.b.cur |= need ? (w >> sh) : 0u;
+    r.b.nxt = need ? ((w << 1) << (31u - sh)) : r.b.nxt;
+    r.b.left += need ? 32u : 0u;
+    r.b.next_word += need ? 1u : 0u;
+    r.pre = fetch_word_pf<FAST>(d, s, r.b.next_word);
+}
+
+template <bool FAST>
+CG_DEV uint32_t lut_lookup(const ImageDesc &d, const HuffShared &s, uint32_t table_off, uint32_t cur)
+{
+    const uint32_t code = cur >> 16;
+    uint32_t e = s.l1[table_off + (code >> 8)];
+    if (e & 0x8000u) {
+        const uint32_t idx = (e & 0x7fffu) + (code & 0xffu);
+        if (FAST) {
+            e = s.l2[idx];
+        } else {
+            uint32_t e2 = s.l2[idx < s.l2_staged ? idx : 0u];
+            if (idx >= s.l2_staged)
+                e2 = idx < d.l2_entries ? CG_GLOBAL(const uint16_t, d.l2)[idx] : 0u;
+            e = e2;
+        }
+    }
+    return e;
+}
+
+// DC difference of the next data unit.  No refill in front of it (quirk Q1);
+// the two consume steps are kept separate so that a category >= 32 from a
+// hostile table shifts exactly like the reference (counts modulo 32).
+CG_DEV int32_t decode_dc_diff(PrefetchReader &r, const ImageDesc &d, const HuffShared &s,
+                              uint32_t dc_off)
+{
+    const uint32_t e = lut_lookup<false>(d, s, dc_off, r.b.cur);
+    consume(r.b, e >> 8);
+    const uint32_t cat = e & 0xffu;
+    const int32_t raw = int32_t(peek(r.b, cat));
+    consume(r.b, cat);
+    return huff_extend(raw, cat); // cat == 0 -> 0, as the reference special-cases
+}
+
+// AC coefficients of one data unit into the lane's (zeroed) LDS slot.
+// Per symbol: code length <= 16 and magnitude bits <= 15, so both fields come
+// out of `cur` alone and one combined consume (<= 31 bits) equals the
+// reference's two.  EOB stores a 0 at the current position and ZRL a 0 at
+// pos+15; both positions are still zero and are never revisited, so the
+// stores need no special case; positions >= 32 (quirk Q3) land in the slot's
+// padding.  ZRL advances 17 positions (quirk Q2).
+template <bool FAST>
+CG_DEV void decode_ac_loop(PrefetchReader &r, const ImageDesc &d, const HuffShared &s,
+                           uint32_t ac_off, int16_t *slot16)
+{
+    uint32_t pos = 1u;
+    while (pos < 64u) {
+        reader_refill<FAST>(r, d, s);
+        const uint32_t e = lut_lookup<FAST>(d, s, ac_off, r.b.cur);
+        const uint32_t len = e >> 8, sym = e & 0xffu, nb = sym & 15u;
+        const uint32_t t = r.b.cur << (len & 31u);
+        const int32_t raw = int32_t((t >> 1) >> (31u - nb));
+        const int32_t val = huff_extend(raw, nb);
+        consume(r.b, len + nb);
+        const uint32_t p = pos + (sym >> 4);
+        slot16[p < uint32_t(kRetained) ? p : uint32_t(kRetained)] = int16_t(val);
+        pos = sym == 0u ? 64u : p + (sym == 0xf0u ? 2u : 1u);
+    }
+}
+
+CG_DEV void decode_ac(PrefetchReader &r, const ImageDesc &d, const HuffShared &s, uint32_t ac_off,
+                      int16_t *slot16)
+{
+    const bool in_window = (r.b.next_word - s.win_base) + kDuWordSlack <= s.win_len;
+    if (in_window && s.l2_staged >= d.l2_entries)
+        decode_ac_loop<true>(r, d, s, ac_off, slot16);
+    else
+        decode_ac_loop<false>(r, d, s, ac_off, slot16);
+}
+
+// Composites the lane's own 4:2:2 MCU (sample words of Y0, Y1, Cb, Cr in
+// registers) to RGBA8.  Same arithmetic as composite_422 below.
+CG_DEV void store_px4(const ImageDesc &d, uint8_t *p, uint32_t x0, const Vec4u &o)
+{
+    if (x0 + 3u < d.out_w && (d.out_pitch & 15u) == 0u) {
+        *CG_GLOBAL(Vec4u, reinterpret_cast<Vec4u *>(p)) = o;
+    } else if (x0 < d.out_w) {
+        auto *q = CG_GLOBAL(uint32_t, reinterpret_cast<uint32_t *>(p));
+        q[0] = o.x;
+        if (x0 + 1u < d.out_w)
+            q[1] = o.y;
+        if (x0 + 2u < d.out_w)
+            q[2] = o.z;
+        if (x0 + 3u < d.out_w)
+            q[3] = o.w;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Composite: 4:2:2 chroma replication + YCbCr -> RGBA8
 // ---------------------------------------------------------------------------
 
@@ -441,9 +627,9 @@ CG_DEV void composite_422(const ImageDesc &d, const uint32_t *px_slots, uint32_t
         o.w = ycbcr_to_rgba(yw >> 24, (cbw >> 8) & 0xffu, (crw >> 8) & 0xffu);
         uint8_t *p = d.out + size_t(y) * d.out_pitch + size_t(x0) * 4u;
         if (x0 + 3u < d.out_w && (d.out_pitch & 15u) == 0u) {
-            *reinterpret_cast<Vec4u *>(p) = o;
+            *CG_GLOBAL(Vec4u, reinterpret_cast<Vec4u *>(p)) = o;
         } else {
-            uint32_t *q = reinterpret_cast<uint32_t *>(p);
+            auto *q = CG_GLOBAL(uint32_t, reinterpret_cast<uint32_t *>(p));
             q[0] = o.x;
             if (x0 + 1u < d.out_w)
                 q[1] = o.y;
@@ -451,6 +637,104 @@ CG_DEV void composite_422(const ImageDesc &d, const uint32_t *px_slots, uint32_t
                 q[2] = o.z;
             if (x0 + 3u < d.out_w)
                 q[3] = o.w;
+        }
+    }
+}
+
+
+CG_DEV uint32_t ycbcr_to_rgba(uint32_t y_, uint32_t cb_, uint32_t cr_);
+
+// px[k][2*row + half]: data unit k (Y0, Y1, Cb, Cr), 4 samples per word.
+CG_DEV void composite_own_mcu_422(const ImageDesc &d, const uint32_t (&px)[4][16], uint32_t mx,
+                                  uint32_t my)
+{
+    const uint32_t x0 = mx * 16u;
+#pragma unroll
+    for (uint32_t row = 0; row < 8; row++) {
+        const uint32_t y = my * 8u + row;
+        if (y >= d.out_h || x0 >= d.out_w)
+            break;
+        uint8_t *line = d.out + size_t(y) * d.out_pitch + size_t(x0) * 4u;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {
+            const uint32_t yw = px[q >> 1][row * 2u + (q & 1u)];
+            const uint32_t cbw = px[2][row * 2u + (q >> 1)] >> ((q & 1u) * 16u);
+            const uint32_t crw = px[3][row * 2u + (q >> 1)] >> ((q & 1u) * 16u);
+            Vec4u o;
+            o.x = ycbcr_to_rgba(yw & 0xffu, cbw & 0xffu, crw & 0xffu);
+            o.y = ycbcr_to_rgba((yw >> 8) & 0xffu, cbw & 0xffu, crw & 0xffu);
+            o.z = ycbcr_to_rgba((yw >> 16) & 0xffu, (cbw >> 8) & 0xffu, (crw >> 8) & 0xffu);
+            o.w = ycbcr_to_rgba(yw >> 24, (cbw >> 8) & 0xffu, (crw >> 8) & 0xffu);
+            store_px4(d, line + q * 16u, x0 + q * 4u, o);
+        }
+    }
+}
+
+// The whole path for one restart interval of a 4:2:2 image: entropy decode,
+// IDCT and composite, data unit by data unit.  Every lane of a wave runs
+// this on its own interval; the per-data-unit `while` loop in decode_ac is
+// where lanes wait for each other (SIMT reconvergence), so that table
+// selectors, quantisers and the IDCT that follows run with a full wave.
+CG_DEV void decode_interval_fused_422(const ImageDesc &d, const HuffShared &s, uint32_t interval,
+                                      uint32_t lane)
+{
+    uint8_t *slot = s.du_slots + lane * kDuSlotBytes;
+    int16_t *slot16 = reinterpret_cast<int16_t *>(slot);
+    zero_slot(slot);
+
+    PrefetchReader r;
+    reader_init(r, d, s, interval < d.nstarts ? CG_GLOBAL(const uint32_t, d.starts)[interval] : 0u);
+    reader_refill<false>(r, d, s);
+
+    uint32_t mcu = interval * d.restart_interval;
+    uint32_t mx = mcu % d.width_mcus, my = mcu / d.width_mcus;
+
+    // The four data units of an MCU pass through one loop body (one copy of
+    // the IDCT in the instruction stream, bounded register pressure); their
+    // sample words ride a 4-deep register shift chain px[0..3].
+    uint32_t px[4][16];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int w = 0; w < 16; w++)
+            px[k][w] = 0u;
+    int32_t pred0 = 0, pred1 = 0, pred2 = 0;
+    const uint32_t du_total = d.restart_interval * 4u;
+#pragma unroll 1
+    for (uint32_t du = 0; du < du_total; du++) {
+        const uint32_t k = du & 3u;
+        const uint32_t comp = k < 2u ? 0u : k - 1u; // Y0 Y1 Cb Cr (wave-uniform)
+        const int32_t diff = decode_dc_diff(r, d, s, d.dc_table[comp] * 256u);
+        int32_t p = comp == 0u ? pred0 : (comp == 1u ? pred1 : pred2);
+        p = int32_t(uint32_t(p) + uint32_t(diff));
+        pred0 = comp == 0u ? p : pred0;
+        pred1 = comp == 1u ? p : pred1;
+        pred2 = comp == 2u ? p : pred2;
+        const int32_t dc = int32_t(uint32_t(p) * d.dc_quant[comp]);
+        decode_ac(r, d, s, d.ac_table[comp] * 256u, slot16);
+
+        alignas(16) Vec4u rec[4];
+        const Vec4u *src = reinterpret_cast<const Vec4u *>(slot);
+        rec[0] = src[0];
+        rec[1] = src[1];
+        rec[2] = src[2];
+        rec[3] = src[3];
+        zero_slot(slot);
+#pragma unroll
+        for (int w = 0; w < 16; w++) {
+            px[0][w] = px[1][w];
+            px[1][w] = px[2][w];
+            px[2][w] = px[3][w];
+        }
+        idct_data_unit(reinterpret_cast<const int16_t *>(rec), dc, d.quant[comp], px[3]);
+
+        if (k == 3u) {
+            composite_own_mcu_422(d, px, mx, my);
+            mx++;
+            if (mx == d.width_mcus) {
+                mx = 0;
+                my++;
+            }
         }
     }
 }

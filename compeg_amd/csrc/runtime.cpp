@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -86,6 +87,18 @@ Status PinnedBuffer::reserve(size_t bytes)
     CG_HIP(hipHostMalloc(&ptr, bytes, hipHostMallocDefault));
     capacity = bytes;
     return Status{};
+}
+
+// Development switch: COMPEG_PIPELINE=split selects the two-kernel pipeline
+// (huffman_kernel -> HBM coefficients -> idct_composite_kernel); the default
+// is the fused single kernel.
+bool use_fused_pipeline()
+{
+    static const bool fused = [] {
+        const char *e = getenv("COMPEG_PIPELINE");
+        return !(e && strcmp(e, "split") == 0);
+    }();
+    return fused;
 }
 
 namespace {
@@ -204,13 +217,20 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
 
     if (total_dus == 0)
         return Status{};
-    const uint32_t avg_words =
-        md.total_restart_intervals ? uint32_t(scan.nwords() / md.total_restart_intervals) + 1 : 1;
-    const HuffLdsPlan plan =
-        plan_huffman(md.total_restart_intervals, 1, uint32_t(img.l2.size()), avg_words);
-    CG_HIP(launch_huffman(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals,
-                          plan, stream));
-    CG_HIP(launch_idct_composite(reinterpret_cast<const ImageDesc *>(db), 1, total_dus, stream));
+    const uint32_t span = max_wave_span(scan.starts(), scan.nstarts(), scan.nwords(),
+                                        md.total_restart_intervals);
+    const HuffLdsPlan plan = plan_huffman(md.total_restart_intervals, 1, uint32_t(img.l2.size()), span);
+    last_plan = plan;
+    if (use_fused_pipeline()) {
+        CG_HIP(launch_fused_422(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals,
+                                plan, stream));
+        coefficients_valid = false;
+    } else {
+        CG_HIP(launch_huffman(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals,
+                              plan, stream));
+        CG_HIP(launch_idct_composite(reinterpret_cast<const ImageDesc *>(db), 1, total_dus, stream));
+        coefficients_valid = true;
+    }
     return Status{};
 }
 
@@ -261,7 +281,7 @@ Status compeg_batch::upload(const ImageData *const *images, size_t n, int thread
     size_t in_total = 0, ac_total = 0, dc_total = 0, out_total = 0;
     max_intervals = max_dus = max_l2 = 0;
     algorithmic_bytes = pixels = 0;
-    uint64_t words_sum = 0, intervals_sum = 0;
+    max_span = 0;
     for (size_t i = 0; i < n; i++) {
         const ImageData &img = *images[i];
         in_off[i] = in_total;
@@ -275,18 +295,20 @@ Status compeg_batch::upload(const ImageData *const *images, size_t n, int thread
         max_intervals = std::max(max_intervals, img.metadata.total_restart_intervals);
         max_dus = std::max(max_dus, img.total_dus());
         max_l2 = std::max<uint32_t>(max_l2, uint32_t(img.l2.size()));
-        words_sum += scans[i].nwords();
-        intervals_sum += img.metadata.total_restart_intervals;
+        max_span = std::max(max_span, max_wave_span(scans[i].starts(), scans[i].nstarts(), scans[i].nwords(),
+                                                    img.metadata.total_restart_intervals));
         algorithmic_bytes += 4ull * scans[i].nwords() + 4ull * img.metadata.total_restart_intervals +
                              COMPEG_METADATA_BYTES + COMPEG_HUFFMAN_L1_BYTES + img.l2.size() * 2 +
                              4ull * img.width * img.height;
         pixels += uint64_t(img.width) * img.height;
     }
-    avg_words = intervals_sum ? uint32_t(words_sum / intervals_sum) + 1 : 1;
 
+    const bool fused = use_fused_pipeline();
     CG_TRY(inputs.reserve(in_total + 256));
-    CG_TRY(ac.reserve(ac_total + 256));
-    CG_TRY(dc.reserve(dc_total + 256));
+    if (!fused) { // the fused kernel keeps coefficients on chip
+        CG_TRY(ac.reserve(ac_total + 256));
+        CG_TRY(dc.reserve(dc_total + 256));
+    }
     CG_TRY(out.reserve(out_total + 256));
     CG_HIP(hipMemset(out.ptr, 0, out.capacity));
     CG_TRY(dev_descs.reserve(n * sizeof(ImageDesc) + 256));
@@ -317,8 +339,8 @@ Status compeg_batch::upload(const ImageData *const *images, size_t n, int thread
             memcpy(hs + o, scans[i].words(), scans[i].nwords() * 4);
         d.words = reinterpret_cast<const uint32_t *>(di + o);
         d.nwords = uint32_t(scans[i].nwords());
-        d.ac = reinterpret_cast<int16_t *>(static_cast<uint8_t *>(ac.ptr) + ac_at);
-        d.dc = reinterpret_cast<int32_t *>(static_cast<uint8_t *>(dc.ptr) + dc_at);
+        d.ac = fused ? nullptr : reinterpret_cast<int16_t *>(static_cast<uint8_t *>(ac.ptr) + ac_at);
+        d.dc = fused ? nullptr : reinterpret_cast<int32_t *>(static_cast<uint8_t *>(dc.ptr) + dc_at);
         ac_at += size_t(img.total_dus()) * kRetained * 2;
         dc_at += size_t(img.total_dus()) * 4;
         d.out = static_cast<uint8_t *>(out.ptr) + out_offset[i];
@@ -356,7 +378,13 @@ Status compeg_batch::decode(hipStream_t stream)
         CG_HIP(hipEventRecord(ev[0], stream));
     for (uint32_t at = 0; at < n; at += step) {
         const uint32_t m = std::min(step, n - at);
-        const HuffLdsPlan plan = plan_huffman(max_intervals, m, max_l2, avg_words);
+        const HuffLdsPlan plan = plan_huffman(max_intervals, m, max_l2, max_span);
+        if (use_fused_pipeline()) {
+            CG_HIP(launch_fused_422(dd + at, m, max_intervals, plan, stream));
+            if (timing && at == 0)
+                CG_HIP(hipEventRecord(ev[1], stream));
+            continue;
+        }
         CG_HIP(launch_huffman(dd + at, m, max_intervals, plan, stream));
         if (timing && at == 0)
             CG_HIP(hipEventRecord(ev[1], stream)); // stage split is exact for unchunked decodes

@@ -19,6 +19,7 @@
 namespace compeg {
 
 Status hip_status(hipError_t e, const char *what);
+bool use_fused_pipeline();
 
 // Grow-only device allocation; contents are not preserved across growth
 // (every user rewrites the buffer in full before reading it).
@@ -74,6 +75,8 @@ struct compeg_decoder {
     // what read_coefficients needs to rebuild the reference's buffer
     compeg::Metadata last_md{};
     bool have_last = false;
+    compeg::HuffLdsPlan last_plan{};
+    bool coefficients_valid = false; // ac/dc hold the last image's coefficients
 
     compeg_decoder();
     ~compeg_decoder();
@@ -86,7 +89,7 @@ struct compeg_batch {
     std::vector<compeg::ImageDesc> descs; // host copy (device pointers inside)
     compeg::DeviceBuffer dev_descs, inputs, ac, dc, out;
     std::vector<size_t> out_offset;
-    uint32_t max_intervals = 0, max_dus = 0, max_l2 = 0, avg_words = 0;
+    uint32_t max_intervals = 0, max_dus = 0, max_l2 = 0, max_span = 0;
     uint64_t algorithmic_bytes = 0, pixels = 0;
     uint32_t chunk = 0; // images per launch pair, 0 = all
     // one event triple per decode since the last upload / timing reset:

@@ -25,7 +25,7 @@ using namespace compeg;
 extern "C" __attribute__((visibility("default")))
 int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, uint32_t tex_h,
                 int16_t *ac_out, int32_t *dc_out, uint32_t waves_per_block, uint32_t window_words,
-                uint32_t l2_in_lds, char *err, size_t errlen)
+                uint32_t l2_in_lds, char *err, size_t errlen, int fused)
 {
     ImageData *img = nullptr;
     Status s = ImageData::parse(jpeg, len, false, &img);
@@ -85,8 +85,12 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
                 stage_window(d, win, wb, wl, lane);
             HuffShared sh{sl1, sl2, umin(l2_in_lds, d.l2_entries), win, wb, wl, slots};
             for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
-                if (wave_first + lane < d.total_intervals)
-                    huff_decode_interval(d, sh, wave_first + lane, lane);
+                if (wave_first + lane < d.total_intervals) {
+                    if (fused)
+                        decode_interval_fused_422(d, sh, wave_first + lane, lane);
+                    else
+                        huff_decode_interval(d, sh, wave_first + lane, lane);
+                }
         }
         free(smem);
     }
@@ -94,6 +98,11 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
         memcpy(ac_out, ac.data(), ac.size() * 2);
     if (dc_out)
         memcpy(dc_out, dc.data(), dc.size() * 4);
+
+    if (fused) {
+        delete img;
+        return 0;
+    }
 
     // ---- idct_composite_kernel ----
     const uint32_t total_mcus = d.dus_per_mcu ? d.total_dus / d.dus_per_mcu : 0;
@@ -161,7 +170,7 @@ int main(int argc, char **argv)
     char err[256] = "";
     int rc = emul_decode(exact, jpeg.size(), rgba.data(), tex_w, tex_h, ac.data(), dc.data(),
                          uint32_t(atoi(argv[5])), uint32_t(atoi(argv[6])), uint32_t(atoi(argv[7])),
-                         err, sizeof err);
+                         err, sizeof err, getenv("EMUL_FUSED") ? 1 : 0);
     free(exact);
     if (rc != 0) {
         printf("error: %s\n", err);
