@@ -12,6 +12,8 @@
 // are bounded by HBM traffic / serial entropy decoding).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "kernels_body.h"
 #include "kernels.h"
 
@@ -65,7 +67,7 @@ huffman_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t
 // Fused path: same prologue as huffman_kernel, then every lane runs the whole
 // decode of its interval (entropy decode -> IDCT -> composite), so neither
 // coefficients nor samples ever touch HBM.
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(512, 2)
 decode_fused_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -161,6 +163,8 @@ HuffLdsPlan plan_huffman(uint32_t max_intervals, uint32_t images, uint32_t max_l
     // oversubscribed, to amortise LUT staging.
     const uint64_t total_waves = uint64_t((max_intervals + kWave - 1) / kWave) * images;
     p.waves_per_block = total_waves <= 2048 ? 1u : 4u;
+    if (const char *e = getenv("COMPEG_WPB")) // experiment knob
+        p.waves_per_block = uint32_t(atoi(e));
     p.l2_entries_in_lds = max_l2 < 8192u ? (max_l2 + 1u) & ~1u : 8192u;
     // window: the largest word span of any wave's 64 intervals (the host knows
     // every start offset) plus the per-data-unit slack, capped at 24 KB;
@@ -170,10 +174,14 @@ HuffLdsPlan plan_huffman(uint32_t max_intervals, uint32_t images, uint32_t max_l
         w = 256u;
     if (w > 6144u)
         w = 6144u;
+    if (const char *e = getenv("COMPEG_WINDOW_CAP")) // experiment knob (words)
+        w = w < uint32_t(atoi(e)) ? w : uint32_t(atoi(e));
     p.window_words = (w + 3u) & ~3u;
     const uint32_t tables = (((kL1Entries + p.l2_entries_in_lds) * 2u) + 15u) & ~15u;
     const uint32_t wave_area = ((p.window_words * 4u + 15u) & ~15u) + kWave * kDuSlotBytes;
     p.total_bytes = tables + p.waves_per_block * wave_area;
+    if (const char *e = getenv("COMPEG_LDS_PAD")) // experiment knob: lowers occupancy
+        p.total_bytes += uint32_t(atoi(e));
     return p;
 }
 

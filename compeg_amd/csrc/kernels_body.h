@@ -395,6 +395,36 @@ CG_DEV uint32_t sample_u8(float f)
     return uint32_t(m);
 }
 
+// clamp(f, 0, 255) then truncation for the 8 samples of a row, sample 0 in
+// the low byte (src/dct.wgsl:174-197).  On the GPU one v_cvt_pk_u8_f32 per
+// sample does the saturation, the conversion and the byte insert; the
+// instruction rounds with the current f32 rounding mode, so the mode is
+// switched to round-toward-zero for exactly these eight instructions.
+CG_DEV void pack_row(const float *f, uint32_t &lo, uint32_t &hi)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t a, b;
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+                 "v_cvt_pk_u8_f32 %0, %2, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %6, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %0, %3, 1, %0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %7, 1, %1\n\t"
+                 "v_cvt_pk_u8_f32 %0, %4, 2, %0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %8, 2, %1\n\t"
+                 "v_cvt_pk_u8_f32 %0, %5, 3, %0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %9, 3, %1\n\t"
+                 "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+                 : "=&v"(a), "=&v"(b)
+                 : "v"(f[0]), "v"(f[1]), "v"(f[2]), "v"(f[3]), "v"(f[4]), "v"(f[5]), "v"(f[6]),
+                   "v"(f[7]));
+    lo = a;
+    hi = b;
+#else
+    lo = sample_u8(f[0]) | sample_u8(f[1]) << 8 | sample_u8(f[2]) << 16 | sample_u8(f[3]) << 24;
+    hi = sample_u8(f[4]) | sample_u8(f[5]) << 8 | sample_u8(f[6]) << 16 | sample_u8(f[7]) << 24;
+#endif
+}
+
 // quant: this component's 32 quantiser values as floats (zig-zag order).
 // px[2*y], px[2*y+1]: the 8 samples of row y, sample 0 in the low byte --
 // the reference's packed pixel format (dct.wgsl:187-201).
@@ -426,12 +456,8 @@ CG_DEV void idct_data_unit(const int16_t *ac, int32_t dc, const float *quant, ui
     for (int r = 0; r < 8; r++)
         aan_1d<1, true>(v + r * 8);
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        px[2 * r + 0] = sample_u8(v[r * 8 + 0]) | sample_u8(v[r * 8 + 1]) << 8 |
-                        sample_u8(v[r * 8 + 2]) << 16 | sample_u8(v[r * 8 + 3]) << 24;
-        px[2 * r + 1] = sample_u8(v[r * 8 + 4]) | sample_u8(v[r * 8 + 5]) << 8 |
-                        sample_u8(v[r * 8 + 6]) << 16 | sample_u8(v[r * 8 + 7]) << 24;
-    }
+    for (int r = 0; r < 8; r++)
+        pack_row(v + r * 8, px[2 * r + 0], px[2 * r + 1]);
 }
 
 // ---------------------------------------------------------------------------
@@ -556,24 +582,6 @@ CG_DEV void decode_ac(PrefetchReader &r, const ImageDesc &d, const HuffShared &s
         decode_ac_loop<false>(r, d, s, ac_off, slot16);
 }
 
-// Composites the lane's own 4:2:2 MCU (sample words of Y0, Y1, Cb, Cr in
-// registers) to RGBA8.  Same arithmetic as composite_422 below.
-CG_DEV void store_px4(const ImageDesc &d, uint8_t *p, uint32_t x0, const Vec4u &o)
-{
-    if (x0 + 3u < d.out_w && (d.out_pitch & 15u) == 0u) {
-        *CG_GLOBAL(Vec4u, reinterpret_cast<Vec4u *>(p)) = o;
-    } else if (x0 < d.out_w) {
-        auto *q = CG_GLOBAL(uint32_t, reinterpret_cast<uint32_t *>(p));
-        q[0] = o.x;
-        if (x0 + 1u < d.out_w)
-            q[1] = o.y;
-        if (x0 + 2u < d.out_w)
-            q[2] = o.z;
-        if (x0 + 3u < d.out_w)
-            q[3] = o.w;
-    }
-}
-
 // ---------------------------------------------------------------------------
 // Composite: 4:2:2 chroma replication + YCbCr -> RGBA8
 // ---------------------------------------------------------------------------
@@ -644,28 +652,100 @@ CG_DEV void composite_422(const ImageDesc &d, const uint32_t *px_slots, uint32_t
 
 CG_DEV uint32_t ycbcr_to_rgba(uint32_t y_, uint32_t cb_, uint32_t cr_);
 
+// Four pixels that share two chroma samples: yw = 4 luma bytes, cb2 / cr2 =
+// the two chroma bytes in bits 0..15.  Integer BT.601 approximation of the
+// reference (src/dct.wgsl:323-334); on the GPU it runs two 16-bit lanes per
+// instruction (all intermediates fit 16 bits: |45*cr'| <= 5760,
+// |11*cb'+23*cr'| <= 4352, |113*cb'| <= 14464).
+CG_DEV Vec4u rgba_quad(uint32_t yw, uint32_t cb2, uint32_t cr2)
+{
+    Vec4u o;
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    const s2 bias = {128, 128};
+    // bytes 0,1 of a word -> the two 16-bit lanes
+    const s2 cb = __builtin_bit_cast(s2, __builtin_amdgcn_perm(0u, cb2, 0x0c010c00u)) - bias;
+    const s2 cr = __builtin_bit_cast(s2, __builtin_amdgcn_perm(0u, cr2, 0x0c010c00u)) - bias;
+    const s2 k45 = {45, 45}, k11 = {11, 11}, k23 = {23, 23}, k113 = {113, 113};
+    const s2 sh5 = {5, 5}, sh6 = {6, 6};
+    const s2 rc = (cr * k45) >> sh5;
+    const s2 gc = (cb * k11 + cr * k23) >> sh5;
+    const s2 bc = (cb * k113) >> sh6;
+    const s2 ya = __builtin_bit_cast(s2, __builtin_amdgcn_perm(0u, yw, 0x0c010c00u));
+    const s2 yb = __builtin_bit_cast(s2, __builtin_amdgcn_perm(0u, yw, 0x0c030c02u));
+    const s2 rc0 = {rc.x, rc.x}, rc1 = {rc.y, rc.y};
+    const s2 gc0 = {gc.x, gc.x}, gc1 = {gc.y, gc.y};
+    const s2 bc0 = {bc.x, bc.x}, bc1 = {bc.y, bc.y};
+    uint32_t ra, ga, ba, rb, gb, bb;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(ra) : "v"(ya + rc0));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(ga) : "v"(ya - gc0));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(ba) : "v"(ya + bc0));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(rb) : "v"(yb + rc1));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(gb) : "v"(yb - gc1));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(bb) : "v"(yb + bc1));
+    const uint32_t rga = (ra & 0xffffu) | (ga << 16), b1a = ba | 0xffff0000u;
+    const uint32_t rgb = (rb & 0xffffu) | (gb << 16), b1b = bb | 0xffff0000u;
+    o.x = __builtin_amdgcn_perm(b1a, rga, 0x06040200u);
+    o.y = __builtin_amdgcn_perm(b1a, rga, 0x07050301u);
+    o.z = __builtin_amdgcn_perm(b1b, rgb, 0x06040200u);
+    o.w = __builtin_amdgcn_perm(b1b, rgb, 0x07050301u);
+#else
+    o.x = ycbcr_to_rgba(yw & 0xffu, cb2 & 0xffu, cr2 & 0xffu);
+    o.y = ycbcr_to_rgba((yw >> 8) & 0xffu, cb2 & 0xffu, cr2 & 0xffu);
+    o.z = ycbcr_to_rgba((yw >> 16) & 0xffu, (cb2 >> 8) & 0xffu, (cr2 >> 8) & 0xffu);
+    o.w = ycbcr_to_rgba(yw >> 24, (cb2 >> 8) & 0xffu, (cr2 >> 8) & 0xffu);
+#endif
+    return o;
+}
+
 // px[k][2*row + half]: data unit k (Y0, Y1, Cb, Cr), 4 samples per word.
 CG_DEV void composite_own_mcu_422(const ImageDesc &d, const uint32_t (&px)[4][16], uint32_t mx,
                                   uint32_t my)
 {
-    const uint32_t x0 = mx * 16u;
+    const uint32_t x0 = mx * 16u, y0 = my * 8u;
+    uint8_t *base = d.out + size_t(y0) * d.out_pitch + size_t(x0) * 4u;
+    const bool whole = x0 + 16u <= d.out_w && y0 + 8u <= d.out_h && (d.out_pitch & 15u) == 0u;
+    if (whole) {
+        // the common case: 8 rows x 64 bytes, unconditional 16-byte stores
 #pragma unroll
-    for (uint32_t row = 0; row < 8; row++) {
-        const uint32_t y = my * 8u + row;
-        if (y >= d.out_h || x0 >= d.out_w)
-            break;
-        uint8_t *line = d.out + size_t(y) * d.out_pitch + size_t(x0) * 4u;
+        for (uint32_t row = 0; row < 8; row++) {
+            auto *line = CG_GLOBAL(Vec4u, reinterpret_cast<Vec4u *>(base + size_t(row) * d.out_pitch));
 #pragma unroll
-        for (uint32_t q = 0; q < 4; q++) {
-            const uint32_t yw = px[q >> 1][row * 2u + (q & 1u)];
-            const uint32_t cbw = px[2][row * 2u + (q >> 1)] >> ((q & 1u) * 16u);
-            const uint32_t crw = px[3][row * 2u + (q >> 1)] >> ((q & 1u) * 16u);
-            Vec4u o;
-            o.x = ycbcr_to_rgba(yw & 0xffu, cbw & 0xffu, crw & 0xffu);
-            o.y = ycbcr_to_rgba((yw >> 8) & 0xffu, cbw & 0xffu, crw & 0xffu);
-            o.z = ycbcr_to_rgba((yw >> 16) & 0xffu, (cbw >> 8) & 0xffu, (crw >> 8) & 0xffu);
-            o.w = ycbcr_to_rgba(yw >> 24, (cbw >> 8) & 0xffu, (crw >> 8) & 0xffu);
-            store_px4(d, line + q * 16u, x0 + q * 4u, o);
+            for (uint32_t q = 0; q < 4; q++)
+                line[q] = rgba_quad(px[q >> 1][row * 2u + (q & 1u)],
+                                    px[2][row * 2u + (q >> 1)] >> ((q & 1u) * 16u),
+                                    px[3][row * 2u + (q >> 1)] >> ((q & 1u) * 16u));
+        }
+    } else {
+        // MCUs cut by the right / bottom edge (stores outside the output are
+        // dropped, like textureStore in the reference) or an unaligned pitch
+#pragma unroll 1
+        for (uint32_t row = 0; row < 8; row++) {
+            if (y0 + row >= d.out_h)
+                break;
+#pragma unroll 1
+            for (uint32_t q = 0; q < 4; q++) {
+                const uint32_t w = row * 2u + (q & 1u), c = row * 2u + (q >> 1);
+                // select the words without dynamic register indexing
+                uint32_t yw = 0, cbw = 0, crw = 0;
+#pragma unroll
+                for (uint32_t i = 0; i < 16; i++) {
+                    yw = (i == w) ? ((q >> 1) ? px[1][i] : px[0][i]) : yw;
+                    cbw = (i == c) ? px[2][i] : cbw;
+                    crw = (i == c) ? px[3][i] : crw;
+                }
+                const Vec4u o = rgba_quad(yw, cbw >> ((q & 1u) * 16u), crw >> ((q & 1u) * 16u));
+                const uint32_t x = x0 + q * 4u;
+                auto *p = CG_GLOBAL(uint32_t, reinterpret_cast<uint32_t *>(base + size_t(row) * d.out_pitch + q * 16u));
+                if (x < d.out_w)
+                    p[0] = o.x;
+                if (x + 1u < d.out_w)
+                    p[1] = o.y;
+                if (x + 2u < d.out_w)
+                    p[2] = o.z;
+                if (x + 3u < d.out_w)
+                    p[3] = o.w;
+            }
         }
     }
 }

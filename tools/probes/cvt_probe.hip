@@ -7,7 +7,13 @@ __global__ void k(const float *in, unsigned *out, int n)
     int i = threadIdx.x + blockIdx.x * blockDim.x;
     if (i < n) {
         unsigned r;
-        asm volatile("v_cvt_pk_u8_f32 %0, %1, 0, 0" : "=v"(r) : "v"(in[i]));
+        float x = in[i];
+        float y = x * 1.0000001f; // a rounding-sensitive op after the block must still be RNE
+        asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+                     "v_cvt_pk_u8_f32 %0, %1, 0, 0\n\t"
+                     "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0" : "=v"(r) : "v"(x));
+        float z = x * 1.0000001f + 0.0f;
+        if (__float_as_uint(y) != __float_as_uint(x * 1.0000001f) || z != y) r |= 0x80000000u;
         out[i] = r;
     }
 }
