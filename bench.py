@@ -50,15 +50,19 @@ def parse_args():
     return p.parse_args()
 
 
-def make_inputs(args, rank, threads):
+def make_inputs(args, rank, world, threads):
+    from compeg_amd.sharding import shard_bounds
     from tools import synth
 
     distinct = args.distinct if args.distinct > 0 else args.batch
     distinct = min(distinct, args.batch)
+    # the job is one batch of args.batch * world frames (config 4: 2048 = 256 x 8), cut into
+    # contiguous per-rank blocks; frame g is synthesised from seed 0xC0FFEE + g
+    lo, hi = shard_bounds(args.batch * world, rank, world)
+    assert hi - lo == args.batch
 
     def one(i):
-        # seeds differ per rank so that every GPU of the node decodes different frames
-        return synth.make_jpeg(args.width, args.height, seed=0xC0FFEE + rank * 100003 + i,
+        return synth.make_jpeg(args.width, args.height, seed=0xC0FFEE + lo + i,
                                kind=args.kind, quality=args.quality, ri=args.ri)
 
     with ThreadPoolExecutor(threads) as ex:
@@ -112,7 +116,7 @@ def main():
 
     threads = max(1, min(16, (os.cpu_count() or 8) // max(1, min(world, 8))))
     t_gen = time.perf_counter()
-    jpegs, distinct = make_inputs(args, rank, threads)
+    jpegs, distinct = make_inputs(args, rank, world, threads)
     t_gen = time.perf_counter() - t_gen
 
     gpu = compeg_amd.Gpu.open(local_rank)
@@ -144,10 +148,8 @@ def main():
 
     n_timed, ev_total_ms, ev_huff_ms, ev_idct_ms = batch.timing(reset=True)
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from compeg_amd.sharding import max_over_ranks
+    elapsed = max_over_ranks(elapsed, device="cuda")
 
     # ---- everything below is outside the timed region -----------------------------------
     verified = None

@@ -1,0 +1,235 @@
+"""CPU-side tests of the product's host logic (no GPU): the C ABI surface, the JPEG front-end,
+the Huffman LUT builder and the scan preprocessor of libcompeg_hip.so against the oracle."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import compeg_amd as ca
+from conftest import GOLDEN, ROOT, read_golden
+from oracle import oracle as orc
+from tools import synth
+
+
+# ---- C ABI surface ---------------------------------------------------------------------------
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "compeg_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(compeg_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+    lib = ctypes.CDLL(ca.LIB_PATH)
+    names = _declared_functions()
+    assert len(names) >= 45
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_python_mirror_binds_every_declared_symbol():
+    from compeg_amd import _lib
+    assert sorted(_lib.lib._signatures) == _declared_functions()
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(ca.Error) as e:
+        ca.Gpu.open()
+    assert e.value.code == ca.E_HIP and "no CPU fallback" in str(e.value)
+
+
+def test_product_never_loads_the_oracle():
+    for root, _, files in os.walk(os.path.join(ROOT, "compeg_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip")) or f == "Makefile":
+                assert "oracle" not in open(os.path.join(root, f)).read().lower().replace(
+                    "cpu oracle", "").replace("the oracle", ""), f
+    import subprocess
+    out = subprocess.run(["ldd", ca.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+
+
+# ---- ImageData parity ----------------------------------------------------------------------
+
+def _same_image(jpeg):
+    """Both front-ends must agree: same bytes when accepted, same message when rejected
+    ("panic:" marks inputs on which the reference aborts; we return an error instead)."""
+    try:
+        want = orc.ImageData(jpeg)
+    except orc.OracleError as oe:
+        with pytest.raises(ca.Error) as pe:
+            ca.ImageData(jpeg)
+        if not str(oe).startswith("panic:"):
+            assert str(pe.value) == str(oe)
+        return False
+    got = ca.ImageData(jpeg)
+    assert (got.width(), got.height(), got.parallelism()) == \
+        (want.width(), want.height(), want.parallelism())
+    assert got.metadata() == want.metadata()
+    assert got.huffman_l1() == want.l1()
+    assert got.huffman_l2() == want.l2()
+    assert got.scan_range() == want.scan_range()
+    return True
+
+
+def _golden_jpegs():
+    out = []
+    for sub in ("parser", "refs"):
+        d = os.path.join(GOLDEN, sub)
+        out += [(sub, f) for f in sorted(os.listdir(d)) if f.endswith(".jpg")]
+    return out
+
+
+@pytest.mark.parametrize("sub,name", _golden_jpegs())
+def test_front_end_on_reference_fixtures(sub, name):
+    _same_image(read_golden(sub, name))
+
+
+def test_front_end_error_codes():
+    with pytest.raises(ca.Error) as e:
+        ca.ImageData(read_golden("parser", "progressive3.jpg"))
+    assert e.value.code == ca.E_UNSUPPORTED
+    with pytest.raises(ca.Error) as e:
+        ca.ImageData(b"\xff\xd8\xff")
+    assert e.value.code == ca.E_MALFORMED
+    assert str(e.value) == "reached end of data while decoding JPEG stream"
+
+
+def test_front_end_on_synthetic_variants():
+    for flags in (0, synth.NO_DHT, synth.JFIF, synth.NO_EOI):
+        for sampling in ((2, 1), (1, 1), (2, 2)):
+            for ri in (0, 1, 4, 7):
+                _same_image(synth.make_jpeg(72, 40, seed=ri, sampling=sampling, ri=ri, flags=flags))
+
+
+def test_front_end_fuzz_mutations():
+    rng = np.random.default_rng(1234)
+    seeds = [synth.make_jpeg(64, 32, seed=1, ri=2), synth.make_jpeg(48, 16, seed=2, ri=1, flags=synth.NO_DHT),
+             read_golden("refs", "64x8-Ri-2.jpg"), read_golden("parser", "restarts.jpg")]
+    accepted = 0
+    for it in range(3000):
+        base = bytearray(seeds[it % len(seeds)])
+        header_end = base.find(b"\xff\xda") + 14
+        for _ in range(int(rng.integers(1, 4))):
+            kind = rng.integers(0, 4)
+            if len(base) < 4:
+                break
+            hdr = max(3, min(header_end, len(base)))
+            if kind == 0:      # flip a header byte
+                base[int(rng.integers(2, hdr))] = int(rng.integers(0, 256))
+            elif kind == 1:    # flip any byte
+                base[int(rng.integers(0, len(base)))] = int(rng.integers(0, 256))
+            elif kind == 2:    # truncate
+                del base[int(rng.integers(3, len(base))):]
+            else:              # insert a byte in the header
+                base.insert(int(rng.integers(2, hdr)), int(rng.integers(0, 256)))
+        accepted += bool(_same_image(bytes(base)))
+    assert accepted > 100  # the corpus exercises both outcomes
+
+
+def test_huffman_tables_fuzz():
+    """Random code-length histograms through a DHT: valid prefix codes give identical LUTs,
+    over-subscribed ones are rejected by both."""
+    rng = np.random.default_rng(99)
+    base = synth.make_jpeg(32, 16, seed=3, ri=1)
+    i = base.find(b"\xff\xc4")
+    ok = bad = 0
+    for it in range(400):
+        counts = np.zeros(16, dtype=np.uint8)
+        budget = 1.0
+        overfull_at = int(rng.integers(1, 17)) if it % 3 == 0 else 0
+        for length in range(1, 17):
+            room = int(budget * (1 << length) + 1e-9)
+            n = 0
+            if length == overfull_at and room < 255:
+                n = room + 1 + int(rng.integers(0, 2))   # one code too many: not a prefix code
+            elif room > 0 and rng.random() < 0.6:
+                n = int(rng.integers(0, min(room, 40) + 1))
+            counts[length - 1] = min(n, 255)
+            budget -= min(n, 255) / (1 << length)
+            if budget < 0:
+                break
+        nsym = int(counts.sum())
+        if nsym == 0:
+            continue
+        syms = rng.integers(0, 256, nsym, dtype=np.uint8)
+        tcth = int(rng.choice([0x00, 0x10, 0x01, 0x11]))
+        seg = bytes([0xFF, 0xC4]) + (2 + 17 + nsym).to_bytes(2, "big") + bytes([tcth]) + counts.tobytes() + syms.tobytes()
+        jpeg = base[:i] + seg + base[i:]
+        if _same_image(jpeg):
+            ok += 1
+        else:
+            bad += 1
+    assert ok > 50 and bad > 5
+
+
+# ---- ScanBuffer parity ---------------------------------------------------------------------
+
+def _scan_both(data, expected):
+    a, b = ca.ScanBuffer(), orc.ScanBuffer()
+    ea = eb = None
+    try:
+        a.process(data, expected)
+    except ca.Error as e:
+        ea = str(e)
+        assert e.code == ca.E_COUNT_MISMATCH
+    try:
+        b.process(data, expected)
+    except orc.OracleError as e:
+        eb = str(e)
+    assert ea == eb
+    assert a.processed_scan_data() == b.processed_scan_data()
+    assert a.start_positions() == b.start_positions()
+    return a
+
+
+def test_scanbuffer_reference_kats():
+    # ref src/scan.rs:151-180
+    sb = _scan_both(bytes([0x12, 0x34, 0x56, 0x78]), 1)
+    assert sb.processed_scan_data() == bytes([0x12, 0x34, 0x56, 0x78])
+    sb = _scan_both(bytes([0xFF, 0xD0, 0xFF, 0xD0]), 3)
+    assert sb.processed_scan_data() == b"" and sb.start_positions() == bytes(12)
+    sb = _scan_both(bytes([0xFF, 0x00, 0x44, 0x55, 0xFF, 0xD0, 0x34]), 2)
+    assert sb.processed_scan_data() == bytes([0xFF, 0x44, 0x55, 0x00, 0x34, 0, 0, 0])
+    sb = _scan_both(bytes([0x11, 0xFF, 0xD0, 0x11, 0xFF, 0xD0, 0x11]), 3)
+    assert sb.processed_scan_data() == bytes([0x11, 0, 0, 0, 0x11, 0, 0, 0, 0x11, 0, 0, 0])
+    with pytest.raises(ca.Error) as e:
+        ca.ScanBuffer().process(bytes([0x11, 0xFF, 0xD0, 0x11, 0xFF, 0xD0, 0x11]), 1)
+    assert str(e.value) == "restart interval count mismatch: counted 3, expected 1"
+
+
+def test_scanbuffer_bench_data():
+    data = read_golden("scan", "scan.dat")   # ref benches/bench.rs:9-19
+    sb = _scan_both(data, 42876)
+    assert len(sb.start_positions()) == 42876 * 4
+    _scan_both(data, 42875)                  # mismatch: identical truncated buffers too
+    _scan_both(data, 50000)
+
+
+def test_scanbuffer_fuzz():
+    rng = np.random.default_rng(7)
+    for it in range(400):
+        n = int(rng.integers(0, 300))
+        data = rng.integers(0, 256, n, dtype=np.uint8)
+        mask = rng.random(n) < 0.15           # plenty of FFs, incl. FF FF and a trailing FF
+        data[mask] = 0xFF
+        zero = rng.random(n) < 0.1
+        data[zero] = 0
+        expected = int(rng.integers(0, 12))
+        _scan_both(data.tobytes(), expected)
+    _scan_both(b"", 0)
+    _scan_both(b"\xff", 1)
+    _scan_both(b"\xff\xff\xff", 2)
+
+
+def test_scanbuffer_reuse_gives_fresh_buffer_output():
+    """Quirk Q7: we always produce what the reference produces on a fresh buffer."""
+    sb = ca.ScanBuffer()
+    sb.process(bytes([0xAA] * 64), 1)
+    sb.process(bytes([0x11, 0xFF, 0xD0, 0x22]), 2)
+    assert sb.processed_scan_data() == bytes([0x11, 0, 0, 0, 0x22, 0, 0, 0])

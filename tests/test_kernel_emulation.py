@@ -1,0 +1,114 @@
+"""The gfx950 kernel bodies (compeg_amd/csrc/kernels_body.h) compiled for the host with
+ASan + UBSan and run lane by lane (tests/emul).  GPU sanitizers are not available on the
+target pool, so this is where out-of-bounds LDS / global accesses and undefined shifts in
+the kernel code are caught, including on corrupt streams and hostile tables.  Results must
+equal the oracle bit for bit.  This is test infrastructure, not a CPU fallback."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, read_golden
+from oracle import oracle as orc
+from tools import synth
+
+EMUL_DIR = os.path.join(ROOT, "tests", "emul")
+RUNNER = os.path.join(EMUL_DIR, "emul_runner")
+
+
+@pytest.fixture(scope="module")
+def runner():
+    subprocess.check_call(["make", "-C", EMUL_DIR, "-s"])
+    return RUNNER
+
+
+def _run(runner, tmp_path, jpeg, fused, waves=1, window=2048, l2=8192):
+    p = tmp_path / "in.jpg"
+    p.write_bytes(jpeg)
+    env = dict(os.environ)
+    env.pop("EMUL_FUSED", None)
+    if fused:
+        env["EMUL_FUSED"] = "1"
+    r = subprocess.run([runner, str(p), str(tmp_path / "rgba"), str(tmp_path / "ac"), str(tmp_path / "dc"),
+                        str(waves), str(window), str(l2)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr[-2000:]
+    _, w, h, _ = r.stdout.split()
+    return np.fromfile(tmp_path / "rgba", dtype=np.uint8).reshape(int(h), int(w), 4)
+
+
+def _check(runner, tmp_path, jpeg, **kw):
+    want = orc.ImageData(jpeg).decode()
+    for fused in (True, False):
+        got = _run(runner, tmp_path, jpeg, fused, **kw)
+        assert np.array_equal(got, want), f"fused={fused}: {(got != want).any(axis=2).sum()} pixels differ"
+
+
+CASES = [
+    (64, 8, 0, 100, 1, 1), (320, 200, 0, 85, 4, 2), (128, 64, 1, 95, 1, 3), (250, 70, 0, 50, 3, 4),
+    (33, 17, 0, 90, 1, 5), (256, 64, 2, 85, 7, 6), (96, 48, 1, 100, 0, 7),
+]
+
+
+@pytest.mark.parametrize("w,h,kind,q,ri,seed", CASES)
+def test_emulated_kernels_match_oracle(runner, tmp_path, w, h, kind, q, ri, seed):
+    _check(runner, tmp_path, synth.make_jpeg(w, h, seed=seed, kind=kind, quality=q, ri=ri))
+
+
+@pytest.mark.parametrize("waves,window,l2", [(4, 64, 512), (2, 80, 0), (1, 4, 0), (3, 300, 1024)])
+def test_emulated_kernels_small_lds_budgets(runner, tmp_path, waves, window, l2):
+    """Windows / LUT staging cut short by the LDS budget: the global-memory paths."""
+    _check(runner, tmp_path, synth.make_jpeg(320, 64, seed=11, kind=1, quality=92, ri=2),
+           waves=waves, window=window, l2=l2)
+
+
+def test_emulated_reference_fixtures(runner, tmp_path):
+    for name in ("64x8-Ri-1.jpg", "64x8-Ri-2.jpg"):
+        _check(runner, tmp_path, read_golden("refs", name))
+
+
+def test_emulated_corrupt_entropy_data(runner, tmp_path):
+    """Bit flips inside the scan: decoding runs off the rails (long codes, huge runs, reads
+    past the interval and past the end of the scan) but must stay memory-safe and must still
+    equal the oracle's restatement of the reference semantics."""
+    rng = np.random.default_rng(5)
+    base = synth.make_jpeg(192, 48, seed=21, kind=0, quality=75, ri=2)
+    scan_at = base.find(b"\xff\xda") + 14
+    for it in range(12):
+        j = bytearray(base)
+        for _ in range(int(rng.integers(1, 30))):
+            pos = int(rng.integers(scan_at, len(j) - 2))
+            if j[pos] != 0xFF and j[pos - 1] != 0xFF:   # keep the marker structure intact
+                j[pos] ^= 1 << int(rng.integers(0, 8))
+                if j[pos] == 0xFF:
+                    j[pos] = 0xFE
+        _check(runner, tmp_path, bytes(j), window=64 if it % 2 else 2048)
+
+
+def test_emulated_hostile_huffman_tables(runner, tmp_path):
+    """DC categories above 15 and other values a baseline encoder never emits: shift counts
+    wrap modulo 32 exactly like the WGSL reference (quirk list in SURVEY.md)."""
+    rng = np.random.default_rng(8)
+    base = synth.make_jpeg(128, 32, seed=31, kind=1, quality=90, ri=1)
+    i = base.find(b"\xff\xc4")
+    for it in range(10):
+        counts = np.zeros(16, dtype=np.uint8)
+        counts[1] = 2
+        counts[2] = 3
+        counts[4] = int(rng.integers(1, 4))
+        counts[8] = int(rng.integers(0, 6))
+        counts[15] = int(rng.integers(0, 30))
+        nsym = int(counts.sum())
+        syms = rng.integers(0, 256, nsym, dtype=np.uint8)   # DC tables with categories up to 255
+        tcth = [0x00, 0x01, 0x10, 0x11][it % 4]
+        seg = bytes([0xFF, 0xC4]) + (2 + 17 + nsym).to_bytes(2, "big") + bytes([tcth]) + counts.tobytes() + syms.tobytes()
+        # put the hostile table AFTER the regular ones so that it wins
+        sos = base.find(b"\xff\xda")
+        _check(runner, tmp_path, base[:sos] + seg + base[sos:], window=128)
+
+
+def test_emulated_count_mismatch_and_truncated_interval(runner, tmp_path):
+    j = bytearray(synth.make_jpeg(128, 32, seed=40, ri=2))
+    i = j.find(b"\xff\xdd")
+    j[i + 4:i + 6] = (3).to_bytes(2, "big")     # DRI says 3, stream has markers every 2 MCUs
+    _check(runner, tmp_path, bytes(j))
