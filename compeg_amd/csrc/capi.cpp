@@ -432,8 +432,10 @@ int compeg_decoder_read_coefficients(compeg_decoder *dec, int32_t *host, size_t 
         if (dus && !dec->coefficients_valid) {
             // the fused kernel keeps coefficients on chip: rerun the entropy
             // stage alone into the scratch buffers for this debug read-back
+            const HuffLdsPlan plan = plan_huffman(md.total_restart_intervals, 1, dec->last_plan.l2_entries_in_lds,
+                                                  dec->last_span, false);
             e = launch_huffman(static_cast<const ImageDesc *>(dec->dev_blob.ptr), 1,
-                               md.total_restart_intervals, dec->last_plan, dec->last_stream);
+                               md.total_restart_intervals, plan, dec->last_stream);
             if (e == hipSuccess)
                 e = hipStreamSynchronize(dec->last_stream);
             if (e != hipSuccess)
@@ -463,6 +465,24 @@ int compeg_decoder_read_coefficients(compeg_decoder *dec, int32_t *host, size_t 
         }
         return ok();
     });
+}
+
+/* Diagnostic builds (-DCG_STAMPS) park per-wave cycle stamps in the dc scratch buffers; these
+ * two undeclared helpers read them back.  Not part of the API. */
+__attribute__((visibility("default"))) int compeg_debug_read_dc(compeg_decoder *dec, void *host, size_t bytes)
+{
+    if (!dec || !dec->dc.ptr || bytes > dec->dc.capacity)
+        return COMPEG_E_INVALID_ARG;
+    (void)hipStreamSynchronize(dec->last_stream);
+    return hipMemcpy(host, dec->dc.ptr, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : COMPEG_E_HIP;
+}
+
+__attribute__((visibility("default"))) int compeg_debug_read_batch_dc(compeg_batch *b, void *host, size_t bytes)
+{
+    if (!b || !b->dc.ptr || bytes > b->dc.capacity)
+        return COMPEG_E_INVALID_ARG;
+    (void)hipStreamSynchronize(b->last_stream);
+    return hipMemcpy(host, b->dc.ptr, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : COMPEG_E_HIP;
 }
 
 /* ---- Batch ---------------------------------------------------------------- */

@@ -1,6 +1,7 @@
 // Translation of the reference-format Metadata block into the kernel-facing
 // descriptor (no HIP dependency: shared with the host-side kernel emulation
 // used by the sanitizer tests).
+#include <cstdlib>
 #include <cstring>
 
 #include "device_types.h"
@@ -16,6 +17,8 @@ void fill_desc(const ImageData &img, ImageDesc &d)
     const Metadata &md = img.metadata;
     memset(&d, 0, sizeof d);
     d.l2_entries = uint32_t(img.l2.size());
+    if (const char *e = getenv("COMPEG_DEBUG_FLAGS"))
+        d.debug_flags = uint32_t(atoi(e));
     d.total_intervals = md.total_restart_intervals;
     d.restart_interval = md.restart_interval;
     d.dus_per_mcu = md.dus_per_mcu;

@@ -10,9 +10,10 @@ constexpr int kRetained = 32;          // zig-zag positions kept per data unit (
 constexpr int kMaxDusPerMcu = 6;
 
 // LDS slot of one lane's data unit while it is being decoded: 32 int16 in
-// zig-zag order, padded to 80 bytes so that the 16-byte flush reads of a
-// 16-lane group fall on 16 distinct 4-bank groups.
-constexpr int kDuSlotBytes = 80;
+// zig-zag order + one dummy position (coefficients >= 32 are dropped there),
+// 17 dwords per lane: an odd dword stride makes both the 2-byte scatter
+// stores and the 4-byte read-back conflict-free across the 32 LDS banks.
+constexpr int kDuSlotBytes = 68;
 
 // Everything the kernels need to know about one image.  Lives in device
 // memory (one array entry per image of a batch); all pointers are device
@@ -50,6 +51,7 @@ struct ImageDesc {
     uint8_t *out; // RGBA8
     uint32_t out_w, out_h;
     uint32_t out_pitch; // bytes
+    uint32_t debug_flags; // experiments only: bit 0 = skip the pixel stores
     // launch bookkeeping for batched grids
     uint32_t first_huff_block; // block index of this image's first huffman block
     uint32_t first_idct_block;

@@ -12,7 +12,7 @@ namespace compeg {
 // L2 entries; max_wave_words (largest scan span of 64 consecutive intervals)
 // sizes the per-wave scan window.
 HuffLdsPlan plan_huffman(uint32_t max_intervals, uint32_t images, uint32_t max_l2,
-                         uint32_t max_wave_words);
+                         uint32_t max_wave_words, bool fused);
 // Largest word span covered by any group of 64 consecutive restart intervals.
 uint32_t max_wave_span(const uint32_t *starts, size_t nstarts, size_t nwords, uint32_t intervals);
 

@@ -12,6 +12,7 @@
 // are bounded by HBM traffic / serial entropy decoding).
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 
 #include "kernels_body.h"
@@ -67,7 +68,7 @@ huffman_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t
 // Fused path: same prologue as huffman_kernel, then every lane runs the whole
 // decode of its interval (entropy decode -> IDCT -> composite), so neither
 // coefficients nor samples ever touch HBM.
-__global__ void __launch_bounds__(512, 2)
+__global__ void __launch_bounds__(768)
 decode_fused_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -133,14 +134,18 @@ idct_composite_kernel(const ImageDesc *__restrict__ descs)
         const uint32_t k = du % d.dus_per_mcu;
         const uint32_t comp = (d.comp_of_du >> (2u * k)) & 3u;
         // 64-byte record, four 16-byte loads
-        Vec4u rec[4];
         auto *src = CG_GLOBAL(const Vec4u, reinterpret_cast<const Vec4u *>(d.ac + size_t(du) * kRetained));
-        rec[0] = src[0];
-        rec[1] = src[1];
-        rec[2] = src[2];
-        rec[3] = src[3];
+        uint32_t rec[kRetained / 2];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const Vec4u v = src[i];
+            rec[4 * i + 0] = v.x;
+            rec[4 * i + 1] = v.y;
+            rec[4 * i + 2] = v.z;
+            rec[4 * i + 3] = v.w;
+        }
         uint32_t out[16];
-        idct_data_unit(reinterpret_cast<const int16_t *>(rec), CG_GLOBAL(const int32_t, d.dc)[du], quant + comp * kRetained, out);
+        idct_data_unit(rec, CG_GLOBAL(const int32_t, d.dc)[du], quant + comp * kRetained, out);
         uint32_t *slot = wave_px + lane * kPxSlotWords;
 #pragma unroll
         for (int i = 0; i < 16; i++)
@@ -153,22 +158,23 @@ idct_composite_kernel(const ImageDesc *__restrict__ descs)
     composite_422(d, wave_px, first_mcu, total_mcus, lane);
 }
 
+namespace {
+constexpr uint32_t kLdsBytesPerCu = 160u * 1024u;
+constexpr uint32_t kMaxWavesFused = 12; // 3 per SIMD: what 147 VGPRs allow
+constexpr uint32_t kMaxWavesSplit = 4;
+} // namespace
+
 HuffLdsPlan plan_huffman(uint32_t max_intervals, uint32_t images, uint32_t max_l2,
-                         uint32_t max_wave_words)
+                         uint32_t max_wave_words, bool fused)
 {
     HuffLdsPlan p;
-    // One wave per workgroup while the whole launch has few waves (a single
-    // 4K frame with DRI=4 is only 254 waves for 256 CUs): every wave then
-    // gets its own CU.  Four waves per workgroup once the chip is
-    // oversubscribed, to amortise LUT staging.
-    const uint64_t total_waves = uint64_t((max_intervals + kWave - 1) / kWave) * images;
-    p.waves_per_block = total_waves <= 2048 ? 1u : 4u;
-    if (const char *e = getenv("COMPEG_WPB")) // experiment knob
-        p.waves_per_block = uint32_t(atoi(e));
     p.l2_entries_in_lds = max_l2 < 8192u ? (max_l2 + 1u) & ~1u : 8192u;
-    // window: the largest word span of any wave's 64 intervals (the host knows
-    // every start offset) plus the per-data-unit slack, capped at 24 KB;
-    // waves that need more fall back to global reads for the excess
+    const uint32_t tables = (((kL1Entries + p.l2_entries_in_lds) * 2u) + 15u) & ~15u;
+    const uint32_t slots = kWave * kDuSlotBytes;
+
+    // Window: the largest word span of any wave's 64 intervals (the host knows
+    // every start offset) plus the per-data-unit slack; waves that need more
+    // than the cap fall back to global reads for the excess.
     uint32_t w = max_wave_words + kDuWordSlack + 4u;
     if (w < 256u)
         w = 256u;
@@ -177,11 +183,30 @@ HuffLdsPlan plan_huffman(uint32_t max_intervals, uint32_t images, uint32_t max_l
     if (const char *e = getenv("COMPEG_WINDOW_CAP")) // experiment knob (words)
         w = w < uint32_t(atoi(e)) ? w : uint32_t(atoi(e));
     p.window_words = (w + 3u) & ~3u;
-    const uint32_t tables = (((kL1Entries + p.l2_entries_in_lds) * 2u) + 15u) & ~15u;
-    const uint32_t wave_area = ((p.window_words * 4u + 15u) & ~15u) + kWave * kDuSlotBytes;
+    const uint32_t wave_area = ((p.window_words * 4u + 15u) & ~15u) + slots;
+
+    // Workgroup shape.  A launch with few waves (one 4K frame with DRI=4 is
+    // 254 waves for 256 CUs) uses one wave per workgroup so that every wave
+    // gets a CU of its own.  Once the chip is oversubscribed, one workgroup
+    // fills a CU: as many waves as the LDS holds, at most 12 (3 per SIMD).
+    const uint64_t total_waves = uint64_t((max_intervals + kWave - 1) / kWave) * images;
+    uint32_t wpb = 1;
+    if (total_waves > 2048) {
+        const uint32_t fit = (kLdsBytesPerCu - tables) / wave_area;
+        wpb = fit < 1u ? 1u : fit;
+        const uint32_t cap = fused ? kMaxWavesFused : kMaxWavesSplit;
+        if (wpb > cap)
+            wpb = cap;
+    }
+    if (const char *e = getenv("COMPEG_WPB")) // experiment knob
+        wpb = uint32_t(atoi(e));
+    p.waves_per_block = wpb;
     p.total_bytes = tables + p.waves_per_block * wave_area;
     if (const char *e = getenv("COMPEG_LDS_PAD")) // experiment knob: lowers occupancy
         p.total_bytes += uint32_t(atoi(e));
+    if (getenv("COMPEG_VERBOSE"))
+        fprintf(stderr, "[compeg] plan: images=%u intervals=%u waves/block=%u window=%u words l2=%u lds=%u B\n",
+                images, max_intervals, p.waves_per_block, p.window_words, p.l2_entries_in_lds, p.total_bytes);
     return p;
 }
 
@@ -192,6 +217,11 @@ hipError_t launch_huffman(const ImageDesc *descs, uint32_t images, uint32_t max_
         return hipSuccess;
     const uint32_t threads = plan.waves_per_block * kWave;
     dim3 grid((max_intervals + threads - 1) / threads, images, 1);
+    static const hipError_t attr = hipFuncSetAttribute(
+        reinterpret_cast<const void *>(huffman_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        int(kLdsBytesPerCu));
+    if (attr != hipSuccess)
+        return attr;
     hipLaunchKernelGGL(huffman_kernel, grid, dim3(threads), plan.total_bytes, stream, descs,
                        plan.l2_entries_in_lds, plan.window_words);
     return hipGetLastError();
@@ -204,6 +234,11 @@ hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t ma
         return hipSuccess;
     const uint32_t threads = plan.waves_per_block * kWave;
     dim3 grid((max_intervals + threads - 1) / threads, images, 1);
+    static const hipError_t attr = hipFuncSetAttribute(
+        reinterpret_cast<const void *>(decode_fused_422_kernel),
+        hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsBytesPerCu));
+    if (attr != hipSuccess)
+        return attr;
     hipLaunchKernelGGL(decode_fused_422_kernel, grid, dim3(threads), plan.total_bytes, stream, descs,
                        plan.l2_entries_in_lds, plan.window_words);
     return hipGetLastError();

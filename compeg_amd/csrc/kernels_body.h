@@ -113,14 +113,28 @@ CG_DEV int32_t huff_extend(int32_t v, uint32_t t)
     return v < vt ? int32_t(ext) : v;
 }
 
+// The slot is written as int16 and read back as dwords: the dword view must be
+// allowed to alias (otherwise the compiler may reorder the two).
+typedef uint32_t __attribute__((may_alias)) slot_word_t;
+
 CG_DEV void zero_slot(uint8_t *slot)
 {
-    const Vec4u z = {0, 0, 0, 0};
-    Vec4u *p = reinterpret_cast<Vec4u *>(slot);
-    p[0] = z;
-    p[1] = z;
-    p[2] = z;
-    p[3] = z;
+    slot_word_t *p = reinterpret_cast<slot_word_t *>(slot);
+#pragma unroll
+    for (int i = 0; i < kRetained / 2; i++)
+        p[i] = 0u;
+}
+
+// Moves a finished data unit out of its slot (and clears the slot).
+CG_DEV void take_slot(uint8_t *slot, uint32_t (&rec)[kRetained / 2])
+{
+    slot_word_t *p = reinterpret_cast<slot_word_t *>(slot);
+#pragma unroll
+    for (int i = 0; i < kRetained / 2; i++)
+        rec[i] = p[i];
+#pragma unroll
+    for (int i = 0; i < kRetained / 2; i++)
+        p[i] = 0u;
 }
 
 constexpr uint32_t kL1Entries = 5 * 256; // 4 tables + the all-zero table
@@ -278,13 +292,12 @@ CG_DEV void huff_decode_interval(const ImageDesc &d, const HuffShared &s, uint32
 
         if (du_done) {
             // 64-byte record out, slot cleared for the next data unit
-            Vec4u *src = reinterpret_cast<Vec4u *>(slot);
+            uint32_t rec[kRetained / 2];
+            take_slot(slot, rec);
             auto *dst = CG_GLOBAL(Vec4u, reinterpret_cast<Vec4u *>(d.ac + size_t(du_global) * kRetained));
-            dst[0] = src[0];
-            dst[1] = src[1];
-            dst[2] = src[2];
-            dst[3] = src[3];
-            zero_slot(slot);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                dst[i] = Vec4u{rec[4 * i], rec[4 * i + 1], rec[4 * i + 2], rec[4 * i + 3]};
 
             du_local++;
             du_global++;
@@ -428,7 +441,8 @@ CG_DEV void pack_row(const float *f, uint32_t &lo, uint32_t &hi)
 // quant: this component's 32 quantiser values as floats (zig-zag order).
 // px[2*y], px[2*y+1]: the 8 samples of row y, sample 0 in the low byte --
 // the reference's packed pixel format (dct.wgsl:187-201).
-CG_DEV void idct_data_unit(const int16_t *ac, int32_t dc, const float *quant, uint32_t px[16])
+CG_DEV void idct_data_unit(const uint32_t (&ac)[kRetained / 2], int32_t dc, const float *quant,
+                           uint32_t px[16])
 {
     float v[64];
 #pragma unroll
@@ -443,7 +457,9 @@ CG_DEV void idct_data_unit(const int16_t *ac, int32_t dc, const float *quant, ui
             } else if (z < kRetained) {
                 // level * q is exact in f32 (|level| < 2^15, q < 2^8), so this
                 // equals f32(i32(level * q)) of the reference
-                const float level = static_cast<float>(static_cast<int32_t>(ac[z]));
+                // zig-zag position z sits in half (z & 1) of dword z / 2
+                const int32_t lv = int32_t(int16_t(uint16_t(ac[z >> 1] >> ((z & 1) * 16))));
+                const float level = static_cast<float>(lv);
                 x = (level * quant[z]) * mul;
             }
             v[r * 8 + c] = x;
@@ -532,6 +548,25 @@ CG_DEV uint32_t lut_lookup(const ImageDesc &d, const HuffShared &s, uint32_t tab
     return e;
 }
 
+// Second half of a lookup whose L1 read was issued earlier: follows the
+// delegate into the L2 LUT when the code is longer than 8 bits.
+template <bool FAST>
+CG_DEV uint32_t lut_resolve(const ImageDesc &d, const HuffShared &s, uint32_t e, uint32_t cur)
+{
+    if (e & 0x8000u) {
+        const uint32_t idx = (e & 0x7fffu) + ((cur >> 16) & 0xffu);
+        if (FAST) {
+            e = s.l2[idx];
+        } else {
+            uint32_t e2 = s.l2[idx < s.l2_staged ? idx : 0u];
+            if (idx >= s.l2_staged)
+                e2 = idx < d.l2_entries ? CG_GLOBAL(const uint16_t, d.l2)[idx] : 0u;
+            e = e2;
+        }
+    }
+    return e;
+}
+
 // DC difference of the next data unit.  No refill in front of it (quirk Q1);
 // the two consume steps are kept separate so that a category >= 32 from a
 // hostile table shifts exactly like the reference (counts modulo 32).
@@ -557,19 +592,47 @@ template <bool FAST>
 CG_DEV void decode_ac_loop(PrefetchReader &r, const ImageDesc &d, const HuffShared &s,
                            uint32_t ac_off, int16_t *slot16)
 {
+    // Software-pipelined: the LUT lookup of the next symbol is issued as soon
+    // as the bit position after the current one is known; magnitude
+    // extraction, sign extension, the coefficient store and the position
+    // update of the current symbol then run under that lookup's latency.
+    // The look-ahead is speculative when the data unit ends here (EOB or
+    // position 64): reader state is committed only if decoding continues, so
+    // the DC code that follows sees exactly the reference's un-refilled
+    // reader (quirk Q1).
     uint32_t pos = 1u;
-    while (pos < 64u) {
-        reader_refill<FAST>(r, d, s);
-        const uint32_t e = lut_lookup<FAST>(d, s, ac_off, r.b.cur);
+    reader_refill<FAST>(r, d, s);
+    uint32_t e = lut_lookup<FAST>(d, s, ac_off, r.b.cur);
+    bool done;
+    do {
         const uint32_t len = e >> 8, sym = e & 0xffu, nb = sym & 15u;
         const uint32_t t = r.b.cur << (len & 31u);
+        consume(r.b, len + nb);
+
+        // state the next symbol would start from; both LDS reads are issued here
+        const bool need = r.b.left < 32u;
+        const uint32_t w = r.pre, sh = r.b.left & 31u;
+        const uint32_t cur_n = r.b.cur | (need ? (w >> sh) : 0u);
+        const uint32_t nw_n = r.b.next_word + (need ? 1u : 0u);
+        const uint32_t e1_n = s.l1[ac_off + (cur_n >> 24)];
+        const uint32_t pre_n = fetch_word_pf<FAST>(d, s, nw_n);
+
+        // the current symbol, under the latency of those reads
         const int32_t raw = int32_t((t >> 1) >> (31u - nb));
         const int32_t val = huff_extend(raw, nb);
-        consume(r.b, len + nb);
         const uint32_t p = pos + (sym >> 4);
         slot16[p < uint32_t(kRetained) ? p : uint32_t(kRetained)] = int16_t(val);
         pos = sym == 0u ? 64u : p + (sym == 0xf0u ? 2u : 1u);
-    }
+        done = pos >= 64u;
+
+        // commit the refill only if decoding continues, then rotate
+        r.b.cur = done ? r.b.cur : cur_n;
+        r.b.nxt = (need && !done) ? ((w << 1) << (31u - sh)) : r.b.nxt;
+        r.b.left += (need && !done) ? 32u : 0u;
+        r.b.next_word = done ? r.b.next_word : nw_n;
+        r.pre = done ? r.pre : pre_n;
+        e = lut_resolve<FAST>(d, s, e1_n, cur_n);
+    } while (!done);
 }
 
 CG_DEV void decode_ac(PrefetchReader &r, const ImageDesc &d, const HuffShared &s, uint32_t ac_off,
@@ -705,7 +768,37 @@ CG_DEV void composite_own_mcu_422(const ImageDesc &d, const uint32_t (&px)[4][16
     const uint32_t x0 = mx * 16u, y0 = my * 8u;
     uint8_t *base = d.out + size_t(y0) * d.out_pitch + size_t(x0) * 4u;
     const bool whole = x0 + 16u <= d.out_w && y0 + 8u <= d.out_h && (d.out_pitch & 15u) == 0u;
-    if (whole) {
+    if (d.debug_flags & 1u) {
+        // timing experiment: everything computed, nothing stored
+        uint32_t acc = 0;
+#pragma unroll
+        for (uint32_t row = 0; row < 8; row++)
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++) {
+                const Vec4u o = rgba_quad(px[q >> 1][row * 2u + (q & 1u)], px[2][row * 2u + (q >> 1)] >> ((q & 1u) * 16u), px[3][row * 2u + (q >> 1)] >> ((q & 1u) * 16u));
+                acc ^= o.x ^ o.y ^ o.z ^ o.w;
+            }
+        if (acc == 0x12345678u)
+            *CG_GLOBAL(uint32_t, reinterpret_cast<uint32_t *>(base)) = acc;
+#if defined(__HIP_DEVICE_COMPILE__)
+    } else if (d.debug_flags & 2u) {
+        // timing experiment: the store pattern a quad transpose would give
+        // (each 4-lane group writes one MCU's 64-byte row segment per store)
+        const uint32_t lane = threadIdx.x & 63u, quad = lane & ~3u, i = lane & 3u;
+        const uint64_t mybase = reinterpret_cast<uint64_t>(base);
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {
+            const uint32_t lo = __shfl(uint32_t(mybase), int(quad + q)), hi = __shfl(uint32_t(mybase >> 32), int(quad + q));
+            uint8_t *other = reinterpret_cast<uint8_t *>(uint64_t(hi) << 32 | lo);
+#pragma unroll
+            for (uint32_t row = 0; row < 8; row++) {
+                auto *line = CG_GLOBAL(Vec4u, reinterpret_cast<Vec4u *>(other + size_t(row) * d.out_pitch));
+                line[i] = rgba_quad(px[q >> 1][row * 2u + (q & 1u)], px[2][row * 2u + (q >> 1)] >> ((q & 1u) * 16u),
+                                    px[3][row * 2u + (q >> 1)] >> ((q & 1u) * 16u));
+            }
+        }
+#endif
+    } else if (whole) {
         // the common case: 8 rows x 64 bytes, unconditional 16-byte stores
 #pragma unroll
         for (uint32_t row = 0; row < 8; row++) {
@@ -769,6 +862,12 @@ CG_DEV void decode_interval_fused_422(const ImageDesc &d, const HuffShared &s, u
     uint32_t mcu = interval * d.restart_interval;
     uint32_t mx = mcu % d.width_mcus, my = mcu / d.width_mcus;
 
+#if defined(CG_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+#define CG_STAMP(acc) do { const uint64_t now_ = __builtin_readcyclecounter(); acc += now_ - tprev; tprev = now_; } while (0)
+    uint64_t tprev = __builtin_readcyclecounter(), t_dc = 0, t_ac = 0, t_idct = 0, t_comp = 0;
+#else
+#define CG_STAMP(acc) do { } while (0)
+#endif
     // The four data units of an MCU pass through one loop body (one copy of
     // the IDCT in the instruction stream, bounded register pressure); their
     // sample words ride a 4-deep register shift chain px[0..3].
@@ -791,25 +890,24 @@ CG_DEV void decode_interval_fused_422(const ImageDesc &d, const HuffShared &s, u
         pred1 = comp == 1u ? p : pred1;
         pred2 = comp == 2u ? p : pred2;
         const int32_t dc = int32_t(uint32_t(p) * d.dc_quant[comp]);
+        CG_STAMP(t_dc);
         decode_ac(r, d, s, d.ac_table[comp] * 256u, slot16);
+        CG_STAMP(t_ac);
 
-        alignas(16) Vec4u rec[4];
-        const Vec4u *src = reinterpret_cast<const Vec4u *>(slot);
-        rec[0] = src[0];
-        rec[1] = src[1];
-        rec[2] = src[2];
-        rec[3] = src[3];
-        zero_slot(slot);
+        uint32_t rec[kRetained / 2];
+        take_slot(slot, rec);
 #pragma unroll
         for (int w = 0; w < 16; w++) {
             px[0][w] = px[1][w];
             px[1][w] = px[2][w];
             px[2][w] = px[3][w];
         }
-        idct_data_unit(reinterpret_cast<const int16_t *>(rec), dc, d.quant[comp], px[3]);
+        idct_data_unit(rec, dc, d.quant[comp], px[3]);
+        CG_STAMP(t_idct);
 
         if (k == 3u) {
             composite_own_mcu_422(d, px, mx, my);
+            CG_STAMP(t_comp);
             mx++;
             if (mx == d.width_mcus) {
                 mx = 0;
@@ -817,6 +915,15 @@ CG_DEV void decode_interval_fused_422(const ImageDesc &d, const HuffShared &s, u
             }
         }
     }
+#if defined(CG_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+    if (lane == 0 && d.dc) { // diagnostic build only: per-wave phase cycles into the (otherwise unused) dc buffer
+        uint64_t *o = reinterpret_cast<uint64_t *>(d.dc) + size_t(interval / 64u) * 4u;
+        o[0] = t_dc;
+        o[1] = t_ac;
+        o[2] = t_idct;
+        o[3] = t_comp;
+    }
+#endif
 }
 
 } // namespace compeg

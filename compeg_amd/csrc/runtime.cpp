@@ -219,7 +219,9 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
         return Status{};
     const uint32_t span = max_wave_span(scan.starts(), scan.nstarts(), scan.nwords(),
                                         md.total_restart_intervals);
-    const HuffLdsPlan plan = plan_huffman(md.total_restart_intervals, 1, uint32_t(img.l2.size()), span);
+    const HuffLdsPlan plan = plan_huffman(md.total_restart_intervals, 1, uint32_t(img.l2.size()), span,
+                                          use_fused_pipeline());
+    last_span = span;
     last_plan = plan;
     if (use_fused_pipeline()) {
         CG_HIP(launch_fused_422(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals,
@@ -305,8 +307,11 @@ Status compeg_batch::upload(const ImageData *const *images, size_t n, int thread
 
     const bool fused = use_fused_pipeline();
     CG_TRY(inputs.reserve(in_total + 256));
+    const bool stamps = getenv("COMPEG_STAMPS") != nullptr; // diagnostic builds park cycle stamps in dc
     if (!fused) { // the fused kernel keeps coefficients on chip
         CG_TRY(ac.reserve(ac_total + 256));
+        CG_TRY(dc.reserve(dc_total + 256));
+    } else if (stamps) {
         CG_TRY(dc.reserve(dc_total + 256));
     }
     CG_TRY(out.reserve(out_total + 256));
@@ -340,7 +345,7 @@ Status compeg_batch::upload(const ImageData *const *images, size_t n, int thread
         d.words = reinterpret_cast<const uint32_t *>(di + o);
         d.nwords = uint32_t(scans[i].nwords());
         d.ac = fused ? nullptr : reinterpret_cast<int16_t *>(static_cast<uint8_t *>(ac.ptr) + ac_at);
-        d.dc = fused ? nullptr : reinterpret_cast<int32_t *>(static_cast<uint8_t *>(dc.ptr) + dc_at);
+        d.dc = (fused && !stamps) ? nullptr : reinterpret_cast<int32_t *>(static_cast<uint8_t *>(dc.ptr) + dc_at);
         ac_at += size_t(img.total_dus()) * kRetained * 2;
         dc_at += size_t(img.total_dus()) * 4;
         d.out = static_cast<uint8_t *>(out.ptr) + out_offset[i];
@@ -378,7 +383,7 @@ Status compeg_batch::decode(hipStream_t stream)
         CG_HIP(hipEventRecord(ev[0], stream));
     for (uint32_t at = 0; at < n; at += step) {
         const uint32_t m = std::min(step, n - at);
-        const HuffLdsPlan plan = plan_huffman(max_intervals, m, max_l2, max_span);
+        const HuffLdsPlan plan = plan_huffman(max_intervals, m, max_l2, max_span, use_fused_pipeline());
         if (use_fused_pipeline()) {
             CG_HIP(launch_fused_422(dd + at, m, max_intervals, plan, stream));
             if (timing && at == 0)

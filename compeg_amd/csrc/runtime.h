@@ -76,6 +76,7 @@ struct compeg_decoder {
     compeg::Metadata last_md{};
     bool have_last = false;
     compeg::HuffLdsPlan last_plan{};
+    uint32_t last_span = 0;
     bool coefficients_valid = false; // ac/dc hold the last image's coefficients
 
     compeg_decoder();

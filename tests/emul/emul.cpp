@@ -116,7 +116,7 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
             if (du >= d.total_dus)
                 continue;
             const uint32_t comp = (d.comp_of_du >> (2u * (du % d.dus_per_mcu))) & 3u;
-            alignas(16) int16_t rec[kRetained];
+            uint32_t rec[kRetained / 2];
             memcpy(rec, d.ac + size_t(du) * kRetained, sizeof rec);
             uint32_t out[16];
             idct_data_unit(rec, d.dc[du], quant.data() + comp * kRetained, out);
