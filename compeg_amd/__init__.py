@@ -122,6 +122,12 @@ class ScanBuffer:
         a = _host_view(scan_data)
         check(lib.compeg_scanbuffer_process(self._h, a.ctypes.data, a.nbytes, expected_restart_intervals))
 
+    def process_on_gpu(self, gpu, scan_data, expected_restart_intervals):
+        """Same buffers, filled by the device-side scan kernels (extension)."""
+        a = _host_view(scan_data)
+        check(lib.compeg_scanbuffer_process_on_gpu(self._h, gpu._h, a.ctypes.data, a.nbytes,
+                                                   expected_restart_intervals))
+
     def _get(self, fn):
         n = C.c_size_t()
         p = fn(self._h, C.byref(n))
@@ -209,6 +215,10 @@ class Decoder:
     def last_warning(self):
         return lib.compeg_decoder_last_warning(self._h).decode()
 
+    def set_device_preprocess(self, on=True):
+        """Extension: preprocess scans with the device-side scan kernels instead of on the host."""
+        check(lib.compeg_decoder_set_device_preprocess(self._h, 1 if on else 0))
+
     def texture(self):
         p, w, h, pitch = C.c_void_p(), C.c_uint32(), C.c_uint32(), C.c_size_t()
         check(lib.compeg_decoder_output(self._h, C.byref(p), C.byref(w), C.byref(h), C.byref(pitch)))
@@ -251,6 +261,13 @@ class Batch:
         self._images = list(images)
         arr = (C.c_void_p * len(self._images))(*[im._h for im in self._images])
         check(lib.compeg_batch_upload(self._h, arr, len(self._images), host_threads))
+
+    def set_device_preprocess(self, mode):
+        """0 host (default), 1 scan kernels once at upload, 2 scan kernels in every decode."""
+        check(lib.compeg_batch_set_device_preprocess(self._h, mode))
+
+    def host_fallbacks(self):
+        return lib.compeg_batch_host_fallbacks(self._h)
 
     def set_chunk(self, images_per_launch):
         check(lib.compeg_batch_set_chunk(self._h, images_per_launch))

@@ -50,6 +50,7 @@ def _load():
         "compeg_scanbuffer_new": (vp, []),
         "compeg_scanbuffer_free": (None, [vp]),
         "compeg_scanbuffer_process": (i, [vp, vp, sz, u32]),
+        "compeg_scanbuffer_process_on_gpu": (i, [vp, vp, vp, sz, u32]),
         "compeg_scanbuffer_data": (vp, [vp, psz]),
         "compeg_scanbuffer_start_positions": (vp, [vp, psz]),
         "compeg_decoder_new": (i, [vp, pvp]),
@@ -58,6 +59,7 @@ def _load():
         "compeg_decoder_start_decode": (i, [vp, vp, pvp]),
         "compeg_decoder_decode_blocking": (i, [vp, vp, pvp]),
         "compeg_decoder_last_warning": (C.c_char_p, [vp]),
+        "compeg_decoder_set_device_preprocess": (i, [vp, i]),
         "compeg_op_wait": (i, [vp]),
         "compeg_op_texture_changed": (i, [vp]),
         "compeg_op_free": (None, [vp]),
@@ -71,6 +73,8 @@ def _load():
         "compeg_batch_upload": (i, [vp, pvp, sz, i]),
         "compeg_batch_decode": (i, [vp, vp]),
         "compeg_batch_set_chunk": (i, [vp, u32]),
+        "compeg_batch_set_device_preprocess": (i, [vp, i]),
+        "compeg_batch_host_fallbacks": (sz, [vp]),
         "compeg_batch_wait": (i, [vp]),
         "compeg_batch_count": (sz, [vp]),
         "compeg_batch_output": (i, [vp, sz, pvp, pu32, pu32, psz]),

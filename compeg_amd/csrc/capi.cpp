@@ -245,6 +245,17 @@ int compeg_scanbuffer_process(compeg_scanbuffer *sb, const uint8_t *scan, size_t
     });
 }
 
+int compeg_scanbuffer_process_on_gpu(compeg_scanbuffer *sb, compeg_gpu *gpu, const uint8_t *scan,
+                                     size_t len, uint32_t expected_restart_intervals)
+{
+    return guarded([&] {
+        if (!sb || !gpu || (!scan && len))
+            return fail(COMPEG_E_INVALID_ARG, "NULL argument");
+        Status s = sb->buf.process_on_gpu(gpu, scan, len, expected_restart_intervals);
+        return s.ok() ? ok() : fail(s);
+    });
+}
+
 const uint8_t *compeg_scanbuffer_data(const compeg_scanbuffer *sb, size_t *nbytes)
 {
     if (nbytes)
@@ -330,6 +341,14 @@ int compeg_decoder_decode_blocking(compeg_decoder *dec, const compeg_image *img,
     if (rc != COMPEG_OK)
         return rc;
     return compeg_op_wait(*op);
+}
+
+int compeg_decoder_set_device_preprocess(compeg_decoder *dec, int on)
+{
+    if (!dec)
+        return fail(COMPEG_E_INVALID_ARG, "dec is NULL");
+    dec->device_preprocess = on != 0;
+    return ok();
 }
 
 const char *compeg_decoder_last_warning(const compeg_decoder *dec)
@@ -548,6 +567,19 @@ int compeg_batch_wait(compeg_batch *batch)
 size_t compeg_batch_count(const compeg_batch *batch)
 {
     return batch ? batch->count : 0;
+}
+
+int compeg_batch_set_device_preprocess(compeg_batch *batch, int mode)
+{
+    if (!batch || mode < 0 || mode > 2)
+        return fail(COMPEG_E_INVALID_ARG, "bad argument");
+    batch->preprocess_mode = mode;
+    return ok();
+}
+
+size_t compeg_batch_host_fallbacks(const compeg_batch *batch)
+{
+    return batch ? batch->host_fallbacks : 0;
 }
 
 int compeg_batch_set_chunk(compeg_batch *batch, uint32_t images_per_launch)

@@ -130,6 +130,77 @@ compeg_decoder::~compeg_decoder()
         compeg_gpu_release(gpu);
 }
 
+// Device-side variant of the preprocess step of enqueue: raw segment to HBM
+// (pinned staging, async copy), scan kernels, then one small synchronous
+// read-back of the result words (interval count, output size, flags).
+Status compeg_decoder::preprocess_on_device(const ImageData &img, hipStream_t stream, uint32_t &nwords,
+                                            uint32_t &nstarts, uint32_t &span, bool &fell_back)
+{
+    fell_back = false;
+    if (img.scan_len > 0xfffffff0u) {
+        fell_back = true;
+        return Status{};
+    }
+    const uint32_t len = uint32_t(img.scan_len), expected = img.metadata.total_restart_intervals;
+    uint32_t slots = 1;
+    while (slots < expected)
+        slots <<= 1;
+    const uint32_t ntiles = scan_tiles(len), capacity = 2 * expected + 64;
+    size_t total = 64;
+    auto take = [&](size_t bytes) {
+        const size_t at = total;
+        total += align_up(bytes, 256);
+        return at;
+    };
+    const size_t o_desc = take(sizeof(ScanDesc)), o_raw = take(size_t(len) + 64),
+                 o_tk = take(size_t(ntiles) * 4 + 4), o_tm = take(size_t(ntiles) * 4 + 4),
+                 o_mp = take(size_t(capacity) * 4), o_is = take(size_t(capacity) * 4),
+                 o_st = take(size_t(slots) * 4), o_w = take(size_t(len) + len / 3 + 64), o_res = take(16);
+    CG_TRY(scan_arena.reserve(total));
+    CG_TRY(raw_stage.reserve(o_raw + len + 64));
+    uint8_t *da = static_cast<uint8_t *>(scan_arena.ptr), *hs = static_cast<uint8_t *>(raw_stage.ptr);
+    ScanDesc s;
+    s.raw = da + o_raw;
+    s.len = len;
+    s.ntiles = ntiles;
+    s.slots = slots;
+    s.marker_capacity = capacity;
+    s.tile_kept = reinterpret_cast<uint32_t *>(da + o_tk);
+    s.tile_markers = reinterpret_cast<uint32_t *>(da + o_tm);
+    s.marker_pos = reinterpret_cast<uint32_t *>(da + o_mp);
+    s.interval_start = reinterpret_cast<uint32_t *>(da + o_is);
+    s.starts_out = reinterpret_cast<uint32_t *>(da + o_st);
+    s.words_out = da + o_w;
+    s.result = reinterpret_cast<uint32_t *>(da + o_res);
+    // descriptor and segment travel in one copy (the descriptor sits in front of the raw bytes)
+    memset(hs, 0, o_raw);
+    memcpy(hs + o_desc, &s, sizeof s);
+    memcpy(hs + o_raw, img.scan_data(), len);
+    CG_HIP(hipMemcpyAsync(da, hs, o_raw + len, hipMemcpyHostToDevice, stream));
+    CG_HIP(hipMemsetAsync(da + o_res, 0, 16, stream));
+    CG_HIP(launch_scan(reinterpret_cast<const ScanDesc *>(da + o_desc), 1, ntiles, stream));
+    uint32_t res[4];
+    CG_HIP(hipMemcpyAsync(res, da + o_res, 16, hipMemcpyDeviceToHost, stream));
+    CG_HIP(hipStreamSynchronize(stream));
+    if ((res[3] & 1u) || res[0] > capacity) {
+        fell_back = true; // FF run beyond the kernels' bound, or far more markers than announced
+        return Status{};
+    }
+    nwords = res[2];
+    nstarts = std::min(res[0], slots);
+    dev_words = da + o_w;
+    dev_starts = da + o_st;
+    // the per-wave span is not read back: size the window generously from the average
+    const uint64_t avg = expected ? (uint64_t(nwords) + expected - 1) / expected : nwords;
+    span = uint32_t(std::min<uint64_t>(2 * avg * kWave + 64, 0x7fffffffu));
+    if (res[0] != expected) {
+        char msg[128];
+        snprintf(msg, sizeof msg, "restart interval count mismatch: counted %u, expected %u", res[0], expected);
+        warning = msg; // the reference drops this error (lib.rs:391-394)
+    }
+    return Status{};
+}
+
 // Counterpart of Decoder::enqueue (src/lib.rs:385-477).
 Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *changed)
 {
@@ -164,20 +235,33 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     }
 
     const Metadata &md = img.metadata;
-    Status pre = scan.process(img.scan_data(), img.scan_len, md.total_restart_intervals);
-    if (!pre.ok()) {
-        if (pre.code != COMPEG_E_COUNT_MISMATCH)
-            return pre;
-        warning = pre.message; // the reference drops this error (lib.rs:391-394)
+    uint32_t dev_nwords = 0, dev_nstarts = 0, dev_span = 0;
+    bool on_device = device_preprocess && use_fused_pipeline();
+    if (on_device) {
+        bool fell_back = false;
+        CG_TRY(preprocess_on_device(img, stream, dev_nwords, dev_nstarts, dev_span, fell_back));
+        on_device = !fell_back;
     }
+    if (!on_device) {
+        Status pre = scan.process(img.scan_data(), img.scan_len, md.total_restart_intervals);
+        if (!pre.ok()) {
+            if (pre.code != COMPEG_E_COUNT_MISMATCH)
+                return pre;
+            warning = pre.message; // the reference drops this error (lib.rs:391-394)
+        }
+    }
+    const size_t n_words = on_device ? dev_nwords : scan.nwords();
+    const size_t n_starts = on_device ? dev_nstarts : scan.nstarts();
 
     const uint32_t total_dus = img.total_dus();
     const size_t l2_bytes = align_up(img.l2.size() * 2, 4);
     const size_t blob_bytes = align_up(sizeof(ImageDesc), 256) + COMPEG_HUFFMAN_L1_BYTES + l2_bytes;
     CG_TRY(host_blob.reserve(blob_bytes));
     CG_TRY(dev_blob.reserve(blob_bytes));
-    CG_TRY(words.reserve(scan.nwords() * 4 + 16));
-    CG_TRY(starts.reserve(scan.nstarts() * 4 + 16));
+    if (!on_device) {
+        CG_TRY(words.reserve(n_words * 4 + 16));
+        CG_TRY(starts.reserve(n_starts * 4 + 16));
+    }
     CG_TRY(ac.reserve(size_t(total_dus) * kRetained * 2 + 64));
     CG_TRY(dc.reserve(size_t(total_dus) * 4 + 64));
 
@@ -186,10 +270,10 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     const size_t l1_off = align_up(sizeof(ImageDesc), 256), l2_off = l1_off + COMPEG_HUFFMAN_L1_BYTES;
     ImageDesc &d = *reinterpret_cast<ImageDesc *>(hb);
     fill_desc(img, d);
-    d.words = static_cast<const uint32_t *>(words.ptr);
-    d.starts = static_cast<const uint32_t *>(starts.ptr);
-    d.nwords = uint32_t(scan.nwords());
-    d.nstarts = uint32_t(scan.nstarts());
+    d.words = static_cast<const uint32_t *>(on_device ? dev_words : words.ptr);
+    d.starts = static_cast<const uint32_t *>(on_device ? dev_starts : starts.ptr);
+    d.nwords = uint32_t(n_words);
+    d.nstarts = uint32_t(n_starts);
     d.l1 = reinterpret_cast<const uint16_t *>(db + l1_off);
     d.l2 = reinterpret_cast<const uint16_t *>(db + l2_off);
     d.ac = static_cast<int16_t *>(ac.ptr);
@@ -203,12 +287,10 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
         memcpy(hb + l2_off, img.l2.data(), img.l2.size() * 2);
 
     CG_HIP(hipMemcpyAsync(db, hb, blob_bytes, hipMemcpyHostToDevice, stream));
-    if (scan.nstarts())
-        CG_HIP(hipMemcpyAsync(starts.ptr, scan.starts(), scan.nstarts() * 4, hipMemcpyHostToDevice,
-                              stream));
-    if (scan.nwords())
-        CG_HIP(hipMemcpyAsync(words.ptr, scan.words(), scan.nwords() * 4, hipMemcpyHostToDevice,
-                              stream));
+    if (!on_device && n_starts)
+        CG_HIP(hipMemcpyAsync(starts.ptr, scan.starts(), n_starts * 4, hipMemcpyHostToDevice, stream));
+    if (!on_device && n_words)
+        CG_HIP(hipMemcpyAsync(words.ptr, scan.words(), n_words * 4, hipMemcpyHostToDevice, stream));
     CG_HIP(hipEventRecord(upload_done, stream));
     upload_pending = true;
     last_stream = stream;
@@ -217,8 +299,9 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
 
     if (total_dus == 0)
         return Status{};
-    const uint32_t span = max_wave_span(scan.starts(), scan.nstarts(), scan.nwords(),
-                                        md.total_restart_intervals);
+    const uint32_t span = on_device ? dev_span
+                                    : max_wave_span(scan.starts(), scan.nstarts(), scan.nwords(),
+                                                    md.total_restart_intervals);
     const HuffLdsPlan plan = plan_huffman(md.total_restart_intervals, 1, uint32_t(img.l2.size()), span,
                                           use_fused_pipeline());
     last_span = span;
@@ -236,6 +319,72 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     return Status{};
 }
 
+// ScanBuffer::process on the device: copy the raw segment to HBM, run the scan
+// kernels, copy words / start positions back into this buffer's host arrays.
+Status compeg::ScanBuffer::process_on_gpu(compeg_gpu *gpu, const uint8_t *scan, size_t len,
+                                          uint32_t expected)
+{
+    if (len > 0xfffffff0u)
+        return Status::error(COMPEG_E_INVALID_ARG, "scan segment too large");
+    CG_HIP(hipSetDevice(gpu->device));
+    uint32_t slots = 1;
+    while (slots < expected)
+        slots <<= 1;
+    const uint32_t ntiles = scan_tiles(uint32_t(len));
+    const uint32_t capacity = uint32_t(std::min<size_t>(len / 2 + 2, 0x3fffffffu)); // every possible marker
+    DeviceBuffer arena, descbuf;
+    size_t total = 64;
+    auto take = [&](size_t bytes) {
+        const size_t at = total;
+        total += align_up(bytes, 256);
+        return at;
+    };
+    const size_t o_raw = take(len + 64), o_tk = take(size_t(ntiles) * 4 + 4), o_tm = take(size_t(ntiles) * 4 + 4),
+                 o_mp = take(size_t(capacity) * 4), o_is = take(size_t(capacity) * 4),
+                 o_st = take(size_t(slots) * 4), o_w = take(len + len / 3 + 64), o_res = take(16);
+    CG_TRY(arena.reserve(total));
+    CG_TRY(descbuf.reserve(sizeof(ScanDesc)));
+    uint8_t *da = static_cast<uint8_t *>(arena.ptr);
+    CG_HIP(hipMemset(da, 0, total));
+    if (len)
+        CG_HIP(hipMemcpy(da + o_raw, scan, len, hipMemcpyHostToDevice));
+    ScanDesc s;
+    s.raw = da + o_raw;
+    s.len = uint32_t(len);
+    s.ntiles = ntiles;
+    s.slots = slots;
+    s.marker_capacity = capacity;
+    s.tile_kept = reinterpret_cast<uint32_t *>(da + o_tk);
+    s.tile_markers = reinterpret_cast<uint32_t *>(da + o_tm);
+    s.marker_pos = reinterpret_cast<uint32_t *>(da + o_mp);
+    s.interval_start = reinterpret_cast<uint32_t *>(da + o_is);
+    s.starts_out = reinterpret_cast<uint32_t *>(da + o_st);
+    s.words_out = da + o_w;
+    s.result = reinterpret_cast<uint32_t *>(da + o_res);
+    CG_HIP(hipMemcpy(descbuf.ptr, &s, sizeof s, hipMemcpyHostToDevice));
+    CG_HIP(launch_scan(static_cast<const ScanDesc *>(descbuf.ptr), 1, ntiles, gpu->stream));
+    CG_HIP(hipStreamSynchronize(gpu->stream));
+    uint32_t res[4];
+    CG_HIP(hipMemcpy(res, da + o_res, 16, hipMemcpyDeviceToHost));
+    if (res[3] & 1u)
+        return process(scan, len, expected); // FF run beyond the kernels' look-back bound
+    const size_t out_cap = ((len + len / 3 + 3) / 4) * 4;
+    if (!words_.reserve(out_cap + 8) || !starts_.reserve(size_t(slots) * 4))
+        return Status::error(COMPEG_E_HIP, "out of host memory in ScanBuffer");
+    nwords_ = res[2];
+    nstarts_ = std::min(res[0], slots);
+    if (nwords_)
+        CG_HIP(hipMemcpy(words_.data, da + o_w, nwords_ * 4, hipMemcpyDeviceToHost));
+    if (nstarts_)
+        CG_HIP(hipMemcpy(starts_.data, da + o_st, nstarts_ * 4, hipMemcpyDeviceToHost));
+    if (res[0] != expected) {
+        char msg[128];
+        snprintf(msg, sizeof msg, "restart interval count mismatch: counted %u, expected %u", res[0], expected);
+        return Status::error(COMPEG_E_COUNT_MISMATCH, msg);
+    }
+    return Status{};
+}
+
 compeg_batch::~compeg_batch()
 {
     (void)hipStreamSynchronize(last_stream);
@@ -247,6 +396,11 @@ compeg_batch::~compeg_batch()
 
 Status compeg_batch::upload(const ImageData *const *images, size_t n, int threads)
 {
+    if (preprocess_mode != 0) {
+        if (!use_fused_pipeline())
+            return Status::error(COMPEG_E_INVALID_ARG, "device preprocessing needs the fused pipeline");
+        return upload_device_scan(images, n);
+    }
     CG_HIP(hipSetDevice(gpu->device));
     CG_HIP(hipStreamSynchronize(last_stream));
     count = 0;
@@ -360,6 +514,155 @@ Status compeg_batch::upload(const ImageData *const *images, size_t n, int thread
     return Status{};
 }
 
+// Device-side preprocessing: raw entropy-coded segments go to HBM as they are
+// and the scan kernels (scan_kernels.hip) produce words / start positions in
+// the reference layout.
+Status compeg_batch::upload_device_scan(const ImageData *const *images, size_t n)
+{
+    CG_HIP(hipSetDevice(gpu->device));
+    CG_HIP(hipStreamSynchronize(last_stream));
+    count = 0;
+    if (n > 65535)
+        return Status::error(COMPEG_E_INVALID_ARG, "at most 65535 images per batch");
+
+    struct Layout {
+        size_t raw, tile_kept, tile_markers, marker_pos, interval_start, starts, words, result, tables;
+        uint32_t ntiles, slots, capacity;
+    };
+    std::vector<Layout> lay(n);
+    size_t total = 0, out_total = 0;
+    max_tiles = 0;
+    max_intervals = max_dus = max_l2 = max_span = 0;
+    algorithmic_bytes = pixels = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = total;
+        total += align_up(bytes, 256);
+        return at;
+    };
+    for (size_t i = 0; i < n; i++) {
+        const ImageData &img = *images[i];
+        if (img.scan_len > 0xfffffff0u)
+            return Status::error(COMPEG_E_INVALID_ARG, "scan segment too large");
+        Layout &L = lay[i];
+        const uint32_t len = uint32_t(img.scan_len), expected = img.metadata.total_restart_intervals;
+        L.ntiles = scan_tiles(len);
+        L.slots = 1;
+        while (L.slots < expected)
+            L.slots <<= 1;
+        L.capacity = 2 * expected + 64;
+        total += 64; // readable bytes in front of the segment
+        L.raw = take(size_t(len) + 64);
+        L.tile_kept = take(size_t(L.ntiles) * 4 + 4);
+        L.tile_markers = take(size_t(L.ntiles) * 4 + 4);
+        L.marker_pos = take(size_t(L.capacity) * 4);
+        L.interval_start = take(size_t(L.capacity) * 4);
+        L.starts = take(size_t(L.slots) * 4);
+        L.words = take(size_t(len) + len / 3 + 64);
+        L.result = take(16);
+        L.tables = take(COMPEG_HUFFMAN_L1_BYTES + align_up(img.l2.size() * 2, 4));
+        out_total += align_up(size_t(img.width) * 4 * img.height, 256);
+        max_tiles = std::max(max_tiles, L.ntiles);
+        max_intervals = std::max(max_intervals, expected);
+        max_dus = std::max(max_dus, img.total_dus());
+        max_l2 = std::max<uint32_t>(max_l2, uint32_t(img.l2.size()));
+        pixels += uint64_t(img.width) * img.height;
+    }
+    CG_TRY(scan_arena.reserve(total + 256));
+    CG_TRY(scan_descs.reserve(n * sizeof(ScanDesc) + 256));
+    CG_TRY(out.reserve(out_total + 256));
+    CG_HIP(hipMemset(out.ptr, 0, out.capacity));
+    CG_TRY(dev_descs.reserve(n * sizeof(ImageDesc) + 256));
+
+    PinnedBuffer stage;
+    CG_TRY(stage.reserve(total + 256));
+    uint8_t *hs = static_cast<uint8_t *>(stage.ptr), *da = static_cast<uint8_t *>(scan_arena.ptr);
+    memset(hs, 0, total);
+    std::vector<ScanDesc> sd(n);
+    for (size_t i = 0; i < n; i++) {
+        const ImageData &img = *images[i];
+        const Layout &L = lay[i];
+        memcpy(hs + L.raw, img.scan_data(), img.scan_len);
+        memcpy(hs + L.tables, img.l1, COMPEG_HUFFMAN_L1_BYTES);
+        if (!img.l2.empty())
+            memcpy(hs + L.tables + COMPEG_HUFFMAN_L1_BYTES, img.l2.data(), img.l2.size() * 2);
+        ScanDesc &s = sd[i];
+        s.raw = da + L.raw;
+        s.len = uint32_t(img.scan_len);
+        s.ntiles = L.ntiles;
+        s.slots = L.slots;
+        s.marker_capacity = L.capacity;
+        s.tile_kept = reinterpret_cast<uint32_t *>(da + L.tile_kept);
+        s.tile_markers = reinterpret_cast<uint32_t *>(da + L.tile_markers);
+        s.marker_pos = reinterpret_cast<uint32_t *>(da + L.marker_pos);
+        s.interval_start = reinterpret_cast<uint32_t *>(da + L.interval_start);
+        s.starts_out = reinterpret_cast<uint32_t *>(da + L.starts);
+        s.words_out = da + L.words;
+        s.result = reinterpret_cast<uint32_t *>(da + L.result);
+    }
+    CG_HIP(hipMemcpy(da, hs, total, hipMemcpyHostToDevice));
+    CG_HIP(hipMemcpy(scan_descs.ptr, sd.data(), n * sizeof(ScanDesc), hipMemcpyHostToDevice));
+    hipStream_t st = gpu->stream;
+    CG_HIP(launch_scan(static_cast<const ScanDesc *>(scan_descs.ptr), uint32_t(n), max_tiles, st));
+    CG_HIP(hipStreamSynchronize(st));
+
+    // read the per-image results back once: sizes for the decode descriptors
+    descs.assign(n, ImageDesc{});
+    out_offset.assign(n, 0);
+    host_fallbacks = 0;
+    size_t out_at = 0;
+    std::vector<uint32_t> starts_host;
+    for (size_t i = 0; i < n; i++) {
+        const ImageData &img = *images[i];
+        const Layout &L = lay[i];
+        uint32_t res[4];
+        CG_HIP(hipMemcpy(res, da + L.result, 16, hipMemcpyDeviceToHost));
+        uint32_t nwords = res[2], nstarts = std::min(res[0], L.slots);
+        const uint32_t expected = img.metadata.total_restart_intervals;
+        starts_host.resize(L.slots);
+        if ((res[3] & 1u) || res[0] > L.capacity) {
+            // pathological FF run or far more markers than announced: the host
+            // preprocessor (same output format) takes this image
+            ScanBuffer sb;
+            Status s = sb.process(img.scan_data(), img.scan_len, expected);
+            if (!s.ok() && s.code != COMPEG_E_COUNT_MISMATCH)
+                return s;
+            nwords = uint32_t(sb.nwords());
+            nstarts = uint32_t(sb.nstarts());
+            if (nwords)
+                CG_HIP(hipMemcpy(da + L.words, sb.words(), size_t(nwords) * 4, hipMemcpyHostToDevice));
+            if (nstarts)
+                CG_HIP(hipMemcpy(da + L.starts, sb.starts(), size_t(nstarts) * 4, hipMemcpyHostToDevice));
+            memcpy(starts_host.data(), sb.starts(), size_t(nstarts) * 4);
+            host_fallbacks++;
+        } else if (nstarts) {
+            CG_HIP(hipMemcpy(starts_host.data(), da + L.starts, size_t(nstarts) * 4, hipMemcpyDeviceToHost));
+        }
+        ImageDesc &d = descs[i];
+        fill_desc(img, d);
+        d.l1 = reinterpret_cast<const uint16_t *>(da + L.tables);
+        d.l2 = reinterpret_cast<const uint16_t *>(da + L.tables + COMPEG_HUFFMAN_L1_BYTES);
+        d.words = reinterpret_cast<const uint32_t *>(da + L.words);
+        d.starts = reinterpret_cast<const uint32_t *>(da + L.starts);
+        d.nwords = nwords;
+        d.nstarts = nstarts;
+        d.ac = nullptr;
+        d.dc = nullptr;
+        out_offset[i] = out_at;
+        d.out = static_cast<uint8_t *>(out.ptr) + out_at;
+        out_at += align_up(size_t(img.width) * 4 * img.height, 256);
+        d.out_w = img.width;
+        d.out_h = img.height;
+        d.out_pitch = img.width * 4;
+        max_span = std::max(max_span, max_wave_span(starts_host.data(), nstarts, nwords, expected));
+        algorithmic_bytes += 4ull * nwords + 4ull * expected + COMPEG_METADATA_BYTES +
+                             COMPEG_HUFFMAN_L1_BYTES + img.l2.size() * 2 + 4ull * img.width * img.height;
+    }
+    CG_HIP(hipMemcpy(dev_descs.ptr, descs.data(), n * sizeof(ImageDesc), hipMemcpyHostToDevice));
+    count = n;
+    decodes_timed = 0;
+    return Status{};
+}
+
 Status compeg_batch::decode(hipStream_t stream)
 {
     if (count == 0)
@@ -381,6 +684,8 @@ Status compeg_batch::decode(hipStream_t stream)
     const uint32_t step = chunk ? std::min(chunk, n) : n;
     if (timing)
         CG_HIP(hipEventRecord(ev[0], stream));
+    if (preprocess_mode == 2 && host_fallbacks == 0)
+        CG_HIP(launch_scan(static_cast<const ScanDesc *>(scan_descs.ptr), n, max_tiles, stream));
     for (uint32_t at = 0; at < n; at += step) {
         const uint32_t m = std::min(step, n - at);
         const HuffLdsPlan plan = plan_huffman(max_intervals, m, max_l2, max_span, use_fused_pipeline());

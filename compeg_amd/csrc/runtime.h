@@ -15,6 +15,7 @@
 #include "front.h"
 #include "kernels.h"
 #include "scan.h"
+#include "scan_kernels.h"
 
 namespace compeg {
 
@@ -79,9 +80,18 @@ struct compeg_decoder {
     uint32_t last_span = 0;
     bool coefficients_valid = false; // ac/dc hold the last image's coefficients
 
+    // false (default): the scan is preprocessed on the host like the reference;
+    // true: the raw entropy-coded segment is uploaded and the scan kernels do it.
+    bool device_preprocess = false;
+    compeg::DeviceBuffer scan_arena;
+    compeg::PinnedBuffer raw_stage;
+    const void *dev_words = nullptr, *dev_starts = nullptr;
+
     compeg_decoder();
     ~compeg_decoder();
     compeg::Status enqueue(const compeg::ImageData &img, hipStream_t stream, bool *changed);
+    compeg::Status preprocess_on_device(const compeg::ImageData &img, hipStream_t stream, uint32_t &nwords,
+                                        uint32_t &nstarts, uint32_t &span, bool &fell_back);
 };
 
 struct compeg_batch {
@@ -99,7 +109,17 @@ struct compeg_batch {
     size_t decodes_timed = 0;
     hipStream_t last_stream = nullptr;
 
+    // 0: scans are preprocessed on the host at upload (the reference's data flow);
+    // 1: raw scans are uploaded and preprocessed once by the scan kernels;
+    // 2: like 1, and every decode() re-runs the scan kernels first, so that a
+    //    timed step covers the whole path from raw entropy-coded bytes to RGBA.
+    int preprocess_mode = 0;
+    compeg::DeviceBuffer scan_descs, scan_arena;
+    uint32_t max_tiles = 0;
+    size_t host_fallbacks = 0; // images the scan kernels handed back to the host
+
     ~compeg_batch();
     compeg::Status upload(const compeg::ImageData *const *images, size_t n, int threads);
+    compeg::Status upload_device_scan(const compeg::ImageData *const *images, size_t n);
     compeg::Status decode(hipStream_t stream);
 };

@@ -9,6 +9,8 @@
 
 #include "front.h"
 
+struct compeg_gpu;
+
 namespace compeg {
 
 // Grow-only byte arena; the decoder plugs in pinned host memory so that the
@@ -37,6 +39,9 @@ class ScanBuffer {
     // COMPEG_E_COUNT_MISMATCH leaves the truncated result in place, like the
     // reference (scan.rs:55-63).
     Status process(const uint8_t *scan, size_t len, uint32_t expected_intervals);
+    // Same buffers, filled by the device-side scan kernels (runtime.cpp).
+    Status process_on_gpu(struct ::compeg_gpu *gpu, const uint8_t *scan, size_t len,
+                          uint32_t expected_intervals);
 
     const uint8_t *data() const { return words_.data; }
     size_t data_bytes() const { return nwords_ * 4; }

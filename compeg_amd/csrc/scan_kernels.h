@@ -1,0 +1,31 @@
+// Device-side scan preprocessing: launchers and the per-image descriptor.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace compeg {
+
+// All pointers are device pointers.  `raw` must be readable 16 bytes before
+// and after the segment (the input arenas are padded accordingly).
+struct ScanDesc {
+    const uint8_t *raw;      // entropy-coded segment incl. RSTn markers and FF 00 stuffing
+    uint32_t len;
+    uint32_t ntiles;         // ceil(len / 4096)
+    uint32_t slots;          // next_power_of_two(expected intervals), >= 1
+    uint32_t marker_capacity; // entries of marker_pos / interval_start
+    uint32_t *tile_kept;     // [ntiles] scratch
+    uint32_t *tile_markers;  // [ntiles] scratch
+    uint32_t *marker_pos;    // [marker_capacity] kept bytes in front of marker m (P[0] = 0)
+    uint32_t *interval_start; // [marker_capacity] start word of interval m
+    uint32_t *starts_out;    // [slots] the reference's start_positions
+    uint8_t *words_out;      // preprocessed scan, (len + len/3 + 4) bytes
+    uint32_t *result;        // [4]: intervals counted, kept bytes, output words, flags (bit 0: FF run too long)
+};
+
+uint32_t scan_tiles(uint32_t len);
+hipError_t launch_scan(const ScanDesc *descs, uint32_t images, uint32_t max_tiles, hipStream_t stream);
+
+} // namespace compeg

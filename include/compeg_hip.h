@@ -99,6 +99,12 @@ void compeg_scanbuffer_free(compeg_scanbuffer *sb);
  * the (truncated) result, as in the reference. */
 int compeg_scanbuffer_process(compeg_scanbuffer *sb, const uint8_t *scan, size_t len,
                               uint32_t expected_restart_intervals);
+/* Same result, computed by the device-side scan kernels: the
+ * segment is copied to HBM, preprocessed there and the two buffers are copied
+ * back.  Inputs the kernels hand back (FF runs longer than 64 KiB) are
+ * processed on the host. */
+int compeg_scanbuffer_process_on_gpu(compeg_scanbuffer *sb, compeg_gpu *gpu, const uint8_t *scan,
+                                     size_t len, uint32_t expected_restart_intervals);
 /* `processed_scan_data()` / `start_positions()`: valid until the next process(). */
 const uint8_t *compeg_scanbuffer_data(const compeg_scanbuffer *sb, size_t *nbytes);
 const uint8_t *compeg_scanbuffer_start_positions(const compeg_scanbuffer *sb, size_t *nbytes);
@@ -122,6 +128,11 @@ int compeg_decoder_start_decode(compeg_decoder *dec, const compeg_image *img, co
 /* `decode_blocking` (lib.rs:508-529): start_decode + wait. */
 int compeg_decoder_decode_blocking(compeg_decoder *dec, const compeg_image *img, compeg_op **op);
 const char *compeg_decoder_last_warning(const compeg_decoder *dec);
+/* Extension: on != 0 moves the scan preprocessing of every following decode
+ * from the host (the reference's data flow, default) to the device-side scan
+ * kernels; the raw entropy-coded segment is uploaded instead of the
+ * preprocessed one.  Results are identical. */
+int compeg_decoder_set_device_preprocess(compeg_decoder *dec, int on);
 
 /* `DecodeOp` (lib.rs:541-574).  compeg_op_wait replaces polling the
  * SubmissionIndex.  Ops are freed by the caller. */
@@ -168,6 +179,14 @@ int compeg_batch_upload(compeg_batch *batch, const compeg_image *const *images, 
 /* Records the decode of every uploaded image on hip_stream (NULL = the gpu's
  * stream) and returns without waiting. */
 int compeg_batch_decode(compeg_batch *batch, void *hip_stream);
+/* Where the scans are preprocessed.  0 (default): on the host during
+ * compeg_batch_upload, like the reference.  1: raw entropy-coded segments are
+ * uploaded and preprocessed once by the scan kernels.  2: like 1, and every
+ * compeg_batch_decode re-runs the scan kernels first, i.e. a decode covers the
+ * whole path from raw scan bytes in HBM to RGBA.  Set before upload. */
+int compeg_batch_set_device_preprocess(compeg_batch *batch, int mode);
+/* Images of the last upload that the scan kernels handed back to the host. */
+size_t compeg_batch_host_fallbacks(const compeg_batch *batch);
 /* Images per kernel-launch pair (0 = the whole batch in one pair, the default).
  * Smaller chunks keep the coefficient intermediates cache-resident. */
 int compeg_batch_set_chunk(compeg_batch *batch, uint32_t images_per_launch);

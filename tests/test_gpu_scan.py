@@ -1,0 +1,123 @@
+"""Device-side scan preprocessing against the oracle's restatement of
+src/scan.rs: byte-identical words and start positions, same error text."""
+import numpy as np
+import pytest
+
+from conftest import read_golden
+from oracle import oracle as orc
+from tools import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ca():
+    import compeg_amd
+    return compeg_amd
+
+
+@pytest.fixture(scope="module")
+def gpu(ca):
+    return ca.Gpu.open(0)
+
+
+def _both(ca, gpu, data, expected):
+    a, b = ca.ScanBuffer(), orc.ScanBuffer()
+    ea = eb = None
+    try:
+        a.process_on_gpu(gpu, data, expected)
+    except ca.Error as e:
+        ea = str(e)
+        assert e.code == ca.E_COUNT_MISMATCH
+    try:
+        b.process(data, expected)
+    except orc.OracleError as e:
+        eb = str(e)
+    assert ea == eb
+    assert a.start_positions() == b.start_positions()
+    assert a.processed_scan_data() == b.processed_scan_data()
+
+
+def test_reference_kats_on_gpu(ca, gpu):
+    # ref src/scan.rs:151-180
+    _both(ca, gpu, bytes([0x12, 0x34, 0x56, 0x78]), 1)
+    _both(ca, gpu, bytes([0xFF, 0xD0, 0xFF, 0xD0]), 3)
+    _both(ca, gpu, bytes([0xFF, 0x00, 0x44, 0x55, 0xFF, 0xD0, 0x34]), 2)
+    _both(ca, gpu, bytes([0x11, 0xFF, 0xD0, 0x11, 0xFF, 0xD0, 0x11]), 3)
+    _both(ca, gpu, bytes([0x11, 0xFF, 0xD0, 0x11, 0xFF, 0xD0, 0x11]), 1)   # the mismatch error text
+    _both(ca, gpu, b"", 0)
+    _both(ca, gpu, b"\xff", 1)
+    _both(ca, gpu, b"\xff\xff\xff", 2)
+    _both(ca, gpu, b"\xff\xff\x00\xff", 2)
+
+
+def test_bench_data_on_gpu(ca, gpu):
+    data = read_golden("scan", "scan.dat")       # ref benches/bench.rs: 42 876 intervals
+    _both(ca, gpu, data, 42876)
+    _both(ca, gpu, data, 42875)                  # count mismatch, wrapped slot indices
+    _both(ca, gpu, data, 1000)
+    _both(ca, gpu, data, 50000)
+
+
+def test_fuzz_on_gpu(ca, gpu):
+    rng = np.random.default_rng(11)
+    for it in range(150):
+        n = int(rng.integers(0, 20000))
+        data = rng.integers(0, 256, n, dtype=np.uint8)
+        data[rng.random(n) < 0.08] = 0xFF         # FF pairs, FF FF, FF runs across tile borders
+        data[rng.random(n) < 0.05] = 0
+        if it % 5 == 0 and n > 5000:
+            s = int(rng.integers(0, n - 300))
+            data[s:s + int(rng.integers(2, 300))] = 0xFF
+        _both(ca, gpu, data.tobytes(), int(rng.integers(0, 400)))
+
+
+def test_long_ff_run_falls_back_to_host(ca, gpu):
+    data = bytes([1, 2, 3]) + b"\xff" * 70000 + bytes([0, 5, 6])
+    _both(ca, gpu, data, 35001)
+
+
+def test_real_scans_on_gpu(ca, gpu):
+    for w, h, kind, q, ri in ((640, 360, 0, 85, 4), (1920, 1080, 1, 95, 1), (3840, 2160, 0, 85, 4)):
+        jpeg = synth.make_jpeg(w, h, seed=w, kind=kind, quality=q, ri=ri)
+        img = orc.ImageData(jpeg)
+        _both(ca, gpu, img.scan_data(), img.parallelism())
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_batch_with_device_preprocess(ca, gpu, mode):
+    jpegs = [synth.make_jpeg(w, h, seed=80 + i, kind=k, quality=q, ri=ri)
+             for i, (w, h, k, q, ri) in enumerate([(640, 360, 0, 85, 4), (320, 240, 1, 95, 1),
+                                                   (1280, 720, 0, 70, 8), (64, 8, 0, 100, 2),
+                                                   (250, 70, 2, 85, 3), (1920, 1080, 0, 85, 4)])]
+    images = [ca.ImageData(j) for j in jpegs]
+    batch = ca.Batch(gpu)
+    batch.set_device_preprocess(mode)
+    batch.upload(images)
+    assert batch.host_fallbacks() == 0
+    for _ in range(2):
+        batch.decode()
+    batch.wait()
+    for i, j in enumerate(jpegs):
+        want = orc.ImageData(j).decode()
+        got = batch.read_output(i)
+        assert np.array_equal(got, want), f"image {i}"
+
+
+def test_decoder_with_device_preprocess(ca, gpu):
+    dec = ca.Decoder(gpu)
+    dec.set_device_preprocess(True)
+    for w, h, kind, q, ri, seed in ((640, 360, 0, 85, 4, 1), (250, 70, 0, 50, 3, 2), (1920, 1080, 1, 95, 1, 3),
+                                    (64, 8, 0, 100, 1, 4), (3840, 2160, 0, 85, 4, 5)):
+        jpeg = synth.make_jpeg(w, h, seed=seed, kind=kind, quality=q, ri=ri)
+        data = ca.ImageData(jpeg)
+        dec.decode_blocking(data)
+        got = dec.read_texture(w, h)
+        assert np.array_equal(got, orc.ImageData(jpeg).decode()), (w, h)
+    # count mismatch is still only a warning
+    j = bytearray(synth.make_jpeg(128, 32, seed=40, ri=2))
+    i = j.find(b"\xff\xdd")
+    j[i + 4:i + 6] = (4).to_bytes(2, "big")
+    dec.decode_blocking(ca.ImageData(bytes(j)))
+    assert dec.last_warning().startswith("restart interval count mismatch: counted")
+    assert np.array_equal(dec.read_texture(128, 32), orc.ImageData(bytes(j)).decode())
