@@ -111,6 +111,81 @@ decode_fused_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds,
     decode_interval_fused_422(d, s, interval, lane);
 }
 
+// Latency-oriented variant of the fused path for launches that cannot fill
+// the chip (a single 4K frame with DRI=4 is 254 waves for 1024 SIMDs): every
+// workgroup is a PAIR of waves working on the same 64 restart intervals.
+// Wave 0 only entropy-decodes; wave 1 takes each finished data unit out of LDS
+// and runs IDCT + composite while wave 0 is already decoding the next one.
+// Coefficient slots and DC terms are double-buffered in LDS; one workgroup
+// barrier per data unit hands a buffer over.  Same arithmetic, same bytes out.
+__global__ void __launch_bounds__(128, 2)
+decode_pair_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const ImageDesc &d = descs[blockIdx.y];
+    const uint32_t first_interval = blockIdx.x * kWave;
+    if (first_interval >= d.total_intervals)
+        return;
+
+    uint16_t *l1 = reinterpret_cast<uint16_t *>(smem);
+    uint16_t *l2 = l1 + kL1Entries;
+    uint8_t *area = smem + align16((kL1Entries + l2_in_lds) * 2u);
+    uint32_t *win = reinterpret_cast<uint32_t *>(area);
+    uint8_t *slots = area + align16(window_words * 4u);          // 2 x 64 slots
+    int32_t *dcs = reinterpret_cast<int32_t *>(slots + 2u * kWave * kDuSlotBytes); // 2 x 64 DC terms
+
+    stage_luts(d, l1, l2, l2_in_lds, threadIdx.x, blockDim.x);
+    const uint32_t wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    uint32_t win_base = 0, win_len = 0;
+    wave_window(d, first_interval, window_words, win_base, win_len);
+    // both waves stage the window: 128 threads, interleaved
+    for (uint32_t i = threadIdx.x; i < win_len; i += blockDim.x)
+        win[i] = win_base + i < d.nwords ? bswap32(CG_GLOBAL(const uint32_t, d.words)[win_base + i]) : 0u;
+    for (uint32_t i = threadIdx.x; i < 2u * kWave * kDuSlotBytes / 4u; i += blockDim.x)
+        reinterpret_cast<slot_word_t *>(slots)[i] = 0u;
+    __syncthreads();
+
+    const uint32_t interval = first_interval + lane;
+    const bool active = interval < d.total_intervals;
+    const uint32_t du_total = d.restart_interval * 4u;
+
+    HuffShared s;
+    s.l1 = l1;
+    s.l2 = l2;
+    s.l2_staged = umin(l2_in_lds, d.l2_entries);
+    s.win = win;
+    s.win_base = win_base;
+    s.win_len = win_len;
+    s.du_slots = slots;
+
+    if (wave == 0) {
+        EntropyState e;
+        if (active)
+            entropy_init(e, d, s, interval);
+#pragma unroll 1
+        for (uint32_t du = 0; du < du_total; du++) {
+            const uint32_t k = du & 3u, comp = k < 2u ? 0u : k - 1u, set = du & 1u;
+            if (active) {
+                uint8_t *slot = slots + (set * kWave + lane) * kDuSlotBytes;
+                dcs[set * kWave + lane] = entropy_data_unit(e, d, s, comp, reinterpret_cast<int16_t *>(slot));
+            }
+            __syncthreads(); // hand data unit `du` to the transformer
+        }
+    } else {
+        PixelState t;
+        pixel_init(t, d, active ? interval : 0u);
+#pragma unroll 1
+        for (uint32_t du = 0; du < du_total; du++) {
+            const uint32_t k = du & 3u, comp = k < 2u ? 0u : k - 1u, set = du & 1u;
+            __syncthreads(); // data unit `du` is complete
+            if (active) {
+                uint8_t *slot = slots + (set * kWave + lane) * kDuSlotBytes;
+                pixel_data_unit(t, d, k, comp, slot, dcs[set * kWave + lane]);
+            }
+        }
+    }
+}
+
 // One lane per data unit for the IDCT, then the same lanes regroup (through
 // LDS) so that every wave-wide store writes 16 MCUs x 64 contiguous bytes.
 __global__ void __launch_bounds__(256)
@@ -240,6 +315,20 @@ hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t ma
     if (attr != hipSuccess)
         return attr;
     hipLaunchKernelGGL(decode_fused_422_kernel, grid, dim3(threads), plan.total_bytes, stream, descs,
+                       plan.l2_entries_in_lds, plan.window_words);
+    return hipGetLastError();
+}
+
+hipError_t launch_pair_422(const ImageDesc *descs, uint32_t images, uint32_t max_intervals,
+                           const HuffLdsPlan &plan, hipStream_t stream)
+{
+    if (images == 0 || max_intervals == 0)
+        return hipSuccess;
+    dim3 grid((max_intervals + kWave - 1) / kWave, images, 1);
+    const uint32_t tables = (((kL1Entries + plan.l2_entries_in_lds) * 2u) + 15u) & ~15u;
+    const uint32_t lds = tables + ((plan.window_words * 4u + 15u) & ~15u) + 2u * kWave * kDuSlotBytes +
+                         2u * kWave * 4u;
+    hipLaunchKernelGGL(decode_pair_422_kernel, grid, dim3(2 * kWave), lds, stream, descs,
                        plan.l2_entries_in_lds, plan.window_words);
     return hipGetLastError();
 }

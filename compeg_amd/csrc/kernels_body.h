@@ -843,6 +843,80 @@ CG_DEV void composite_own_mcu_422(const ImageDesc &d, const uint32_t (&px)[4][16
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same work as two cooperating roles (decoder wave + transformer wave)
+// ---------------------------------------------------------------------------
+
+// Entropy-decoder role: reader and DC predictors of one restart interval.
+struct EntropyState {
+    PrefetchReader r;
+    int32_t pred0, pred1, pred2;
+};
+
+CG_DEV void entropy_init(EntropyState &e, const ImageDesc &d, const HuffShared &s, uint32_t interval)
+{
+    reader_init(e.r, d, s, interval < d.nstarts ? CG_GLOBAL(const uint32_t, d.starts)[interval] : 0u);
+    reader_refill<false>(e.r, d, s);
+    e.pred0 = e.pred1 = e.pred2 = 0;
+}
+
+// One data unit: DC difference + AC coefficients into `slot16` (zeroed by the
+// consumer); returns the dequantised DC term.  comp is wave-uniform.
+CG_DEV int32_t entropy_data_unit(EntropyState &e, const ImageDesc &d, const HuffShared &s, uint32_t comp,
+                                 int16_t *slot16)
+{
+    const int32_t diff = decode_dc_diff(e.r, d, s, d.dc_table[comp] * 256u);
+    int32_t p = comp == 0u ? e.pred0 : (comp == 1u ? e.pred1 : e.pred2);
+    p = int32_t(uint32_t(p) + uint32_t(diff));
+    e.pred0 = comp == 0u ? p : e.pred0;
+    e.pred1 = comp == 1u ? p : e.pred1;
+    e.pred2 = comp == 2u ? p : e.pred2;
+    decode_ac(e.r, d, s, d.ac_table[comp] * 256u, slot16);
+    return int32_t(uint32_t(p) * d.dc_quant[comp]);
+}
+
+// Transformer role: the samples of the MCU being assembled and where it goes.
+struct PixelState {
+    uint32_t px[4][16]; // 4-deep shift chain: after Cr it holds Y0 Y1 Cb Cr
+    uint32_t mx, my;
+};
+
+CG_DEV void pixel_init(PixelState &t, const ImageDesc &d, uint32_t interval)
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int w = 0; w < 16; w++)
+            t.px[k][w] = 0u;
+    const uint32_t mcu = interval * d.restart_interval;
+    t.mx = mcu % d.width_mcus;
+    t.my = mcu / d.width_mcus;
+}
+
+// One data unit: coefficients out of `slot` (cleared for reuse), IDCT, and
+// after the MCU's last data unit (k == 3) the composite of the whole MCU.
+CG_DEV void pixel_data_unit(PixelState &t, const ImageDesc &d, uint32_t k, uint32_t comp, uint8_t *slot,
+                            int32_t dc)
+{
+    uint32_t rec[kRetained / 2];
+    take_slot(slot, rec);
+#pragma unroll
+    for (int w = 0; w < 16; w++) {
+        t.px[0][w] = t.px[1][w];
+        t.px[1][w] = t.px[2][w];
+        t.px[2][w] = t.px[3][w];
+    }
+    idct_data_unit(rec, dc, d.quant[comp], t.px[3]);
+    if (k == 3u) {
+        composite_own_mcu_422(d, t.px, t.mx, t.my);
+        t.mx++;
+        if (t.mx == d.width_mcus) {
+            t.mx = 0;
+            t.my++;
+        }
+    }
+}
+
 // The whole path for one restart interval of a 4:2:2 image: entropy decode,
 // IDCT and composite, data unit by data unit.  Every lane of a wave runs
 // this on its own interval; the per-data-unit `while` loop in decode_ac is

@@ -101,6 +101,21 @@ bool use_fused_pipeline()
     return fused;
 }
 
+// Launches too small to fill the chip (fewer decoder waves than 3/4 of the
+// SIMDs) use the paired-wave kernel: it halves the critical path of a wave
+// at the price of a second wave per 64 intervals.
+bool use_pair_kernel(uint32_t max_intervals, uint32_t images)
+{
+    static const int forced = [] {
+        const char *e = getenv("COMPEG_PAIR"); // experiment knob: 0 / 1
+        return e ? atoi(e) : -1;
+    }();
+    if (forced >= 0)
+        return forced != 0;
+    const uint64_t waves = uint64_t((max_intervals + kWave - 1) / kWave) * images;
+    return waves <= 768;
+}
+
 namespace {
 
 void *pinned_alloc(size_t n)
@@ -307,8 +322,12 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     last_span = span;
     last_plan = plan;
     if (use_fused_pipeline()) {
-        CG_HIP(launch_fused_422(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals,
-                                plan, stream));
+        if (use_pair_kernel(md.total_restart_intervals, 1))
+            CG_HIP(launch_pair_422(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals,
+                                   plan, stream));
+        else
+            CG_HIP(launch_fused_422(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals,
+                                    plan, stream));
         coefficients_valid = false;
     } else {
         CG_HIP(launch_huffman(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals,
@@ -690,7 +709,10 @@ Status compeg_batch::decode(hipStream_t stream)
         const uint32_t m = std::min(step, n - at);
         const HuffLdsPlan plan = plan_huffman(max_intervals, m, max_l2, max_span, use_fused_pipeline());
         if (use_fused_pipeline()) {
-            CG_HIP(launch_fused_422(dd + at, m, max_intervals, plan, stream));
+            if (use_pair_kernel(max_intervals, m))
+                CG_HIP(launch_pair_422(dd + at, m, max_intervals, plan, stream));
+            else
+                CG_HIP(launch_fused_422(dd + at, m, max_intervals, plan, stream));
             if (timing && at == 0)
                 CG_HIP(hipEventRecord(ev[1], stream));
             continue;

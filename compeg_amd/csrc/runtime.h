@@ -21,6 +21,7 @@ namespace compeg {
 
 Status hip_status(hipError_t e, const char *what);
 bool use_fused_pipeline();
+bool use_pair_kernel(uint32_t max_intervals, uint32_t images);
 
 // Grow-only device allocation; contents are not preserved across growth
 // (every user rewrites the buffer in full before reading it).

@@ -60,6 +60,54 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
     d.out_h = tex_h;
     d.out_pitch = tex_w * 4;
 
+    if (fused == 2) {
+        // ---- decode_pair_422_kernel: decoder role and transformer role, data unit by data unit ----
+        l2_in_lds &= ~1u;
+        const uint32_t lds_bytes = align16((kL1Entries + l2_in_lds) * 2u) + align16(window_words * 4u) +
+                                   2u * kWave * kDuSlotBytes + 2u * kWave * 4u;
+        for (uint32_t first = 0; first < d.total_intervals; first += kWave) {
+            uint8_t *smem = static_cast<uint8_t *>(aligned_alloc(16, align16(lds_bytes)));
+            memset(smem, 0xa5, lds_bytes);
+            uint16_t *sl1 = reinterpret_cast<uint16_t *>(smem);
+            uint16_t *sl2 = sl1 + kL1Entries;
+            uint8_t *area = smem + align16((kL1Entries + l2_in_lds) * 2u);
+            uint32_t *win = reinterpret_cast<uint32_t *>(area);
+            uint8_t *slots = area + align16(window_words * 4u);
+            int32_t *dcs = reinterpret_cast<int32_t *>(slots + 2u * kWave * kDuSlotBytes);
+            for (uint32_t tid = 0; tid < 128; tid++)
+                stage_luts(d, sl1, sl2, l2_in_lds, tid, 128);
+            uint32_t wb = 0, wl = 0;
+            wave_window(d, first, window_words, wb, wl);
+            for (uint32_t i = 0; i < wl; i++)
+                win[i] = wb + i < d.nwords ? bswap32(d.words[wb + i]) : 0u;
+            memset(slots, 0, 2u * kWave * kDuSlotBytes);
+            HuffShared sh{sl1, sl2, umin(l2_in_lds, d.l2_entries), win, wb, wl, slots};
+            std::vector<EntropyState> es(kWave);
+            std::vector<PixelState> ps(kWave);
+            for (uint32_t lane = 0; lane < uint32_t(kWave); lane++) {
+                if (first + lane >= d.total_intervals)
+                    continue;
+                entropy_init(es[lane], d, sh, first + lane);
+                pixel_init(ps[lane], d, first + lane);
+            }
+            const uint32_t du_total = d.restart_interval * 4u;
+            for (uint32_t du = 0; du < du_total; du++) {
+                const uint32_t k = du & 3u, comp = k < 2u ? 0u : k - 1u, set = du & 1u;
+                for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
+                    if (first + lane < d.total_intervals)
+                        dcs[set * kWave + lane] = entropy_data_unit(
+                            es[lane], d, sh, comp, reinterpret_cast<int16_t *>(slots + (set * kWave + lane) * kDuSlotBytes));
+                for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
+                    if (first + lane < d.total_intervals)
+                        pixel_data_unit(ps[lane], d, k, comp, slots + (set * kWave + lane) * kDuSlotBytes,
+                                        dcs[set * kWave + lane]);
+            }
+            free(smem);
+        }
+        delete img;
+        return 0;
+    }
+
     // ---- huffman_kernel ----
     l2_in_lds &= ~1u;
     const uint32_t threads = waves_per_block * kWave;
@@ -170,7 +218,7 @@ int main(int argc, char **argv)
     char err[256] = "";
     int rc = emul_decode(exact, jpeg.size(), rgba.data(), tex_w, tex_h, ac.data(), dc.data(),
                          uint32_t(atoi(argv[5])), uint32_t(atoi(argv[6])), uint32_t(atoi(argv[7])),
-                         err, sizeof err, getenv("EMUL_FUSED") ? 1 : 0);
+                         err, sizeof err, getenv("EMUL_FUSED") ? atoi(getenv("EMUL_FUSED")) : 0);
     free(exact);
     if (rc != 0) {
         printf("error: %s\n", err);

@@ -29,7 +29,7 @@ def _run(runner, tmp_path, jpeg, fused, waves=1, window=2048, l2=8192):
     env = dict(os.environ)
     env.pop("EMUL_FUSED", None)
     if fused:
-        env["EMUL_FUSED"] = "1"
+        env["EMUL_FUSED"] = str(int(fused))   # 1 = fused kernel, 2 = paired-wave kernel
     r = subprocess.run([runner, str(p), str(tmp_path / "rgba"), str(tmp_path / "ac"), str(tmp_path / "dc"),
                         str(waves), str(window), str(l2)], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr[-2000:]
@@ -39,7 +39,7 @@ def _run(runner, tmp_path, jpeg, fused, waves=1, window=2048, l2=8192):
 
 def _check(runner, tmp_path, jpeg, **kw):
     want = orc.ImageData(jpeg).decode()
-    for fused in (True, False):
+    for fused in (1, 2, 0):   # fused kernel, paired-wave kernel, split kernels
         got = _run(runner, tmp_path, jpeg, fused, **kw)
         assert np.array_equal(got, want), f"fused={fused}: {(got != want).any(axis=2).sum()} pixels differ"
 
