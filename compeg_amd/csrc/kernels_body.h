@@ -480,14 +480,40 @@ CG_DEV void idct_data_unit(const uint32_t (&ac)[kRetained / 2], int32_t dc, cons
 // Fused path: one lane decodes, transforms and composites its own MCUs
 // ---------------------------------------------------------------------------
 
-// Bit reader with the next stream word already in flight: the LDS (or global)
-// read issued at one refill is consumed at the next, so its latency hides
-// behind the symbols in between.  State and arithmetic are those of the
-// reference reader (cur / nxt / left), only the fetch is hoisted.
+// Bit reader of the fused path.  Same state as the reference reader
+// (src/huffman.wgsl:35-79) in a different shape: its two 32-bit words cur / nxt
+// are the halves of one 64-bit register, so that
+//   consume(n) : cur = cur << n | nxt >> (32 - n); nxt <<= n   is   buf <<= n
+//   refill     : cur |= w >> left; nxt = (w << 1) << (31 - left)
+//                is   hi(buf) |= hi(w << (32 - left)); lo(buf) = lo(w << (32 - left))
+// (nxt is assigned, not merged: that matters only after a hostile DC category
+// >= 32 made `left` lose track of the buffer).  `left` keeps the reference's
+// wrapping u32 arithmetic, including its behaviour after an underflow at a DC
+// code (quirk Q1: left wraps and no further word is ever loaded).  The next
+// stream word is kept in flight: the read issued at one refill is consumed at
+// the next, so its latency hides behind the symbols in between.
 struct PrefetchReader {
-    BitReader b;
-    uint32_t pre; // == word[b.next_word], MSB-first
+    uint64_t buf;   // cur = high half, nxt = low half
+    uint32_t left;
+    uint32_t next_word;
+    uint32_t pre;   // == word[next_word], MSB-first
 };
+
+CG_DEV uint32_t reader_cur(const PrefetchReader &r)
+{
+    return uint32_t(r.buf >> 32);
+}
+
+CG_DEV void reader_consume(PrefetchReader &r, uint32_t n)
+{
+    r.buf <<= (n & 31u); // the reference's shift counts are modulo 32
+    r.left -= n;
+}
+
+CG_DEV uint32_t reader_peek(const PrefetchReader &r, uint32_t n)
+{
+    return (reader_cur(r) >> 1) >> ((31u - n) & 31u);
+}
 
 // FAST: the caller has checked that every word this data unit can touch lies
 // inside the LDS window and that the whole L2 LUT is staged, so the loop body
@@ -507,26 +533,35 @@ CG_DEV uint32_t fetch_word_pf(const ImageDesc &d, const HuffShared &s, uint32_t 
     return w;
 }
 
+// The reference refill on the 64-bit register: cur |= w >> left, nxt := the
+// bits of w that did not fit (callers pass need = left < 32).
+CG_DEV uint64_t merge_word(uint64_t buf, uint32_t w, uint32_t left, bool need)
+{
+    const uint64_t ins = uint64_t(w) << ((32u - left) & 63u);
+    const uint32_t hi = uint32_t(buf >> 32) | (need ? uint32_t(ins >> 32) : 0u);
+    const uint32_t lo = need ? uint32_t(ins) : uint32_t(buf);
+    return uint64_t(hi) << 32 | lo;
+}
+
 CG_DEV void reader_init(PrefetchReader &r, const ImageDesc &d, const HuffShared &s, uint32_t start)
 {
-    r.b.next_word = start;
-    r.b.cur = r.b.nxt = r.b.left = 0u;
+    r.next_word = start;
+    r.buf = 0u;
+    r.left = 0u;
     r.pre = fetch_word_pf<false>(d, s, start);
 }
 
-// Branch-free form of the reference refill (src/huffman.wgsl:52-67): the
-// updates are selected on `left < 32`, and the next word is (re)read every
-// time -- when nothing was consumed it is the same word again.
+// Branch-free form of the reference refill (src/huffman.wgsl:52-67): the word
+// is merged only when `left < 32`, and the next word is (re)read every time --
+// when nothing was consumed it is the same word again.
 template <bool FAST>
 CG_DEV void reader_refill(PrefetchReader &r, const ImageDesc &d, const HuffShared &s)
 {
-    const bool need = r.b.left < 32u;
-    const uint32_t w = r.pre, sh = r.b.left & 31u;
-    r.b.cur |= need ? (w >> sh) : 0u;
-    r.b.nxt = need ? ((w << 1) << (31u - sh)) : r.b.nxt;
-    r.b.left += need ? 32u : 0u;
-    r.b.next_word += need ? 1u : 0u;
-    r.pre = fetch_word_pf<FAST>(d, s, r.b.next_word);
+    const bool need = r.left < 32u;
+    r.buf = merge_word(r.buf, r.pre, r.left, need);
+    r.left += need ? 32u : 0u;
+    r.next_word += need ? 1u : 0u;
+    r.pre = fetch_word_pf<FAST>(d, s, r.next_word);
 }
 
 template <bool FAST>
@@ -573,11 +608,11 @@ CG_DEV uint32_t lut_resolve(const ImageDesc &d, const HuffShared &s, uint32_t e,
 CG_DEV int32_t decode_dc_diff(PrefetchReader &r, const ImageDesc &d, const HuffShared &s,
                               uint32_t dc_off)
 {
-    const uint32_t e = lut_lookup<false>(d, s, dc_off, r.b.cur);
-    consume(r.b, e >> 8);
+    const uint32_t e = lut_lookup<false>(d, s, dc_off, reader_cur(r));
+    reader_consume(r, e >> 8);
     const uint32_t cat = e & 0xffu;
-    const int32_t raw = int32_t(peek(r.b, cat));
-    consume(r.b, cat);
+    const int32_t raw = int32_t(reader_peek(r, cat));
+    reader_consume(r, cat);
     return huff_extend(raw, cat); // cat == 0 -> 0, as the reference special-cases
 }
 
@@ -602,43 +637,43 @@ CG_DEV void decode_ac_loop(PrefetchReader &r, const ImageDesc &d, const HuffShar
     // reader (quirk Q1).
     uint32_t pos = 1u;
     reader_refill<FAST>(r, d, s);
-    uint32_t e = lut_lookup<FAST>(d, s, ac_off, r.b.cur);
+    uint32_t e = lut_lookup<FAST>(d, s, ac_off, reader_cur(r));
     bool done;
     do {
         const uint32_t len = e >> 8, sym = e & 0xffu, nb = sym & 15u;
-        const uint32_t t = r.b.cur << (len & 31u);
-        consume(r.b, len + nb);
+        const uint32_t t = reader_cur(r) << (len & 31u); // magnitude bits at the top
+        reader_consume(r, len + nb);
 
         // state the next symbol would start from; both LDS reads are issued here
-        const bool need = r.b.left < 32u;
-        const uint32_t w = r.pre, sh = r.b.left & 31u;
-        const uint32_t cur_n = r.b.cur | (need ? (w >> sh) : 0u);
-        const uint32_t nw_n = r.b.next_word + (need ? 1u : 0u);
-        const uint32_t e1_n = s.l1[ac_off + (cur_n >> 24)];
+        const bool need = r.left < 32u;
+        const uint64_t buf_n = merge_word(r.buf, r.pre, r.left, need);
+        const uint32_t nw_n = r.next_word + (need ? 1u : 0u);
+        const uint32_t e1_n = s.l1[ac_off + uint32_t(buf_n >> 56)];
         const uint32_t pre_n = fetch_word_pf<FAST>(d, s, nw_n);
 
-        // the current symbol, under the latency of those reads
-        const int32_t raw = int32_t((t >> 1) >> (31u - nb));
-        const int32_t val = huff_extend(raw, nb);
+        // the current symbol, under the latency of those reads.  Sign extension:
+        // a magnitude whose first bit is 0 encodes raw - (2^nb - 1).
+        const uint32_t raw = (t >> 1) >> (31u - nb);
+        const uint32_t neg = ~uint32_t(int32_t(t) >> 31);      // all ones when that first bit is 0
+        const uint32_t val = raw + (neg & ((0xffffffffu << nb) + 1u));
         const uint32_t p = pos + (sym >> 4);
         slot16[p < uint32_t(kRetained) ? p : uint32_t(kRetained)] = int16_t(val);
         pos = sym == 0u ? 64u : p + (sym == 0xf0u ? 2u : 1u);
         done = pos >= 64u;
 
         // commit the refill only if decoding continues, then rotate
-        r.b.cur = done ? r.b.cur : cur_n;
-        r.b.nxt = (need && !done) ? ((w << 1) << (31u - sh)) : r.b.nxt;
-        r.b.left += (need && !done) ? 32u : 0u;
-        r.b.next_word = done ? r.b.next_word : nw_n;
+        r.buf = done ? r.buf : buf_n;
+        r.left += (need && !done) ? 32u : 0u;
+        r.next_word = done ? r.next_word : nw_n;
         r.pre = done ? r.pre : pre_n;
-        e = lut_resolve<FAST>(d, s, e1_n, cur_n);
+        e = lut_resolve<FAST>(d, s, e1_n, uint32_t(buf_n >> 32));
     } while (!done);
 }
 
 CG_DEV void decode_ac(PrefetchReader &r, const ImageDesc &d, const HuffShared &s, uint32_t ac_off,
                       int16_t *slot16)
 {
-    const bool in_window = (r.b.next_word - s.win_base) + kDuWordSlack <= s.win_len;
+    const bool in_window = (r.next_word - s.win_base) + kDuWordSlack <= s.win_len;
     if (in_window && s.l2_staged >= d.l2_entries)
         decode_ac_loop<true>(r, d, s, ac_off, slot16);
     else
