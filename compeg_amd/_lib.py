@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcompeg_hip.so")
+# COMPEG_LIB: developer override for A/B runs of two builds of the same library (tools/ab_bench.sh)
+LIB_PATH = os.environ.get("COMPEG_LIB") or os.path.join(_HERE, "libcompeg_hip.so")
 
 OK, E_INVALID_ARG, E_UNSUPPORTED, E_MALFORMED, E_COUNT_MISMATCH, E_HIP = 0, -1, -2, -3, -4, -5
 METADATA_BYTES = 1112

@@ -17,6 +17,7 @@ void fill_desc(const ImageData &img, ImageDesc &d)
     const Metadata &md = img.metadata;
     memset(&d, 0, sizeof d);
     d.l2_entries = uint32_t(img.l2.size());
+    d.fast_off = uint32_t((img.l2.size() + 1) & ~size_t(1));
     if (const char *e = getenv("COMPEG_DEBUG_FLAGS"))
         d.debug_flags = uint32_t(atoi(e));
     d.total_intervals = md.total_restart_intervals;
@@ -36,6 +37,7 @@ void fill_desc(const ImageData &img, ImageDesc &d)
         // reference (robust buffer access): route them to the all-zero table
         d.dc_table[c] = cm.dchuff < 4 ? cm.dchuff : 4;
         d.ac_table[c] = cm.achuff < 4 ? cm.achuff : 4;
+        d.fast_table[c] = (cm.achuff == 1 || cm.achuff == 3) ? cm.achuff >> 1 : 2;
         d.dc_quant[c] = md.qtables[cm.qtable & 3][0];
         d.hsample[c] = cm.hsample;
         d.vsample[c] = cm.vsample;

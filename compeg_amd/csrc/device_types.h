@@ -9,6 +9,25 @@ constexpr int kWave = 64;              // CDNA wavefront
 constexpr int kRetained = 32;          // zig-zag positions kept per data unit (metadata.rs:43)
 constexpr int kMaxDusPerMcu = 6;
 
+// Direct AC tables (decode-side acceleration, derived from the reference LUTs;
+// not part of the reference's upload format): one u16 per 11-bit code prefix,
+//   bits 0..3   magnitude bits of the symbol
+//   bits 4..8   code length + magnitude bits (<= 31)
+//   bits 9..15  zig-zag positions to advance: run + 1; 17 for ZRL (quirk Q2);
+//               64 for EOB (ends the data unit); 127 = escape: the code is
+//               longer than 11 bits
+constexpr uint32_t kFastBits = 11;
+constexpr uint32_t kFastEntries = 1u << kFastBits;
+constexpr uint32_t kFastAdvEob = 64, kFastAdvEscape = 127;
+constexpr uint32_t kFastEscape = kFastAdvEscape << 9;
+
+// ref: an entry of the reference's LUTs, code length << 8 | symbol
+constexpr uint32_t fast_entry(uint32_t ref)
+{
+    return (((ref & 0xffu) == 0u ? kFastAdvEob : ((ref & 0xffu) == 0xf0u ? 17u : ((ref >> 4) & 15u) + 1u)) << 9) |
+           ((((ref >> 8) & 31u) + (ref & 15u)) << 4) | (ref & 15u);
+}
+
 // LDS slot of one lane's data unit while it is being decoded: 32 int16 in
 // zig-zag order + one dummy position (coefficients >= 32 are dropped there),
 // 17 dwords per lane: an odd dword stride makes both the 2-byte scatter
@@ -27,6 +46,9 @@ struct ImageDesc {
     uint32_t nwords;
     uint32_t nstarts;
     uint32_t l2_entries;
+    // two 2048-entry direct AC tables stored behind the L2 LUT (u16 index from l2)
+    uint32_t fast_off;
+    uint32_t fast_table[3]; // per component: 0 / 1, or 2 = none (out-of-range selector)
     // geometry
     uint32_t total_intervals;
     uint32_t restart_interval; // MCUs per interval

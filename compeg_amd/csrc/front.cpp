@@ -468,6 +468,35 @@ Status ImageData::parse(const uint8_t *jpeg, size_t len, bool copy, ImageData **
         rebase += tables[t].l2.size();
     }
 
+    // 11-bit direct table for the AC codes (tables 1 and 3): an entry is the
+    // two-level lookup's result when that does not depend on the bits behind
+    // the prefix, i.e. for codes of at most 11 bits (and for prefixes no code
+    // starts with); longer codes escape to the two-level tables.
+    img->ac_fast.assign(2 * kFastEntries, uint16_t(kFastEscape));
+    for (int t = 0; t < 2; t++) {
+        const uint16_t *l1 = img->l1 + (2 * t + 1) * 256;
+        for (uint32_t x = 0; x < kFastEntries; x++) {
+            const uint16_t e1 = l1[x >> (kFastBits - 8)];
+            uint16_t e = uint16_t(kFastEscape);
+            if (!(e1 & 0x8000)) {
+                e = uint16_t(fast_entry(e1));
+            } else {
+                // all 16-bit continuations of this prefix must agree
+                const uint32_t lowbits = 16 - kFastBits;
+                const size_t first = size_t(e1 & 0x7fff) + ((x << lowbits) & 0xff);
+                uint16_t v = first < img->l2.size() ? img->l2[first] : 0;
+                bool same = true;
+                for (uint32_t i = 1; i < (1u << lowbits) && same; i++) {
+                    const size_t idx = first + i;
+                    same = (idx < img->l2.size() ? img->l2[idx] : 0) == v;
+                }
+                if (same && (v >> 8) <= kFastBits)
+                    e = uint16_t(fast_entry(v));
+            }
+            img->ac_fast[size_t(t) * kFastEntries + x] = e;
+        }
+    }
+
     guard.p = nullptr;
     *out = img;
     return Status{};

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "compeg_hip.h"
+#include "device_types.h"
 
 namespace compeg {
 
@@ -58,6 +59,10 @@ struct ImageData {
     uint32_t width = 0, height = 0;
     uint16_t l1[4 * 256];
     std::vector<uint16_t> l2;
+    // Decode-side acceleration table derived from l1/l2 (not part of the
+    // reference's upload format): for each of the two AC tables, one entry per
+    // 11-bit prefix in the format device_types.h describes.
+    std::vector<uint16_t> ac_fast; // 2 x kFastEntries
     std::vector<uint8_t> owned; // Cow::Owned
     const uint8_t *jpeg = nullptr;
     size_t jpeg_len = 0;

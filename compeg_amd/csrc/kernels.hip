@@ -57,7 +57,7 @@ huffman_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t
     HuffShared s;
     s.l1 = l1;
     s.l2 = l2;
-    s.l2_staged = umin(l2_in_lds, d.l2_entries);
+    s.l2_staged = umin(l2_in_lds, d.fast_off + 2u * kFastEntries);
     s.win = win;
     s.win_base = win_base;
     s.win_len = win_len;
@@ -103,7 +103,7 @@ decode_fused_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds,
     HuffShared s;
     s.l1 = l1;
     s.l2 = l2;
-    s.l2_staged = umin(l2_in_lds, d.l2_entries);
+    s.l2_staged = umin(l2_in_lds, d.fast_off + 2u * kFastEntries);
     s.win = win;
     s.win_base = win_base;
     s.win_len = win_len;
@@ -152,7 +152,7 @@ decode_pair_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, 
     HuffShared s;
     s.l1 = l1;
     s.l2 = l2;
-    s.l2_staged = umin(l2_in_lds, d.l2_entries);
+    s.l2_staged = umin(l2_in_lds, d.fast_off + 2u * kFastEntries);
     s.win = win;
     s.win_base = win_base;
     s.win_len = win_len;
@@ -243,7 +243,8 @@ HuffLdsPlan plan_huffman(uint32_t max_intervals, uint32_t images, uint32_t max_l
                          uint32_t max_wave_words, bool fused)
 {
     HuffLdsPlan p;
-    p.l2_entries_in_lds = max_l2 < 8192u ? (max_l2 + 1u) & ~1u : 8192u;
+    // everything behind L1: the L2 LUT and the two direct AC tables (at most 24 KB of LDS)
+    p.l2_entries_in_lds = max_l2 < 12288u ? (max_l2 + 1u) & ~1u : 12288u;
     const uint32_t tables = (((kL1Entries + p.l2_entries_in_lds) * 2u) + 15u) & ~15u;
     const uint32_t slots = kWave * kDuSlotBytes;
 

@@ -42,6 +42,11 @@
 #define CG_PIN_SCALAR(x) (void)(x)
 #endif
 
+#ifndef CG_EXP
+#define CG_EXP 0 // diagnostic builds only (tools/build_variant.sh, tools/ab_bench.sh): 3 = AC loop twice,
+                 // 4 = no IDCT, 5 = no colour arithmetic -- what each phase costs inside the real mix
+#endif
+
 namespace compeg {
 
 struct alignas(16) Vec4u {
@@ -171,7 +176,7 @@ CG_DEV void stage_luts(const ImageDesc &d, uint16_t *l1, uint16_t *l2, uint32_t 
     copy_words_to_lds(dst, reinterpret_cast<const uint32_t *>(d.l1), 4 * 128, tid, nthreads);
     for (uint32_t i = tid; i < 128; i += nthreads)
         dst[4 * 128 + i] = 0u;
-    const uint32_t n2 = umin(l2_in_lds, d.l2_entries);
+    const uint32_t n2 = umin(l2_in_lds, d.fast_off + 2u * kFastEntries);
     copy_words_to_lds(reinterpret_cast<uint32_t *>(l2), reinterpret_cast<const uint32_t *>(d.l2),
                       (n2 + 1) / 2, tid, nthreads);
 }
@@ -255,7 +260,7 @@ CG_DEV void huff_decode_interval(const ImageDesc &d, const HuffShared &s, uint32
         uint32_t e = s.l1[(is_dc ? dc_off : ac_off) + (code >> 8)];
         if (e & 0x8000u) {
             const uint32_t idx = (e & 0x7fffu) + (code & 0xffu);
-            e = idx < s.l2_staged ? s.l2[idx] : (idx < d.l2_entries ? CG_GLOBAL(const uint16_t, d.l2)[idx] : 0u);
+            e = idx >= d.l2_entries ? 0u : (idx < s.l2_staged ? s.l2[idx] : CG_GLOBAL(const uint16_t, d.l2)[idx]);
         }
         consume(b, e >> 8);
         const uint32_t sym = e & 0xffu;
@@ -572,12 +577,12 @@ CG_DEV uint32_t lut_lookup(const ImageDesc &d, const HuffShared &s, uint32_t tab
     if (e & 0x8000u) {
         const uint32_t idx = (e & 0x7fffu) + (code & 0xffu);
         if (FAST) {
-            e = s.l2[idx];
+            e = idx < d.l2_entries ? s.l2[idx] : 0u;
         } else {
             uint32_t e2 = s.l2[idx < s.l2_staged ? idx : 0u];
             if (idx >= s.l2_staged)
-                e2 = idx < d.l2_entries ? CG_GLOBAL(const uint16_t, d.l2)[idx] : 0u;
-            e = e2;
+                e2 = CG_GLOBAL(const uint16_t, d.l2)[idx < d.l2_entries ? idx : 0u];
+            e = idx < d.l2_entries ? e2 : 0u;
         }
     }
     return e;
@@ -591,12 +596,12 @@ CG_DEV uint32_t lut_resolve(const ImageDesc &d, const HuffShared &s, uint32_t e,
     if (e & 0x8000u) {
         const uint32_t idx = (e & 0x7fffu) + ((cur >> 16) & 0xffu);
         if (FAST) {
-            e = s.l2[idx];
+            e = idx < d.l2_entries ? s.l2[idx] : 0u;
         } else {
             uint32_t e2 = s.l2[idx < s.l2_staged ? idx : 0u];
             if (idx >= s.l2_staged)
-                e2 = idx < d.l2_entries ? CG_GLOBAL(const uint16_t, d.l2)[idx] : 0u;
-            e = e2;
+                e2 = CG_GLOBAL(const uint16_t, d.l2)[idx < d.l2_entries ? idx : 0u];
+            e = idx < d.l2_entries ? e2 : 0u;
         }
     }
     return e;
@@ -623,6 +628,8 @@ CG_DEV int32_t decode_dc_diff(PrefetchReader &r, const ImageDesc &d, const HuffS
 // pos+15; both positions are still zero and are never revisited, so the
 // stores need no special case; positions >= 32 (quirk Q3) land in the slot's
 // padding.  ZRL advances 17 positions (quirk Q2).
+// AC coefficients of one data unit, reference-exact reader (see fast_ac for
+// the path normally taken).
 template <bool FAST>
 CG_DEV void decode_ac_loop(PrefetchReader &r, const ImageDesc &d, const HuffShared &s,
                            uint32_t ac_off, int16_t *slot16)
@@ -648,7 +655,8 @@ CG_DEV void decode_ac_loop(PrefetchReader &r, const ImageDesc &d, const HuffShar
         const bool need = r.left < 32u;
         const uint64_t buf_n = merge_word(r.buf, r.pre, r.left, need);
         const uint32_t nw_n = r.next_word + (need ? 1u : 0u);
-        const uint32_t e1_n = s.l1[ac_off + uint32_t(buf_n >> 56)];
+        const uint32_t cur_n = uint32_t(buf_n >> 32);
+        const uint32_t e1_n = s.l1[ac_off + (cur_n >> 24)];
         const uint32_t pre_n = fetch_word_pf<FAST>(d, s, nw_n);
 
         // the current symbol, under the latency of those reads.  Sign extension:
@@ -666,18 +674,217 @@ CG_DEV void decode_ac_loop(PrefetchReader &r, const ImageDesc &d, const HuffShar
         r.left += (need && !done) ? 32u : 0u;
         r.next_word = done ? r.next_word : nw_n;
         r.pre = done ? r.pre : pre_n;
-        e = lut_resolve<FAST>(d, s, e1_n, uint32_t(buf_n >> 32));
+        e = lut_resolve<FAST>(d, s, e1_n, cur_n);
     } while (!done);
 }
 
-CG_DEV void decode_ac(PrefetchReader &r, const ImageDesc &d, const HuffShared &s, uint32_t ac_off,
-                      int16_t *slot16)
+// ---------------------------------------------------------------------------
+// Fast mode
+// ---------------------------------------------------------------------------
+// The reference reader is what the results are defined by, but it is an
+// expensive thing to step: a conditional word load in front of every AC
+// symbol, none in front of a DC code (quirk Q1), two table levels.  Fast mode
+// decodes the same symbols from a reader of its own and reconstructs the one
+// piece of reference state that can influence a result:
+//
+//  * Its buffer holds true stream bits only and is topped up right after every
+//    symbol (>= 32 valid bits before each AC symbol, like the reference, so an
+//    AC symbol -- at most 31 bits -- never sees anything but stream bits in
+//    either reader).
+//  * The reference's `left` is congruent to minus the interval's consumed bit
+//    count modulo 32 and lies in 32..63 after each of its refills, so its value
+//    at the DC code that follows a data unit is
+//        32 + ((left_fast + tot_last) & 31) - tot_last        (1..63)
+//    where tot_last is the size of the data unit's last symbol.  The DC code
+//    is then decoded from the buffer cut to that many bits (the reference
+//    sees zeros behind them).  If the DC symbol needs more bits than that the
+//    reference underflows; such a lane -- and any lane about to leave its LDS
+//    window -- converts its state into the reference reader's and stays in
+//    exact mode for the rest of the interval.
+//  * AC symbols come from the direct tables (device_types.h): one LDS read
+//    per symbol yields magnitude size, total size and position advance; codes
+//    longer than 11 bits escape to the reference's two-level tables.
+struct EntropyState {
+    PrefetchReader r;     // fast mode: left = valid bits in buf, next_word unused
+    const uint32_t *wptr; // fast mode: address (in the LDS window) of the next stream word; r.pre == *wptr
+    uint32_t ref_left;    // fast mode: the reference reader's `left` at the coming DC code
+    bool fast;
+    int32_t pred0, pred1, pred2;
+};
+
+// tests/emul counts how often the rare paths run (to prove the tests reach them)
+#if defined(CG_EMUL_STATS)
+struct EmulStats {
+    unsigned long fast_dus, exact_dus, left_window, left_underflow, dc_cut, escapes;
+    unsigned long symbols, lane_symbols, wave_steps, wave_step_symbols; // AC symbols; per-step maximum over a wave's lanes
+};
+inline EmulStats g_emul_stats{};
+#define CG_COUNT(field) (++g_emul_stats.field)
+#else
+#define CG_COUNT(field) ((void)0)
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CG_LDS(T, p) (reinterpret_cast<__attribute__((address_space(3))) T *>(reinterpret_cast<uintptr_t>(p)))
+#else
+#define CG_LDS(T, p) (p)
+#endif
+
+CG_DEV bool fast_tables_usable(const ImageDesc &d, const HuffShared &s)
 {
-    const bool in_window = (r.next_word - s.win_base) + kDuWordSlack <= s.win_len;
-    if (in_window && s.l2_staged >= d.l2_entries)
-        decode_ac_loop<true>(r, d, s, ac_off, slot16);
-    else
-        decode_ac_loop<false>(r, d, s, ac_off, slot16);
+    return d.fast_table[0] < 2u && d.fast_table[1] < 2u && d.fast_table[2] < 2u &&
+           s.l2_staged >= d.fast_off + 2u * kFastEntries;
+}
+
+CG_DEV void entropy_init(EntropyState &e, const ImageDesc &d, const HuffShared &s, uint32_t interval)
+{
+    reader_init(e.r, d, s, interval < d.nstarts ? CG_GLOBAL(const uint32_t, d.starts)[interval] : 0u);
+    reader_refill<false>(e.r, d, s); // left == 32: also a valid fast-mode state
+    e.pred0 = e.pred1 = e.pred2 = 0;
+    e.ref_left = 32u;
+    const uint32_t rel = e.r.next_word - s.win_base;
+    e.fast = fast_tables_usable(d, s) && rel < s.win_len;
+    e.wptr = s.win + (e.fast ? rel : 0u);
+}
+
+// Fast -> exact: drop what was loaded ahead of the reference.
+CG_DEV void leave_fast_mode(EntropyState &e, const ImageDesc &d, const HuffShared &s)
+{
+    PrefetchReader &r = e.r;
+    const uint32_t ahead = (r.left - e.ref_left) >> 5; // 0 or 1 word
+    r.next_word = s.win_base + uint32_t(e.wptr - s.win) - ahead;
+    if (ahead)
+        r.pre = fetch_word_pf<false>(d, s, r.next_word);
+    r.buf &= ~uint64_t(0) << (64u - e.ref_left);
+    r.left = e.ref_left;
+    e.fast = false;
+}
+
+// Branch-free top-up: merges the stream word in flight when fewer than 32
+// bits are left (0 <= left <= 63) and puts the next one in flight.
+CG_DEV void fast_refill(EntropyState &e)
+{
+    PrefetchReader &r = e.r;
+    const uint32_t t = r.left - 32u;
+    const uint32_t f = t >> 31;                         // 1 when left < 32
+    const uint32_t w = r.pre & uint32_t(int32_t(t) >> 31);
+    r.buf |= (uint64_t(w) << 32) >> (r.left & 63u);     // w == 0 when left >= 32
+    r.left += f << 5;
+    e.wptr += f;
+    r.pre = *CG_LDS(const uint32_t, e.wptr);
+}
+
+// nb-bit field that ends `tot` bits below the top of cur, sign-extended (0 for nb == 0)
+CG_DEV int32_t signed_field(uint32_t cur, uint32_t tot, uint32_t nb)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sbfe(int32_t(cur), 32u - tot, nb); // v_bfe_i32 takes the offset modulo 32
+#else
+    return nb ? int32_t(cur << (tot - nb)) >> (32u - nb) : 0;
+#endif
+}
+
+// DC difference in fast mode; false (nothing consumed) when the reference
+// would run out of buffered bits here.
+CG_DEV bool fast_dc(EntropyState &e, const ImageDesc &d, const HuffShared &s, uint32_t dc_off, int32_t &diff)
+{
+    PrefetchReader &r = e.r;
+    const uint32_t seen = e.ref_left < 32u ? e.ref_left : 32u;
+    if (e.ref_left < 32u)
+        CG_COUNT(dc_cut);
+    const uint32_t cur = reader_cur(r) & ~uint32_t(uint64_t(0xffffffffu) >> seen);
+    const uint32_t ent = lut_lookup<true>(d, s, dc_off, cur);
+    const uint32_t len = ent >> 8, cat = ent & 0xffu, n = len + cat;
+    if (n > e.ref_left || cat > 16u)
+        return false;
+    const int32_t raw = int32_t(((cur << (len & 31u)) >> 1) >> (31u - cat));
+    diff = huff_extend(raw, cat);
+    r.buf <<= n;
+    r.left -= n;
+    return true;
+}
+
+CG_DEV void fast_ac(EntropyState &e, const ImageDesc &d, const HuffShared &s, uint32_t ac_off,
+                    uint32_t fast_base, int16_t *slot16)
+{
+    PrefetchReader &r = e.r;
+    const uint16_t *tab = s.l2 + fast_base;
+    fast_refill(e);
+    uint32_t ent = CG_LDS(const uint16_t, tab)[reader_cur(r) >> (32u - kFastBits)];
+    uint32_t at = 0u, tot = 0u; // at: zig-zag position of the coefficient decoded last
+    // Software-pipelined like the exact loop, but nothing is speculative:
+    // topping the buffer up early cannot change a result.
+    while (at < 63u) {
+        if (ent >= kFastEscape) {
+            // code longer than 11 bits: this symbol through the reference's tables
+            CG_COUNT(escapes);
+            ent = fast_entry(lut_lookup<true>(d, s, ac_off, reader_cur(r)));
+        }
+        const uint32_t nb = ent & 15u;
+        tot = (ent >> 4) & 31u;
+        const uint32_t cur = reader_cur(r);
+        r.buf <<= tot;
+        r.left -= tot;
+        fast_refill(e);
+        const uint32_t next = CG_LDS(const uint16_t, tab)[reader_cur(r) >> (32u - kFastBits)];
+        // a magnitude whose first bit is 0 encodes field - (2^nb - 1)
+        const int32_t sx = signed_field(cur, tot, nb);
+        const uint32_t val = uint32_t(sx) + (((0xffffffffu << nb) ^ uint32_t(sx >> 31)) + 1u);
+        at += ent >> 9;
+        CG_COUNT(symbols);
+        CG_COUNT(lane_symbols);
+        // EOB / ZRL store a zero at a position that is zero anyway (or at the
+        // slot's padding)
+        slot16[umin(at, uint32_t(kRetained))] = int16_t(val);
+        ent = next;
+    }
+    e.ref_left = 32u + ((r.left + tot) & 31u) - tot;
+}
+
+// One data unit: DC difference + AC coefficients into `slot16` (zeroed by the
+// consumer); returns the dequantised DC term.  comp is wave-uniform.
+CG_DEV int32_t entropy_data_unit(EntropyState &e, const ImageDesc &d, const HuffShared &s, uint32_t comp,
+                                 int16_t *slot16)
+{
+    const uint32_t dc_off = d.dc_table[comp] * 256u, ac_off = d.ac_table[comp] * 256u;
+    int32_t diff = 0;
+    bool decoded = false;
+    if (e.fast) {
+        const uint32_t rel = uint32_t(e.wptr - s.win);
+        if (s.win_len - rel < kDuWordSlack) { // rel < win_len holds in fast mode
+            CG_COUNT(left_window);
+            leave_fast_mode(e, d, s);
+        }
+    }
+    if (e.fast) {
+        if (fast_dc(e, d, s, dc_off, diff)) {
+#if CG_EXP == 3 // diagnostic build: the AC loop twice (idempotent: same coefficients, same final state)
+            {
+                const EntropyState saved = e;
+                fast_ac(e, d, s, ac_off, d.fast_off + d.fast_table[comp] * kFastEntries, slot16);
+                e = saved;
+            }
+#endif
+            fast_ac(e, d, s, ac_off, d.fast_off + d.fast_table[comp] * kFastEntries, slot16);
+            decoded = true;
+            CG_COUNT(fast_dus);
+        } else {
+            CG_COUNT(left_underflow);
+            leave_fast_mode(e, d, s);
+        }
+    }
+    if (!decoded) {
+        CG_COUNT(exact_dus);
+        diff = decode_dc_diff(e.r, d, s, dc_off);
+        decode_ac_loop<false>(e.r, d, s, ac_off, slot16);
+    }
+    // (values, not addresses, are selected: the state has to stay in registers)
+    const int32_t p0 = e.pred0, p1 = e.pred1, p2 = e.pred2;
+    const int32_t p = int32_t(uint32_t(comp == 0u ? p0 : (comp == 1u ? p1 : p2)) + uint32_t(diff));
+    e.pred0 = comp == 0u ? p : p0;
+    e.pred1 = comp == 1u ? p : p1;
+    e.pred2 = comp == 2u ? p : p2;
+    return int32_t(uint32_t(p) * d.dc_quant[comp]);
 }
 
 // ---------------------------------------------------------------------------
@@ -815,24 +1022,6 @@ CG_DEV void composite_own_mcu_422(const ImageDesc &d, const uint32_t (&px)[4][16
             }
         if (acc == 0x12345678u)
             *CG_GLOBAL(uint32_t, reinterpret_cast<uint32_t *>(base)) = acc;
-#if defined(__HIP_DEVICE_COMPILE__)
-    } else if (d.debug_flags & 2u) {
-        // timing experiment: the store pattern a quad transpose would give
-        // (each 4-lane group writes one MCU's 64-byte row segment per store)
-        const uint32_t lane = threadIdx.x & 63u, quad = lane & ~3u, i = lane & 3u;
-        const uint64_t mybase = reinterpret_cast<uint64_t>(base);
-#pragma unroll
-        for (uint32_t q = 0; q < 4; q++) {
-            const uint32_t lo = __shfl(uint32_t(mybase), int(quad + q)), hi = __shfl(uint32_t(mybase >> 32), int(quad + q));
-            uint8_t *other = reinterpret_cast<uint8_t *>(uint64_t(hi) << 32 | lo);
-#pragma unroll
-            for (uint32_t row = 0; row < 8; row++) {
-                auto *line = CG_GLOBAL(Vec4u, reinterpret_cast<Vec4u *>(other + size_t(row) * d.out_pitch));
-                line[i] = rgba_quad(px[q >> 1][row * 2u + (q & 1u)], px[2][row * 2u + (q >> 1)] >> ((q & 1u) * 16u),
-                                    px[3][row * 2u + (q >> 1)] >> ((q & 1u) * 16u));
-            }
-        }
-#endif
     } else if (whole) {
         // the common case: 8 rows x 64 bytes, unconditional 16-byte stores
 #pragma unroll
@@ -840,9 +1029,13 @@ CG_DEV void composite_own_mcu_422(const ImageDesc &d, const uint32_t (&px)[4][16
             auto *line = CG_GLOBAL(Vec4u, reinterpret_cast<Vec4u *>(base + size_t(row) * d.out_pitch));
 #pragma unroll
             for (uint32_t q = 0; q < 4; q++)
+#if CG_EXP == 5 // diagnostic build: stores without the colour arithmetic
+                line[q] = Vec4u{px[q >> 1][row * 2u + (q & 1u)], px[2][row * 2u + (q >> 1)], px[3][row * 2u + (q >> 1)], q};
+#else
                 line[q] = rgba_quad(px[q >> 1][row * 2u + (q & 1u)],
                                     px[2][row * 2u + (q >> 1)] >> ((q & 1u) * 16u),
                                     px[3][row * 2u + (q >> 1)] >> ((q & 1u) * 16u));
+#endif
         }
     } else {
         // MCUs cut by the right / bottom edge (stores outside the output are
@@ -881,34 +1074,6 @@ CG_DEV void composite_own_mcu_422(const ImageDesc &d, const uint32_t (&px)[4][16
 // ---------------------------------------------------------------------------
 // The same work as two cooperating roles (decoder wave + transformer wave)
 // ---------------------------------------------------------------------------
-
-// Entropy-decoder role: reader and DC predictors of one restart interval.
-struct EntropyState {
-    PrefetchReader r;
-    int32_t pred0, pred1, pred2;
-};
-
-CG_DEV void entropy_init(EntropyState &e, const ImageDesc &d, const HuffShared &s, uint32_t interval)
-{
-    reader_init(e.r, d, s, interval < d.nstarts ? CG_GLOBAL(const uint32_t, d.starts)[interval] : 0u);
-    reader_refill<false>(e.r, d, s);
-    e.pred0 = e.pred1 = e.pred2 = 0;
-}
-
-// One data unit: DC difference + AC coefficients into `slot16` (zeroed by the
-// consumer); returns the dequantised DC term.  comp is wave-uniform.
-CG_DEV int32_t entropy_data_unit(EntropyState &e, const ImageDesc &d, const HuffShared &s, uint32_t comp,
-                                 int16_t *slot16)
-{
-    const int32_t diff = decode_dc_diff(e.r, d, s, d.dc_table[comp] * 256u);
-    int32_t p = comp == 0u ? e.pred0 : (comp == 1u ? e.pred1 : e.pred2);
-    p = int32_t(uint32_t(p) + uint32_t(diff));
-    e.pred0 = comp == 0u ? p : e.pred0;
-    e.pred1 = comp == 1u ? p : e.pred1;
-    e.pred2 = comp == 2u ? p : e.pred2;
-    decode_ac(e.r, d, s, d.ac_table[comp] * 256u, slot16);
-    return int32_t(uint32_t(p) * d.dc_quant[comp]);
-}
 
 // Transformer role: the samples of the MCU being assembled and where it goes.
 struct PixelState {
@@ -964,9 +1129,8 @@ CG_DEV void decode_interval_fused_422(const ImageDesc &d, const HuffShared &s, u
     int16_t *slot16 = reinterpret_cast<int16_t *>(slot);
     zero_slot(slot);
 
-    PrefetchReader r;
-    reader_init(r, d, s, interval < d.nstarts ? CG_GLOBAL(const uint32_t, d.starts)[interval] : 0u);
-    reader_refill<false>(r, d, s);
+    EntropyState e;
+    entropy_init(e, d, s, interval);
 
     uint32_t mcu = interval * d.restart_interval;
     uint32_t mx = mcu % d.width_mcus, my = mcu / d.width_mcus;
@@ -986,21 +1150,12 @@ CG_DEV void decode_interval_fused_422(const ImageDesc &d, const HuffShared &s, u
 #pragma unroll
         for (int w = 0; w < 16; w++)
             px[k][w] = 0u;
-    int32_t pred0 = 0, pred1 = 0, pred2 = 0;
     const uint32_t du_total = d.restart_interval * 4u;
 #pragma unroll 1
     for (uint32_t du = 0; du < du_total; du++) {
         const uint32_t k = du & 3u;
         const uint32_t comp = k < 2u ? 0u : k - 1u; // Y0 Y1 Cb Cr (wave-uniform)
-        const int32_t diff = decode_dc_diff(r, d, s, d.dc_table[comp] * 256u);
-        int32_t p = comp == 0u ? pred0 : (comp == 1u ? pred1 : pred2);
-        p = int32_t(uint32_t(p) + uint32_t(diff));
-        pred0 = comp == 0u ? p : pred0;
-        pred1 = comp == 1u ? p : pred1;
-        pred2 = comp == 2u ? p : pred2;
-        const int32_t dc = int32_t(uint32_t(p) * d.dc_quant[comp]);
-        CG_STAMP(t_dc);
-        decode_ac(r, d, s, d.ac_table[comp] * 256u, slot16);
+        const int32_t dc = entropy_data_unit(e, d, s, comp, slot16);
         CG_STAMP(t_ac);
 
         uint32_t rec[kRetained / 2];
@@ -1011,7 +1166,13 @@ CG_DEV void decode_interval_fused_422(const ImageDesc &d, const HuffShared &s, u
             px[1][w] = px[2][w];
             px[2][w] = px[3][w];
         }
+#if CG_EXP == 4 // diagnostic build: no IDCT (same data flow)
+#pragma unroll
+        for (int w = 0; w < 16; w++)
+            px[3][w] = rec[w] + uint32_t(dc);
+#else
         idct_data_unit(rec, dc, d.quant[comp], px[3]);
+#endif
         CG_STAMP(t_idct);
 
         if (k == 3u) {

@@ -128,6 +128,29 @@ void pinned_free(void *p) { (void)hipHostFree(p); }
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Per-image LUT blob: [L1 2048 B][L2, padded to 4 B][two 11-bit direct AC tables]
+size_t table_blob_bytes(const ImageData &img)
+{
+    return COMPEG_HUFFMAN_L1_BYTES + align_up(img.l2.size() * 2, 4) + img.ac_fast.size() * 2;
+}
+
+void write_tables(uint8_t *dst, const ImageData &img)
+{
+    memcpy(dst, img.l1, COMPEG_HUFFMAN_L1_BYTES);
+    uint8_t *l2 = dst + COMPEG_HUFFMAN_L1_BYTES;
+    const size_t l2_bytes = align_up(img.l2.size() * 2, 4);
+    memset(l2, 0, l2_bytes);
+    if (!img.l2.empty())
+        memcpy(l2, img.l2.data(), img.l2.size() * 2);
+    memcpy(l2 + l2_bytes, img.ac_fast.data(), img.ac_fast.size() * 2);
+}
+
+// LUT entries a kernel should stage in LDS behind L1: the L2 LUT and the direct AC tables
+uint32_t staged_lut_entries(const ImageData &img)
+{
+    return uint32_t(align_up(img.l2.size() * 2, 4) / 2 + img.ac_fast.size());
+}
+
 } // namespace
 } // namespace compeg
 
@@ -269,8 +292,7 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     const size_t n_starts = on_device ? dev_nstarts : scan.nstarts();
 
     const uint32_t total_dus = img.total_dus();
-    const size_t l2_bytes = align_up(img.l2.size() * 2, 4);
-    const size_t blob_bytes = align_up(sizeof(ImageDesc), 256) + COMPEG_HUFFMAN_L1_BYTES + l2_bytes;
+    const size_t blob_bytes = align_up(sizeof(ImageDesc), 256) + table_blob_bytes(img);
     CG_TRY(host_blob.reserve(blob_bytes));
     CG_TRY(dev_blob.reserve(blob_bytes));
     if (!on_device) {
@@ -297,9 +319,7 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     d.out_w = out_w;
     d.out_h = out_h;
     d.out_pitch = uint32_t(out_pitch);
-    memcpy(hb + l1_off, img.l1, COMPEG_HUFFMAN_L1_BYTES);
-    if (!img.l2.empty())
-        memcpy(hb + l2_off, img.l2.data(), img.l2.size() * 2);
+    write_tables(hb + l1_off, img);
 
     CG_HIP(hipMemcpyAsync(db, hb, blob_bytes, hipMemcpyHostToDevice, stream));
     if (!on_device && n_starts)
@@ -317,7 +337,7 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     const uint32_t span = on_device ? dev_span
                                     : max_wave_span(scan.starts(), scan.nstarts(), scan.nwords(),
                                                     md.total_restart_intervals);
-    const HuffLdsPlan plan = plan_huffman(md.total_restart_intervals, 1, uint32_t(img.l2.size()), span,
+    const HuffLdsPlan plan = plan_huffman(md.total_restart_intervals, 1, staged_lut_entries(img), span,
                                           use_fused_pipeline());
     last_span = span;
     last_plan = plan;
@@ -460,16 +480,14 @@ Status compeg_batch::upload(const ImageData *const *images, size_t n, int thread
     for (size_t i = 0; i < n; i++) {
         const ImageData &img = *images[i];
         in_off[i] = in_total;
-        in_total += align_up(COMPEG_HUFFMAN_L1_BYTES + align_up(img.l2.size() * 2, 4) +
-                                 scans[i].nstarts() * 4 + scans[i].nwords() * 4 + 16,
-                             256);
+        in_total += align_up(table_blob_bytes(img) + scans[i].nstarts() * 4 + scans[i].nwords() * 4 + 16, 256);
         out_offset[i] = out_total;
         out_total += align_up(size_t(img.width) * 4 * img.height, 256);
         ac_total += size_t(img.total_dus()) * kRetained * 2;
         dc_total += size_t(img.total_dus()) * 4;
         max_intervals = std::max(max_intervals, img.metadata.total_restart_intervals);
         max_dus = std::max(max_dus, img.total_dus());
-        max_l2 = std::max<uint32_t>(max_l2, uint32_t(img.l2.size()));
+        max_l2 = std::max<uint32_t>(max_l2, staged_lut_entries(img));
         max_span = std::max(max_span, max_wave_span(scans[i].starts(), scans[i].nstarts(), scans[i].nwords(),
                                                     img.metadata.total_restart_intervals));
         algorithmic_bytes += 4ull * scans[i].nwords() + 4ull * img.metadata.total_restart_intervals +
@@ -501,13 +519,10 @@ Status compeg_batch::upload(const ImageData *const *images, size_t n, int thread
         ImageDesc &d = descs[i];
         fill_desc(img, d);
         size_t o = in_off[i];
-        memcpy(hs + o, img.l1, COMPEG_HUFFMAN_L1_BYTES);
+        write_tables(hs + o, img);
         d.l1 = reinterpret_cast<const uint16_t *>(di + o);
-        o += COMPEG_HUFFMAN_L1_BYTES;
-        if (!img.l2.empty())
-            memcpy(hs + o, img.l2.data(), img.l2.size() * 2);
-        d.l2 = reinterpret_cast<const uint16_t *>(di + o);
-        o += align_up(img.l2.size() * 2, 4);
+        d.l2 = reinterpret_cast<const uint16_t *>(di + o + COMPEG_HUFFMAN_L1_BYTES);
+        o += table_blob_bytes(img);
         if (scans[i].nstarts())
             memcpy(hs + o, scans[i].starts(), scans[i].nstarts() * 4);
         d.starts = reinterpret_cast<const uint32_t *>(di + o);
@@ -578,12 +593,12 @@ Status compeg_batch::upload_device_scan(const ImageData *const *images, size_t n
         L.starts = take(size_t(L.slots) * 4);
         L.words = take(size_t(len) + len / 3 + 64);
         L.result = take(16);
-        L.tables = take(COMPEG_HUFFMAN_L1_BYTES + align_up(img.l2.size() * 2, 4));
+        L.tables = take(table_blob_bytes(img));
         out_total += align_up(size_t(img.width) * 4 * img.height, 256);
         max_tiles = std::max(max_tiles, L.ntiles);
         max_intervals = std::max(max_intervals, expected);
         max_dus = std::max(max_dus, img.total_dus());
-        max_l2 = std::max<uint32_t>(max_l2, uint32_t(img.l2.size()));
+        max_l2 = std::max<uint32_t>(max_l2, staged_lut_entries(img));
         pixels += uint64_t(img.width) * img.height;
     }
     CG_TRY(scan_arena.reserve(total + 256));
@@ -601,9 +616,7 @@ Status compeg_batch::upload_device_scan(const ImageData *const *images, size_t n
         const ImageData &img = *images[i];
         const Layout &L = lay[i];
         memcpy(hs + L.raw, img.scan_data(), img.scan_len);
-        memcpy(hs + L.tables, img.l1, COMPEG_HUFFMAN_L1_BYTES);
-        if (!img.l2.empty())
-            memcpy(hs + L.tables + COMPEG_HUFFMAN_L1_BYTES, img.l2.data(), img.l2.size() * 2);
+        write_tables(hs + L.tables, img);
         ScanDesc &s = sd[i];
         s.raw = da + L.raw;
         s.len = uint32_t(img.scan_len);

@@ -7,6 +7,7 @@
 // accesses and undefined shifts in the kernel bodies get caught.  It is not a
 // fallback: nothing in compeg_amd loads this library.
 #include <cstdint>
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -45,6 +46,10 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
     std::vector<uint32_t> words(scan.words(), scan.words() + scan.nwords());
     std::vector<uint32_t> starts(scan.starts(), scan.starts() + scan.nstarts());
     std::vector<uint16_t> l1(img->l1, img->l1 + 1024), l2(img->l2);
+    // global LUT blob as the runtime lays it out: L2, padded to a dword, then the direct AC tables
+    if (l2.size() & 1)
+        l2.push_back(0);
+    l2.insert(l2.end(), img->ac_fast.begin(), img->ac_fast.end());
     std::vector<int16_t> ac(size_t(d.total_dus) * kRetained);
     std::vector<int32_t> dc(d.total_dus);
     d.words = words.data();
@@ -81,7 +86,7 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
             for (uint32_t i = 0; i < wl; i++)
                 win[i] = wb + i < d.nwords ? bswap32(d.words[wb + i]) : 0u;
             memset(slots, 0, 2u * kWave * kDuSlotBytes);
-            HuffShared sh{sl1, sl2, umin(l2_in_lds, d.l2_entries), win, wb, wl, slots};
+            HuffShared sh{sl1, sl2, umin(l2_in_lds, d.fast_off + 2u * kFastEntries), win, wb, wl, slots};
             std::vector<EntropyState> es(kWave);
             std::vector<PixelState> ps(kWave);
             for (uint32_t lane = 0; lane < uint32_t(kWave); lane++) {
@@ -93,10 +98,16 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
             const uint32_t du_total = d.restart_interval * 4u;
             for (uint32_t du = 0; du < du_total; du++) {
                 const uint32_t k = du & 3u, comp = k < 2u ? 0u : k - 1u, set = du & 1u;
+                unsigned long step_max = 0;
                 for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
-                    if (first + lane < d.total_intervals)
+                    if (first + lane < d.total_intervals) {
+                        g_emul_stats.lane_symbols = 0;
                         dcs[set * kWave + lane] = entropy_data_unit(
                             es[lane], d, sh, comp, reinterpret_cast<int16_t *>(slots + (set * kWave + lane) * kDuSlotBytes));
+                        step_max = std::max(step_max, g_emul_stats.lane_symbols);
+                    }
+                g_emul_stats.wave_steps++;
+                g_emul_stats.wave_step_symbols += step_max;
                 for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
                     if (first + lane < d.total_intervals)
                         pixel_data_unit(ps[lane], d, k, comp, slots + (set * kWave + lane) * kDuSlotBytes,
@@ -131,7 +142,7 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
             wave_window(d, wave_first, window_words, wb, wl);
             for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
                 stage_window(d, win, wb, wl, lane);
-            HuffShared sh{sl1, sl2, umin(l2_in_lds, d.l2_entries), win, wb, wl, slots};
+            HuffShared sh{sl1, sl2, umin(l2_in_lds, d.fast_off + 2u * kFastEntries), win, wb, wl, slots};
             for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
                 if (wave_first + lane < d.total_intervals) {
                     if (fused)
@@ -235,5 +246,9 @@ int main(int argc, char **argv)
     dump(argv[3], ac.data(), ac.size() * 2);
     dump(argv[4], dc.data(), dc.size() * 4);
     printf("ok %u %u %u\n", tex_w, tex_h, dus);
+    const EmulStats &st = g_emul_stats;
+    fprintf(stderr, "stats fast_dus=%lu exact_dus=%lu left_window=%lu left_underflow=%lu dc_cut=%lu escapes=%lu symbols=%lu wave_steps=%lu wave_step_symbols=%lu\n",
+            st.fast_dus, st.exact_dus, st.left_window, st.left_underflow, st.dc_cut, st.escapes, st.symbols, st.wave_steps,
+            st.wave_step_symbols);
     return 0;
 }

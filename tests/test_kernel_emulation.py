@@ -23,7 +23,10 @@ def runner():
     return RUNNER
 
 
-def _run(runner, tmp_path, jpeg, fused, waves=1, window=2048, l2=8192):
+STATS = {}   # rare-path counters of the emulated kernels, summed over every run of this module
+
+
+def _run(runner, tmp_path, jpeg, fused, waves=1, window=2048, l2=12288):
     p = tmp_path / "in.jpg"
     p.write_bytes(jpeg)
     env = dict(os.environ)
@@ -34,6 +37,11 @@ def _run(runner, tmp_path, jpeg, fused, waves=1, window=2048, l2=8192):
                         str(waves), str(window), str(l2)], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr[-2000:]
     _, w, h, _ = r.stdout.split()
+    for line in r.stderr.splitlines():
+        if line.startswith("stats "):
+            for kv in line.split()[1:]:
+                k, v = kv.split("=")
+                STATS[k] = STATS.get(k, 0) + int(v)
     return np.fromfile(tmp_path / "rgba", dtype=np.uint8).reshape(int(h), int(w), 4)
 
 
@@ -55,7 +63,8 @@ def test_emulated_kernels_match_oracle(runner, tmp_path, w, h, kind, q, ri, seed
     _check(runner, tmp_path, synth.make_jpeg(w, h, seed=seed, kind=kind, quality=q, ri=ri))
 
 
-@pytest.mark.parametrize("waves,window,l2", [(4, 64, 512), (2, 80, 0), (1, 4, 0), (3, 300, 1024)])
+@pytest.mark.parametrize("waves,window,l2", [(4, 64, 512), (2, 80, 0), (1, 4, 0), (3, 300, 1024), (2, 2048, 3000),
+                                              (2, 80, 12288), (1, 70, 12288), (3, 300, 12288)])
 def test_emulated_kernels_small_lds_budgets(runner, tmp_path, waves, window, l2):
     """Windows / LUT staging cut short by the LDS budget: the global-memory paths."""
     _check(runner, tmp_path, synth.make_jpeg(320, 64, seed=11, kind=1, quality=92, ri=2),
@@ -112,3 +121,21 @@ def test_emulated_count_mismatch_and_truncated_interval(runner, tmp_path):
     i = j.find(b"\xff\xdd")
     j[i + 4:i + 6] = (3).to_bytes(2, "big")     # DRI says 3, stream has markers every 2 MCUs
     _check(runner, tmp_path, bytes(j))
+
+
+def test_emulated_long_codes_and_dense_blocks(runner, tmp_path):
+    """Noise at quality 100: AC codes of up to 16 bits (escapes from the direct tables), data
+    units that end at position 63 without EOB and large DC differences -- the data units after
+    which the reference reader reaches a DC code with few buffered bits (quirk Q1)."""
+    for seed in (51, 52):
+        _check(runner, tmp_path, synth.make_jpeg(96, 32, seed=seed, kind=1, quality=100, ri=3))
+
+
+def test_emulated_rare_paths_were_reached():
+    """Runs last in this module: the cases above must have exercised every branch of the fast
+    entropy path (counters come from the emulator build, -DCG_EMUL_STATS)."""
+    print("emulation path counters:", STATS)
+    assert STATS.get("fast_dus", 0) > 10000
+    assert STATS.get("exact_dus", 0) > 100
+    for key in ("left_window", "left_underflow", "dc_cut", "escapes"):
+        assert STATS.get(key, 0) > 0, (key, STATS)

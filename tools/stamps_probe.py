@@ -41,3 +41,13 @@ tot = b.sum(axis=1)
 print("batch of %d: cycles/wave mean %.0f max %.0f" % (n, tot.mean(), tot.max()))
 for name, col in zip(("dc", "ac", "idct+slot", "composite"), b.T):
     print("  %-10s %8.0f cycles/wave  %5.1f %%" % (name, col.mean(), 100 * col.sum() / tot.sum()))
+# imbalance inside workgroups: a block's LDS is held until its slowest wave is done
+wpb = int(os.environ.get("COMPEG_WPB", "12"))
+per_img = tot.reshape(n, waves)
+loss = []
+for img_t in per_img:
+    nb = (waves + wpb - 1) // wpb
+    pad = np.concatenate([img_t, np.zeros(nb * wpb - waves)])
+    blk = pad.reshape(nb, wpb)
+    loss.append(blk.max(axis=1).sum() * wpb / max(img_t.sum(), 1))
+print("block time / mean wave time (12-wave blocks): %.3f" % np.mean(loss))
