@@ -486,6 +486,13 @@ int compeg_decoder_read_coefficients(compeg_decoder *dec, int32_t *host, size_t 
     });
 }
 
+#if defined(CG_STAMPS)
+extern "C" __attribute__((visibility("default"))) int compeg_debug_ac_stamps(unsigned long long *out, int reset)
+{
+    return compeg::read_ac_stamps(out, reset != 0) == hipSuccess ? 0 : -1;
+}
+#endif
+
 /* Diagnostic builds (-DCG_STAMPS) park per-wave cycle stamps in the dc scratch buffers; these
  * two undeclared helpers read them back.  Not part of the API. */
 __attribute__((visibility("default"))) int compeg_debug_read_dc(compeg_decoder *dec, void *host, size_t bytes)

@@ -20,6 +20,9 @@ uint32_t max_wave_span(const uint32_t *starts, size_t nstarts, size_t nwords, ui
 // largest image, images); blocks past an image's own extent exit at once.
 hipError_t launch_huffman(const ImageDesc *descs, uint32_t images, uint32_t max_intervals,
                           const HuffLdsPlan &plan, hipStream_t stream);
+// Same outputs as launch_huffman (coefficient records + DC terms) from the fast-mode decoder.
+hipError_t launch_entropy(const ImageDesc *descs, uint32_t images, uint32_t max_intervals,
+                          const HuffLdsPlan &plan, hipStream_t stream);
 hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t max_intervals,
                             const HuffLdsPlan &plan, hipStream_t stream);
 // Latency variant: one decoder wave + one transformer wave per 64 intervals.
@@ -27,5 +30,10 @@ hipError_t launch_pair_422(const ImageDesc *descs, uint32_t images, uint32_t max
                            const HuffLdsPlan &plan, hipStream_t stream);
 hipError_t launch_idct_composite(const ImageDesc *descs, uint32_t images, uint32_t max_dus,
                                  hipStream_t stream);
+
+#if defined(CG_STAMPS)
+// diagnostic build: AC-loop cycle counters (kernels_body.h)
+hipError_t read_ac_stamps(unsigned long long out[4], bool reset);
+#endif
 
 } // namespace compeg

@@ -22,7 +22,7 @@ namespace compeg {
 
 // LDS layout (dynamic, 16-byte aligned carve-outs):
 //   [L1: 5*256 u16][L2: l2_in_lds u16][per wave: window_words u32 | 64 DU slots]
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 huffman_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -63,6 +63,50 @@ huffman_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t
     s.win_len = win_len;
     s.du_slots = slots;
     huff_decode_interval(d, s, interval, lane);
+}
+
+// Entropy stage of the two-kernel pipeline: the fast-mode decoder of the fused
+// path, writing coefficient records instead of feeding the IDCT.  Few
+// registers, so the workgroup is as large as the LDS allows.
+__global__ void __launch_bounds__(1024)
+entropy_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const ImageDesc &d = descs[blockIdx.y];
+    const uint32_t first_interval = blockIdx.x * blockDim.x;
+    if (first_interval >= d.total_intervals)
+        return;
+
+    uint16_t *l1 = reinterpret_cast<uint16_t *>(smem);
+    uint16_t *l2 = l1 + kL1Entries;
+    const uint32_t wave_area = align16(window_words * 4u) + kWave * kDuSlotBytes;
+    uint8_t *wave_base = smem + align16((kL1Entries + l2_in_lds) * 2u);
+
+    stage_luts(d, l1, l2, l2_in_lds, threadIdx.x, blockDim.x);
+
+    const uint32_t wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    uint32_t *win = reinterpret_cast<uint32_t *>(wave_base + wave * wave_area);
+    const uint32_t wave_first = first_interval + wave * kWave;
+    uint32_t win_base = 0, win_len = 0;
+    if (wave_first < d.total_intervals) {
+        wave_window(d, wave_first, window_words, win_base, win_len);
+        stage_window(d, win, win_base, win_len, lane);
+    }
+    __syncthreads();
+
+    const uint32_t interval = wave_first + lane;
+    if (interval >= d.total_intervals)
+        return;
+
+    HuffShared s;
+    s.l1 = l1;
+    s.l2 = l2;
+    s.l2_staged = umin(l2_in_lds, d.fast_off + 2u * kFastEntries);
+    s.win = win;
+    s.win_base = win_base;
+    s.win_len = win_len;
+    s.du_slots = reinterpret_cast<uint8_t *>(win) + align16(window_words * 4u);
+    entropy_interval_to_records(d, s, interval, lane);
 }
 
 // Fused path: same prologue as huffman_kernel, then every lane runs the whole
@@ -233,10 +277,22 @@ idct_composite_kernel(const ImageDesc *__restrict__ descs)
     composite_422(d, wave_px, first_mcu, total_mcus, lane);
 }
 
+#if defined(CG_STAMPS)
+hipError_t read_ac_stamps(unsigned long long out[4], bool reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ac_stamps), sizeof(unsigned long long) * 4);
+    if (e == hipSuccess && reset) {
+        const unsigned long long z[4] = {0, 0, 0, 0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_ac_stamps), z, sizeof z);
+    }
+    return e;
+}
+#endif
+
 namespace {
 constexpr uint32_t kLdsBytesPerCu = 160u * 1024u;
 constexpr uint32_t kMaxWavesFused = 12; // 3 per SIMD: what 147 VGPRs allow
-constexpr uint32_t kMaxWavesSplit = 4;
+constexpr uint32_t kMaxWavesSplit = 16; // entropy_kernel: 4 per SIMD
 } // namespace
 
 HuffLdsPlan plan_huffman(uint32_t max_intervals, uint32_t images, uint32_t max_l2,
@@ -299,6 +355,23 @@ hipError_t launch_huffman(const ImageDesc *descs, uint32_t images, uint32_t max_
     if (attr != hipSuccess)
         return attr;
     hipLaunchKernelGGL(huffman_kernel, grid, dim3(threads), plan.total_bytes, stream, descs,
+                       plan.l2_entries_in_lds, plan.window_words);
+    return hipGetLastError();
+}
+
+hipError_t launch_entropy(const ImageDesc *descs, uint32_t images, uint32_t max_intervals,
+                          const HuffLdsPlan &plan, hipStream_t stream)
+{
+    if (images == 0 || max_intervals == 0)
+        return hipSuccess;
+    const uint32_t threads = plan.waves_per_block * kWave;
+    dim3 grid((max_intervals + threads - 1) / threads, images, 1);
+    static const hipError_t attr = hipFuncSetAttribute(
+        reinterpret_cast<const void *>(entropy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        int(kLdsBytesPerCu));
+    if (attr != hipSuccess)
+        return attr;
+    hipLaunchKernelGGL(entropy_kernel, grid, dim3(threads), plan.total_bytes, stream, descs,
                        plan.l2_entries_in_lds, plan.window_words);
     return hipGetLastError();
 }

@@ -730,6 +730,41 @@ inline EmulStats g_emul_stats{};
 #define CG_LDS(T, p) (p)
 #endif
 
+// LDS reads whose position in the instruction stream matters (the compiler
+// otherwise sinks a load to its first use and the software pipelining is
+// gone).  The value may only be used after lds_reads_done() on it.
+CG_DEV uint32_t lds_read_u16_early(const uint16_t *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t v;
+    asm volatile("ds_read_u16 %0, %1" : "=v"(v) : "v"(uint32_t(reinterpret_cast<uintptr_t>(p))) : "memory");
+    return v;
+#else
+    return *p;
+#endif
+}
+
+CG_DEV uint32_t lds_read_u32_early(const uint32_t *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t v;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(uint32_t(reinterpret_cast<uintptr_t>(p))) : "memory");
+    return v;
+#else
+    return *p;
+#endif
+}
+
+CG_DEV void lds_reads_done(uint32_t &a, uint32_t &b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)::"memory");
+#else
+    (void)a;
+    (void)b;
+#endif
+}
+
 CG_DEV bool fast_tables_usable(const ImageDesc &d, const HuffShared &s)
 {
     return d.fast_table[0] < 2u && d.fast_table[1] < 2u && d.fast_table[2] < 2u &&
@@ -771,7 +806,7 @@ CG_DEV void fast_refill(EntropyState &e)
     r.buf |= (uint64_t(w) << 32) >> (r.left & 63u);     // w == 0 when left >= 32
     r.left += f << 5;
     e.wptr += f;
-    r.pre = *CG_LDS(const uint32_t, e.wptr);
+    r.pre = lds_read_u32_early(e.wptr); // due at the next lds_reads_done()
 }
 
 // nb-bit field that ends `tot` bits below the top of cur, sign-extended (0 for nb == 0)
@@ -804,40 +839,75 @@ CG_DEV bool fast_dc(EntropyState &e, const ImageDesc &d, const HuffShared &s, ui
     return true;
 }
 
+#if defined(CG_STAMPS) && defined(__HIPCC__)
+// diagnostic build: [0] cycles inside the AC loop, [1] of those at the LDS wait, [2] iterations, [3] calls
+__device__ unsigned long long g_ac_stamps[4];
+#endif
+#if defined(CG_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+#define CG_AC_STAMP(x) x
+#else
+#define CG_AC_STAMP(x)
+#endif
+
 CG_DEV void fast_ac(EntropyState &e, const ImageDesc &d, const HuffShared &s, uint32_t ac_off,
                     uint32_t fast_base, int16_t *slot16)
 {
+    CG_AC_STAMP(const uint64_t ts0 = __builtin_readcyclecounter(); uint64_t tw = 0; uint32_t its = 0;)
     PrefetchReader &r = e.r;
     const uint16_t *tab = s.l2 + fast_base;
     fast_refill(e);
-    uint32_t ent = CG_LDS(const uint16_t, tab)[reader_cur(r) >> (32u - kFastBits)];
+    uint32_t ent = lds_read_u16_early(tab + (reader_cur(r) >> (32u - kFastBits)));
     uint32_t at = 0u, tot = 0u; // at: zig-zag position of the coefficient decoded last
     // Software-pipelined like the exact loop, but nothing is speculative:
-    // topping the buffer up early cannot change a result.
+    // topping the buffer up early cannot change a result.  One LDS wait per
+    // symbol: the lookup of the next symbol and the next stream word are
+    // issued as early as the bit position allows and are both due at the top
+    // of the next iteration; the coefficient store of a symbol is issued one
+    // iteration late (ahead of those reads in the LDS queue), so that its
+    // completion is never waited for.
+    int16_t *pend_at = slot16 + kRetained; // the slot's padding
+    int16_t pend_val = 0;
     while (at < 63u) {
-        if (ent >= kFastEscape) {
+        CG_AC_STAMP(const uint64_t tw0 = __builtin_readcyclecounter();)
+        lds_reads_done(ent, r.pre);
+        CG_AC_STAMP(tw += __builtin_readcyclecounter() - tw0; its++;)
+        *pend_at = pend_val;
+#if CG_EXP != 7 // (7: diagnostic build without the escape test)
+        if (ent >= kFastEscape)
+#else
+        if (false)
+#endif
+        {
             // code longer than 11 bits: this symbol through the reference's tables
             CG_COUNT(escapes);
             ent = fast_entry(lut_lookup<true>(d, s, ac_off, reader_cur(r)));
         }
-        const uint32_t nb = ent & 15u;
+        const uint32_t nb = ent & 15u, adv = ent >> 9;
         tot = (ent >> 4) & 31u;
         const uint32_t cur = reader_cur(r);
         r.buf <<= tot;
         r.left -= tot;
         fast_refill(e);
-        const uint32_t next = CG_LDS(const uint16_t, tab)[reader_cur(r) >> (32u - kFastBits)];
+        ent = lds_read_u16_early(tab + (reader_cur(r) >> (32u - kFastBits)));
         // a magnitude whose first bit is 0 encodes field - (2^nb - 1)
         const int32_t sx = signed_field(cur, tot, nb);
         const uint32_t val = uint32_t(sx) + (((0xffffffffu << nb) ^ uint32_t(sx >> 31)) + 1u);
-        at += ent >> 9;
+        at += adv;
         CG_COUNT(symbols);
         CG_COUNT(lane_symbols);
         // EOB / ZRL store a zero at a position that is zero anyway (or at the
         // slot's padding)
-        slot16[umin(at, uint32_t(kRetained))] = int16_t(val);
-        ent = next;
+        pend_at = slot16 + umin(at, uint32_t(kRetained));
+        pend_val = int16_t(val);
     }
+    lds_reads_done(ent, r.pre);
+    *pend_at = pend_val;
+    CG_AC_STAMP(if ((threadIdx.x & 63u) == 0u) {
+        atomicAdd(&g_ac_stamps[0], __builtin_readcyclecounter() - ts0);
+        atomicAdd(&g_ac_stamps[1], tw);
+        atomicAdd(&g_ac_stamps[2], its);
+        atomicAdd(&g_ac_stamps[3], 1ull);
+    })
     e.ref_left = 32u + ((r.left + tot) & 31u) - tot;
 }
 
@@ -1022,6 +1092,25 @@ CG_DEV void composite_own_mcu_422(const ImageDesc &d, const uint32_t (&px)[4][16
             }
         if (acc == 0x12345678u)
             *CG_GLOBAL(uint32_t, reinterpret_cast<uint32_t *>(base)) = acc;
+#if CG_EXP == 8 && defined(__HIP_DEVICE_COMPILE__)
+    } else if (whole) {
+        // diagnostic build: the store pattern a quad transpose would give (each
+        // 4-lane group writes one MCU's 64-byte row segment per store); wrong
+        // pixels, same bytes, same arithmetic
+        const uint32_t lane = threadIdx.x & 63u, quad = lane & ~3u, i = lane & 3u;
+        const uint64_t mybase = reinterpret_cast<uint64_t>(base);
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {
+            const uint32_t lo = __shfl(uint32_t(mybase), int(quad + q)), hi = __shfl(uint32_t(mybase >> 32), int(quad + q));
+            uint8_t *other = reinterpret_cast<uint8_t *>(uint64_t(hi) << 32 | lo);
+#pragma unroll
+            for (uint32_t row = 0; row < 8; row++) {
+                auto *line = CG_GLOBAL(Vec4u, reinterpret_cast<Vec4u *>(other + size_t(row) * d.out_pitch));
+                line[i] = rgba_quad(px[q >> 1][row * 2u + (q & 1u)], px[2][row * 2u + (q >> 1)] >> ((q & 1u) * 16u),
+                                    px[3][row * 2u + (q >> 1)] >> ((q & 1u) * 16u));
+            }
+        }
+#endif
     } else if (whole) {
         // the common case: 8 rows x 64 bytes, unconditional 16-byte stores
 #pragma unroll
@@ -1074,6 +1163,40 @@ CG_DEV void composite_own_mcu_422(const ImageDesc &d, const uint32_t (&px)[4][16
 // ---------------------------------------------------------------------------
 // The same work as two cooperating roles (decoder wave + transformer wave)
 // ---------------------------------------------------------------------------
+
+// Entropy decode of one restart interval into the coefficient records the
+// IDCT kernel reads (two-kernel pipeline): per data unit one 64-byte record of
+// quantised AC levels (zig-zag order, position 0 unused) in d.ac and the
+// dequantised DC term in d.dc.  Any sampling the front-end accepts.
+CG_DEV void entropy_interval_to_records(const ImageDesc &d, const HuffShared &s, uint32_t interval,
+                                        uint32_t lane)
+{
+    uint8_t *slot = s.du_slots + lane * kDuSlotBytes;
+    int16_t *slot16 = reinterpret_cast<int16_t *>(slot);
+    zero_slot(slot);
+
+    EntropyState e;
+    entropy_init(e, d, s, interval);
+
+    const uint32_t dpm = d.dus_per_mcu;
+    const uint32_t du_count = d.restart_interval * dpm;
+    uint32_t du_global = interval * du_count;
+    uint32_t k = 0; // data unit inside the MCU (wave-uniform)
+#pragma unroll 1
+    for (uint32_t du = 0; du < du_count; du++) {
+        const uint32_t comp = (d.comp_of_du >> (2u * k)) & 3u;
+        const int32_t dc = entropy_data_unit(e, d, s, comp < 3u ? comp : 2u, slot16);
+        uint32_t rec[kRetained / 2];
+        take_slot(slot, rec);
+        auto *dst = CG_GLOBAL(Vec4u, reinterpret_cast<Vec4u *>(d.ac + size_t(du_global) * kRetained));
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            dst[i] = Vec4u{rec[4 * i], rec[4 * i + 1], rec[4 * i + 2], rec[4 * i + 3]};
+        CG_GLOBAL(int32_t, d.dc)[du_global] = dc;
+        du_global++;
+        k = k + 1u == dpm ? 0u : k + 1u;
+    }
+}
 
 // Transformer role: the samples of the MCU being assembled and where it goes.
 struct PixelState {

@@ -350,7 +350,7 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
                                     plan, stream));
         coefficients_valid = false;
     } else {
-        CG_HIP(launch_huffman(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals,
+        CG_HIP(launch_entropy(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals,
                               plan, stream));
         CG_HIP(launch_idct_composite(reinterpret_cast<const ImageDesc *>(db), 1, total_dus, stream));
         coefficients_valid = true;
@@ -730,7 +730,7 @@ Status compeg_batch::decode(hipStream_t stream)
                 CG_HIP(hipEventRecord(ev[1], stream));
             continue;
         }
-        CG_HIP(launch_huffman(dd + at, m, max_intervals, plan, stream));
+        CG_HIP(launch_entropy(dd + at, m, max_intervals, plan, stream));
         if (timing && at == 0)
             CG_HIP(hipEventRecord(ev[1], stream)); // stage split is exact for unchunked decodes
         CG_HIP(launch_idct_composite(dd + at, m, max_dus, stream));

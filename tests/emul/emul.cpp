@@ -145,7 +145,9 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
             HuffShared sh{sl1, sl2, umin(l2_in_lds, d.fast_off + 2u * kFastEntries), win, wb, wl, slots};
             for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
                 if (wave_first + lane < d.total_intervals) {
-                    if (fused)
+                    if (fused == 3)
+                        entropy_interval_to_records(d, sh, wave_first + lane, lane);
+                    else if (fused)
                         decode_interval_fused_422(d, sh, wave_first + lane, lane);
                     else
                         huff_decode_interval(d, sh, wave_first + lane, lane);
@@ -158,7 +160,7 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
     if (dc_out)
         memcpy(dc_out, dc.data(), dc.size() * 4);
 
-    if (fused) {
+    if (fused && fused != 3) {
         delete img;
         return 0;
     }

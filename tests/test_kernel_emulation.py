@@ -32,7 +32,7 @@ def _run(runner, tmp_path, jpeg, fused, waves=1, window=2048, l2=12288):
     env = dict(os.environ)
     env.pop("EMUL_FUSED", None)
     if fused:
-        env["EMUL_FUSED"] = str(int(fused))   # 1 = fused kernel, 2 = paired-wave kernel
+        env["EMUL_FUSED"] = str(int(fused))   # 1 = fused kernel, 2 = paired-wave kernel, 3 = entropy + IDCT kernels
     r = subprocess.run([runner, str(p), str(tmp_path / "rgba"), str(tmp_path / "ac"), str(tmp_path / "dc"),
                         str(waves), str(window), str(l2)], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr[-2000:]
@@ -47,7 +47,7 @@ def _run(runner, tmp_path, jpeg, fused, waves=1, window=2048, l2=12288):
 
 def _check(runner, tmp_path, jpeg, **kw):
     want = orc.ImageData(jpeg).decode()
-    for fused in (1, 2, 0):   # fused kernel, paired-wave kernel, split kernels
+    for fused in (1, 2, 3, 0):   # fused kernel, paired-wave kernel, two-kernel pipeline, reference-style split kernels
         got = _run(runner, tmp_path, jpeg, fused, **kw)
         assert np.array_equal(got, want), f"fused={fused}: {(got != want).any(axis=2).sum()} pixels differ"
 

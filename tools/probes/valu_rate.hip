@@ -92,6 +92,50 @@ PROBE(k_ds_write_b64, "ds_write_b64 %0, v[12:13]\n", "v16")
 PROBE(k_pk_mad_i16, "v_pk_mad_i16 v10, %0, %1, %1\n", "v16")
 PROBE(k_pk_max_i16, "v_pk_max_i16 v10, %0, %1\n", "v16")
 PROBE(k_cvt_f32_i32, "v_cvt_f32_i32 v10, %0\n", "v16")
+#define REP8x4(a,b,c,d) a b c d a b c d a b c d a b c d a b c d a b c d a b c d a b c d
+#define PROBE4(name, i0, i1, i2, i3)                                                          \
+    __global__ void name(uint64_t *out, int iters)                                           \
+    {                                                                                        \
+        float a = __builtin_bit_cast(float, (threadIdx.x & 63u) * 8u), b = blockIdx.x + 1.5f; \
+        uint64_t t0 = __builtin_readcyclecounter();                                          \
+        for (int i = 0; i < iters; i++) {                                                    \
+            asm volatile(REP8x4(i0, i1, i2, i3) : "+v"(a), "+v"(b)::"v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "vcc", "scc");  \
+        }                                                                                    \
+        uint64_t t1 = __builtin_readcyclecounter();                                          \
+        if ((threadIdx.x & 63) == 0)                                                         \
+            out[(blockIdx.x * blockDim.x + threadIdx.x) / 64] = t1 - t0;                     \
+        if (a == 12345.f && b == 1.25f)                                                      \
+            out[0] = 0;                                                                      \
+    }
+#define PROBE_N(name, REPS, N)                                                                 \
+    __global__ void name(uint64_t *out, int iters)                                           \
+    {                                                                                        \
+        float a = __builtin_bit_cast(float, (threadIdx.x & 63u) * 8u), b = blockIdx.x + 1.5f; \
+        const int loops = iters * 32 / N;                                                    \
+        uint64_t t0 = __builtin_readcyclecounter();                                          \
+        for (int i = 0; i < loops; i++) {                                                    \
+            asm volatile(REPS("v_add_f32 v10, %0, %1\n") : "+v"(a), "+v"(b)::"v10");        \
+        }                                                                                    \
+        uint64_t t1 = __builtin_readcyclecounter();                                          \
+        if ((threadIdx.x & 63) == 0)                                                         \
+            out[(blockIdx.x * blockDim.x + threadIdx.x) / 64] = t1 - t0;                     \
+        if (a == 12345.f && b == 1.25f)                                                      \
+            out[0] = 0;                                                                      \
+    }
+#define REP1(x) x
+#define REP2(x) x x
+#define REP8(x) REP4(x) REP4(x)
+#define REP128(x) REP32(x) REP32(x) REP32(x) REP32(x)
+PROBE_N(k_body2, REP2, 2)
+PROBE_N(k_body4, REP4, 4)
+PROBE_N(k_body8, REP8, 8)
+PROBE_N(k_body128, REP128, 128)
+PROBE4(k_ilp_add_f32, "v_add_f32 v10, %0, %1\n", "v_add_f32 v11, %0, %1\n", "v_add_f32 v12, %0, %1\n", "v_add_f32 v13, %0, %1\n")
+PROBE4(k_ilp_chain4, "v_add_f32 v10, v10, %1\n", "v_add_f32 v11, v11, %1\n", "v_add_f32 v12, v12, %1\n", "v_add_f32 v13, v13, %1\n")
+PROBE4(k_ilp_chain2, "v_add_f32 v10, v10, %1\n", "v_add_f32 v11, v11, %1\n", "v_add_f32 v10, v10, %1\n", "v_add_f32 v11, v11, %1\n")
+PROBE4(k_ilp_perm, "v_perm_b32 v10, %0, %1, v14\n", "v_perm_b32 v11, %0, %1, v14\n", "v_perm_b32 v12, %0, %1, v14\n", "v_perm_b32 v13, %0, %1, v14\n")
+PROBE4(k_ilp_pk, "v_pk_add_f32 v[10:11], v[14:15], v[16:17]\n", "v_pk_add_f32 v[12:13], v[14:15], v[16:17]\n", "v_pk_add_f32 v[18:19], v[14:15], v[16:17]\n", "v_pk_add_f32 v[10:11], v[14:15], v[16:17]\n")
+PROBE4(k_ilp_mix, "v_add_f32 v10, %0, %1\n", "v_lshlrev_b64 v[12:13], %0, v[14:15]\n", "v_sub_f32 v11, %0, %1\n", "v_perm_b32 v16, %0, %1, v14\n")
 PROBE(k_dep_add, "v_add_u32 %0, %0, %1\n", "v16")
 PROBE(k_dep_lshl64, "v_lshlrev_b64 v[12:13], %0, v[12:13]\n", "v16")
 PROBE(k_dep_perm, "v_perm_b32 %0, %0, %1, v12\n", "v16")
@@ -122,6 +166,9 @@ int main()
         {"ds_read_b64", k_ds_read_b64}, {"ds_read_b64 +1", k_ds_read_b64_u1}, {"ds_read_b64 +5", k_ds_read_b64_u5},
         {"ds_read2_b32", k_ds_read2_b32}, {"ds_read_b96", k_ds_read_b96}, {"ds_write_b32", k_ds_write_b32}, {"ds_write_b64", k_ds_write_b64},
         {"v_pk_mad_i16", k_pk_mad_i16}, {"v_pk_max_i16", k_pk_max_i16}, {"v_cvt_f32_i32", k_cvt_f32_i32},
+        {"loop body 2 v_add", k_body2}, {"loop body 4 v_add", k_body4}, {"loop body 8 v_add", k_body8}, {"loop body 128 v_add", k_body128},
+        {"ILP4 v_add_f32", k_ilp_add_f32}, {"4 chains v_add_f32", k_ilp_chain4}, {"2 chains v_add_f32", k_ilp_chain2},
+        {"ILP4 v_perm_b32", k_ilp_perm}, {"ILP3 v_pk_add_f32", k_ilp_pk}, {"ILP4 mix", k_ilp_mix},
         {"dep v_add_u32", k_dep_add}, {"dep v_lshlrev_b64", k_dep_lshl64}, {"dep v_perm_b32", k_dep_perm}, {"dep v_cndmask", k_dep_cnd},
     };
     setvbuf(stdout, nullptr, _IONBF, 0);
