@@ -29,10 +29,12 @@ constexpr uint32_t fast_entry(uint32_t ref)
 }
 
 // LDS slot of one lane's data unit while it is being decoded: 32 int16 in
-// zig-zag order + one dummy position (coefficients >= 32 are dropped there),
-// 17 dwords per lane: an odd dword stride makes both the 2-byte scatter
-// stores and the 4-byte read-back conflict-free across the 32 LDS banks.
-constexpr int kDuSlotBytes = 68;
+// zig-zag order + one dummy position (coefficients >= 32 are dropped there).
+// 80 bytes per lane: 16-byte aligned, so that the slot is read back, cleared
+// and -- as the quad exchange buffer of the composite -- written and read with
+// 16-byte LDS accesses, and 20 dwords apart, which keeps the 16 lanes of each
+// access phase on different banks.
+constexpr int kDuSlotBytes = 80;
 
 // Everything the kernels need to know about one image.  Lives in device
 // memory (one array entry per image of a batch); all pointers are device
@@ -73,7 +75,6 @@ struct ImageDesc {
     uint8_t *out; // RGBA8
     uint32_t out_w, out_h;
     uint32_t out_pitch; // bytes
-    uint32_t debug_flags; // experiments only: bit 0 = skip the pixel stores
     // launch bookkeeping for batched grids
     uint32_t first_huff_block; // block index of this image's first huffman block
     uint32_t first_idct_block;

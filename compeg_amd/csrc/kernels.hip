@@ -140,9 +140,8 @@ decode_fused_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds,
     }
     __syncthreads();
 
-    const uint32_t interval = wave_first + lane;
-    if (interval >= d.total_intervals)
-        return;
+    if (wave_first >= d.total_intervals)
+        return; // the whole wave; lanes past the last interval of a partly used wave stay (quad exchange)
 
     HuffShared s;
     s.l1 = l1;
@@ -152,7 +151,7 @@ decode_fused_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds,
     s.win_base = win_base;
     s.win_len = win_len;
     s.du_slots = slots;
-    decode_interval_fused_422(d, s, interval, lane);
+    decode_wave_fused_422(d, s, wave_first + lane, lane);
 }
 
 // Latency-oriented variant of the fused path for launches that cannot fill
@@ -217,15 +216,16 @@ decode_pair_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, 
         }
     } else {
         PixelState t;
-        pixel_init(t, d, active ? interval : 0u);
+        pixel_init(t, d, active ? interval : 0u, active);
 #pragma unroll 1
         for (uint32_t du = 0; du < du_total; du++) {
             const uint32_t k = du & 3u, comp = k < 2u ? 0u : k - 1u, set = du & 1u;
             __syncthreads(); // data unit `du` is complete
-            if (active) {
-                uint8_t *slot = slots + (set * kWave + lane) * kDuSlotBytes;
-                pixel_data_unit(t, d, k, comp, slot, dcs[set * kWave + lane]);
-            }
+            uint8_t *set_slots = slots + set * kWave * kDuSlotBytes;
+            if (active)
+                pixel_transform(t, d, comp, set_slots + lane * kDuSlotBytes, dcs[set * kWave + lane]);
+            if (k == 3u)
+                composite_mcus_422<false>(t, d, set_slots, lane);
         }
     }
 }

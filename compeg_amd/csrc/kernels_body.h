@@ -118,28 +118,34 @@ CG_DEV int32_t huff_extend(int32_t v, uint32_t t)
     return v < vt ? int32_t(ext) : v;
 }
 
-// The slot is written as int16 and read back as dwords: the dword view must be
-// allowed to alias (otherwise the compiler may reorder the two).
+// The slot is written as int16 and read back in 16-byte pieces: that view must
+// be allowed to alias (otherwise the compiler may reorder the two).
 typedef uint32_t __attribute__((may_alias)) slot_word_t;
+struct __attribute__((may_alias, aligned(16))) SlotVec {
+    uint32_t x, y, z, w;
+};
 
 CG_DEV void zero_slot(uint8_t *slot)
 {
-    slot_word_t *p = reinterpret_cast<slot_word_t *>(slot);
+    SlotVec *p = reinterpret_cast<SlotVec *>(slot);
 #pragma unroll
-    for (int i = 0; i < kRetained / 2; i++)
-        p[i] = 0u;
+    for (int i = 0; i < kRetained / 8; i++)
+        p[i] = SlotVec{0u, 0u, 0u, 0u};
 }
 
 // Moves a finished data unit out of its slot (and clears the slot).
 CG_DEV void take_slot(uint8_t *slot, uint32_t (&rec)[kRetained / 2])
 {
-    slot_word_t *p = reinterpret_cast<slot_word_t *>(slot);
+    SlotVec *p = reinterpret_cast<SlotVec *>(slot);
 #pragma unroll
-    for (int i = 0; i < kRetained / 2; i++)
-        rec[i] = p[i];
-#pragma unroll
-    for (int i = 0; i < kRetained / 2; i++)
-        p[i] = 0u;
+    for (int i = 0; i < kRetained / 8; i++) {
+        const SlotVec v = p[i];
+        rec[4 * i + 0] = v.x;
+        rec[4 * i + 1] = v.y;
+        rec[4 * i + 2] = v.z;
+        rec[4 * i + 3] = v.w;
+    }
+    zero_slot(slot);
 }
 
 constexpr uint32_t kL1Entries = 5 * 256; // 4 tables + the all-zero table
@@ -1074,88 +1080,81 @@ CG_DEV Vec4u rgba_quad(uint32_t yw, uint32_t cb2, uint32_t cr2)
 }
 
 // px[k][2*row + half]: data unit k (Y0, Y1, Cb, Cr), 4 samples per word.
-CG_DEV void composite_own_mcu_422(const ImageDesc &d, const uint32_t (&px)[4][16], uint32_t mx,
-                                  uint32_t my)
+//
+// The composite of an MCU (16x8 pixels, 8 rows of 64 bytes) goes out through
+// the lane's quad: every lane converts its own MCU row by row, the four lanes
+// of a quad exchange the row through LDS (each lane's coefficient slot is idle
+// at this point and serves as the exchange buffer), and lane i of the quad
+// stores piece i (16 bytes) of each of the quad's four rows.  A wave-wide
+// store then writes 16 segments of 64 contiguous bytes instead of 64 separate
+// 16-byte pieces; the vector memory path processes it in a quarter of the time.
+
+// Row `row` of the lane's MCU into its slot (4 x 16 bytes).
+CG_DEV void composite_row_to_slot(const uint32_t (&px)[4][16], uint32_t row, uint8_t *slot)
+{
+    SlotVec *p = reinterpret_cast<SlotVec *>(slot);
+#pragma unroll
+    for (uint32_t q = 0; q < 4; q++) {
+#if CG_EXP == 5 // diagnostic build: stores without the colour arithmetic
+        p[q] = SlotVec{px[q >> 1][row * 2u + (q & 1u)], px[2][row * 2u + (q >> 1)], px[3][row * 2u + (q >> 1)], q};
+#else
+        const Vec4u o = rgba_quad(px[q >> 1][row * 2u + (q & 1u)], px[2][row * 2u + (q >> 1)] >> ((q & 1u) * 16u),
+                                  px[3][row * 2u + (q >> 1)] >> ((q & 1u) * 16u));
+        p[q] = SlotVec{o.x, o.y, o.z, o.w};
+#endif
+    }
+}
+
+// Lane `lane` stores its piece of row `row` of the four MCUs of its quad.
+// bases[j]: top-left byte of the MCU of the quad's lane j; bit j of whole_mask:
+// that MCU lies entirely inside the output and is stored this way.
+CG_DEV void composite_row_from_quad(const ImageDesc &d, const uint8_t *wave_slots, uint32_t lane, uint32_t row,
+                                    uint8_t *const (&bases)[4], uint32_t whole_mask)
+{
+    const uint32_t quad = lane & ~3u, piece = lane & 3u;
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) {
+        const SlotVec v = reinterpret_cast<const SlotVec *>(wave_slots + (quad + j) * kDuSlotBytes)[piece];
+        if (whole_mask >> j & 1u) {
+            uint8_t *p = bases[j] + size_t(row) * d.out_pitch + piece * 16u;
+            *CG_GLOBAL(Vec4u, reinterpret_cast<Vec4u *>(p)) = Vec4u{v.x, v.y, v.z, v.w};
+        }
+    }
+}
+
+// An MCU cut by the right / bottom edge of the output (stores outside it are
+// dropped, like textureStore in the reference) or an unaligned pitch: the
+// owning lane stores it pixel by pixel.
+CG_DEV void composite_edge_mcu(const ImageDesc &d, const uint32_t (&px)[4][16], uint32_t mx, uint32_t my)
 {
     const uint32_t x0 = mx * 16u, y0 = my * 8u;
     uint8_t *base = d.out + size_t(y0) * d.out_pitch + size_t(x0) * 4u;
-    const bool whole = x0 + 16u <= d.out_w && y0 + 8u <= d.out_h && (d.out_pitch & 15u) == 0u;
-    if (d.debug_flags & 1u) {
-        // timing experiment: everything computed, nothing stored
-        uint32_t acc = 0;
-#pragma unroll
-        for (uint32_t row = 0; row < 8; row++)
-#pragma unroll
-            for (uint32_t q = 0; q < 4; q++) {
-                const Vec4u o = rgba_quad(px[q >> 1][row * 2u + (q & 1u)], px[2][row * 2u + (q >> 1)] >> ((q & 1u) * 16u), px[3][row * 2u + (q >> 1)] >> ((q & 1u) * 16u));
-                acc ^= o.x ^ o.y ^ o.z ^ o.w;
-            }
-        if (acc == 0x12345678u)
-            *CG_GLOBAL(uint32_t, reinterpret_cast<uint32_t *>(base)) = acc;
-#if CG_EXP == 8 && defined(__HIP_DEVICE_COMPILE__)
-    } else if (whole) {
-        // diagnostic build: the store pattern a quad transpose would give (each
-        // 4-lane group writes one MCU's 64-byte row segment per store); wrong
-        // pixels, same bytes, same arithmetic
-        const uint32_t lane = threadIdx.x & 63u, quad = lane & ~3u, i = lane & 3u;
-        const uint64_t mybase = reinterpret_cast<uint64_t>(base);
-#pragma unroll
+#pragma unroll 1
+    for (uint32_t row = 0; row < 8; row++) {
+        if (y0 + row >= d.out_h)
+            break;
+#pragma unroll 1
         for (uint32_t q = 0; q < 4; q++) {
-            const uint32_t lo = __shfl(uint32_t(mybase), int(quad + q)), hi = __shfl(uint32_t(mybase >> 32), int(quad + q));
-            uint8_t *other = reinterpret_cast<uint8_t *>(uint64_t(hi) << 32 | lo);
+            const uint32_t w = row * 2u + (q & 1u), c = row * 2u + (q >> 1);
+            // select the words without dynamic register indexing
+            uint32_t yw = 0, cbw = 0, crw = 0;
 #pragma unroll
-            for (uint32_t row = 0; row < 8; row++) {
-                auto *line = CG_GLOBAL(Vec4u, reinterpret_cast<Vec4u *>(other + size_t(row) * d.out_pitch));
-                line[i] = rgba_quad(px[q >> 1][row * 2u + (q & 1u)], px[2][row * 2u + (q >> 1)] >> ((q & 1u) * 16u),
-                                    px[3][row * 2u + (q >> 1)] >> ((q & 1u) * 16u));
+            for (uint32_t i = 0; i < 16; i++) {
+                yw = (i == w) ? ((q >> 1) ? px[1][i] : px[0][i]) : yw;
+                cbw = (i == c) ? px[2][i] : cbw;
+                crw = (i == c) ? px[3][i] : crw;
             }
-        }
-#endif
-    } else if (whole) {
-        // the common case: 8 rows x 64 bytes, unconditional 16-byte stores
-#pragma unroll
-        for (uint32_t row = 0; row < 8; row++) {
-            auto *line = CG_GLOBAL(Vec4u, reinterpret_cast<Vec4u *>(base + size_t(row) * d.out_pitch));
-#pragma unroll
-            for (uint32_t q = 0; q < 4; q++)
-#if CG_EXP == 5 // diagnostic build: stores without the colour arithmetic
-                line[q] = Vec4u{px[q >> 1][row * 2u + (q & 1u)], px[2][row * 2u + (q >> 1)], px[3][row * 2u + (q >> 1)], q};
-#else
-                line[q] = rgba_quad(px[q >> 1][row * 2u + (q & 1u)],
-                                    px[2][row * 2u + (q >> 1)] >> ((q & 1u) * 16u),
-                                    px[3][row * 2u + (q >> 1)] >> ((q & 1u) * 16u));
-#endif
-        }
-    } else {
-        // MCUs cut by the right / bottom edge (stores outside the output are
-        // dropped, like textureStore in the reference) or an unaligned pitch
-#pragma unroll 1
-        for (uint32_t row = 0; row < 8; row++) {
-            if (y0 + row >= d.out_h)
-                break;
-#pragma unroll 1
-            for (uint32_t q = 0; q < 4; q++) {
-                const uint32_t w = row * 2u + (q & 1u), c = row * 2u + (q >> 1);
-                // select the words without dynamic register indexing
-                uint32_t yw = 0, cbw = 0, crw = 0;
-#pragma unroll
-                for (uint32_t i = 0; i < 16; i++) {
-                    yw = (i == w) ? ((q >> 1) ? px[1][i] : px[0][i]) : yw;
-                    cbw = (i == c) ? px[2][i] : cbw;
-                    crw = (i == c) ? px[3][i] : crw;
-                }
-                const Vec4u o = rgba_quad(yw, cbw >> ((q & 1u) * 16u), crw >> ((q & 1u) * 16u));
-                const uint32_t x = x0 + q * 4u;
-                auto *p = CG_GLOBAL(uint32_t, reinterpret_cast<uint32_t *>(base + size_t(row) * d.out_pitch + q * 16u));
-                if (x < d.out_w)
-                    p[0] = o.x;
-                if (x + 1u < d.out_w)
-                    p[1] = o.y;
-                if (x + 2u < d.out_w)
-                    p[2] = o.z;
-                if (x + 3u < d.out_w)
-                    p[3] = o.w;
-            }
+            const Vec4u o = rgba_quad(yw, cbw >> ((q & 1u) * 16u), crw >> ((q & 1u) * 16u));
+            const uint32_t x = x0 + q * 4u;
+            auto *p = CG_GLOBAL(uint32_t, reinterpret_cast<uint32_t *>(base + size_t(row) * d.out_pitch + q * 16u));
+            if (x < d.out_w)
+                p[0] = o.x;
+            if (x + 1u < d.out_w)
+                p[1] = o.y;
+            if (x + 2u < d.out_w)
+                p[2] = o.z;
+            if (x + 3u < d.out_w)
+                p[3] = o.w;
         }
     }
 }
@@ -1202,9 +1201,10 @@ CG_DEV void entropy_interval_to_records(const ImageDesc &d, const HuffShared &s,
 struct PixelState {
     uint32_t px[4][16]; // 4-deep shift chain: after Cr it holds Y0 Y1 Cb Cr
     uint32_t mx, my;
+    bool active;        // false: a lane past the image's last interval; it only helps its quad store
 };
 
-CG_DEV void pixel_init(PixelState &t, const ImageDesc &d, uint32_t interval)
+CG_DEV void pixel_init(PixelState &t, const ImageDesc &d, uint32_t interval, bool active)
 {
 #pragma unroll
     for (int k = 0; k < 4; k++)
@@ -1214,12 +1214,11 @@ CG_DEV void pixel_init(PixelState &t, const ImageDesc &d, uint32_t interval)
     const uint32_t mcu = interval * d.restart_interval;
     t.mx = mcu % d.width_mcus;
     t.my = mcu / d.width_mcus;
+    t.active = active;
 }
 
-// One data unit: coefficients out of `slot` (cleared for reuse), IDCT, and
-// after the MCU's last data unit (k == 3) the composite of the whole MCU.
-CG_DEV void pixel_data_unit(PixelState &t, const ImageDesc &d, uint32_t k, uint32_t comp, uint8_t *slot,
-                            int32_t dc)
+// One data unit: coefficients out of `slot` (cleared for reuse) and IDCT.
+CG_DEV void pixel_transform(PixelState &t, const ImageDesc &d, uint32_t comp, uint8_t *slot, int32_t dc)
 {
     uint32_t rec[kRetained / 2];
     take_slot(slot, rec);
@@ -1229,34 +1228,121 @@ CG_DEV void pixel_data_unit(PixelState &t, const ImageDesc &d, uint32_t k, uint3
         t.px[1][w] = t.px[2][w];
         t.px[2][w] = t.px[3][w];
     }
+#if CG_EXP == 4 // diagnostic build: no IDCT (same data flow)
+#pragma unroll
+    for (int w = 0; w < 16; w++)
+        t.px[3][w] = rec[w] + uint32_t(dc);
+#else
     idct_data_unit(rec, dc, d.quant[comp], t.px[3]);
-    if (k == 3u) {
-        composite_own_mcu_422(d, t.px, t.mx, t.my);
-        t.mx++;
-        if (t.mx == d.width_mcus) {
-            t.mx = 0;
-            t.my++;
-        }
+#endif
+}
+
+// Where the MCU the lane has just finished goes.
+struct McuTarget {
+    uint8_t *base; // top-left byte
+    bool whole;    // entirely inside the output, 16-byte aligned rows: stored through the quad
+};
+
+CG_DEV McuTarget mcu_target(const PixelState &t, const ImageDesc &d)
+{
+    const uint32_t x0 = t.mx * 16u, y0 = t.my * 8u;
+    McuTarget g;
+    g.base = d.out + size_t(y0) * d.out_pitch + size_t(x0) * 4u;
+    g.whole = t.active && x0 + 16u <= d.out_w && y0 + 8u <= d.out_h && (d.out_pitch & 15u) == 0u;
+    return g;
+}
+
+CG_DEV void pixel_next_mcu(PixelState &t, const ImageDesc &d)
+{
+    t.mx++;
+    if (t.mx == d.width_mcus) {
+        t.mx = 0;
+        t.my++;
     }
 }
 
-// The whole path for one restart interval of a 4:2:2 image: entropy decode,
-// IDCT and composite, data unit by data unit.  Every lane of a wave runs
-// this on its own interval; the per-data-unit `while` loop in decode_ac is
-// where lanes wait for each other (SIMT reconvergence), so that table
-// selectors, quantisers and the IDCT that follows run with a full wave.
-CG_DEV void decode_interval_fused_422(const ImageDesc &d, const HuffShared &s, uint32_t interval,
-                                      uint32_t lane)
+#if defined(__HIPCC__)
+// value of lane j of the caller's quad
+template <int J>
+CG_DEV uint32_t quad_lane(uint32_t v)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return uint32_t(__builtin_amdgcn_update_dpp(0, int(v), J * 0x55, 0xf, 0xf, true));
+#else
+    return v; // host pass of hipcc: never executed
+#endif
+}
+
+// The composite of the wave's 64 current MCUs; every lane of the wave calls
+// this together (tests/emul drives the same steps lane by lane).
+// wave_slots: the 64 slots the data units came through.
+// QUADS = false: every lane stores its own MCU, 16 bytes at a time -- less
+// latency (no LDS round trip per row) for launches that leave the vector
+// memory path idle anyway (the paired kernel).
+template <bool QUADS>
+CG_DEV void composite_mcus_422(PixelState &t, const ImageDesc &d, uint8_t *wave_slots, uint32_t lane)
+{
+    const McuTarget g = mcu_target(t, d);
+    if (!QUADS) {
+        if (g.whole) {
+#pragma unroll
+            for (uint32_t row = 0; row < 8; row++) {
+                auto *line = CG_GLOBAL(Vec4u, reinterpret_cast<Vec4u *>(g.base + size_t(row) * d.out_pitch));
+#pragma unroll
+                for (uint32_t q = 0; q < 4; q++)
+                    line[q] = rgba_quad(t.px[q >> 1][row * 2u + (q & 1u)], t.px[2][row * 2u + (q >> 1)] >> ((q & 1u) * 16u),
+                                        t.px[3][row * 2u + (q >> 1)] >> ((q & 1u) * 16u));
+            }
+        } else if (t.active) {
+            composite_edge_mcu(d, t.px, t.mx, t.my);
+        }
+        pixel_next_mcu(t, d);
+        return;
+    }
+    const uint64_t addr = reinterpret_cast<uint64_t>(g.base);
+    const uint32_t lo = uint32_t(addr), hi = uint32_t(addr >> 32), wh = g.whole ? 1u : 0u;
+    uint8_t *bases[4] = {
+        reinterpret_cast<uint8_t *>(uint64_t(quad_lane<0>(hi)) << 32 | quad_lane<0>(lo)),
+        reinterpret_cast<uint8_t *>(uint64_t(quad_lane<1>(hi)) << 32 | quad_lane<1>(lo)),
+        reinterpret_cast<uint8_t *>(uint64_t(quad_lane<2>(hi)) << 32 | quad_lane<2>(lo)),
+        reinterpret_cast<uint8_t *>(uint64_t(quad_lane<3>(hi)) << 32 | quad_lane<3>(lo)),
+    };
+    const uint32_t whole_mask = quad_lane<0>(wh) | quad_lane<1>(wh) << 1 | quad_lane<2>(wh) << 2 | quad_lane<3>(wh) << 3;
+    uint8_t *slot = wave_slots + lane * kDuSlotBytes;
+#pragma unroll
+    for (uint32_t row = 0; row < 8; row++) {
+        composite_row_to_slot(t.px, row, slot);
+        composite_row_from_quad(d, wave_slots, lane, row, bases, whole_mask);
+        // rows stay apart in the schedule: interleaving them only costs registers
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    zero_slot(slot);
+    if (t.active && !g.whole)
+        composite_edge_mcu(d, t.px, t.mx, t.my);
+    pixel_next_mcu(t, d);
+}
+
+// The whole path for 64 restart intervals of a 4:2:2 image, one per lane:
+// entropy decode, IDCT and composite, data unit by data unit.  The
+// per-data-unit loop in the entropy decoder is where lanes wait for each other
+// (SIMT reconvergence), so that table selectors, quantisers, the IDCT and the
+// quad exchange run with a full wave.  Lanes past the last interval stay for
+// the exchange.
+CG_DEV void decode_wave_fused_422(const ImageDesc &d, const HuffShared &s, uint32_t interval, uint32_t lane)
+{
+    // A lane past the image's last interval decodes that last interval once
+    // more (it lies in this wave's window) and simply never stores its own
+    // MCUs: no divergent region around the main body.
+    const bool active = interval < d.total_intervals;
+    interval = active ? interval : d.total_intervals - 1u;
     uint8_t *slot = s.du_slots + lane * kDuSlotBytes;
     int16_t *slot16 = reinterpret_cast<int16_t *>(slot);
     zero_slot(slot);
 
     EntropyState e;
+    PixelState t;
     entropy_init(e, d, s, interval);
-
-    uint32_t mcu = interval * d.restart_interval;
-    uint32_t mx = mcu % d.width_mcus, my = mcu / d.width_mcus;
+    pixel_init(t, d, interval, active);
 
 #if defined(CG_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
 #define CG_STAMP(acc) do { const uint64_t now_ = __builtin_readcyclecounter(); acc += now_ - tprev; tprev = now_; } while (0)
@@ -1267,12 +1353,6 @@ CG_DEV void decode_interval_fused_422(const ImageDesc &d, const HuffShared &s, u
     // The four data units of an MCU pass through one loop body (one copy of
     // the IDCT in the instruction stream, bounded register pressure); their
     // sample words ride a 4-deep register shift chain px[0..3].
-    uint32_t px[4][16];
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-#pragma unroll
-        for (int w = 0; w < 16; w++)
-            px[k][w] = 0u;
     const uint32_t du_total = d.restart_interval * 4u;
 #pragma unroll 1
     for (uint32_t du = 0; du < du_total; du++) {
@@ -1280,32 +1360,11 @@ CG_DEV void decode_interval_fused_422(const ImageDesc &d, const HuffShared &s, u
         const uint32_t comp = k < 2u ? 0u : k - 1u; // Y0 Y1 Cb Cr (wave-uniform)
         const int32_t dc = entropy_data_unit(e, d, s, comp, slot16);
         CG_STAMP(t_ac);
-
-        uint32_t rec[kRetained / 2];
-        take_slot(slot, rec);
-#pragma unroll
-        for (int w = 0; w < 16; w++) {
-            px[0][w] = px[1][w];
-            px[1][w] = px[2][w];
-            px[2][w] = px[3][w];
-        }
-#if CG_EXP == 4 // diagnostic build: no IDCT (same data flow)
-#pragma unroll
-        for (int w = 0; w < 16; w++)
-            px[3][w] = rec[w] + uint32_t(dc);
-#else
-        idct_data_unit(rec, dc, d.quant[comp], px[3]);
-#endif
+        pixel_transform(t, d, comp, slot, dc);
         CG_STAMP(t_idct);
-
         if (k == 3u) {
-            composite_own_mcu_422(d, px, mx, my);
+            composite_mcus_422<true>(t, d, s.du_slots, lane);
             CG_STAMP(t_comp);
-            mx++;
-            if (mx == d.width_mcus) {
-                mx = 0;
-                my++;
-            }
         }
     }
 #if defined(CG_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
@@ -1318,5 +1377,6 @@ CG_DEV void decode_interval_fused_422(const ImageDesc &d, const HuffShared &s, u
     }
 #endif
 }
+#endif // __HIPCC__
 
 } // namespace compeg

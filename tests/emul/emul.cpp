@@ -65,53 +65,83 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
     d.out_h = tex_h;
     d.out_pitch = tex_w * 4;
 
-    if (fused == 2) {
-        // ---- decode_pair_422_kernel: decoder role and transformer role, data unit by data unit ----
+    if (fused == 1 || fused == 2) {
+        // ---- decode_fused_422_kernel (one slot set) / decode_pair_422_kernel (two sets, decoder role and
+        // transformer role): the 64 lanes of a wave advance data unit by data unit, and through the quad
+        // exchange of the composite phase by phase, as the wave does on the GPU ----
+        const uint32_t nsets = fused == 2 ? 2u : 1u;
         l2_in_lds &= ~1u;
         const uint32_t lds_bytes = align16((kL1Entries + l2_in_lds) * 2u) + align16(window_words * 4u) +
-                                   2u * kWave * kDuSlotBytes + 2u * kWave * 4u;
+                                   nsets * kWave * kDuSlotBytes + nsets * kWave * 4u;
         for (uint32_t first = 0; first < d.total_intervals; first += kWave) {
             uint8_t *smem = static_cast<uint8_t *>(aligned_alloc(16, align16(lds_bytes)));
-            memset(smem, 0xa5, lds_bytes);
+            memset(smem, 0xa5, lds_bytes); // LDS is not zero-initialised
             uint16_t *sl1 = reinterpret_cast<uint16_t *>(smem);
             uint16_t *sl2 = sl1 + kL1Entries;
             uint8_t *area = smem + align16((kL1Entries + l2_in_lds) * 2u);
             uint32_t *win = reinterpret_cast<uint32_t *>(area);
             uint8_t *slots = area + align16(window_words * 4u);
-            int32_t *dcs = reinterpret_cast<int32_t *>(slots + 2u * kWave * kDuSlotBytes);
+            int32_t *dcs = reinterpret_cast<int32_t *>(slots + nsets * kWave * kDuSlotBytes);
             for (uint32_t tid = 0; tid < 128; tid++)
                 stage_luts(d, sl1, sl2, l2_in_lds, tid, 128);
             uint32_t wb = 0, wl = 0;
             wave_window(d, first, window_words, wb, wl);
             for (uint32_t i = 0; i < wl; i++)
                 win[i] = wb + i < d.nwords ? bswap32(d.words[wb + i]) : 0u;
-            memset(slots, 0, 2u * kWave * kDuSlotBytes);
+            for (uint32_t i = 0; i < nsets * kWave; i++)
+                zero_slot(slots + i * kDuSlotBytes);
             HuffShared sh{sl1, sl2, umin(l2_in_lds, d.fast_off + 2u * kFastEntries), win, wb, wl, slots};
             std::vector<EntropyState> es(kWave);
             std::vector<PixelState> ps(kWave);
+            std::vector<McuTarget> tg(kWave);
             for (uint32_t lane = 0; lane < uint32_t(kWave); lane++) {
-                if (first + lane >= d.total_intervals)
-                    continue;
-                entropy_init(es[lane], d, sh, first + lane);
-                pixel_init(ps[lane], d, first + lane);
+                const bool active = first + lane < d.total_intervals;
+                if (active)
+                    entropy_init(es[lane], d, sh, first + lane);
+                pixel_init(ps[lane], d, active ? first + lane : 0u, active);
             }
             const uint32_t du_total = d.restart_interval * 4u;
             for (uint32_t du = 0; du < du_total; du++) {
-                const uint32_t k = du & 3u, comp = k < 2u ? 0u : k - 1u, set = du & 1u;
+                const uint32_t k = du & 3u, comp = k < 2u ? 0u : k - 1u, set = nsets == 2 ? (du & 1u) : 0u;
+                uint8_t *set_slots = slots + set * kWave * kDuSlotBytes;
                 unsigned long step_max = 0;
                 for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
-                    if (first + lane < d.total_intervals) {
+                    if (ps[lane].active) {
                         g_emul_stats.lane_symbols = 0;
                         dcs[set * kWave + lane] = entropy_data_unit(
-                            es[lane], d, sh, comp, reinterpret_cast<int16_t *>(slots + (set * kWave + lane) * kDuSlotBytes));
+                            es[lane], d, sh, comp, reinterpret_cast<int16_t *>(set_slots + lane * kDuSlotBytes));
                         step_max = std::max(step_max, g_emul_stats.lane_symbols);
                     }
                 g_emul_stats.wave_steps++;
                 g_emul_stats.wave_step_symbols += step_max;
                 for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
-                    if (first + lane < d.total_intervals)
-                        pixel_data_unit(ps[lane], d, k, comp, slots + (set * kWave + lane) * kDuSlotBytes,
-                                        dcs[set * kWave + lane]);
+                    if (ps[lane].active)
+                        pixel_transform(ps[lane], d, comp, set_slots + lane * kDuSlotBytes, dcs[set * kWave + lane]);
+                if (k != 3u)
+                    continue;
+                // composite_mcus_422, phase by phase
+                for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
+                    tg[lane] = mcu_target(ps[lane], d);
+                for (uint32_t row = 0; row < 8; row++) {
+                    for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
+                        composite_row_to_slot(ps[lane].px, row, set_slots + lane * kDuSlotBytes);
+                    for (uint32_t lane = 0; lane < uint32_t(kWave); lane++) {
+                        const uint32_t quad = lane & ~3u;
+                        uint8_t *bases[4];
+                        uint32_t whole_mask = 0;
+                        for (uint32_t j = 0; j < 4; j++) {
+                            bases[j] = tg[quad + j].base;
+                            whole_mask |= (tg[quad + j].whole ? 1u : 0u) << j;
+                        }
+                        composite_row_from_quad(d, set_slots, lane, row, bases, whole_mask);
+                    }
+                }
+                for (uint32_t lane = 0; lane < uint32_t(kWave); lane++) {
+                    zero_slot(set_slots + lane * kDuSlotBytes);
+                    if (ps[lane].active && !tg[lane].whole)
+                        composite_edge_mcu(d, ps[lane].px, ps[lane].mx, ps[lane].my);
+                    pixel_next_mcu(ps[lane], d);
+                }
             }
             free(smem);
         }
@@ -147,8 +177,6 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
                 if (wave_first + lane < d.total_intervals) {
                     if (fused == 3)
                         entropy_interval_to_records(d, sh, wave_first + lane, lane);
-                    else if (fused)
-                        decode_interval_fused_422(d, sh, wave_first + lane, lane);
                     else
                         huff_decode_interval(d, sh, wave_first + lane, lane);
                 }
@@ -159,11 +187,6 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
         memcpy(ac_out, ac.data(), ac.size() * 2);
     if (dc_out)
         memcpy(dc_out, dc.data(), dc.size() * 4);
-
-    if (fused && fused != 3) {
-        delete img;
-        return 0;
-    }
 
     // ---- idct_composite_kernel ----
     const uint32_t total_mcus = d.dus_per_mcu ? d.total_dus / d.dus_per_mcu : 0;
