@@ -486,7 +486,7 @@ int compeg_decoder_read_coefficients(compeg_decoder *dec, int32_t *host, size_t 
     });
 }
 
-#if defined(CG_STAMPS)
+#if defined(CG_AC_STAMPS)
 extern "C" __attribute__((visibility("default"))) int compeg_debug_ac_stamps(unsigned long long *out, int reset)
 {
     return compeg::read_ac_stamps(out, reset != 0) == hipSuccess ? 0 : -1;

@@ -31,7 +31,7 @@ hipError_t launch_pair_422(const ImageDesc *descs, uint32_t images, uint32_t max
 hipError_t launch_idct_composite(const ImageDesc *descs, uint32_t images, uint32_t max_dus,
                                  hipStream_t stream);
 
-#if defined(CG_STAMPS)
+#if defined(CG_AC_STAMPS)
 // diagnostic build: AC-loop cycle counters (kernels_body.h)
 hipError_t read_ac_stamps(unsigned long long out[4], bool reset);
 #endif

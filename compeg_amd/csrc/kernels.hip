@@ -277,7 +277,7 @@ idct_composite_kernel(const ImageDesc *__restrict__ descs)
     composite_422(d, wave_px, first_mcu, total_mcus, lane);
 }
 
-#if defined(CG_STAMPS)
+#if defined(CG_AC_STAMPS)
 hipError_t read_ac_stamps(unsigned long long out[4], bool reset)
 {
     hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ac_stamps), sizeof(unsigned long long) * 4);

@@ -845,11 +845,11 @@ CG_DEV bool fast_dc(EntropyState &e, const ImageDesc &d, const HuffShared &s, ui
     return true;
 }
 
-#if defined(CG_STAMPS) && defined(__HIPCC__)
+#if defined(CG_AC_STAMPS) && defined(__HIPCC__)
 // diagnostic build: [0] cycles inside the AC loop, [1] of those at the LDS wait, [2] iterations, [3] calls
 __device__ unsigned long long g_ac_stamps[4];
 #endif
-#if defined(CG_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(CG_AC_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
 #define CG_AC_STAMP(x) x
 #else
 #define CG_AC_STAMP(x)
@@ -879,7 +879,7 @@ CG_DEV void fast_ac(EntropyState &e, const ImageDesc &d, const HuffShared &s, ui
         CG_AC_STAMP(tw += __builtin_readcyclecounter() - tw0; its++;)
         *pend_at = pend_val;
 #if CG_EXP != 7 // (7: diagnostic build without the escape test)
-        if (ent >= kFastEscape)
+        if (__builtin_expect(ent >= kFastEscape, 0))
 #else
         if (false)
 #endif
@@ -1115,7 +1115,13 @@ CG_DEV void composite_row_from_quad(const ImageDesc &d, const uint8_t *wave_slot
 #pragma unroll
     for (uint32_t j = 0; j < 4; j++) {
         const SlotVec v = reinterpret_cast<const SlotVec *>(wave_slots + (quad + j) * kDuSlotBytes)[piece];
-        if (whole_mask >> j & 1u) {
+#if CG_EXP == 9 && defined(__HIP_DEVICE_COMPILE__) // diagnostic build: everything but the global stores
+        asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+        if (v.x == 0x12345678u && v.y == 0x9abcdef0u && bases[j] == nullptr)
+#else
+        if (whole_mask >> j & 1u)
+#endif
+        {
             uint8_t *p = bases[j] + size_t(row) * d.out_pitch + piece * 16u;
             *CG_GLOBAL(Vec4u, reinterpret_cast<Vec4u *>(p)) = Vec4u{v.x, v.y, v.z, v.w};
         }
@@ -1309,12 +1315,22 @@ CG_DEV void composite_mcus_422(PixelState &t, const ImageDesc &d, uint8_t *wave_
     };
     const uint32_t whole_mask = quad_lane<0>(wh) | quad_lane<1>(wh) << 1 | quad_lane<2>(wh) << 2 | quad_lane<3>(wh) << 3;
     uint8_t *slot = wave_slots + lane * kDuSlotBytes;
+    // (rows stay apart in the schedule: interleaving them only costs registers)
+    if (__builtin_amdgcn_ballot_w64(whole_mask != 0xfu) == 0u) {
+        // the common case, all 64 MCUs inside the output: unconditional stores
 #pragma unroll
-    for (uint32_t row = 0; row < 8; row++) {
-        composite_row_to_slot(t.px, row, slot);
-        composite_row_from_quad(d, wave_slots, lane, row, bases, whole_mask);
-        // rows stay apart in the schedule: interleaving them only costs registers
-        __builtin_amdgcn_sched_barrier(0);
+        for (uint32_t row = 0; row < 8; row++) {
+            composite_row_to_slot(t.px, row, slot);
+            composite_row_from_quad(d, wave_slots, lane, row, bases, 0xfu);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+#pragma unroll
+        for (uint32_t row = 0; row < 8; row++) {
+            composite_row_to_slot(t.px, row, slot);
+            composite_row_from_quad(d, wave_slots, lane, row, bases, whole_mask);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     zero_slot(slot);
     if (t.active && !g.whole)
