@@ -233,3 +233,16 @@ def test_scanbuffer_reuse_gives_fresh_buffer_output():
     sb.process(bytes([0xAA] * 64), 1)
     sb.process(bytes([0x11, 0xFF, 0xD0, 0x22]), 2)
     assert sb.processed_scan_data() == bytes([0x11, 0, 0, 0, 0x22, 0, 0, 0])
+
+
+def test_rust_binding_covers_the_header():
+    """integration/rust/compeg-hip/src/ffi.rs (the reference-side binding) declares exactly
+    the entry points include/compeg_hip.h declares."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "compeg_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    in_header = set(re.findall(r"\b(compeg_[a-z0-9_]+)\s*\(", header))
+    ffi = open(os.path.join(root, "integration", "rust", "compeg-hip", "src", "ffi.rs")).read()
+    in_ffi = set(re.findall(r"pub fn (compeg_[a-z0-9_]+)\s*\(", ffi))
+    assert in_header == in_ffi, (sorted(in_header - in_ffi), sorted(in_ffi - in_header))
