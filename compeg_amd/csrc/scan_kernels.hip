@@ -221,26 +221,29 @@ __global__ void __launch_bounds__(kThreads) interval_scan_kernel(const ScanDesc 
     const ScanDesc &d = descs[blockIdx.x];
     const uint32_t count = min(d.result[0], d.marker_capacity);
     const uint32_t kept = d.result[1];
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < count; base += kThreads) {
-        const uint32_t m = base + threadIdx.x;
-        uint32_t words = 0;
-        if (m < count) {
-            const uint32_t lo = d.marker_pos[m], hi = m + 1 < count ? d.marker_pos[m + 1] : kept;
-            words = (hi - lo + 3u) / 4u;
-        }
-        uint32_t total;
-        const uint32_t start = carry + block_exclusive_scan(words, lds, total);
-        if (m < count) {
-            d.interval_start[m] = start;
-            // the last writer of a slot wins in the reference's sequential loop
-            if (m + d.slots >= count && m != 0)
-                d.starts_out[m & (d.slots - 1u)] = start;
-        }
-        carry += total;
+    // Every thread owns a contiguous run of intervals: one pass for the run's
+    // word total, one block-wide scan of the totals, one pass for the starts
+    // (a chunk-by-chunk block scan costs two barriers per 256 intervals, which
+    // is what a single 4K frame -- 16 200 intervals, one block -- waits for).
+    const uint32_t per = (count + kThreads - 1u) / kThreads;
+    const uint32_t first = threadIdx.x * per, last = min(first + per, count);
+    uint32_t mine = 0;
+    for (uint32_t m = first; m < last; m++) {
+        const uint32_t lo = d.marker_pos[m], hi = m + 1 < count ? d.marker_pos[m + 1] : kept;
+        mine += (hi - lo + 3u) / 4u;
+    }
+    uint32_t total;
+    uint32_t start = block_exclusive_scan(mine, lds, total);
+    for (uint32_t m = first; m < last; m++) {
+        const uint32_t lo = d.marker_pos[m], hi = m + 1 < count ? d.marker_pos[m + 1] : kept;
+        d.interval_start[m] = start;
+        // the last writer of a slot wins in the reference's sequential loop
+        if (m + d.slots >= count && m != 0)
+            d.starts_out[m & (d.slots - 1u)] = start;
+        start += (hi - lo + 3u) / 4u;
     }
     if (threadIdx.x == 0) {
-        d.result[2] = carry; // total output words
+        d.result[2] = total; // total output words
         // entry 0 keeps its initial 0 unless a wrapped index (m = k * slots) hit it above
         if (count <= d.slots)
             d.starts_out[0] = 0u;
