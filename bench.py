@@ -41,6 +41,9 @@ def parse_args():
     p.add_argument("--ri", type=int, default=4, help="MCUs per restart interval (DRI)")
     p.add_argument("--quality", type=int, default=85)
     p.add_argument("--kind", type=int, default=0, help="0 natural-like, 1 random RGB, 2 sparse")
+    p.add_argument("--sampling", default="2x1",
+                   help="luma sampling HxV: 2x1 = 4:2:2 (the reference's only layout, default); 1x1, 1x2, 2x2 "
+                        "= 4:4:4, 4:4:0, 4:2:0 through the extension pipeline (not the headline metric)")
     p.add_argument("--distinct", type=int, default=0,
                    help="number of distinct synthetic images (0 = one per batch slot)")
     p.add_argument("--chunk", type=int, default=0, help="images per kernel-launch pair (0 = all)")
@@ -66,7 +69,7 @@ def make_inputs(args, rank, world, threads):
 
     def one(i):
         return synth.make_jpeg(args.width, args.height, seed=0xC0FFEE + lo + i,
-                               kind=args.kind, quality=args.quality, ri=args.ri)
+                               kind=args.kind, quality=args.quality, ri=args.ri, sampling=args.sampling_hv)
 
     with ThreadPoolExecutor(threads) as ex:
         jpegs = list(ex.map(one, range(distinct)))
@@ -80,7 +83,7 @@ def cpu_baseline(jpegs, budget_s, pixels_per_image):
 
     done, t0 = 0, time.perf_counter()
     while True:
-        img = orc.ImageData(jpegs[done % len(jpegs)])
+        img = orc.ImageData(jpegs[done % len(jpegs)], allow_sampling=True)
         img.decode()
         done += 1
         el = time.perf_counter() - t0
@@ -94,6 +97,8 @@ def cpu_baseline(jpegs, budget_s, pixels_per_image):
 
 def main():
     args = parse_args()
+    args.sampling_hv = tuple(int(v) for v in args.sampling.lower().split("x"))
+    ext = args.sampling_hv != (2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -123,7 +128,7 @@ def main():
     t_gen = time.perf_counter() - t_gen
 
     gpu = compeg_amd.Gpu.open(local_rank)
-    images = [compeg_amd.ImageData(j, copy=False) for j in jpegs[:distinct]]
+    images = [compeg_amd.ImageData(j, copy=False, allow_sampling=ext) for j in jpegs[:distinct]]
     images = [images[i % distinct] for i in range(args.batch)]
     batch = compeg_amd.Batch(gpu)
     batch.set_device_preprocess({"host": 0, "device": 1, "device-per-step": 2}[args.preprocess])
@@ -161,7 +166,7 @@ def main():
         import numpy as np
         from oracle import oracle as orc
         got = batch.read_output(0)
-        want = orc.ImageData(jpegs[0]).decode()
+        want = orc.ImageData(jpegs[0], allow_sampling=ext).decode()
         verified = bool(np.array_equal(got, want))
         if not verified:
             raise SystemExit("bench: GPU output differs from the oracle -- refusing to report a number")
@@ -230,7 +235,8 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "Mpixels/s decoded (4K 4:2:2 restart-interval baseline JPEG -> RGBA8 in HBM)",
+            "metric": "Mpixels/s decoded (4K 4:2:2 restart-interval baseline JPEG -> RGBA8 in HBM)" if not ext else
+                      f"Mpixels/s decoded (extension layout, luma {args.sampling}; not the headline metric)",
             "value": round(total_pixels / elapsed / 1e6, 1),
             "unit": "Mpixels/s",
             "n_gpus": world,
@@ -244,7 +250,7 @@ def main():
             "dtype": "u32 bit-reader / i16 levels / f32 IDCT / u8 RGBA",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.batch} x {args.width}x{args.height} YUV 4:2:2 baseline JPEG, DRI={args.ri}, "
+                "workload": f"{args.batch} x {args.width}x{args.height} YUV {'4:2:2' if not ext else 'luma ' + args.sampling} baseline JPEG, DRI={args.ri}, "
                             f"q{args.quality} Annex-K tables, per GPU per step (BASELINE configs[1] frame; "
                             f"256/GPU = configs[3]'s 2048-frame batch over 8 GPUs)",
                 "images_per_gpu": args.batch, "distinct_images": distinct,

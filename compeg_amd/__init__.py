@@ -69,11 +69,17 @@ class Gpu:
 class ImageData:
     """A parsed JPEG (ref: `ImageData`, src/lib.rs:576-851)."""
 
-    def __init__(self, jpeg, copy=True):
+    def __init__(self, jpeg, copy=True, allow_sampling=False):
+        """allow_sampling: extension beyond the reference (COMPEG_PARSE_ANY_LUMA_SAMPLING) -- 4:4:4,
+        4:4:0 and 4:2:0 are accepted as well as 4:2:2."""
         self._h = None
         self._keep = _host_view(jpeg)
         h = C.c_void_p()
-        check(lib.compeg_image_parse(self._keep.ctypes.data, self._keep.nbytes, 1 if copy else 0, C.byref(h)))
+        if allow_sampling:
+            check(lib.compeg_image_parse_ext(self._keep.ctypes.data, self._keep.nbytes, 1 if copy else 0, 1,
+                                             C.byref(h)))
+        else:
+            check(lib.compeg_image_parse(self._keep.ctypes.data, self._keep.nbytes, 1 if copy else 0, C.byref(h)))
         self._h = h
         if copy:
             self._keep = None

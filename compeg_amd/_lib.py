@@ -40,6 +40,7 @@ def _load():
         "compeg_gpu_device": (i, [vp]),
         "compeg_gpu_name": (C.c_char_p, [vp]),
         "compeg_image_parse": (i, [vp, sz, i, pvp]),
+        "compeg_image_parse_ext": (i, [vp, sz, i, C.c_uint, pvp]),
         "compeg_image_free": (None, [vp]),
         "compeg_image_width": (u32, [vp]),
         "compeg_image_height": (u32, [vp]),

@@ -157,12 +157,19 @@ const char *compeg_gpu_name(const compeg_gpu *gpu)
 
 int compeg_image_parse(const uint8_t *jpeg, size_t len, int copy, compeg_image **out)
 {
+    return compeg_image_parse_ext(jpeg, len, copy, 0u, out);
+}
+
+int compeg_image_parse_ext(const uint8_t *jpeg, size_t len, int copy, unsigned flags, compeg_image **out)
+{
     return guarded([&] {
         if (!out)
             return fail(COMPEG_E_INVALID_ARG, "out is NULL");
         *out = nullptr;
+        if (flags & ~COMPEG_PARSE_ANY_LUMA_SAMPLING)
+            return fail(COMPEG_E_INVALID_ARG, "unknown parse flags");
         ImageData *d = nullptr;
-        Status s = ImageData::parse(jpeg, len, copy != 0, &d);
+        Status s = ImageData::parse(jpeg, len, copy != 0, &d, flags);
         if (!s.ok())
             return fail(s);
         *out = new compeg_image{d};

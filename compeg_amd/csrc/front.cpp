@@ -205,7 +205,7 @@ HuffmanLut HuffmanLut::annex_k(int which)
     return t;
 }
 
-Status ImageData::parse(const uint8_t *jpeg, size_t len, bool copy, ImageData **out)
+Status ImageData::parse(const uint8_t *jpeg, size_t len, bool copy, ImageData **out, unsigned flags)
 {
     *out = nullptr;
     if (!jpeg && len)
@@ -344,7 +344,9 @@ Status ImageData::parse(const uint8_t *jpeg, size_t len, bool copy, ImageData **
                 return unsupported(fmt(
                     "invalid quantization table selection [%u,%u,%u] (only tables 0-3 are valid)",
                     tq[0], tq[1], tq[2]));
-            if (hv[0] != 0x21)
+            const bool any_luma = (flags & COMPEG_PARSE_ANY_LUMA_SAMPLING) &&
+                                  (hv[0] == 0x11 || hv[0] == 0x21 || hv[0] == 0x12 || hv[0] == 0x22);
+            if (hv[0] != 0x21 && !any_luma)
                 return unsupported(
                     fmt("invalid sampling factors %ux%u for Y component (expected 2x1)",
                         hv[0] >> 4, hv[0] & 15));
@@ -423,9 +425,10 @@ Status ImageData::parse(const uint8_t *jpeg, size_t len, bool copy, ImageData **
 
     if (frame_w + 7 > 0xffff || frame_h + 7 > 0xffff)
         return malformed("image dimensions overflow 16-bit arithmetic");
-    md.max_hsample = 2;
-    md.max_vsample = 1;
-    md.dus_per_mcu = 4;
+    // 2, 1, 4 for the only layout the reference accepts (Y 2x1, Cb/Cr 1x1)
+    md.max_hsample = hv[0] >> 4;
+    md.max_vsample = hv[0] & 15;
+    md.dus_per_mcu = md.max_hsample * md.max_vsample + 2;
     const uint32_t width_dus = (frame_w + 7) / 8, height_dus = (frame_h + 7) / 8;
     md.width_mcus = (width_dus + md.max_hsample - 1) / md.max_hsample;
     const uint32_t height_mcus = (height_dus + md.max_vsample - 1) / md.max_vsample;

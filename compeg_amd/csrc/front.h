@@ -75,7 +75,8 @@ struct ImageData {
     }
     uint32_t total_dus() const { return total_mcus() * metadata.dus_per_mcu; }
 
-    static Status parse(const uint8_t *jpeg, size_t len, bool copy, ImageData **out);
+    // flags: COMPEG_PARSE_* (compeg_hip.h); 0 = exactly the reference's accept / reject behaviour
+    static Status parse(const uint8_t *jpeg, size_t len, bool copy, ImageData **out, unsigned flags = 0);
 };
 
 } // namespace compeg

@@ -289,6 +289,31 @@ hipError_t read_ac_stamps(unsigned long long out[4], bool reset)
 }
 #endif
 
+// Extension pipeline for layouts other than 4:2:2 (kernels_body.h): lane per data unit ...
+__global__ void __launch_bounds__(256)
+idct_in_place_kernel(const ImageDesc *__restrict__ descs)
+{
+    __shared__ float quant[3 * kRetained];
+    const ImageDesc &d = descs[blockIdx.y];
+    if (blockIdx.x * blockDim.x >= d.total_dus)
+        return;
+    if (threadIdx.x < 3 * kRetained)
+        quant[threadIdx.x] = d.quant[threadIdx.x / kRetained][threadIdx.x % kRetained];
+    __syncthreads();
+    const uint32_t du = blockIdx.x * blockDim.x + threadIdx.x;
+    if (du < d.total_dus)
+        idct_record_in_place(d, quant, du);
+}
+
+// ... then lane per four pixels of a row.
+__global__ void __launch_bounds__(256)
+composite_generic_kernel(const ImageDesc *__restrict__ descs)
+{
+    const ImageDesc &d = descs[blockIdx.z];
+    const uint32_t x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4u, y = blockIdx.y;
+    composite_generic_4px(d, x0, y);
+}
+
 namespace {
 constexpr uint32_t kLdsBytesPerCu = 160u * 1024u;
 constexpr uint32_t kMaxWavesFused = 12; // 3 per SIMD: what 147 VGPRs allow
@@ -414,6 +439,21 @@ hipError_t launch_idct_composite(const ImageDesc *descs, uint32_t images, uint32
         return hipSuccess;
     dim3 grid((max_dus + 255) / 256, images, 1);
     hipLaunchKernelGGL(idct_composite_kernel, grid, dim3(256), 0, stream, descs);
+    return hipGetLastError();
+}
+
+hipError_t launch_generic_transform(const ImageDesc *descs, uint32_t images, uint32_t max_dus, uint32_t max_w,
+                                    uint32_t max_h, hipStream_t stream)
+{
+    if (images == 0 || max_dus == 0 || max_w == 0 || max_h == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(idct_in_place_kernel, dim3((max_dus + 255) / 256, images, 1), dim3(256), 0, stream, descs);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return e;
+    // y is limited to 65535 rows per launch dimension: more than any baseline JPEG has
+    hipLaunchKernelGGL(composite_generic_kernel, dim3(((max_w + 3) / 4 + 255) / 256, max_h, images), dim3(256), 0,
+                       stream, descs);
     return hipGetLastError();
 }
 

@@ -1203,6 +1203,73 @@ CG_DEV void entropy_interval_to_records(const ImageDesc &d, const HuffShared &s,
     }
 }
 
+// ---------------------------------------------------------------------------
+// Layouts other than 4:2:2 (extension): three plain kernels
+// ---------------------------------------------------------------------------
+// entropy_kernel writes coefficient records; then every data unit's 64-byte
+// record is replaced in place by its 64 samples (what the reference's dct pass
+// does with its coefficient buffer, src/dct.wgsl:187-201), and a last pass
+// converts four horizontally adjacent pixels per lane (the reference's finalize
+// pass, src/dct.wgsl:257-321, continued to 16-row MCUs as orc_finalize_pass
+// states it).
+
+// quant: 3 x 32 quantiser values (component-major)
+CG_DEV void idct_record_in_place(const ImageDesc &d, const float *quant, uint32_t du)
+{
+    const uint32_t k = du % d.dus_per_mcu;
+    const uint32_t comp = (d.comp_of_du >> (2u * k)) & 3u;
+    auto *record = CG_GLOBAL(Vec4u, reinterpret_cast<Vec4u *>(d.ac + size_t(du) * kRetained));
+    uint32_t rec[kRetained / 2];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const Vec4u v = record[i];
+        rec[4 * i + 0] = v.x;
+        rec[4 * i + 1] = v.y;
+        rec[4 * i + 2] = v.z;
+        rec[4 * i + 3] = v.w;
+    }
+    uint32_t px[16];
+    idct_data_unit(rec, CG_GLOBAL(const int32_t, d.dc)[du], quant + (comp < 3u ? comp : 2u) * kRetained, px);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        record[i] = Vec4u{px[4 * i], px[4 * i + 1], px[4 * i + 2], px[4 * i + 3]};
+}
+
+// Pixels x0 .. x0+3 (x0 a multiple of 4) of output row y.
+CG_DEV void composite_generic_4px(const ImageDesc &d, uint32_t x0, uint32_t y)
+{
+    if (x0 >= d.out_w || y >= d.out_h)
+        return;
+    const uint32_t mcu_x = x0 / d.mcu_w, mcu_y = y / d.mcu_h;
+    const uint32_t mcu = mcu_y * d.width_mcus + mcu_x;
+    // right of the last MCU column, or behind the last decoded MCU (a truncated
+    // last restart interval): nothing is stored there, the output keeps its zeros
+    if (mcu_x >= d.width_mcus || mcu >= d.total_intervals * d.restart_interval)
+        return;
+    const uint32_t col = x0 % d.mcu_w, row = y % d.mcu_h;
+    const uint32_t max_h = d.mcu_w / 8u, max_v = d.mcu_h / 8u;
+    auto *samples = CG_GLOBAL(const uint8_t, reinterpret_cast<const uint8_t *>(d.ac));
+    uint32_t val[3][4];
+#pragma unroll
+    for (uint32_t c = 0; c < 3; c++) {
+        const uint32_t hs = d.hsample[c], vs = d.vsample[c];
+        const uint32_t xscale = max_h / hs, yscale = max_v / vs;
+        const uint32_t yy = (row / yscale) & 7u;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) {
+            const uint32_t cc = col + i;
+            const uint32_t du = d.du_base[c] + (row * vs / d.mcu_h) * hs + cc * hs / d.mcu_w;
+            const uint32_t x = (cc / xscale) & 7u;
+            val[c][i] = samples[(size_t(mcu) * d.dus_per_mcu + du) * (kRetained * 2u) + yy * 8u + x];
+        }
+    }
+    auto *p = CG_GLOBAL(uint32_t, reinterpret_cast<uint32_t *>(d.out + size_t(y) * d.out_pitch + size_t(x0) * 4u));
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++)
+        if (x0 + i < d.out_w)
+            p[i] = ycbcr_to_rgba(val[0][i], val[1][i], val[2][i]);
+}
+
 // Transformer role: the samples of the MCU being assembled and where it goes.
 struct PixelState {
     uint32_t px[4][16]; // 4-deep shift chain: after Cr it holds Y0 Y1 Cb Cr

@@ -126,6 +126,11 @@ void *pinned_alloc(size_t n)
 
 void pinned_free(void *p) { (void)hipHostFree(p); }
 
+bool is_422(const ImageData &img)
+{
+    return img.metadata.max_hsample == 2 && img.metadata.max_vsample == 1;
+}
+
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Per-image LUT blob: [L1 2048 B][L2, padded to 4 B][two 11-bit direct AC tables]
@@ -337,11 +342,18 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     const uint32_t span = on_device ? dev_span
                                     : max_wave_span(scan.starts(), scan.nstarts(), scan.nwords(),
                                                     md.total_restart_intervals);
-    const HuffLdsPlan plan = plan_huffman(md.total_restart_intervals, 1, staged_lut_entries(img), span,
-                                          use_fused_pipeline());
+    const bool fused = use_fused_pipeline() && is_422(img);
+    const HuffLdsPlan plan = plan_huffman(md.total_restart_intervals, 1, staged_lut_entries(img), span, fused);
     last_span = span;
     last_plan = plan;
-    if (use_fused_pipeline()) {
+    if (!is_422(img)) {
+        // extension layouts (4:4:4, 4:4:0, 4:2:0): entropy stage, IDCT in place, generic composite
+        CG_HIP(launch_entropy(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals, plan,
+                              stream));
+        CG_HIP(launch_generic_transform(reinterpret_cast<const ImageDesc *>(db), 1, total_dus, out_w, out_h,
+                                        stream));
+        coefficients_valid = false;
+    } else if (fused) {
         if (use_pair_kernel(md.total_restart_intervals, 1))
             CG_HIP(launch_pair_422(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals,
                                    plan, stream));
@@ -435,9 +447,19 @@ compeg_batch::~compeg_batch()
 
 Status compeg_batch::upload(const ImageData *const *images, size_t n, int threads)
 {
+    generic_layout = false;
+    max_out_w = max_out_h = 0;
+    for (size_t i = 0; i < n; i++) {
+        generic_layout = generic_layout || !is_422(*images[i]);
+        max_out_w = std::max(max_out_w, images[i]->width);
+        max_out_h = std::max(max_out_h, images[i]->height);
+    }
     if (preprocess_mode != 0) {
         if (!use_fused_pipeline())
             return Status::error(COMPEG_E_INVALID_ARG, "device preprocessing needs the fused pipeline");
+        if (generic_layout)
+            return Status::error(COMPEG_E_UNSUPPORTED,
+                                 "device preprocessing of a batch supports 4:2:2 images only");
         return upload_device_scan(images, n);
     }
     CG_HIP(hipSetDevice(gpu->device));
@@ -496,7 +518,7 @@ Status compeg_batch::upload(const ImageData *const *images, size_t n, int thread
         pixels += uint64_t(img.width) * img.height;
     }
 
-    const bool fused = use_fused_pipeline();
+    const bool fused = use_fused_pipeline() && !generic_layout;
     CG_TRY(inputs.reserve(in_total + 256));
     const bool stamps = getenv("COMPEG_STAMPS") != nullptr; // diagnostic builds park cycle stamps in dc
     if (!fused) { // the fused kernel keeps coefficients on chip
@@ -720,8 +742,16 @@ Status compeg_batch::decode(hipStream_t stream)
         CG_HIP(launch_scan(static_cast<const ScanDesc *>(scan_descs.ptr), n, max_tiles, stream));
     for (uint32_t at = 0; at < n; at += step) {
         const uint32_t m = std::min(step, n - at);
-        const HuffLdsPlan plan = plan_huffman(max_intervals, m, max_l2, max_span, use_fused_pipeline());
-        if (use_fused_pipeline()) {
+        const bool fused = use_fused_pipeline() && !generic_layout;
+        const HuffLdsPlan plan = plan_huffman(max_intervals, m, max_l2, max_span, fused);
+        if (generic_layout) {
+            CG_HIP(launch_entropy(dd + at, m, max_intervals, plan, stream));
+            if (timing && at == 0)
+                CG_HIP(hipEventRecord(ev[1], stream));
+            CG_HIP(launch_generic_transform(dd + at, m, max_dus, max_out_w, max_out_h, stream));
+            continue;
+        }
+        if (fused) {
             if (use_pair_kernel(max_intervals, m))
                 CG_HIP(launch_pair_422(dd + at, m, max_intervals, plan, stream));
             else

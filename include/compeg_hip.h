@@ -78,6 +78,16 @@ const char *compeg_gpu_name(const compeg_gpu *gpu);
  * copy of the bytes (Cow::Owned); copy == 0 borrows them (Cow::Borrowed): the
  * caller keeps `jpeg` alive and unchanged while the image is in use. */
 int compeg_image_parse(const uint8_t *jpeg, size_t len, int copy, compeg_image **out);
+/* Extension: flags widen the accepted subset.  With
+ * COMPEG_PARSE_ANY_LUMA_SAMPLING the luma component may be sampled 1x1, 2x1,
+ * 1x2 or 2x2 against 1x1 chroma (4:4:4, 4:2:2, 4:4:0, 4:2:0); the reference
+ * rejects all but 2x1 (lib.rs:650-660).  4:4:4 decodes as the reference's
+ * shaders would decode it if its front-end let it through; for the 16-row
+ * MCUs of 4:4:0 / 4:2:0 the shaders' nearest-neighbour chroma rule is
+ * continued vertically (oracle/compeg_oracle.c, orc_finalize_pass).  flags == 0
+ * is compeg_image_parse. */
+#define COMPEG_PARSE_ANY_LUMA_SAMPLING 1u
+int compeg_image_parse_ext(const uint8_t *jpeg, size_t len, int copy, unsigned flags, compeg_image **out);
 void compeg_image_free(compeg_image *img);
 uint32_t compeg_image_width(const compeg_image *img);       /* lib.rs:828-831 */
 uint32_t compeg_image_height(const compeg_image *img);      /* lib.rs:834-837 */

@@ -1,7 +1,7 @@
 //! Raw declarations of `include/compeg_hip.h`, one group per reference type.
 #![allow(non_camel_case_types)]
 
-use std::os::raw::{c_char, c_double, c_int, c_void};
+use std::os::raw::{c_char, c_double, c_int, c_uint, c_void};
 
 macro_rules! opaque {
     ($($name:ident),*) => { $(#[repr(C)] pub struct $name { _private: [u8; 0] })* };
@@ -14,6 +14,7 @@ pub const COMPEG_E_UNSUPPORTED: c_int = -2;
 pub const COMPEG_E_MALFORMED: c_int = -3;
 pub const COMPEG_E_COUNT_MISMATCH: c_int = -4;
 pub const COMPEG_E_HIP: c_int = -5;
+pub const COMPEG_PARSE_ANY_LUMA_SAMPLING: c_uint = 1;
 
 extern "C" {
     pub fn compeg_last_error() -> *const c_char;
@@ -29,6 +30,8 @@ extern "C" {
 
     // ImageData
     pub fn compeg_image_parse(jpeg: *const u8, len: usize, copy: c_int, out: *mut *mut compeg_image) -> c_int;
+    pub fn compeg_image_parse_ext(jpeg: *const u8, len: usize, copy: c_int, flags: c_uint,
+                                  out: *mut *mut compeg_image) -> c_int;
     pub fn compeg_image_free(img: *mut compeg_image);
     pub fn compeg_image_width(img: *const compeg_image) -> u32;
     pub fn compeg_image_height(img: *const compeg_image) -> u32;

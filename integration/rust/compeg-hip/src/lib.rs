@@ -141,6 +141,16 @@ impl<'a> ImageData<'a> {
         Ok(ImageData { raw: NonNull::new(raw).expect("compeg_image_parse returned null"), _jpeg: jpeg })
     }
 
+    /// Extension: like `new`, but 4:4:4, 4:4:0 and 4:2:0 are accepted as well as 4:2:2.
+    pub fn new_any_sampling(jpeg: impl Into<Cow<'a, [u8]>>) -> Result<Self> {
+        let jpeg = jpeg.into();
+        let mut raw = ptr::null_mut();
+        check(unsafe {
+            ffi::compeg_image_parse_ext(jpeg.as_ptr(), jpeg.len(), 0, ffi::COMPEG_PARSE_ANY_LUMA_SAMPLING, &mut raw)
+        })?;
+        Ok(ImageData { raw: NonNull::new(raw).expect("compeg_image_parse_ext returned null"), _jpeg: jpeg })
+    }
+
     pub fn width(&self) -> u32 {
         unsafe { ffi::compeg_image_width(self.raw.as_ptr()) }
     }

@@ -869,7 +869,14 @@ struct orc_image {
     size_t scan_off, scan_len;
 };
 
+/* flags & 1 (extension, not the reference): luma sampling 1x1, 2x1, 1x2 or 2x2 is accepted, i.e.
+ * 4:4:4, 4:2:2, 4:4:0 and 4:2:0; see orc_finalize_pass for what that means for the output. */
 orc_image *orc_image_parse(const uint8_t *jpeg, size_t len, char *err)
+{
+    return orc_image_parse_ext(jpeg, len, 0, err);
+}
+
+orc_image *orc_image_parse_ext(const uint8_t *jpeg, size_t len, unsigned flags, char *err)
 {
     perr_t e = {{0}, 0};
     orc_table *tables[4] = {orc_table_default(0), orc_table_default(1), orc_table_default(2),
@@ -927,7 +934,9 @@ orc_image *orc_image_parse(const uint8_t *jpeg, size_t len, char *err)
                      fc[0].tqi, fc[1].tqi, fc[2].tqi);
                 goto out;
             }
-            if (fc[0].hi != 2 || fc[0].vi != 1) {
+            if ((flags & 1u) && fc[0].hi >= 1 && fc[0].hi <= 2 && fc[0].vi >= 1 && fc[0].vi <= 2) {
+                /* extension: any of the four luma samplings */
+            } else if (fc[0].hi != 2 || fc[0].vi != 1) {
                 fail(&e, "invalid sampling factors %ux%u for Y component (expected 2x1)",
                      fc[0].hi, fc[0].vi);
                 goto out;
@@ -1390,32 +1399,37 @@ void orc_finalize_pass(const uint8_t *md, const int32_t *coef, size_t ncoef, uin
     uint32_t width_mcus = md_get(md, MD_WMCU);
     uint32_t max_h = md_get(md, MD_MAXH), max_v = md_get(md, MD_MAXV);
     uint32_t msx = max_h * 8, msy = max_v * 8;
-    (void)msy;
 
+    /* The reference's shader assigns one thread to each of the 8 rows of an MCU and keeps four
+     * data units per MCU in workgroup memory: it covers MCUs that are 8 rows tall with at most
+     * four data units (4:2:2 -- the only layout its front-end accepts -- and 4:4:4).  With
+     * max_v == 1 the loops below are that shader, statement by statement.  For the 16-row MCUs
+     * of 4:4:0 / 4:2:0 (extension) the same formulas are continued to rows 8..15: a component's
+     * data unit is picked by block row as well as block column, its sample by row / yscale. */
     for (uint32_t mcu = 0; mcu < total_mcus; mcu++) {
-        uint32_t rows[4][8][2]; /* databuf[local_mcu].du[i].rows[row] */
+        uint32_t rows[6][8][2]; /* databuf[local_mcu].du[i].rows[row] */
         memset(rows, 0, sizeof rows);
         for (uint32_t row = 0; row < 8; row++) {
-            for (uint32_t i = 0; i < dus_per_mcu && i < 4; i++) {
+            for (uint32_t i = 0; i < dus_per_mcu && i < 6; i++) {
                 size_t off = ((size_t)mcu * dus_per_mcu + i) * retained + row * 2;
                 rows[i][row][0] = off < ncoef ? (uint32_t)coef[off] : 0;
                 rows[i][row][1] = off + 1 < ncoef ? (uint32_t)coef[off + 1] : 0;
             }
         }
         uint32_t mx = mcu % width_mcus, my = mcu / width_mcus;
-        for (uint32_t row = 0; row < 8; row++) { /* one thread per MCU row */
+        for (uint32_t row = 0; row < msy; row++) { /* reference: one thread per MCU row, 8 rows */
             for (uint32_t col = 0; col < msx; col++) {
-                uint32_t cx = mx * msx + col, cy = my * (max_v * 8) + row;
+                uint32_t cx = mx * msx + col, cy = my * msy + row;
                 uint32_t du_offset = 0, comp_val[3];
                 for (uint32_t comp = 0; comp < 3; comp++) {
                     const size_t o = MD_COMP + (size_t)comp * 20;
                     uint32_t vs = md_get(md, o + 0), hs = md_get(md, o + 4);
-                    uint32_t du = du_offset + col * hs / msx;
+                    uint32_t du = du_offset + (row * vs / msy) * hs + col * hs / msx;
                     uint32_t xscale = max_h / hs, yscale = max_v / vs;
                     uint32_t x = col / xscale, y = row / yscale;
                     uint32_t word = (x & 7u) > 3u;
                     uint32_t shift = (x & 7u) * 8u;
-                    comp_val[comp] = SHR(rows[du & 3][y & 7][word], shift);
+                    comp_val[comp] = SHR(rows[du < 6 ? du : 0][y & 7][word], shift);
                     du_offset += hs * vs;
                 }
                 int32_t yy = (int32_t)(comp_val[0] & 0xffu);

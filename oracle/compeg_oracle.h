@@ -76,6 +76,8 @@ typedef struct orc_image orc_image;
 /* returns NULL and fills err on rejection.  err text equals the reference's
  * message where it has one; "panic: ..." marks inputs the reference aborts on. */
 orc_image *orc_image_parse(const uint8_t *jpeg, size_t len, char *err);
+/* flags & 1: also accept luma sampling 1x1 / 1x2 / 2x2 (extension beyond the reference) */
+orc_image *orc_image_parse_ext(const uint8_t *jpeg, size_t len, unsigned flags, char *err);
 void orc_image_free(orc_image *img);
 uint32_t orc_image_width(const orc_image *img);
 uint32_t orc_image_height(const orc_image *img);

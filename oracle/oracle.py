@@ -55,6 +55,7 @@ def lib():
             "orc_huff_extend": (C.c_int32, [C.c_int32, u32]),
             "orc_parser_dump": (sz, [vp, sz, cp, sz]),
             "orc_image_parse": (vp, [vp, sz, cp]),
+            "orc_image_parse_ext": (vp, [vp, sz, C.c_uint, cp]),
             "orc_image_free": (None, [vp]),
             "orc_image_width": (u32, [vp]),
             "orc_image_height": (u32, [vp]),
@@ -193,11 +194,15 @@ def parser_dump(jpeg):
 class ImageData:
     """ref: src/lib.rs:576-851"""
 
-    def __init__(self, jpeg):
+    def __init__(self, jpeg, allow_sampling=False):
+        """allow_sampling: extension beyond the reference -- 4:4:4, 4:4:0 and 4:2:0 are accepted too."""
         self.jpeg = bytes(jpeg)
         ptr, n, self._keep = _buf(self.jpeg)
         err = C.create_string_buffer(ERRLEN)
-        self._p = lib().orc_image_parse(ptr, n, err)
+        if allow_sampling:
+            self._p = lib().orc_image_parse_ext(ptr, n, 1, err)
+        else:
+            self._p = lib().orc_image_parse(ptr, n, err)
         if not self._p:
             raise OracleError(err.value.decode())
 

@@ -29,7 +29,8 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
                 uint32_t l2_in_lds, char *err, size_t errlen, int fused)
 {
     ImageData *img = nullptr;
-    Status s = ImageData::parse(jpeg, len, false, &img);
+    // mode 4 = the extension pipeline: any luma sampling is accepted
+    Status s = ImageData::parse(jpeg, len, false, &img, fused == 4 ? COMPEG_PARSE_ANY_LUMA_SAMPLING : 0u);
     if (!s.ok()) {
         snprintf(err, errlen, "%s", s.message.c_str());
         return s.code;
@@ -175,7 +176,7 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
             HuffShared sh{sl1, sl2, umin(l2_in_lds, d.fast_off + 2u * kFastEntries), win, wb, wl, slots};
             for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
                 if (wave_first + lane < d.total_intervals) {
-                    if (fused == 3)
+                    if (fused == 3 || fused == 4)
                         entropy_interval_to_records(d, sh, wave_first + lane, lane);
                     else
                         huff_decode_interval(d, sh, wave_first + lane, lane);
@@ -187,6 +188,21 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
         memcpy(ac_out, ac.data(), ac.size() * 2);
     if (dc_out)
         memcpy(dc_out, dc.data(), dc.size() * 4);
+
+    if (fused == 4) {
+        // ---- idct_in_place_kernel + composite_generic_kernel (extension layouts) ----
+        // coefficient read-back is taken before the records are overwritten by samples
+        std::vector<float> quant(3 * kRetained);
+        for (uint32_t t = 0; t < 3 * kRetained; t++)
+            quant[t] = d.quant[t / kRetained][t % kRetained];
+        for (uint32_t du = 0; du < d.total_dus; du++)
+            idct_record_in_place(d, quant.data(), du);
+        for (uint32_t y = 0; y < tex_h; y++)
+            for (uint32_t x0 = 0; x0 < ((tex_w + 3u) & ~3u) + 8u; x0 += 4) // a few lanes past the row end, like the grid
+                composite_generic_4px(d, x0, y);
+        delete img;
+        return 0;
+    }
 
     // ---- idct_composite_kernel ----
     const uint32_t total_mcus = d.dus_per_mcu ? d.total_dus / d.dus_per_mcu : 0;
@@ -238,7 +254,8 @@ int main(int argc, char **argv)
     memcpy(exact, jpeg.data(), jpeg.size());
 
     ImageData *probe = nullptr;
-    Status s = ImageData::parse(exact, jpeg.size(), false, &probe);
+    const int mode = getenv("EMUL_FUSED") ? atoi(getenv("EMUL_FUSED")) : 0;
+    Status s = ImageData::parse(exact, jpeg.size(), false, &probe, mode == 4 ? COMPEG_PARSE_ANY_LUMA_SAMPLING : 0u);
     if (!s.ok()) {
         printf("error: %s\n", s.message.c_str());
         free(exact);
@@ -254,7 +271,7 @@ int main(int argc, char **argv)
     char err[256] = "";
     int rc = emul_decode(exact, jpeg.size(), rgba.data(), tex_w, tex_h, ac.data(), dc.data(),
                          uint32_t(atoi(argv[5])), uint32_t(atoi(argv[6])), uint32_t(atoi(argv[7])),
-                         err, sizeof err, getenv("EMUL_FUSED") ? atoi(getenv("EMUL_FUSED")) : 0);
+                         err, sizeof err, mode);
     free(exact);
     if (rc != 0) {
         printf("error: %s\n", err);

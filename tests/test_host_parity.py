@@ -246,3 +246,31 @@ def test_rust_binding_covers_the_header():
     ffi = open(os.path.join(root, "integration", "rust", "compeg-hip", "src", "ffi.rs")).read()
     in_ffi = set(re.findall(r"pub fn (compeg_[a-z0-9_]+)\s*\(", ffi))
     assert in_header == in_ffi, (sorted(in_header - in_ffi), sorted(in_ffi - in_header))
+
+
+def test_sampling_extension_front_end():
+    """COMPEG_PARSE_ANY_LUMA_SAMPLING: without the flag the reference's rejection and
+    message; with it the same metadata block / LUTs as the oracle with its own extension switched on.
+    Luma samplings outside 1..2 x 1..2 and sub-sampled-the-other-way chroma stay rejected."""
+    for sampling in ((1, 1), (1, 2), (2, 2)):
+        jpeg = synth.make_jpeg(100, 52, seed=9, sampling=sampling, ri=3)
+        with pytest.raises(ca.Error) as e:
+            ca.ImageData(jpeg)
+        assert str(e.value) == f"invalid sampling factors {sampling[0]}x{sampling[1]} for Y component (expected 2x1)"
+        got, want = ca.ImageData(jpeg, allow_sampling=True), orc.ImageData(jpeg, allow_sampling=True)
+        assert (got.width(), got.height(), got.parallelism()) == (want.width(), want.height(), want.parallelism())
+        assert got.metadata() == want.metadata()
+        assert got.huffman_l1() == want.l1() and got.huffman_l2() == want.l2()
+    jpeg = bytearray(synth.make_jpeg(64, 32, seed=1, sampling=(2, 1), ri=2))
+    sof = jpeg.find(b"\xff\xc0")
+    jpeg[sof + 11] = 0x41                      # Y sampled 4x1
+    for image_data in (ca.ImageData, orc.ImageData):
+        with pytest.raises((ca.Error, orc.OracleError)) as e:
+            image_data(bytes(jpeg), allow_sampling=True)
+        assert "invalid sampling factors 4x1 for Y component" in str(e.value)
+    jpeg[sof + 11] = 0x22
+    jpeg[sof + 14] = 0x21                      # Cb sampled 2x1
+    for image_data in (ca.ImageData, orc.ImageData):
+        with pytest.raises((ca.Error, orc.OracleError)) as e:
+            image_data(bytes(jpeg), allow_sampling=True)
+        assert "invalid U/V sampling factors" in str(e.value)

@@ -131,6 +131,17 @@ def test_emulated_long_codes_and_dense_blocks(runner, tmp_path):
         _check(runner, tmp_path, synth.make_jpeg(96, 32, seed=seed, kind=1, quality=100, ri=3))
 
 
+@pytest.mark.parametrize("sampling", [(1, 1), (2, 1), (1, 2), (2, 2)])
+def test_emulated_extension_layouts(runner, tmp_path, sampling):
+    """4:4:4, 4:2:2, 4:4:0, 4:2:0 through the extension pipeline (entropy records, IDCT in place,
+    generic composite) against the oracle with the same extension switched on."""
+    for (w, h, kind, q, ri, seed) in [(96, 48, 0, 90, 2, 91), (250, 70, 1, 75, 3, 92), (33, 17, 2, 85, 1, 93)]:
+        jpeg = synth.make_jpeg(w, h, seed=seed, kind=kind, quality=q, ri=ri, sampling=sampling)
+        want = orc.ImageData(jpeg, allow_sampling=True).decode()
+        got = _run(runner, tmp_path, jpeg, 4)
+        assert np.array_equal(got, want), f"{sampling} {w}x{h}: {(got != want).any(axis=2).sum()} pixels differ"
+
+
 def test_emulated_rare_paths_were_reached():
     """Runs last in this module: the cases above must have exercised every branch of the fast
     entropy path (counters come from the emulator build, -DCG_EMUL_STATS)."""
