@@ -285,3 +285,22 @@ def test_cross_check_against_survey_probe_hashes():
     assert m.shape == (720, 960, 4)
     assert hashlib.sha256(m.tobytes()).hexdigest() == \
         "502b1b9c9a0401b20a04c3220710ae6c6c8a1068719a58018739b258602f9905"
+
+
+@pytest.mark.parametrize("sampling", [(1, 1), (2, 1), (1, 2), (2, 2)])
+def test_extension_layouts_against_libjpeg(sampling):
+    """The oracle's sampling extension (orc_image_parse_ext) has no reference vectors; its geometry
+    -- which data unit, which sample, which pixel -- is pinned against an independent decoder (libjpeg
+    through PIL) on smooth content, where the reference's approximations (32 retained coefficients,
+    nearest-neighbour chroma, its own colour constants) stay within a few levels.  4:2:2, the layout
+    the reference accepts, sets the yardstick: the extension layouts must be as close as it is."""
+    io = pytest.importorskip("io")
+    Image = pytest.importorskip("PIL.Image")
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tools import synth
+    jpeg = synth.make_jpeg(160, 96, seed=5, kind=2, quality=90, ri=2, sampling=sampling)
+    mine = orc.ImageData(jpeg, allow_sampling=True).decode()[:, :, :3].astype(int)
+    ref = np.asarray(Image.open(io.BytesIO(jpeg)).convert("RGB")).astype(int)
+    diff = np.abs(mine - ref)
+    assert diff.mean() < 0.5 and np.percentile(diff, 99) <= 8, (diff.mean(), np.percentile(diff, 99))
