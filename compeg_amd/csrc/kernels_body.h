@@ -1248,20 +1248,24 @@ CG_DEV void composite_generic_4px(const ImageDesc &d, uint32_t x0, uint32_t y)
         return;
     const uint32_t col = x0 % d.mcu_w, row = y % d.mcu_h;
     const uint32_t max_h = d.mcu_w / 8u, max_v = d.mcu_h / 8u;
-    auto *samples = CG_GLOBAL(const uint8_t, reinterpret_cast<const uint8_t *>(d.ac));
+    // the four pixels read one 8-sample row of one data unit per component (col is a
+    // multiple of 4 and a data unit spans 8 or 16 pixel columns): one 8-byte load each
+    struct alignas(8) Row8 {
+        uint32_t lo, hi;
+    };
+    auto *samples = CG_GLOBAL(const Row8, reinterpret_cast<const Row8 *>(d.ac));
     uint32_t val[3][4];
 #pragma unroll
     for (uint32_t c = 0; c < 3; c++) {
         const uint32_t hs = d.hsample[c], vs = d.vsample[c];
         const uint32_t xscale = max_h / hs, yscale = max_v / vs;
         const uint32_t yy = (row / yscale) & 7u;
+        const uint32_t du = d.du_base[c] + (row * vs / d.mcu_h) * hs + col * hs / d.mcu_w;
+        const Row8 r = samples[(size_t(mcu) * d.dus_per_mcu + du) * 8u + yy];
+        const uint64_t bits = uint64_t(r.hi) << 32 | r.lo;
 #pragma unroll
-        for (uint32_t i = 0; i < 4; i++) {
-            const uint32_t cc = col + i;
-            const uint32_t du = d.du_base[c] + (row * vs / d.mcu_h) * hs + cc * hs / d.mcu_w;
-            const uint32_t x = (cc / xscale) & 7u;
-            val[c][i] = samples[(size_t(mcu) * d.dus_per_mcu + du) * (kRetained * 2u) + yy * 8u + x];
-        }
+        for (uint32_t i = 0; i < 4; i++)
+            val[c][i] = uint32_t(bits >> ((((col + i) / xscale) & 7u) * 8u)) & 0xffu;
     }
     auto *p = CG_GLOBAL(uint32_t, reinterpret_cast<uint32_t *>(d.out + size_t(y) * d.out_pitch + size_t(x0) * 4u));
 #pragma unroll
