@@ -1235,19 +1235,20 @@ CG_DEV void idct_record_in_place(const ImageDesc &d, const float *quant, uint32_
         record[i] = Vec4u{px[4 * i], px[4 * i + 1], px[4 * i + 2], px[4 * i + 3]};
 }
 
-// Pixels x0 .. x0+3 (x0 a multiple of 4) of output row y.
+// Pixels x0 .. x0+3 (x0 a multiple of 4) of output row y.  Sampling factors
+// are 1 or 2 and MCU sizes 8 or 16, so every division below is a shift.
 CG_DEV void composite_generic_4px(const ImageDesc &d, uint32_t x0, uint32_t y)
 {
     if (x0 >= d.out_w || y >= d.out_h)
         return;
-    const uint32_t mcu_x = x0 / d.mcu_w, mcu_y = y / d.mcu_h;
+    const uint32_t wsh = d.mcu_w == 16u ? 4u : 3u, hsh = d.mcu_h == 16u ? 4u : 3u; // log2 of the MCU size
+    const uint32_t mcu_x = x0 >> wsh, mcu_y = y >> hsh;
     const uint32_t mcu = mcu_y * d.width_mcus + mcu_x;
     // right of the last MCU column, or behind the last decoded MCU (a truncated
     // last restart interval): nothing is stored there, the output keeps its zeros
     if (mcu_x >= d.width_mcus || mcu >= d.total_intervals * d.restart_interval)
         return;
-    const uint32_t col = x0 % d.mcu_w, row = y % d.mcu_h;
-    const uint32_t max_h = d.mcu_w / 8u, max_v = d.mcu_h / 8u;
+    const uint32_t col = x0 & (d.mcu_w - 1u), row = y & (d.mcu_h - 1u);
     // the four pixels read one 8-sample row of one data unit per component (col is a
     // multiple of 4 and a data unit spans 8 or 16 pixel columns): one 8-byte load each
     struct alignas(8) Row8 {
@@ -1257,17 +1258,23 @@ CG_DEV void composite_generic_4px(const ImageDesc &d, uint32_t x0, uint32_t y)
     uint32_t val[3][4];
 #pragma unroll
     for (uint32_t c = 0; c < 3; c++) {
-        const uint32_t hs = d.hsample[c], vs = d.vsample[c];
-        const uint32_t xscale = max_h / hs, yscale = max_v / vs;
-        const uint32_t yy = (row / yscale) & 7u;
-        const uint32_t du = d.du_base[c] + (row * vs / d.mcu_h) * hs + col * hs / d.mcu_w;
+        const uint32_t hs = d.hsample[c], vs = d.vsample[c]; // 1 or 2
+        const uint32_t xsh = (wsh - 3u) - (hs - 1u), ysh = (hsh - 3u) - (vs - 1u); // log2 of xscale, yscale
+        const uint32_t yy = (row >> ysh) & 7u;
+        const uint32_t du = d.du_base[c] + ((row * vs) >> hsh) * hs + ((col * hs) >> wsh);
         const Row8 r = samples[(size_t(mcu) * d.dus_per_mcu + du) * 8u + yy];
         const uint64_t bits = uint64_t(r.hi) << 32 | r.lo;
 #pragma unroll
         for (uint32_t i = 0; i < 4; i++)
-            val[c][i] = uint32_t(bits >> ((((col + i) / xscale) & 7u) * 8u)) & 0xffu;
+            val[c][i] = uint32_t(bits >> ((((col + i) >> xsh) & 7u) * 8u)) & 0xffu;
     }
     auto *p = CG_GLOBAL(uint32_t, reinterpret_cast<uint32_t *>(d.out + size_t(y) * d.out_pitch + size_t(x0) * 4u));
+    if (x0 + 3u < d.out_w && (d.out_pitch & 15u) == 0u) {
+        *CG_GLOBAL(Vec4u, reinterpret_cast<Vec4u *>(d.out + size_t(y) * d.out_pitch + size_t(x0) * 4u)) =
+            Vec4u{ycbcr_to_rgba(val[0][0], val[1][0], val[2][0]), ycbcr_to_rgba(val[0][1], val[1][1], val[2][1]),
+                  ycbcr_to_rgba(val[0][2], val[1][2], val[2][2]), ycbcr_to_rgba(val[0][3], val[1][3], val[2][3])};
+        return;
+    }
 #pragma unroll
     for (uint32_t i = 0; i < 4; i++)
         if (x0 + i < d.out_w)
