@@ -294,3 +294,49 @@ def test_extension_layouts(ca, gpu, sampling):
     batch.wait()
     for i, j in enumerate(mixed):
         _assert_equal(batch.read_output(i), orc.ImageData(j, allow_sampling=True).decode())
+
+
+def test_zero_copy_consumer_and_caller_stream(ca, gpu):
+    """the decoded frame is consumed where it is -- torch wraps the output through
+    __cuda_array_interface__ without a copy (same device pointer), and a decode recorded on the
+    consumer's own stream (the viewer's command encoder in the reference, examples/viewer.rs:244-246)
+    is ordered in front of the consumer's work on that stream.  Runs in a process of its own that
+    imports torch first (torch brings its own copy of the HIP runtime; bench.py has the same order)."""
+    import subprocess
+    import sys
+    code = r'''
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, %r)
+import compeg_amd as ca
+from oracle import oracle as orc
+from tools import synth
+jpeg = synth.make_jpeg(640, 360, seed=401, ri=4)
+want = orc.ImageData(jpeg).decode()
+data = ca.ImageData(jpeg)
+torch.cuda.set_device(0)
+stream = torch.cuda.Stream()
+g = ca.Gpu.from_stream(0, stream.cuda_stream)
+dec = ca.Decoder(g)
+with torch.cuda.stream(stream):
+    changed = dec.enqueue(data, stream.cuda_stream)
+    tex = dec.texture()
+    view = torch.as_tensor(tex, device="cuda")           # no copy
+    luma = view[..., :3].to(torch.float32).mean()         # consumer work, same stream, no host sync
+    host = view.cpu()
+stream.synchronize()
+assert changed
+assert view.data_ptr() == tex.ptr and tuple(view.shape) == (360, 640, 4)
+assert np.array_equal(host.numpy(), want)
+assert abs(float(luma) - want[..., :3].mean()) < 1e-3
+batch = ca.Batch(g)                                        # a batch output is consumable the same way
+batch.upload([data])
+batch.decode(stream.cuda_stream)
+with torch.cuda.stream(stream):
+    bview = torch.as_tensor(batch.output(0), device="cuda")
+    assert np.array_equal(bview.cpu().numpy(), want)
+print("zero-copy ok")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "zero-copy ok" in r.stdout, r.stdout + r.stderr[-3000:]
