@@ -94,9 +94,8 @@ entropy_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t
     }
     __syncthreads();
 
-    const uint32_t interval = wave_first + lane;
-    if (interval >= d.total_intervals)
-        return;
+    if (wave_first >= d.total_intervals)
+        return; // the whole wave; lanes past the last interval of a partly used wave stay (quad stores)
 
     HuffShared s;
     s.l1 = l1;
@@ -106,7 +105,7 @@ entropy_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t
     s.win_base = win_base;
     s.win_len = win_len;
     s.du_slots = reinterpret_cast<uint8_t *>(win) + align16(window_words * 4u);
-    entropy_interval_to_records(d, s, interval, lane);
+    entropy_wave_to_records(d, s, wave_first + lane, lane);
 }
 
 // Fused path: same prologue as huffman_kernel, then every lane runs the whole

@@ -42,6 +42,9 @@
 #define CG_PIN_SCALAR(x) (void)(x)
 #endif
 
+#ifndef CG_IDCT_PACKED
+#define CG_IDCT_PACKED 1 // IDCT butterflies on pairs of floats (packed f32 instructions on the GPU)
+#endif
 #ifndef CG_EXP
 #define CG_EXP 0 // diagnostic builds only (tools/build_variant.sh, tools/ab_bench.sh): 3 = AC loop twice,
                  // 4 = no IDCT, 5 = no colour arithmetic -- what each phase costs inside the real mix
@@ -366,40 +369,56 @@ CG_DEV int zigzag_of(int natural)
 // One 8-point AAN pass over v[0], v[stride], ... (libjpeg-turbo jidctflt
 // structure as used by the reference).  `bias` is added to the DC input
 // (128.5 in the row pass).
-template <int STRIDE, bool ROW_PASS>
-CG_DEV void aan_1d(float *v)
+// T = float, or a pair of floats that the GPU handles with packed
+// instructions (v_pk_add_f32 / v_pk_mul_f32: two independent IEEE operations,
+// no contraction) -- two columns, or two rows, per instruction.
+#if defined(__clang__)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#else
+typedef float f32x2 __attribute__((vector_size(8)));
+#endif
+CG_DEV float aan_splat(float c, float) { return c; }
+CG_DEV f32x2 aan_splat(float c, f32x2) { return f32x2{c, c}; }
+template <class T> CG_DEV T aan_const(float c)
 {
-    float in0 = v[0 * STRIDE], in1 = v[1 * STRIDE], in2 = v[2 * STRIDE], in3 = v[3 * STRIDE];
-    float in4 = v[4 * STRIDE], in5 = v[5 * STRIDE], in6 = v[6 * STRIDE], in7 = v[7 * STRIDE];
+    return aan_splat(c, T{});
+}
+
+template <class T, int STRIDE, bool ROW_PASS>
+CG_DEV void aan_1d(T *v)
+{
+    T in0 = v[0 * STRIDE], in1 = v[1 * STRIDE], in2 = v[2 * STRIDE], in3 = v[3 * STRIDE];
+    T in4 = v[4 * STRIDE], in5 = v[5 * STRIDE], in6 = v[6 * STRIDE], in7 = v[7 * STRIDE];
     if (ROW_PASS) {
-        in0 = in0 + 128.5f;
+        in0 = in0 + aan_const<T>(128.5f);
     } else {
-        in0 = in0 * 0.125f;
-        in1 = in1 * 0.125f;
-        in2 = in2 * 0.125f;
-        in3 = in3 * 0.125f;
-        in4 = in4 * 0.125f;
-        in5 = in5 * 0.125f;
-        in6 = in6 * 0.125f;
-        in7 = in7 * 0.125f;
+        const T eighth = aan_const<T>(0.125f);
+        in0 = in0 * eighth;
+        in1 = in1 * eighth;
+        in2 = in2 * eighth;
+        in3 = in3 * eighth;
+        in4 = in4 * eighth;
+        in5 = in5 * eighth;
+        in6 = in6 * eighth;
+        in7 = in7 * eighth;
     }
     // even part
-    const float tmp10 = in0 + in4, tmp11 = in0 - in4;
-    const float tmp13 = in2 + in6;
-    const float tmp12 = (in2 - in6) * CG_C1414 - tmp13;
-    const float e0 = tmp10 + tmp13, e3 = tmp10 - tmp13;
-    const float e1 = tmp11 + tmp12, e2 = tmp11 - tmp12;
+    const T tmp10 = in0 + in4, tmp11 = in0 - in4;
+    const T tmp13 = in2 + in6;
+    const T tmp12 = (in2 - in6) * aan_const<T>(CG_C1414) - tmp13;
+    const T e0 = tmp10 + tmp13, e3 = tmp10 - tmp13;
+    const T e1 = tmp11 + tmp12, e2 = tmp11 - tmp12;
     // odd part
-    const float z13 = in5 + in3, z10 = in5 - in3;
-    const float z11 = in1 + in7, z12 = in1 - in7;
-    const float o7 = z11 + z13;
-    const float t11 = (z11 - z13) * CG_C1414;
-    const float z5 = (z10 + z12) * CG_C1847;
-    const float t10 = z5 - z12 * CG_C1082;
-    const float t12 = z5 - z10 * CG_C2613;
-    const float o6 = t12 - o7;
-    const float o5 = t11 - o6;
-    const float o4 = t10 - o5;
+    const T z13 = in5 + in3, z10 = in5 - in3;
+    const T z11 = in1 + in7, z12 = in1 - in7;
+    const T o7 = z11 + z13;
+    const T t11 = (z11 - z13) * aan_const<T>(CG_C1414);
+    const T z5 = (z10 + z12) * aan_const<T>(CG_C1847);
+    const T t10 = z5 - z12 * aan_const<T>(CG_C1082);
+    const T t12 = z5 - z10 * aan_const<T>(CG_C2613);
+    const T o6 = t12 - o7;
+    const T o5 = t11 - o6;
+    const T o4 = t10 - o5;
 
     v[0 * STRIDE] = e0 + o7;
     v[7 * STRIDE] = e0 - o7;
@@ -476,15 +495,46 @@ CG_DEV void idct_data_unit(const uint32_t (&ac)[kRetained / 2], int32_t dc, cons
             v[r * 8 + c] = x;
         }
     }
-#pragma unroll
-    for (int c = 0; c < 8; c++)
-        aan_1d<8, false>(v + c);
+#if CG_IDCT_PACKED
+    // column pass on column pairs, row pass on row pairs; element by element the
+    // same operations in the same order as the scalar form below
+    f32x2 cols[8][4];
 #pragma unroll
     for (int r = 0; r < 8; r++)
-        aan_1d<1, true>(v + r * 8);
+#pragma unroll
+        for (int cp = 0; cp < 4; cp++)
+            cols[r][cp] = f32x2{v[r * 8 + 2 * cp], v[r * 8 + 2 * cp + 1]};
+#pragma unroll
+    for (int cp = 0; cp < 4; cp++)
+        aan_1d<f32x2, 4, false>(&cols[0][cp]);
+    f32x2 rows[4][8];
+#pragma unroll
+    for (int rp = 0; rp < 4; rp++)
+#pragma unroll
+        for (int c = 0; c < 8; c++)
+            rows[rp][c] = f32x2{cols[2 * rp][c >> 1][c & 1], cols[2 * rp + 1][c >> 1][c & 1]};
+#pragma unroll
+    for (int rp = 0; rp < 4; rp++)
+        aan_1d<f32x2, 1, true>(&rows[rp][0]);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        float f[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++)
+            f[c] = rows[r >> 1][c][r & 1];
+        pack_row(f, px[2 * r + 0], px[2 * r + 1]);
+    }
+#else
+#pragma unroll
+    for (int c = 0; c < 8; c++)
+        aan_1d<float, 8, false>(v + c);
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+        aan_1d<float, 1, true>(v + r * 8);
 #pragma unroll
     for (int r = 0; r < 8; r++)
         pack_row(v + r * 8, px[2 * r + 0], px[2 * r + 1]);
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -812,7 +862,11 @@ CG_DEV void fast_refill(EntropyState &e)
     r.buf |= (uint64_t(w) << 32) >> (r.left & 63u);     // w == 0 when left >= 32
     r.left += f << 5;
     e.wptr += f;
+#if CG_EXP == 12
+    r.pre = uint32_t(reinterpret_cast<uintptr_t>(e.wptr)) * 2654435761u;
+#else
     r.pre = lds_read_u32_early(e.wptr); // due at the next lds_reads_done()
+#endif
 }
 
 // nb-bit field that ends `tot` bits below the top of cur, sign-extended (0 for nb == 0)
@@ -877,7 +931,9 @@ CG_DEV void fast_ac(EntropyState &e, const ImageDesc &d, const HuffShared &s, ui
         CG_AC_STAMP(const uint64_t tw0 = __builtin_readcyclecounter();)
         lds_reads_done(ent, r.pre);
         CG_AC_STAMP(tw += __builtin_readcyclecounter() - tw0; its++;)
+#if CG_EXP != 12
         *pend_at = pend_val;
+#endif
 #if CG_EXP != 7 // (7: diagnostic build without the escape test)
         if (__builtin_expect(ent >= kFastEscape, 0))
 #else
@@ -888,13 +944,22 @@ CG_DEV void fast_ac(EntropyState &e, const ImageDesc &d, const HuffShared &s, ui
             CG_COUNT(escapes);
             ent = fast_entry(lut_lookup<true>(d, s, ac_off, reader_cur(r)));
         }
+#if CG_EXP >= 10 && CG_EXP <= 12 // diagnostic builds: every symbol is "5 bits, 2 of them magnitude, next position
+                                  // + 5" (13 symbols per data unit in every lane); 11: without the table
+                                  // read; 12: also without the stream-word read and the coefficient store
+        ent = (5u << 9) | (5u << 4) | 2u;
+#endif
         const uint32_t nb = ent & 15u, adv = ent >> 9;
         tot = (ent >> 4) & 31u;
         const uint32_t cur = reader_cur(r);
         r.buf <<= tot;
         r.left -= tot;
         fast_refill(e);
+#if CG_EXP == 11 || CG_EXP == 12
+        ent = reader_cur(r) >> 30;
+#else
         ent = lds_read_u16_early(tab + (reader_cur(r) >> (32u - kFastBits)));
+#endif
         // a magnitude whose first bit is 0 encodes field - (2^nb - 1)
         const int32_t sx = signed_field(cur, tot, nb);
         const uint32_t val = uint32_t(sx) + (((0xffffffffu << nb) ^ uint32_t(sx >> 31)) + 1u);
@@ -1169,39 +1234,62 @@ CG_DEV void composite_edge_mcu(const ImageDesc &d, const uint32_t (&px)[4][16], 
 // The same work as two cooperating roles (decoder wave + transformer wave)
 // ---------------------------------------------------------------------------
 
-// Entropy decode of one restart interval into the coefficient records the
-// IDCT kernel reads (two-kernel pipeline): per data unit one 64-byte record of
-// quantised AC levels (zig-zag order, position 0 unused) in d.ac and the
-// dequantised DC term in d.dc.  Any sampling the front-end accepts.
-CG_DEV void entropy_interval_to_records(const ImageDesc &d, const HuffShared &s, uint32_t interval,
-                                        uint32_t lane)
+// Entropy decode of restart intervals into the coefficient records the IDCT
+// kernels read (two-kernel pipeline, extension layouts): per data unit one
+// 64-byte record of quantised AC levels (zig-zag order, position 0 unused) in
+// d.ac and the dequantised DC term in d.dc.  Any sampling the front-end accepts.
+//
+// The records leave through the lane's quad, like the pixels of the fused
+// kernel: lane i of a quad stores piece i (16 bytes) of the four records of
+// its quad, straight out of the four LDS slots, so that a wave-wide store
+// covers 16 x 64 contiguous bytes (a scattered one occupies the vector memory
+// path for 64 cycles, and there are five per data unit otherwise).
+// interval: this lane's (possibly past the image's last) restart interval.
+CG_DEV void records_flush_quad(const ImageDesc &d, const uint8_t *wave_slots, uint32_t lane, uint32_t interval,
+                               uint32_t du_in_interval, int32_t dc)
+{
+    const uint32_t quad = lane & ~3u, piece = lane & 3u;
+    const uint32_t du_count = d.restart_interval * d.dus_per_mcu;
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) {
+        const uint32_t other = interval - piece + j; // the interval of the quad's lane j
+        if (other < d.total_intervals) {
+            const SlotVec v = reinterpret_cast<const SlotVec *>(wave_slots + (quad + j) * kDuSlotBytes)[piece];
+            auto *rec = CG_GLOBAL(Vec4u, reinterpret_cast<Vec4u *>(
+                                             d.ac + (size_t(other) * du_count + du_in_interval) * kRetained));
+            rec[piece] = Vec4u{v.x, v.y, v.z, v.w};
+        }
+    }
+    if (interval < d.total_intervals)
+        CG_GLOBAL(int32_t, d.dc)[size_t(interval) * du_count + du_in_interval] = dc;
+}
+
+#if defined(__HIPCC__)
+// All 64 lanes of a wave call this together (tests/emul drives the same steps
+// lane by lane); lanes past the last interval decode the last one again and
+// only help their quad store.
+CG_DEV void entropy_wave_to_records(const ImageDesc &d, const HuffShared &s, uint32_t interval, uint32_t lane)
 {
     uint8_t *slot = s.du_slots + lane * kDuSlotBytes;
     int16_t *slot16 = reinterpret_cast<int16_t *>(slot);
     zero_slot(slot);
 
     EntropyState e;
-    entropy_init(e, d, s, interval);
+    entropy_init(e, d, s, interval < d.total_intervals ? interval : d.total_intervals - 1u);
 
     const uint32_t dpm = d.dus_per_mcu;
     const uint32_t du_count = d.restart_interval * dpm;
-    uint32_t du_global = interval * du_count;
     uint32_t k = 0; // data unit inside the MCU (wave-uniform)
 #pragma unroll 1
     for (uint32_t du = 0; du < du_count; du++) {
         const uint32_t comp = (d.comp_of_du >> (2u * k)) & 3u;
         const int32_t dc = entropy_data_unit(e, d, s, comp < 3u ? comp : 2u, slot16);
-        uint32_t rec[kRetained / 2];
-        take_slot(slot, rec);
-        auto *dst = CG_GLOBAL(Vec4u, reinterpret_cast<Vec4u *>(d.ac + size_t(du_global) * kRetained));
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-            dst[i] = Vec4u{rec[4 * i], rec[4 * i + 1], rec[4 * i + 2], rec[4 * i + 3]};
-        CG_GLOBAL(int32_t, d.dc)[du_global] = dc;
-        du_global++;
+        records_flush_quad(d, s.du_slots, lane, interval, du, dc);
+        zero_slot(slot);
         k = k + 1u == dpm ? 0u : k + 1u;
     }
 }
+#endif
 
 // ---------------------------------------------------------------------------
 // Layouts other than 4:2:2 (extension): three plain kernels

@@ -174,13 +174,31 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
             for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
                 stage_window(d, win, wb, wl, lane);
             HuffShared sh{sl1, sl2, umin(l2_in_lds, d.fast_off + 2u * kFastEntries), win, wb, wl, slots};
-            for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
-                if (wave_first + lane < d.total_intervals) {
-                    if (fused == 3 || fused == 4)
-                        entropy_interval_to_records(d, sh, wave_first + lane, lane);
-                    else
-                        huff_decode_interval(d, sh, wave_first + lane, lane);
+            if (fused == 3 || fused == 4) {
+                // entropy_wave_to_records, data unit by data unit and phase by phase
+                std::vector<EntropyState> es(kWave);
+                std::vector<int32_t> dcs(kWave);
+                for (uint32_t lane = 0; lane < uint32_t(kWave); lane++) {
+                    zero_slot(slots + lane * kDuSlotBytes);
+                    const uint32_t iv = wave_first + lane;
+                    entropy_init(es[lane], d, sh, iv < d.total_intervals ? iv : d.total_intervals - 1u);
                 }
+                const uint32_t du_count = d.restart_interval * d.dus_per_mcu;
+                for (uint32_t du = 0, k = 0; du < du_count; du++, k = k + 1u == d.dus_per_mcu ? 0u : k + 1u) {
+                    const uint32_t comp = (d.comp_of_du >> (2u * k)) & 3u;
+                    for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
+                        dcs[lane] = entropy_data_unit(es[lane], d, sh, comp < 3u ? comp : 2u,
+                                                      reinterpret_cast<int16_t *>(slots + lane * kDuSlotBytes));
+                    for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
+                        records_flush_quad(d, slots, lane, wave_first + lane, du, dcs[lane]);
+                    for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
+                        zero_slot(slots + lane * kDuSlotBytes);
+                }
+                continue;
+            }
+            for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
+                if (wave_first + lane < d.total_intervals)
+                    huff_decode_interval(d, sh, wave_first + lane, lane);
         }
         free(smem);
     }
