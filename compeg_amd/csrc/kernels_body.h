@@ -45,6 +45,12 @@
 #ifndef CG_IDCT_PACKED
 #define CG_IDCT_PACKED 1 // IDCT butterflies on pairs of floats (packed f32 instructions on the GPU)
 #endif
+#ifndef CG_PRIO_IDCT
+#define CG_PRIO_IDCT 1 // wave priority (0..3) in the IDCT and, below, the composite; the entropy decode runs at 0
+#endif
+#ifndef CG_PRIO_COMPOSITE
+#define CG_PRIO_COMPOSITE 3
+#endif
 #ifndef CG_EXP
 #define CG_EXP 0 // diagnostic builds only (tools/build_variant.sh, tools/ab_bench.sh): 3 = AC loop twice,
                  // 4 = no IDCT, 5 = no colour arithmetic -- what each phase costs inside the real mix
@@ -1540,14 +1546,21 @@ CG_DEV void decode_wave_fused_422(const ImageDesc &d, const HuffShared &s, uint3
     for (uint32_t du = 0; du < du_total; du++) {
         const uint32_t k = du & 3u;
         const uint32_t comp = k < 2u ? 0u : k - 1u; // Y0 Y1 Cb Cr (wave-uniform)
+        // Wave priority by phase: a wave in the dense, stall-free phases (IDCT,
+        // composite) goes in front of waves in the entropy decode, whose
+        // dependent chain leaves most issue slots unused anyway; the dense phases
+        // finish sooner and their stores enter the memory system earlier.
         const int32_t dc = entropy_data_unit(e, d, s, comp, slot16);
         CG_STAMP(t_ac);
+        __builtin_amdgcn_s_setprio(CG_PRIO_IDCT);
         pixel_transform(t, d, comp, slot, dc);
         CG_STAMP(t_idct);
         if (k == 3u) {
+            __builtin_amdgcn_s_setprio(CG_PRIO_COMPOSITE);
             composite_mcus_422<true>(t, d, s.du_slots, lane);
             CG_STAMP(t_comp);
         }
+        __builtin_amdgcn_s_setprio(0);
     }
 #if defined(CG_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
     if (lane == 0 && d.dc) { // diagnostic build only: per-wave phase cycles into the (otherwise unused) dc buffer
