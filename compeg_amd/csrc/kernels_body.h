@@ -51,6 +51,9 @@
 #ifndef CG_PRIO_COMPOSITE
 #define CG_PRIO_COMPOSITE 3
 #endif
+#ifndef CG_NT_STORES
+#define CG_NT_STORES 1 // the output is written once and not read back by the kernel: non-temporal stores
+#endif
 #ifndef CG_EXP
 #define CG_EXP 0 // diagnostic builds only (tools/build_variant.sh, tools/ab_bench.sh): 3 = AC loop twice,
                  // 4 = no IDCT, 5 = no colour arithmetic -- what each phase costs inside the real mix
@@ -61,6 +64,27 @@ namespace compeg {
 struct alignas(16) Vec4u {
     uint32_t x, y, z, w;
 };
+
+// 16 bytes of output pixels.  The output is written once and never read by the
+// kernels: where a wave-wide store covers whole 64-byte segments (STREAM), a
+// non-temporal store keeps it from displacing the L2's contents (7 % on
+// 128-frame batches; `sc1` / `sc0 sc1` write-through variants were slower).
+// Lone 16-byte pieces that the L2 has to merge with their neighbours (the
+// paired kernel's per-lane stores) stay ordinary stores: non-temporal cost them 7 %.
+template <bool STREAM>
+CG_DEV void store_pixels(uint8_t *p, const Vec4u &v)
+{
+#if CG_NT_STORES && defined(__HIP_DEVICE_COMPILE__)
+    if (STREAM) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(
+            u32x4{v.x, v.y, v.z, v.w},
+            reinterpret_cast<__attribute__((address_space(1))) u32x4 *>(reinterpret_cast<uintptr_t>(p)));
+        return;
+    }
+#endif
+    *CG_GLOBAL(Vec4u, reinterpret_cast<Vec4u *>(p)) = v;
+}
 
 // ---------------------------------------------------------------------------
 // Huffman / RLE decode, one lane per restart interval
@@ -1087,7 +1111,7 @@ CG_DEV void composite_422(const ImageDesc &d, const uint32_t *px_slots, uint32_t
         o.w = ycbcr_to_rgba(yw >> 24, (cbw >> 8) & 0xffu, (crw >> 8) & 0xffu);
         uint8_t *p = d.out + size_t(y) * d.out_pitch + size_t(x0) * 4u;
         if (x0 + 3u < d.out_w && (d.out_pitch & 15u) == 0u) {
-            *CG_GLOBAL(Vec4u, reinterpret_cast<Vec4u *>(p)) = o;
+            store_pixels<true>(p, o);
         } else {
             auto *q = CG_GLOBAL(uint32_t, reinterpret_cast<uint32_t *>(p));
             q[0] = o.x;
@@ -1193,8 +1217,7 @@ CG_DEV void composite_row_from_quad(const ImageDesc &d, const uint8_t *wave_slot
         if (whole_mask >> j & 1u)
 #endif
         {
-            uint8_t *p = bases[j] + size_t(row) * d.out_pitch + piece * 16u;
-            *CG_GLOBAL(Vec4u, reinterpret_cast<Vec4u *>(p)) = Vec4u{v.x, v.y, v.z, v.w};
+            store_pixels<true>(bases[j] + size_t(row) * d.out_pitch + piece * 16u, Vec4u{v.x, v.y, v.z, v.w});
         }
     }
 }
@@ -1364,9 +1387,9 @@ CG_DEV void composite_generic_4px(const ImageDesc &d, uint32_t x0, uint32_t y)
     }
     auto *p = CG_GLOBAL(uint32_t, reinterpret_cast<uint32_t *>(d.out + size_t(y) * d.out_pitch + size_t(x0) * 4u));
     if (x0 + 3u < d.out_w && (d.out_pitch & 15u) == 0u) {
-        *CG_GLOBAL(Vec4u, reinterpret_cast<Vec4u *>(d.out + size_t(y) * d.out_pitch + size_t(x0) * 4u)) =
-            Vec4u{ycbcr_to_rgba(val[0][0], val[1][0], val[2][0]), ycbcr_to_rgba(val[0][1], val[1][1], val[2][1]),
-                  ycbcr_to_rgba(val[0][2], val[1][2], val[2][2]), ycbcr_to_rgba(val[0][3], val[1][3], val[2][3])};
+        store_pixels<true>(d.out + size_t(y) * d.out_pitch + size_t(x0) * 4u,
+                     Vec4u{ycbcr_to_rgba(val[0][0], val[1][0], val[2][0]), ycbcr_to_rgba(val[0][1], val[1][1], val[2][1]),
+                           ycbcr_to_rgba(val[0][2], val[1][2], val[2][2]), ycbcr_to_rgba(val[0][3], val[1][3], val[2][3])});
         return;
     }
 #pragma unroll
@@ -1465,11 +1488,11 @@ CG_DEV void composite_mcus_422(PixelState &t, const ImageDesc &d, uint8_t *wave_
         if (g.whole) {
 #pragma unroll
             for (uint32_t row = 0; row < 8; row++) {
-                auto *line = CG_GLOBAL(Vec4u, reinterpret_cast<Vec4u *>(g.base + size_t(row) * d.out_pitch));
 #pragma unroll
                 for (uint32_t q = 0; q < 4; q++)
-                    line[q] = rgba_quad(t.px[q >> 1][row * 2u + (q & 1u)], t.px[2][row * 2u + (q >> 1)] >> ((q & 1u) * 16u),
-                                        t.px[3][row * 2u + (q >> 1)] >> ((q & 1u) * 16u));
+                    store_pixels<false>(g.base + size_t(row) * d.out_pitch + q * 16u,
+                                 rgba_quad(t.px[q >> 1][row * 2u + (q & 1u)], t.px[2][row * 2u + (q >> 1)] >> ((q & 1u) * 16u),
+                                           t.px[3][row * 2u + (q >> 1)] >> ((q & 1u) * 16u)));
             }
         } else if (t.active) {
             composite_edge_mcu(d, t.px, t.mx, t.my);
