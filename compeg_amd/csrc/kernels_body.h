@@ -1138,33 +1138,32 @@ CG_DEV Vec4u rgba_quad(uint32_t yw, uint32_t cb2, uint32_t cr2)
     Vec4u o;
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef short s2 __attribute__((ext_vector_type(2)));
-    const s2 bias = {128, 128};
-    // bytes 0,1 of a word -> the two 16-bit lanes
-    const s2 cb = __builtin_bit_cast(s2, __builtin_amdgcn_perm(0u, cb2, 0x0c010c00u)) - bias;
-    const s2 cr = __builtin_bit_cast(s2, __builtin_amdgcn_perm(0u, cr2, 0x0c010c00u)) - bias;
+    // the two chroma bytes -> the two 16-bit lanes; the -128 bias is folded
+    // into the constant term of each product (45 * 128 = 5760, ...)
+    const s2 cb = __builtin_bit_cast(s2, __builtin_amdgcn_perm(0u, cb2, 0x0c010c00u));
+    const s2 cr = __builtin_bit_cast(s2, __builtin_amdgcn_perm(0u, cr2, 0x0c010c00u));
     const s2 k45 = {45, 45}, k11 = {11, 11}, k23 = {23, 23}, k113 = {113, 113};
+    const s2 b45 = {-5760, -5760}, b34 = {-4352, -4352}, b113 = {-14464, -14464};
     const s2 sh5 = {5, 5}, sh6 = {6, 6};
-    const s2 rc = (cr * k45) >> sh5;
-    const s2 gc = (cb * k11 + cr * k23) >> sh5;
-    const s2 bc = (cb * k113) >> sh6;
-    const s2 ya = __builtin_bit_cast(s2, __builtin_amdgcn_perm(0u, yw, 0x0c010c00u));
-    const s2 yb = __builtin_bit_cast(s2, __builtin_amdgcn_perm(0u, yw, 0x0c030c02u));
-    const s2 rc0 = {rc.x, rc.x}, rc1 = {rc.y, rc.y};
-    const s2 gc0 = {gc.x, gc.x}, gc1 = {gc.y, gc.y};
-    const s2 bc0 = {bc.x, bc.x}, bc1 = {bc.y, bc.y};
-    uint32_t ra, ga, ba, rb, gb, bb;
-    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(ra) : "v"(ya + rc0));
-    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(ga) : "v"(ya - gc0));
-    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(ba) : "v"(ya + bc0));
-    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(rb) : "v"(yb + rc1));
-    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(gb) : "v"(yb - gc1));
-    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(bb) : "v"(yb + bc1));
-    const uint32_t rga = (ra & 0xffffu) | (ga << 16), b1a = ba | 0xffff0000u;
-    const uint32_t rgb = (rb & 0xffffu) | (gb << 16), b1b = bb | 0xffff0000u;
-    o.x = __builtin_amdgcn_perm(b1a, rga, 0x06040200u);
-    o.y = __builtin_amdgcn_perm(b1a, rga, 0x07050301u);
-    o.z = __builtin_amdgcn_perm(b1b, rgb, 0x06040200u);
-    o.w = __builtin_amdgcn_perm(b1b, rgb, 0x07050301u);
+    const s2 rc = (cr * k45 + b45) >> sh5;
+    const s2 gc = (cb * k11 + (cr * k23 + b34)) >> sh5;
+    const s2 bc = (cb * k113 + b113) >> sh6;
+    // luma lanes (p0, p2) and (p1, p3): lane 0 uses chroma sample 0, lane 1 sample 1
+    const s2 ya = __builtin_bit_cast(s2, yw & 0x00ff00ffu);
+    const s2 yb = __builtin_bit_cast(s2, (yw >> 8) & 0x00ff00ffu);
+    uint32_t ra, ga, ba, rb, gb, bb; // saturated bytes of the two lanes in bits 0..15, upper half zero
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(ra) : "v"(ya + rc));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(ga) : "v"(ya - gc));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(ba) : "v"(ya + bc));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(rb) : "v"(yb + rc));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(gb) : "v"(yb - gc));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(bb) : "v"(yb + bc));
+    const uint32_t rga = ga << 16 | ra, rgb = gb << 16 | rb; // bytes R(p0) R(p2) G(p0) G(p2)
+    // pixel = R, G, B, 255: selector bytes 0..3 pick from the second source, 4..7 from the first, 0x0d = 0xff
+    o.x = __builtin_amdgcn_perm(ba, rga, 0x0d040200u);
+    o.z = __builtin_amdgcn_perm(ba, rga, 0x0d050301u);
+    o.y = __builtin_amdgcn_perm(bb, rgb, 0x0d040200u);
+    o.w = __builtin_amdgcn_perm(bb, rgb, 0x0d050301u);
 #else
     o.x = ycbcr_to_rgba(yw & 0xffu, cb2 & 0xffu, cr2 & 0xffu);
     o.y = ycbcr_to_rgba((yw >> 8) & 0xffu, cb2 & 0xffu, cr2 & 0xffu);
