@@ -1,15 +1,21 @@
-// gfx950 kernels of libcompeg_hip.
+// gfx950 kernels of libcompeg_hip (bodies in kernels_body.h, design in DESIGN.md section 5).
 //
-//   huffman_kernel        replaces src/huffman.wgsl (one lane per restart
-//                         interval, like the reference, but with the LUTs,
-//                         the compressed stream and the data unit being
-//                         decoded all resident in LDS)
-//   idct_composite_kernel replaces both passes of src/dct.wgsl: IDCT,
-//                         4:2:2 chroma replication and YCbCr->RGBA in one
-//                         kernel; decoded samples never leave the CU.
+//   decode_fused_422_kernel   the product path for launches that fill the chip: entropy
+//                             decode, IDCT and composite of 64 restart intervals per wave,
+//                             coefficients in LDS, samples in registers, nothing but the
+//                             RGBA output written to HBM (replaces src/huffman.wgsl and both
+//                             passes of src/dct.wgsl)
+//   decode_pair_422_kernel    the same work as a decoder wave + a transformer wave per 64
+//                             intervals, for launches that cannot fill the chip (one frame)
+//   entropy_kernel            entropy stage alone -> coefficient records in HBM
+//   idct_composite_kernel     IDCT + 4:2:2 composite from those records (two-kernel pipeline)
+//   idct_in_place_kernel,     IDCT and composite for the extension layouts (4:4:4, 4:4:0,
+//   composite_generic_kernel  4:2:0)
+//   huffman_kernel            a literal restatement of the reference's decode loop; debug
+//                             coefficient read-back and cross-check of the fast path
 //
-// No MFMA: there is no dense contraction anywhere on this path (both kernels
-// are bounded by HBM traffic / serial entropy decoding).
+// No MFMA: there is no dense contraction anywhere on this path; the kernels are bounded by
+// instruction issue of the serial entropy decode and by HBM writes.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
