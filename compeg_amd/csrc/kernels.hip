@@ -131,18 +131,15 @@ decode_fused_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds,
     const uint32_t wave_area = align16(window_words * 4u) + kWave * kDuSlotBytes;
     uint8_t *wave_base = smem + align16((kL1Entries + l2_in_lds) * 2u);
 
-    stage_luts(d, l1, l2, l2_in_lds, threadIdx.x, blockDim.x);
-
     const uint32_t wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
     uint32_t *win = reinterpret_cast<uint32_t *>(wave_base + wave * wave_area);
     uint8_t *slots = reinterpret_cast<uint8_t *>(win) + align16(window_words * 4u);
 
     const uint32_t wave_first = first_interval + wave * kWave;
     uint32_t win_base = 0, win_len = 0;
-    if (wave_first < d.total_intervals) {
+    if (wave_first < d.total_intervals)
         wave_window(d, wave_first, window_words, win_base, win_len);
-        stage_window(d, win, win_base, win_len, lane);
-    }
+    stage_luts_and_window(d, l1, l2, l2_in_lds, threadIdx.x, blockDim.x, win, win_base, win_len, lane);
     __syncthreads();
 
     if (wave_first >= d.total_intervals)

@@ -189,23 +189,33 @@ constexpr uint32_t kDuWordSlack = 66;
 CG_DEV uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
 CG_DEV uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
-// Workgroup prologue, thread `tid` of `nthreads`: copies the image's LUTs
-// into LDS with 4-byte accesses (both tables are 4-byte aligned and padded).
+// Four consecutive dwords from a dword-aligned global address.
+struct __attribute__((packed, aligned(4))) Dwords4 {
+    uint32_t x, y, z, w;
+};
+
+// Workgroup prologue, thread `tid` of `nthreads`: copies the image's LUTs into
+// LDS, 16 bytes per thread and load (both tables are 16-byte aligned in the
+// upload blob and in LDS; tails shorter than 16 bytes go dword by dword), all of
+// a thread's loads in flight before its first LDS write.
 CG_DEV void copy_words_to_lds(uint32_t *dst, const uint32_t *src_, uint32_t n, uint32_t tid,
                               uint32_t nthreads)
 {
+    auto *src4 = CG_GLOBAL(const Dwords4, reinterpret_cast<const Dwords4 *>(src_));
     auto *src = CG_GLOBAL(const uint32_t, src_);
+    const uint32_t n4 = n / 4u;
     uint32_t i = tid;
-    for (; i + 3u * nthreads < n; i += 4u * nthreads) {
-        const uint32_t a = src[i], b = src[i + nthreads], c = src[i + 2u * nthreads],
-                       e = src[i + 3u * nthreads];
-        dst[i] = a;
-        dst[i + nthreads] = b;
-        dst[i + 2u * nthreads] = c;
-        dst[i + 3u * nthreads] = e;
+    for (; i + nthreads < n4; i += 2u * nthreads) {
+        const Dwords4 a = src4[i], b = src4[i + nthreads];
+        reinterpret_cast<SlotVec *>(dst)[i] = SlotVec{a.x, a.y, a.z, a.w};
+        reinterpret_cast<SlotVec *>(dst)[i + nthreads] = SlotVec{b.x, b.y, b.z, b.w};
     }
-    for (; i < n; i += nthreads)
-        dst[i] = src[i];
+    for (; i < n4; i += nthreads) {
+        const Dwords4 a = src4[i];
+        reinterpret_cast<SlotVec *>(dst)[i] = SlotVec{a.x, a.y, a.z, a.w};
+    }
+    for (uint32_t k = n4 * 4u + tid; k < n; k += nthreads)
+        reinterpret_cast<slot_word_t *>(dst)[k] = src[k];
 }
 
 CG_DEV void stage_luts(const ImageDesc &d, uint16_t *l1, uint16_t *l2, uint32_t l2_in_lds,
@@ -214,7 +224,7 @@ CG_DEV void stage_luts(const ImageDesc &d, uint16_t *l1, uint16_t *l2, uint32_t 
     uint32_t *dst = reinterpret_cast<uint32_t *>(l1);
     copy_words_to_lds(dst, reinterpret_cast<const uint32_t *>(d.l1), 4 * 128, tid, nthreads);
     for (uint32_t i = tid; i < 128; i += nthreads)
-        dst[4 * 128 + i] = 0u;
+        reinterpret_cast<slot_word_t *>(dst)[4 * 128 + i] = 0u;
     const uint32_t n2 = umin(l2_in_lds, d.fast_off + 2u * kFastEntries);
     copy_words_to_lds(reinterpret_cast<uint32_t *>(l2), reinterpret_cast<const uint32_t *>(d.l2),
                       (n2 + 1) / 2, tid, nthreads);
@@ -236,25 +246,76 @@ CG_DEV void wave_window(const ImageDesc &d, uint32_t wave_first, uint32_t window
     len = end > base ? umin(end - base, window_words) : 0u;
 }
 
+// Words idx .. idx+3 of the scan (zero past its end), MSB-first.
+CG_DEV SlotVec scan_words4(const ImageDesc &d, uint32_t idx)
+{
+    Dwords4 w{0u, 0u, 0u, 0u};
+    if (idx + 3u < d.nwords) {
+        w = *CG_GLOBAL(const Dwords4, reinterpret_cast<const Dwords4 *>(d.words + idx));
+    } else {
+        auto *words = CG_GLOBAL(const uint32_t, d.words);
+        w.x = idx < d.nwords ? words[idx] : 0u;
+        w.y = idx + 1u < d.nwords ? words[idx + 1u] : 0u;
+        w.z = idx + 2u < d.nwords ? words[idx + 2u] : 0u;
+    }
+    return SlotVec{bswap32(w.x), bswap32(w.y), bswap32(w.z), bswap32(w.w)};
+}
+
+// One wave stages its window: 16 bytes per lane and load, eight loads in
+// flight per lane before the first LDS write -- a window of up to 2048 words
+// (the benchmark frames need 1750) costs one memory round trip.  The window's
+// LDS allocation is a multiple of 16 bytes, so the last vector may spill up to
+// three words past `len` (they are never read).
+// (in two halves, so that a kernel can put other loads between them)
+CG_DEV void window_load_round(const ImageDesc &d, uint32_t base, uint32_t len, uint32_t v0, SlotVec (&w)[8])
+{
+    const uint32_t nvec = (len + 3u) / 4u;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t v = v0 + uint32_t(j) * kWave;
+        w[j] = v < nvec ? scan_words4(d, base + 4u * v) : SlotVec{0u, 0u, 0u, 0u};
+    }
+}
+
+CG_DEV void window_store_round(uint32_t *win, uint32_t len, uint32_t v0, const SlotVec (&w)[8])
+{
+    const uint32_t nvec = (len + 3u) / 4u;
+    SlotVec *dst = reinterpret_cast<SlotVec *>(win);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t v = v0 + uint32_t(j) * kWave;
+        if (v < nvec)
+            dst[v] = w[j];
+    }
+}
+
+// first_round: the first round's loads have been issued by the caller already
 CG_DEV void stage_window(const ImageDesc &d, uint32_t *win, uint32_t base, uint32_t len,
                          uint32_t lane)
 {
-    // eight independent loads in flight per lane before the first LDS write
-    // (a plain load/store loop serialises on every load's latency)
-    uint32_t i = lane;
-    for (; i + 7u * kWave < len; i += 8u * kWave) {
-        uint32_t w[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-            w[j] = base + i + uint32_t(j) * kWave < d.nwords
-                       ? CG_GLOBAL(const uint32_t, d.words)[base + i + uint32_t(j) * kWave]
-                       : 0u;
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-            win[i + uint32_t(j) * kWave] = bswap32(w[j]);
+    const uint32_t nvec = (len + 3u) / 4u;
+    for (uint32_t v0 = lane; v0 < nvec; v0 += 8u * kWave) {
+        SlotVec w[8];
+        window_load_round(d, base, len, v0, w);
+        window_store_round(win, len, v0, w);
     }
-    for (; i < len; i += kWave)
-        win[i] = base + i < d.nwords ? bswap32(CG_GLOBAL(const uint32_t, d.words)[base + i]) : 0u;
+}
+
+// The workgroup prologue of the decode kernels: the wave's window loads are
+// issued first, the LUT copy runs under their latency.
+CG_DEV void stage_luts_and_window(const ImageDesc &d, uint16_t *l1, uint16_t *l2, uint32_t l2_in_lds,
+                                  uint32_t tid, uint32_t nthreads, uint32_t *win, uint32_t base, uint32_t len,
+                                  uint32_t lane)
+{
+    SlotVec w[8];
+    window_load_round(d, base, len, lane, w);
+    stage_luts(d, l1, l2, l2_in_lds, tid, nthreads);
+    window_store_round(win, len, lane, w);
+    const uint32_t nvec = (len + 3u) / 4u;
+    for (uint32_t v0 = lane + 8u * kWave; v0 < nvec; v0 += 8u * kWave) {
+        window_load_round(d, base, len, v0, w);
+        window_store_round(win, len, v0, w);
+    }
 }
 
 // Decodes restart interval `interval` of image d.  Quantised AC levels go
