@@ -529,33 +529,83 @@ CG_DEV uint32_t sample_u8(float f)
     return uint32_t(m);
 }
 
-// clamp(f, 0, 255) then truncation for the 8 samples of a row, sample 0 in
-// the low byte (src/dct.wgsl:174-197).  On the GPU one v_cvt_pk_u8_f32 per
-// sample does the saturation, the conversion and the byte insert; the
-// instruction rounds with the current f32 rounding mode, so the mode is
-// switched to round-toward-zero for exactly these eight instructions.
-CG_DEV void pack_row(const float *f, uint32_t &lo, uint32_t &hi)
+// clamp(f, 0, 255) then truncation for the 8 samples of each row, sample 0 in
+// the low byte (src/dct.wgsl:174-197); o[2*r], o[2*r + 1]: row r.  On the GPU
+// one v_cvt_pk_u8_f32 per sample does the saturation, the conversion and the
+// byte insert; the instruction rounds with the current f32 rounding mode, so
+// the mode is switched to round-toward-zero for exactly these instructions --
+// inside one asm statement, so that nothing else can be scheduled between the
+// two mode switches (which cost ~15 cycles each: rows go three at a time, as
+// many as the operand limit of an asm statement allows).
+CG_DEV void pack_rows3(const float *f0, const float *f1, const float *f2, uint32_t *o)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t a, b;
     asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
-                 "v_cvt_pk_u8_f32 %0, %2, 0, 0\n\t"
-                 "v_cvt_pk_u8_f32 %1, %6, 0, 0\n\t"
-                 "v_cvt_pk_u8_f32 %0, %3, 1, %0\n\t"
-                 "v_cvt_pk_u8_f32 %1, %7, 1, %1\n\t"
-                 "v_cvt_pk_u8_f32 %0, %4, 2, %0\n\t"
-                 "v_cvt_pk_u8_f32 %1, %8, 2, %1\n\t"
-                 "v_cvt_pk_u8_f32 %0, %5, 3, %0\n\t"
-                 "v_cvt_pk_u8_f32 %1, %9, 3, %1\n\t"
+                 "v_cvt_pk_u8_f32 %0, %6, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %0, %7, 1, %0\n\t"
+                 "v_cvt_pk_u8_f32 %0, %8, 2, %0\n\t"
+                 "v_cvt_pk_u8_f32 %0, %9, 3, %0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %10, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %11, 1, %1\n\t"
+                 "v_cvt_pk_u8_f32 %1, %12, 2, %1\n\t"
+                 "v_cvt_pk_u8_f32 %1, %13, 3, %1\n\t"
+                 "v_cvt_pk_u8_f32 %2, %14, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %2, %15, 1, %2\n\t"
+                 "v_cvt_pk_u8_f32 %2, %16, 2, %2\n\t"
+                 "v_cvt_pk_u8_f32 %2, %17, 3, %2\n\t"
+                 "v_cvt_pk_u8_f32 %3, %18, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %3, %19, 1, %3\n\t"
+                 "v_cvt_pk_u8_f32 %3, %20, 2, %3\n\t"
+                 "v_cvt_pk_u8_f32 %3, %21, 3, %3\n\t"
+                 "v_cvt_pk_u8_f32 %4, %22, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %4, %23, 1, %4\n\t"
+                 "v_cvt_pk_u8_f32 %4, %24, 2, %4\n\t"
+                 "v_cvt_pk_u8_f32 %4, %25, 3, %4\n\t"
+                 "v_cvt_pk_u8_f32 %5, %26, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %5, %27, 1, %5\n\t"
+                 "v_cvt_pk_u8_f32 %5, %28, 2, %5\n\t"
+                 "v_cvt_pk_u8_f32 %5, %29, 3, %5\n\t"
                  "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
-                 : "=&v"(a), "=&v"(b)
-                 : "v"(f[0]), "v"(f[1]), "v"(f[2]), "v"(f[3]), "v"(f[4]), "v"(f[5]), "v"(f[6]),
-                   "v"(f[7]));
-    lo = a;
-    hi = b;
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5])
+                 : "v"(f0[0]), "v"(f0[1]), "v"(f0[2]), "v"(f0[3]), "v"(f0[4]), "v"(f0[5]), "v"(f0[6]), "v"(f0[7]), "v"(f1[0]), "v"(f1[1]), "v"(f1[2]), "v"(f1[3]), "v"(f1[4]), "v"(f1[5]), "v"(f1[6]), "v"(f1[7]), "v"(f2[0]), "v"(f2[1]), "v"(f2[2]), "v"(f2[3]), "v"(f2[4]), "v"(f2[5]), "v"(f2[6]), "v"(f2[7]));
 #else
-    lo = sample_u8(f[0]) | sample_u8(f[1]) << 8 | sample_u8(f[2]) << 16 | sample_u8(f[3]) << 24;
-    hi = sample_u8(f[4]) | sample_u8(f[5]) << 8 | sample_u8(f[6]) << 16 | sample_u8(f[7]) << 24;
+    o[0] = sample_u8(f0[0]) | sample_u8(f0[1]) << 8 | sample_u8(f0[2]) << 16 | sample_u8(f0[3]) << 24;
+    o[1] = sample_u8(f0[4]) | sample_u8(f0[5]) << 8 | sample_u8(f0[6]) << 16 | sample_u8(f0[7]) << 24;
+    o[2] = sample_u8(f1[0]) | sample_u8(f1[1]) << 8 | sample_u8(f1[2]) << 16 | sample_u8(f1[3]) << 24;
+    o[3] = sample_u8(f1[4]) | sample_u8(f1[5]) << 8 | sample_u8(f1[6]) << 16 | sample_u8(f1[7]) << 24;
+    o[4] = sample_u8(f2[0]) | sample_u8(f2[1]) << 8 | sample_u8(f2[2]) << 16 | sample_u8(f2[3]) << 24;
+    o[5] = sample_u8(f2[4]) | sample_u8(f2[5]) << 8 | sample_u8(f2[6]) << 16 | sample_u8(f2[7]) << 24;
+#endif
+}
+
+CG_DEV void pack_rows2(const float *f0, const float *f1, uint32_t *o)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+                 "v_cvt_pk_u8_f32 %0, %4, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %0, %5, 1, %0\n\t"
+                 "v_cvt_pk_u8_f32 %0, %6, 2, %0\n\t"
+                 "v_cvt_pk_u8_f32 %0, %7, 3, %0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %8, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %9, 1, %1\n\t"
+                 "v_cvt_pk_u8_f32 %1, %10, 2, %1\n\t"
+                 "v_cvt_pk_u8_f32 %1, %11, 3, %1\n\t"
+                 "v_cvt_pk_u8_f32 %2, %12, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %2, %13, 1, %2\n\t"
+                 "v_cvt_pk_u8_f32 %2, %14, 2, %2\n\t"
+                 "v_cvt_pk_u8_f32 %2, %15, 3, %2\n\t"
+                 "v_cvt_pk_u8_f32 %3, %16, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %3, %17, 1, %3\n\t"
+                 "v_cvt_pk_u8_f32 %3, %18, 2, %3\n\t"
+                 "v_cvt_pk_u8_f32 %3, %19, 3, %3\n\t"
+                 "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
+                 : "v"(f0[0]), "v"(f0[1]), "v"(f0[2]), "v"(f0[3]), "v"(f0[4]), "v"(f0[5]), "v"(f0[6]), "v"(f0[7]), "v"(f1[0]), "v"(f1[1]), "v"(f1[2]), "v"(f1[3]), "v"(f1[4]), "v"(f1[5]), "v"(f1[6]), "v"(f1[7]));
+#else
+    o[0] = sample_u8(f0[0]) | sample_u8(f0[1]) << 8 | sample_u8(f0[2]) << 16 | sample_u8(f0[3]) << 24;
+    o[1] = sample_u8(f0[4]) | sample_u8(f0[5]) << 8 | sample_u8(f0[6]) << 16 | sample_u8(f0[7]) << 24;
+    o[2] = sample_u8(f1[0]) | sample_u8(f1[1]) << 8 | sample_u8(f1[2]) << 16 | sample_u8(f1[3]) << 24;
+    o[3] = sample_u8(f1[4]) | sample_u8(f1[5]) << 8 | sample_u8(f1[6]) << 16 | sample_u8(f1[7]) << 24;
 #endif
 }
 
@@ -607,14 +657,15 @@ CG_DEV void idct_data_unit(const uint32_t (&ac)[kRetained / 2], int32_t dc, cons
 #pragma unroll
     for (int rp = 0; rp < 4; rp++)
         aan_1d<f32x2, 1, true>(&rows[rp][0]);
+    float f[8][8];
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        float f[8];
+    for (int r = 0; r < 8; r++)
 #pragma unroll
         for (int c = 0; c < 8; c++)
-            f[c] = rows[r >> 1][c][r & 1];
-        pack_row(f, px[2 * r + 0], px[2 * r + 1]);
-    }
+            f[r][c] = rows[r >> 1][c][r & 1];
+    pack_rows3(f[0], f[1], f[2], px + 0);
+    pack_rows3(f[3], f[4], f[5], px + 6);
+    pack_rows2(f[6], f[7], px + 12);
 #else
 #pragma unroll
     for (int c = 0; c < 8; c++)
@@ -622,9 +673,9 @@ CG_DEV void idct_data_unit(const uint32_t (&ac)[kRetained / 2], int32_t dc, cons
 #pragma unroll
     for (int r = 0; r < 8; r++)
         aan_1d<float, 1, true>(v + r * 8);
-#pragma unroll
-    for (int r = 0; r < 8; r++)
-        pack_row(v + r * 8, px[2 * r + 0], px[2 * r + 1]);
+    pack_rows3(v + 0, v + 8, v + 16, px + 0);
+    pack_rows3(v + 24, v + 32, v + 40, px + 6);
+    pack_rows2(v + 48, v + 56, px + 12);
 #endif
 }
 
