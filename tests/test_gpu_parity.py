@@ -340,3 +340,71 @@ print("zero-copy ok")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "zero-copy ok" in r.stdout, r.stdout + r.stderr[-3000:]
+
+
+def _corrupt_variants(n):
+    """Bit flips inside the scan of a small image (the generator of the emulation tests): decoding
+    runs off the rails -- long codes, huge runs, reads past the interval and past the scan."""
+    rng = np.random.default_rng(5)
+    base = synth.make_jpeg(192, 48, seed=21, kind=0, quality=75, ri=2)
+    scan_at = base.find(b"\xff\xda") + 14
+    out = []
+    for _ in range(n):
+        j = bytearray(base)
+        for _ in range(int(rng.integers(1, 30))):
+            pos = int(rng.integers(scan_at, len(j) - 2))
+            if j[pos] != 0xFF and j[pos - 1] != 0xFF:
+                j[pos] ^= 1 << int(rng.integers(0, 8))
+                if j[pos] == 0xFF:
+                    j[pos] = 0xFE
+        out.append(bytes(j))
+    return out
+
+
+def _hostile_table_variants(n):
+    """DHT segments with DC categories up to 255 and other symbols a baseline encoder never emits."""
+    rng = np.random.default_rng(8)
+    base = synth.make_jpeg(128, 32, seed=31, kind=1, quality=90, ri=1)
+    out = []
+    for it in range(n):
+        counts = np.zeros(16, dtype=np.uint8)
+        counts[1], counts[2] = 2, 3
+        counts[4] = int(rng.integers(1, 4))
+        counts[8] = int(rng.integers(0, 6))
+        counts[15] = int(rng.integers(0, 30))
+        nsym = int(counts.sum())
+        syms = rng.integers(0, 256, nsym, dtype=np.uint8)
+        tcth = [0x00, 0x01, 0x10, 0x11][it % 4]
+        seg = bytes([0xFF, 0xC4]) + (2 + 17 + nsym).to_bytes(2, "big") + bytes([tcth]) + counts.tobytes() + syms.tobytes()
+        sos = base.find(b"\xff\xda")
+        out.append(base[:sos] + seg + base[sos:])
+    return out
+
+
+def test_corrupt_streams_and_hostile_tables_on_the_gpu(ca, gpu):
+    """The rare paths of the entropy decoder (cut DC codes, reader underflow -> exact mode, escapes,
+    reads past the window and past the scan) as the GPU executes them -- through the paired kernel
+    (single decodes) and through the throughput kernel (one batch of more than 768 waves) --
+    byte-equal to the oracle.  tests/test_kernel_emulation.py runs the same inputs under ASan."""
+    variants = []
+    for j in _corrupt_variants(12) + _hostile_table_variants(10):
+        try:
+            want = orc.ImageData(j).decode()
+        except orc.OracleError:
+            with pytest.raises(ca.Error):
+                ca.ImageData(j)
+            continue
+        variants.append((j, want))
+    assert len(variants) >= 12
+    for j, want in variants:
+        _, _, got = _decode(ca, gpu, j)
+        _assert_equal(got, want)
+    images = [ca.ImageData(j) for j, _ in variants]
+    n = 800
+    assert sum((images[i % len(images)].parallelism() + 63) // 64 for i in range(n)) > 768
+    batch = ca.Batch(gpu)
+    batch.upload([images[i % len(images)] for i in range(n)])
+    batch.decode()
+    batch.wait()
+    for i in list(range(len(variants))) + [n - 1]:
+        _assert_equal(batch.read_output(i), variants[i % len(variants)][1])
