@@ -69,14 +69,16 @@ class Gpu:
 class ImageData:
     """A parsed JPEG (ref: `ImageData`, src/lib.rs:576-851)."""
 
-    def __init__(self, jpeg, copy=True, allow_sampling=False):
-        """allow_sampling: extension beyond the reference (COMPEG_PARSE_ANY_LUMA_SAMPLING) -- 4:4:4,
-        4:4:0 and 4:2:0 are accepted as well as 4:2:2."""
+    def __init__(self, jpeg, copy=True, allow_sampling=False, standard_entropy=False):
+        """Extensions beyond the reference (compeg_image_parse_ext): allow_sampling -- 4:4:4, 4:4:0 and
+        4:2:0 are accepted as well as 4:2:2; standard_entropy -- the bit reader is topped up in front of
+        DC codes and ZRL skips 16 positions, as ITU-T T.81 has it (the reference deviates in both)."""
         self._h = None
         self._keep = _host_view(jpeg)
         h = C.c_void_p()
-        if allow_sampling:
-            check(lib.compeg_image_parse_ext(self._keep.ctypes.data, self._keep.nbytes, 1 if copy else 0, 1,
+        flags = (1 if allow_sampling else 0) | (2 if standard_entropy else 0)
+        if flags:
+            check(lib.compeg_image_parse_ext(self._keep.ctypes.data, self._keep.nbytes, 1 if copy else 0, flags,
                                              C.byref(h)))
         else:
             check(lib.compeg_image_parse(self._keep.ctypes.data, self._keep.nbytes, 1 if copy else 0, C.byref(h)))

@@ -166,7 +166,7 @@ int compeg_image_parse_ext(const uint8_t *jpeg, size_t len, int copy, unsigned f
         if (!out)
             return fail(COMPEG_E_INVALID_ARG, "out is NULL");
         *out = nullptr;
-        if (flags & ~COMPEG_PARSE_ANY_LUMA_SAMPLING)
+        if (flags & ~(COMPEG_PARSE_ANY_LUMA_SAMPLING | COMPEG_PARSE_STANDARD_ENTROPY))
             return fail(COMPEG_E_INVALID_ARG, "unknown parse flags");
         ImageData *d = nullptr;
         Status s = ImageData::parse(jpeg, len, copy != 0, &d, flags);

@@ -18,6 +18,7 @@ void fill_desc(const ImageData &img, ImageDesc &d)
     memset(&d, 0, sizeof d);
     d.l2_entries = uint32_t(img.l2.size());
     d.fast_off = uint32_t((img.l2.size() + 1) & ~size_t(1));
+    d.standard_entropy = (img.flags & COMPEG_PARSE_STANDARD_ENTROPY) ? 1u : 0u;
     d.total_intervals = md.total_restart_intervals;
     d.restart_interval = md.restart_interval;
     d.dus_per_mcu = md.dus_per_mcu;

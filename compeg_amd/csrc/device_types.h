@@ -21,10 +21,11 @@ constexpr uint32_t kFastEntries = 1u << kFastBits;
 constexpr uint32_t kFastAdvEob = 64, kFastAdvEscape = 127;
 constexpr uint32_t kFastEscape = kFastAdvEscape << 9;
 
-// ref: an entry of the reference's LUTs, code length << 8 | symbol
-constexpr uint32_t fast_entry(uint32_t ref)
+// ref: an entry of the reference's LUTs, code length << 8 | symbol;
+// zrl_advance: 17 like the reference (quirk Q2), 16 with COMPEG_PARSE_STANDARD_ENTROPY
+constexpr uint32_t fast_entry(uint32_t ref, uint32_t zrl_advance)
 {
-    return (((ref & 0xffu) == 0u ? kFastAdvEob : ((ref & 0xffu) == 0xf0u ? 17u : ((ref >> 4) & 15u) + 1u)) << 9) |
+    return (((ref & 0xffu) == 0u ? kFastAdvEob : ((ref & 0xffu) == 0xf0u ? zrl_advance : ((ref >> 4) & 15u) + 1u)) << 9) |
            ((((ref >> 8) & 31u) + (ref & 15u)) << 4) | (ref & 15u);
 }
 
@@ -51,6 +52,8 @@ struct ImageDesc {
     // two 2048-entry direct AC tables stored behind the L2 LUT (u16 index from l2)
     uint32_t fast_off;
     uint32_t fast_table[3]; // per component: 0 / 1, or 2 = none (out-of-range selector)
+    // COMPEG_PARSE_STANDARD_ENTROPY: refill in front of DC codes, ZRL advances 16 (else 0: the reference)
+    uint32_t standard_entropy;
     // geometry
     uint32_t total_intervals;
     uint32_t restart_interval; // MCUs per interval

@@ -475,6 +475,8 @@ Status ImageData::parse(const uint8_t *jpeg, size_t len, bool copy, ImageData **
     // two-level lookup's result when that does not depend on the bits behind
     // the prefix, i.e. for codes of at most 11 bits (and for prefixes no code
     // starts with); longer codes escape to the two-level tables.
+    img->flags = flags;
+    const uint32_t zrl_advance = (flags & COMPEG_PARSE_STANDARD_ENTROPY) ? 16u : 17u; // quirk Q2
     img->ac_fast.assign(2 * kFastEntries, uint16_t(kFastEscape));
     for (int t = 0; t < 2; t++) {
         const uint16_t *l1 = img->l1 + (2 * t + 1) * 256;
@@ -482,7 +484,7 @@ Status ImageData::parse(const uint8_t *jpeg, size_t len, bool copy, ImageData **
             const uint16_t e1 = l1[x >> (kFastBits - 8)];
             uint16_t e = uint16_t(kFastEscape);
             if (!(e1 & 0x8000)) {
-                e = uint16_t(fast_entry(e1));
+                e = uint16_t(fast_entry(e1, zrl_advance));
             } else {
                 // all 16-bit continuations of this prefix must agree
                 const uint32_t lowbits = 16 - kFastBits;
@@ -494,7 +496,7 @@ Status ImageData::parse(const uint8_t *jpeg, size_t len, bool copy, ImageData **
                     same = (idx < img->l2.size() ? img->l2[idx] : 0) == v;
                 }
                 if (same && (v >> 8) <= kFastBits)
-                    e = uint16_t(fast_entry(v));
+                    e = uint16_t(fast_entry(v, zrl_advance));
             }
             img->ac_fast[size_t(t) * kFastEntries + x] = e;
         }

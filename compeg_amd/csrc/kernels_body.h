@@ -352,8 +352,8 @@ CG_DEV void huff_decode_interval(const ImageDesc &d, const HuffShared &s, uint32
 
     while (du_local < du_count) {
         const bool is_dc = pos == 0u;
-        if (!is_dc)
-            refill(b, d, s); // no refill in front of a DC code (quirk Q1)
+        if (!is_dc || d.standard_entropy)
+            refill(b, d, s); // the reference: no refill in front of a DC code (quirk Q1)
 
         // two-level LUT lookup on the next 16 bits (src/huffman.wgsl:85-113)
         const uint32_t code = b.cur >> 16;
@@ -391,7 +391,7 @@ CG_DEV void huff_decode_interval(const ImageDesc &d, const HuffShared &s, uint32
             const bool zrl = sym == 0xf0u;
             if (!zrl && p < uint32_t(kRetained))
                 slot16[p] = int16_t(val);
-            pos = p + (zrl ? 2u : 1u); // ZRL skips 17 in total (quirk Q2)
+            pos = p + ((zrl && !d.standard_entropy) ? 2u : 1u); // the reference: ZRL skips 17 in total (quirk Q2)
             du_done = pos >= 64u;
         }
 
@@ -811,6 +811,8 @@ CG_DEV uint32_t lut_resolve(const ImageDesc &d, const HuffShared &s, uint32_t e,
 CG_DEV int32_t decode_dc_diff(PrefetchReader &r, const ImageDesc &d, const HuffShared &s,
                               uint32_t dc_off)
 {
+    if (d.standard_entropy)
+        reader_refill<false>(r, d, s);
     const uint32_t e = lut_lookup<false>(d, s, dc_off, reader_cur(r));
     reader_consume(r, e >> 8);
     const uint32_t cat = e & 0xffu;
@@ -864,7 +866,7 @@ CG_DEV void decode_ac_loop(PrefetchReader &r, const ImageDesc &d, const HuffShar
         const uint32_t val = raw + (neg & ((0xffffffffu << nb) + 1u));
         const uint32_t p = pos + (sym >> 4);
         slot16[p < uint32_t(kRetained) ? p : uint32_t(kRetained)] = int16_t(val);
-        pos = sym == 0u ? 64u : p + (sym == 0xf0u ? 2u : 1u);
+        pos = sym == 0u ? 64u : p + ((sym == 0xf0u && !d.standard_entropy) ? 2u : 1u);
         done = pos >= 64u;
 
         // commit the refill only if decoding continues, then rotate
@@ -984,6 +986,8 @@ CG_DEV void entropy_init(EntropyState &e, const ImageDesc &d, const HuffShared &
 CG_DEV void leave_fast_mode(EntropyState &e, const ImageDesc &d, const HuffShared &s)
 {
     PrefetchReader &r = e.r;
+    if (d.standard_entropy)
+        e.ref_left = r.left; // nothing to drop: the standard reader is topped up in front of DC codes too
     const uint32_t ahead = (r.left - e.ref_left) >> 5; // 0 or 1 word
     r.next_word = s.win_base + uint32_t(e.wptr - s.win) - ahead;
     if (ahead)
@@ -1026,6 +1030,8 @@ CG_DEV int32_t signed_field(uint32_t cur, uint32_t tot, uint32_t nb)
 CG_DEV bool fast_dc(EntropyState &e, const ImageDesc &d, const HuffShared &s, uint32_t dc_off, int32_t &diff)
 {
     PrefetchReader &r = e.r;
+    if (d.standard_entropy)
+        e.ref_left = r.left; // the reader was topped up behind the last symbol: >= 32 true bits
     const uint32_t seen = e.ref_left < 32u ? e.ref_left : 32u;
     if (e.ref_left < 32u)
         CG_COUNT(dc_cut);
@@ -1084,7 +1090,7 @@ CG_DEV void fast_ac(EntropyState &e, const ImageDesc &d, const HuffShared &s, ui
         {
             // code longer than 11 bits: this symbol through the reference's tables
             CG_COUNT(escapes);
-            ent = fast_entry(lut_lookup<true>(d, s, ac_off, reader_cur(r)));
+            ent = fast_entry(lut_lookup<true>(d, s, ac_off, reader_cur(r)), d.standard_entropy ? 16u : 17u);
         }
 #if CG_EXP >= 10 && CG_EXP <= 12 // diagnostic builds: every symbol is "5 bits, 2 of them magnitude, next position
                                   // + 5" (13 symbols per data unit in every lane); 11: without the table

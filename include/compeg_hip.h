@@ -87,6 +87,15 @@ int compeg_image_parse(const uint8_t *jpeg, size_t len, int copy, compeg_image *
  * continued vertically (oracle/compeg_oracle.c, orc_finalize_pass).  flags == 0
  * is compeg_image_parse. */
 #define COMPEG_PARSE_ANY_LUMA_SAMPLING 1u
+/* COMPEG_PARSE_STANDARD_ENTROPY: the image is entropy-decoded as ITU-T T.81 has
+ * it in the two places where the reference deviates -- the bit reader is topped
+ * up in front of DC codes as well (the reference does not, huffman.wgsl:157-160,
+ * and loses the rest of a restart interval when a DC code needs more bits than
+ * it has buffered), and ZRL skips 16 positions (the reference skips 17,
+ * huffman.wgsl:176-179).  Everything else (32 retained coefficients, IDCT,
+ * colour conversion) stays the reference's.  On valid streams the output then
+ * no longer depends on the restart interval. */
+#define COMPEG_PARSE_STANDARD_ENTROPY 2u
 int compeg_image_parse_ext(const uint8_t *jpeg, size_t len, int copy, unsigned flags, compeg_image **out);
 void compeg_image_free(compeg_image *img);
 uint32_t compeg_image_width(const compeg_image *img);       /* lib.rs:828-831 */

@@ -15,6 +15,7 @@ pub const COMPEG_E_MALFORMED: c_int = -3;
 pub const COMPEG_E_COUNT_MISMATCH: c_int = -4;
 pub const COMPEG_E_HIP: c_int = -5;
 pub const COMPEG_PARSE_ANY_LUMA_SAMPLING: c_uint = 1;
+pub const COMPEG_PARSE_STANDARD_ENTROPY: c_uint = 2;
 
 extern "C" {
     pub fn compeg_last_error() -> *const c_char;

@@ -122,6 +122,15 @@ impl Drop for Gpu {
     }
 }
 
+/// Extensions of `ImageData::with_flags`; all off = the reference's behaviour.
+#[derive(Clone, Copy, Default)]
+pub struct ParseFlags {
+    /// 4:4:4, 4:4:0 and 4:2:0 are accepted as well as 4:2:2.
+    pub any_luma_sampling: bool,
+    /// Bit reader topped up in front of DC codes, ZRL = 16 positions (ITU-T T.81).
+    pub standard_entropy: bool,
+}
+
 /// A parsed and validated JPEG (baseline, 8 bit, YCbCr 4:2:2, restart intervals).
 /// Borrows or owns the bytes exactly like the reference's `Cow`.
 pub struct ImageData<'a> {
@@ -143,11 +152,17 @@ impl<'a> ImageData<'a> {
 
     /// Extension: like `new`, but 4:4:4, 4:4:0 and 4:2:0 are accepted as well as 4:2:2.
     pub fn new_any_sampling(jpeg: impl Into<Cow<'a, [u8]>>) -> Result<Self> {
+        Self::with_flags(jpeg, ParseFlags { any_luma_sampling: true, standard_entropy: false })
+    }
+
+    /// Extension: `ParseFlags` widen the accepted subset / switch the entropy decoder to ITU-T T.81
+    /// behaviour where the reference deviates (see `include/compeg_hip.h`).
+    pub fn with_flags(jpeg: impl Into<Cow<'a, [u8]>>, flags: ParseFlags) -> Result<Self> {
         let jpeg = jpeg.into();
         let mut raw = ptr::null_mut();
-        check(unsafe {
-            ffi::compeg_image_parse_ext(jpeg.as_ptr(), jpeg.len(), 0, ffi::COMPEG_PARSE_ANY_LUMA_SAMPLING, &mut raw)
-        })?;
+        let bits = if flags.any_luma_sampling { ffi::COMPEG_PARSE_ANY_LUMA_SAMPLING } else { 0 }
+            | if flags.standard_entropy { ffi::COMPEG_PARSE_STANDARD_ENTROPY } else { 0 };
+        check(unsafe { ffi::compeg_image_parse_ext(jpeg.as_ptr(), jpeg.len(), 0, bits, &mut raw) })?;
         Ok(ImageData { raw: NonNull::new(raw).expect("compeg_image_parse_ext returned null"), _jpeg: jpeg })
     }
 

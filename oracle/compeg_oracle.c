@@ -867,10 +867,14 @@ struct orc_image {
     uint16_t *l2;
     size_t l2_len;
     size_t scan_off, scan_len;
+    unsigned flags; /* orc_image_parse_ext */
 };
 
 /* flags & 1 (extension, not the reference): luma sampling 1x1, 2x1, 1x2 or 2x2 is accepted, i.e.
- * 4:4:4, 4:2:2, 4:4:0 and 4:2:0; see orc_finalize_pass for what that means for the output. */
+ * 4:4:4, 4:2:2, 4:4:0 and 4:2:0; see orc_finalize_pass for what that means for the output.
+ * flags & 2 (extension): entropy decoding as ITU-T T.81 has it where the reference deviates --
+ * the reader is refilled in front of a DC code as well (quirk Q1) and ZRL skips 16 positions, not
+ * 17 (quirk Q2); see orc_huffman_pass_ext. */
 orc_image *orc_image_parse(const uint8_t *jpeg, size_t len, char *err)
 {
     return orc_image_parse_ext(jpeg, len, 0, err);
@@ -1091,6 +1095,7 @@ orc_image *orc_image_parse_ext(const uint8_t *jpeg, size_t len, unsigned flags, 
         img->height = height;
         img->scan_off = scan_off;
         img->scan_len = scan_len;
+        img->flags = flags;
 
         /* ref: src/huffman.rs:247-271 -- concatenate, rebasing delegate indices */
         size_t total_l2 = 0;
@@ -1199,6 +1204,15 @@ void orc_huffman_pass(const uint8_t *md, const uint8_t *l1, const uint8_t *l2, s
                       const uint32_t *words, size_t nwords, const uint32_t *starts,
                       size_t nstarts, int32_t *coef, size_t ncoef)
 {
+    orc_huffman_pass_ext(md, l1, l2, l2_bytes, words, nwords, starts, nstarts, coef, ncoef, 0);
+}
+
+/* flags & 2: the two deviations from T.81 switched off (extension; the reference is flags == 0) */
+void orc_huffman_pass_ext(const uint8_t *md, const uint8_t *l1, const uint8_t *l2, size_t l2_bytes,
+                          const uint32_t *words, size_t nwords, const uint32_t *starts,
+                          size_t nstarts, int32_t *coef, size_t ncoef, unsigned flags)
+{
+    const int standard = (flags & 2u) != 0;
     hctx_t c = {md, l1, 2048, l2, l2_bytes};
     uint32_t count = md_get(md, MD_TOTAL);
     uint32_t ri = md_get(md, MD_RI);
@@ -1223,6 +1237,8 @@ void orc_huffman_pass(const uint8_t *md, const uint8_t *l1, const uint8_t *l2, s
                     for (uint32_t h = 0; h < hs; h++) {
                         uint32_t start = du_index * retained;
                         /* DC: note there is no refill here (quirk Q1) */
+                        if (standard)
+                            orc_bits_refill(&b);
                         uint32_t dccat = huffdecode(&b, &c, dct);
                         int32_t diff = (int32_t)orc_bits_peek(&b, dccat);
                         orc_bits_consume(&b, dccat);
@@ -1237,7 +1253,7 @@ void orc_huffman_pass(const uint8_t *md, const uint8_t *l1, const uint8_t *l2, s
                             if (rs == 0)
                                 break;
                             if (rs == 0xf0) {
-                                pos += 16; /* +1 from the loop: 17 in total (quirk Q2) */
+                                pos += standard ? 15 : 16; /* +1 from the loop: 17 in total (quirk Q2) */
                                 continue;
                             }
                             uint32_t ssss = rs & 15u;
@@ -1466,9 +1482,9 @@ int orc_image_decode(const orc_image *img, const uint8_t *jpeg, uint8_t *rgba, u
     int rc = orc_scanbuf_process(sb, jpeg + img->scan_off, img->scan_len, total, err);
 
     int32_t *coef = (int32_t *)malloc((ncoef ? ncoef : 1) * sizeof(int32_t));
-    orc_huffman_pass(img->md, (const uint8_t *)img->l1, (const uint8_t *)img->l2,
-                     img->l2_len * 2, sb->words, sb->words_len, sb->starts, sb->starts_len, coef,
-                     ncoef);
+    orc_huffman_pass_ext(img->md, (const uint8_t *)img->l1, (const uint8_t *)img->l2,
+                         img->l2_len * 2, sb->words, sb->words_len, sb->starts, sb->starts_len, coef,
+                         ncoef, img->flags);
     if (coef_out)
         memcpy(coef_out, coef, ncoef * sizeof(int32_t));
     orc_dct_pass(img->md, coef, ncoef);

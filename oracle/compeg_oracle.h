@@ -76,7 +76,8 @@ typedef struct orc_image orc_image;
 /* returns NULL and fills err on rejection.  err text equals the reference's
  * message where it has one; "panic: ..." marks inputs the reference aborts on. */
 orc_image *orc_image_parse(const uint8_t *jpeg, size_t len, char *err);
-/* flags & 1: also accept luma sampling 1x1 / 1x2 / 2x2 (extension beyond the reference) */
+/* flags & 1: also accept luma sampling 1x1 / 1x2 / 2x2; flags & 2: entropy decoding per T.81 (refill
+ * in front of DC codes, ZRL = 16 positions) -- both extensions beyond the reference */
 orc_image *orc_image_parse_ext(const uint8_t *jpeg, size_t len, unsigned flags, char *err);
 void orc_image_free(orc_image *img);
 uint32_t orc_image_width(const orc_image *img);
@@ -94,6 +95,9 @@ void orc_huffman_pass(const uint8_t *metadata, const uint8_t *l1, const uint8_t 
                       size_t l2_bytes, const uint32_t *words, size_t nwords,
                       const uint32_t *starts, size_t nstarts, int32_t *coefficients,
                       size_t ncoef);
+void orc_huffman_pass_ext(const uint8_t *metadata, const uint8_t *l1, const uint8_t *l2,
+                          size_t l2_bytes, const uint32_t *words, size_t nwords, const uint32_t *starts,
+                          size_t nstarts, int32_t *coefficients, size_t ncoef, unsigned flags);
 void orc_dct_pass(const uint8_t *metadata, int32_t *coefficients, size_t ncoef);
 /* rgba: tex_w*tex_h*4 bytes, stores outside the texture are dropped. */
 void orc_finalize_pass(const uint8_t *metadata, const int32_t *coefficients, size_t ncoef,

@@ -194,13 +194,14 @@ def parser_dump(jpeg):
 class ImageData:
     """ref: src/lib.rs:576-851"""
 
-    def __init__(self, jpeg, allow_sampling=False):
-        """allow_sampling: extension beyond the reference -- 4:4:4, 4:4:0 and 4:2:0 are accepted too."""
+    def __init__(self, jpeg, allow_sampling=False, standard_entropy=False):
+        """Extensions beyond the reference: allow_sampling -- 4:4:4, 4:4:0 and 4:2:0 are accepted too;
+        standard_entropy -- refill in front of DC codes and ZRL = 16 positions, as T.81 has it."""
         self.jpeg = bytes(jpeg)
         ptr, n, self._keep = _buf(self.jpeg)
         err = C.create_string_buffer(ERRLEN)
-        if allow_sampling:
-            self._p = lib().orc_image_parse_ext(ptr, n, 1, err)
+        if allow_sampling or standard_entropy:
+            self._p = lib().orc_image_parse_ext(ptr, n, (1 if allow_sampling else 0) | (2 if standard_entropy else 0), err)
         else:
             self._p = lib().orc_image_parse(ptr, n, err)
         if not self._p:

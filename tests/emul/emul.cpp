@@ -30,7 +30,9 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
 {
     ImageData *img = nullptr;
     // mode 4 = the extension pipeline: any luma sampling is accepted
-    Status s = ImageData::parse(jpeg, len, false, &img, fused == 4 ? COMPEG_PARSE_ANY_LUMA_SAMPLING : 0u);
+    const unsigned parse_flags = (fused == 4 ? COMPEG_PARSE_ANY_LUMA_SAMPLING : 0u) |
+                                 (getenv("EMUL_STANDARD") ? COMPEG_PARSE_STANDARD_ENTROPY : 0u);
+    Status s = ImageData::parse(jpeg, len, false, &img, parse_flags);
     if (!s.ok()) {
         snprintf(err, errlen, "%s", s.message.c_str());
         return s.code;

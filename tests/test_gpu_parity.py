@@ -408,3 +408,31 @@ def test_corrupt_streams_and_hostile_tables_on_the_gpu(ca, gpu):
     batch.wait()
     for i in list(range(len(variants))) + [n - 1]:
         _assert_equal(batch.read_output(i), variants[i % len(variants)][1])
+
+
+def test_standard_entropy_extension(ca, gpu):
+    """COMPEG_PARSE_STANDARD_ENTROPY (opt-in): bit-exact against the oracle with the same switch, through
+    the paired kernel, the throughput kernel and an extension layout; and what the switch is for: the
+    output no longer depends on the restart interval."""
+    outs = []
+    for ri in (1, 4, 8, 0):   # divisors of the 16 200 MCUs: a trailing partial interval is not decoded (lib.rs:785)
+        jpeg = synth.make_jpeg(1920, 1080, seed=77, kind=0, quality=85, ri=ri)
+        dec = ca.Decoder(gpu)
+        dec.decode_blocking(ca.ImageData(jpeg, standard_entropy=True))
+        got = dec.read_texture(1920, 1080)
+        _assert_equal(got, orc.ImageData(jpeg, standard_entropy=True).decode())
+        outs.append(got)
+    for other in outs[1:]:
+        assert np.array_equal(outs[0], other)
+    # throughput kernel (more than 768 waves) and a 4:2:0 image, both with the switch
+    jpegs = [synth.make_jpeg(1000, 1000, seed=210 + i, kind=i % 2, quality=92, ri=3) for i in range(20)]
+    batch = ca.Batch(gpu)
+    batch.upload([ca.ImageData(j, standard_entropy=True) for j in jpegs])
+    batch.decode()
+    batch.wait()
+    for i in (0, 1, 19):
+        _assert_equal(batch.read_output(i), orc.ImageData(jpegs[i], standard_entropy=True).decode())
+    j420 = synth.make_jpeg(640, 360, seed=230, kind=0, quality=95, ri=2, sampling=(2, 2))
+    dec = ca.Decoder(gpu)
+    dec.decode_blocking(ca.ImageData(j420, allow_sampling=True, standard_entropy=True))
+    _assert_equal(dec.read_texture(640, 360), orc.ImageData(j420, allow_sampling=True, standard_entropy=True).decode())

@@ -26,11 +26,14 @@ def runner():
 STATS = {}   # rare-path counters of the emulated kernels, summed over every run of this module
 
 
-def _run(runner, tmp_path, jpeg, fused, waves=1, window=2048, l2=12288):
+def _run(runner, tmp_path, jpeg, fused, waves=1, window=2048, l2=12288, standard=False):
     p = tmp_path / "in.jpg"
     p.write_bytes(jpeg)
     env = dict(os.environ)
     env.pop("EMUL_FUSED", None)
+    env.pop("EMUL_STANDARD", None)
+    if standard:
+        env["EMUL_STANDARD"] = "1"
     if fused:
         env["EMUL_FUSED"] = str(int(fused))   # 1 = fused kernel, 2 = paired-wave kernel, 3 = entropy + IDCT kernels
     r = subprocess.run([runner, str(p), str(tmp_path / "rgba"), str(tmp_path / "ac"), str(tmp_path / "dc"),
@@ -140,6 +143,21 @@ def test_emulated_extension_layouts(runner, tmp_path, sampling):
         want = orc.ImageData(jpeg, allow_sampling=True).decode()
         got = _run(runner, tmp_path, jpeg, 4)
         assert np.array_equal(got, want), f"{sampling} {w}x{h}: {(got != want).any(axis=2).sum()} pixels differ"
+
+
+def test_emulated_standard_entropy_extension(runner, tmp_path):
+    """COMPEG_PARSE_STANDARD_ENTROPY: refill in front of DC codes, ZRL = 16 -- every pipeline against the
+    oracle with the same switch, on content where the reference's reader underflows (noise at
+    quality 100) and with cut-short windows (exact-mode path)."""
+    for (w, h, kind, q, ri, seed, window) in [(96, 32, 1, 100, 3, 51, 2048), (320, 64, 1, 92, 2, 11, 80),
+                                              (250, 70, 0, 50, 3, 4, 2048), (320, 200, 0, 95, 4, 5, 2048)]:
+        jpeg = synth.make_jpeg(w, h, seed=seed, kind=kind, quality=q, ri=ri)
+        want = orc.ImageData(jpeg, standard_entropy=True).decode()
+        if kind == 0:
+            assert not np.array_equal(want, orc.ImageData(jpeg).decode())   # the switch matters on this input
+        for fused in (1, 2, 3, 0):
+            got = _run(runner, tmp_path, jpeg, fused, window=window, standard=True)
+            assert np.array_equal(got, want), f"fused={fused} {w}x{h}: {(got != want).any(axis=2).sum()} pixels differ"
 
 
 def test_emulated_rare_paths_were_reached():

@@ -304,3 +304,20 @@ def test_extension_layouts_against_libjpeg(sampling):
     ref = np.asarray(Image.open(io.BytesIO(jpeg)).convert("RGB")).astype(int)
     diff = np.abs(mine - ref)
     assert diff.mean() < 0.5 and np.percentile(diff, 99) <= 8, (diff.mean(), np.percentile(diff, 99))
+
+
+def test_standard_entropy_extension_against_libjpeg():
+    """orc_image_parse_ext flag 2 (refill in front of DC codes, ZRL = 16) has no reference vectors: on a
+    valid stream it must bring the oracle close to an independent decoder everywhere, while the
+    reference behaviour (quirks Q1, Q2) leaves restart intervals that are visibly wrong."""
+    io = pytest.importorskip("io")
+    Image = pytest.importorskip("PIL.Image")
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tools import synth
+    jpeg = synth.make_jpeg(640, 360, seed=5, kind=0, quality=95, ri=4)
+    ref = np.asarray(Image.open(io.BytesIO(jpeg)).convert("RGB")).astype(int)
+    as_reference = np.abs(orc.ImageData(jpeg).decode()[:, :, :3].astype(int) - ref)
+    standard = np.abs(orc.ImageData(jpeg, standard_entropy=True).decode()[:, :, :3].astype(int) - ref)
+    assert (as_reference.max(axis=2) > 32).sum() > 1000      # the quirks at work
+    assert standard.max() <= 32 and standard.mean() < 5       # what is left: 32 retained coefficients, colour constants
