@@ -1,16 +1,22 @@
 // Per-lane bodies of the gfx950 kernels.
 //
-// The functions here are what one lane executes between two workgroup
-// barriers; kernels.hip wraps them in __global__ entry points.  They are kept
-// free of HIP-only intrinsics so that tests/emul can compile the very same
-// code with g++ under ASan/UBSan and run the lanes one after another (GPU
-// sanitizers are not available on the target pool).
+// The functions here are what one lane executes; kernels.hip wraps them in
+// __global__ entry points.  Steps in which the lanes of a wave work together
+// (the quad exchange of the composite, the record flush of the entropy kernel)
+// are split into phases that every lane runs before any lane runs the next
+// one, and GPU-only instructions (DPP, packed conversion, non-temporal stores,
+// wave priority) sit behind __HIP_DEVICE_COMPILE__ next to a plain C++
+// equivalent, so that tests/emul can compile the very same code with g++ under
+// ASan/UBSan and drive it lane by lane, phase by phase (GPU sanitizers are not
+// available on the target pool).
 //
 // Arithmetic contract (bit-exact with the reference's WGSL):
 //   - bit reader: u32 arithmetic wraps, shift counts are taken modulo 32
 //     (src/huffman.wgsl:35-79), including the reference's behaviour when the
-//     buffer underflows at a DC code (quirk Q1);
+//     buffer underflows at a DC code (quirk Q1) -- reproduced literally by the
+//     exact path and arithmetically by the fast mode;
 //   - ZRL advances 17 positions (Q2); only zig-zag positions < 32 are kept (Q3);
+//     (Q1 and Q2 are switched off per image by COMPEG_PARSE_STANDARD_ENTROPY)
 //   - IDCT: every operation is an individually rounded f32 operation in the
 //     reference's order (src/dct.wgsl:73-201) -- this file must be compiled
 //     with -ffp-contract=off;
@@ -239,7 +245,7 @@ CG_DEV void wave_window(const ImageDesc &d, uint32_t wave_first, uint32_t window
     base = wave_first < d.nstarts ? CG_GLOBAL(const uint32_t, d.starts)[wave_first] : 0u;
     const uint32_t after = wave_first + kWave;
     uint32_t end = (after < d.total_intervals && after < d.nstarts) ? CG_GLOBAL(const uint32_t, d.starts)[after] : d.nwords;
-    // the slack lets the last intervals of the wave pass decode_ac's in-window
+    // the slack lets the last intervals of the wave pass the fast mode's in-window
     // test; positions past the end of the scan are staged as zeros
     end = umin(end, d.nwords) + kDuWordSlack;
     base = umin(base, d.nwords);
@@ -680,7 +686,7 @@ CG_DEV void idct_data_unit(const uint32_t (&ac)[kRetained / 2], int32_t dc, cons
 }
 
 // ---------------------------------------------------------------------------
-// Fused path: one lane decodes, transforms and composites its own MCUs
+// Exact path: the reference reader, literally (fused / paired / entropy kernels fall back to it)
 // ---------------------------------------------------------------------------
 
 // Bit reader of the fused path.  Same state as the reference reader
