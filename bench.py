@@ -53,6 +53,9 @@ def parse_args():
     p.add_argument("--cpu-seconds", type=float, default=12.0,
                    help="budget for the CPU-oracle baseline sample (0 disables it)")
     p.add_argument("--no-verify", action="store_true")
+    p.add_argument("--rehearse-on-one-gpu", action="store_true",
+                   help="development only: run the multi-rank code path with every rank on cuda:0 and gloo "
+                        "for the barrier / max (RCCL needs one device per rank); the number is meaningless")
     return p.parse_args()
 
 
@@ -114,8 +117,12 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible and there is no CPU path")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 and args.rehearse_on_one_gpu:
+        dist.init_process_group("gloo")
+    elif world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     def barrier():
@@ -158,7 +165,7 @@ def main():
     n_timed, ev_total_ms, ev_huff_ms, ev_idct_ms = batch.timing(reset=True)
 
     from compeg_amd.sharding import max_over_ranks
-    elapsed = max_over_ranks(elapsed, device="cuda")
+    elapsed = max_over_ranks(elapsed, device="cpu" if args.rehearse_on_one_gpu else "cuda")
 
     # ---- everything below is outside the timed region -----------------------------------
     verified = None
