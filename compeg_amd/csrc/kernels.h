@@ -31,10 +31,12 @@ hipError_t launch_pair_422(const ImageDesc *descs, uint32_t images, uint32_t max
 hipError_t launch_idct_composite(const ImageDesc *descs, uint32_t images, uint32_t max_dus,
                                  hipStream_t stream);
 
-// Extension pipeline for layouts other than 4:2:2: after launch_entropy, IDCT of every record in
-// place, then the composite of every output the descriptors name (max_w x max_h: largest output).
-hipError_t launch_generic_transform(const ImageDesc *descs, uint32_t images, uint32_t max_dus, uint32_t max_w,
-                                    uint32_t max_h, hipStream_t stream);
+// Extension pipeline for layouts other than 4:2:2: entropy decode + IDCT into sample records (plan as for
+// the fused kernel), then the composite of every output the descriptors name (max_w x max_h: largest output).
+hipError_t launch_entropy_samples(const ImageDesc *descs, uint32_t images, uint32_t max_intervals,
+                                  const HuffLdsPlan &plan, hipStream_t stream);
+hipError_t launch_generic_composite(const ImageDesc *descs, uint32_t images, uint32_t max_w, uint32_t max_h,
+                                    hipStream_t stream);
 
 #if defined(CG_AC_STAMPS)
 // diagnostic build: AC-loop cycle counters (kernels_body.h)

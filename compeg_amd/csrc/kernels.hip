@@ -9,8 +9,8 @@
 //                             intervals, for launches that cannot fill the chip (one frame)
 //   entropy_kernel            entropy stage alone -> coefficient records in HBM
 //   idct_composite_kernel     IDCT + 4:2:2 composite from those records (two-kernel pipeline)
-//   idct_in_place_kernel,     IDCT and composite for the extension layouts (4:4:4, 4:4:0,
-//   composite_generic_kernel  4:2:0)
+//   entropy_samples_kernel,   entropy decode + IDCT -> sample records, and the composite from
+//   composite_generic_kernel  them, for the extension layouts (4:4:4, 4:4:0, 4:2:0)
 //   huffman_kernel            a literal restatement of the reference's decode loop; debug
 //                             coefficient read-back and cross-check of the fast path
 //
@@ -74,8 +74,9 @@ huffman_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t
 // Entropy stage of the two-kernel pipeline: the fast-mode decoder of the fused
 // path, writing coefficient records instead of feeding the IDCT.  Few
 // registers, so the workgroup is as large as the LDS allows.
-__global__ void __launch_bounds__(1024)
-entropy_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words)
+template <bool SAMPLES>
+__device__ __forceinline__ void entropy_kernel_body(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds,
+                                                    uint32_t window_words)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const ImageDesc &d = descs[blockIdx.y];
@@ -111,7 +112,21 @@ entropy_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t
     s.win_base = win_base;
     s.win_len = win_len;
     s.du_slots = reinterpret_cast<uint8_t *>(win) + align16(window_words * 4u);
-    entropy_wave_to_records(d, s, wave_first + lane, lane);
+    entropy_wave_to_records<SAMPLES>(d, s, wave_first + lane, lane);
+}
+
+__global__ void __launch_bounds__(1024)
+entropy_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words)
+{
+    entropy_kernel_body<false>(descs, l2_in_lds, window_words);
+}
+
+// Extension layouts: the same with the IDCT on top (the records carry samples).
+// 768 threads: the IDCT's registers allow three waves per SIMD.
+__global__ void __launch_bounds__(768)
+entropy_samples_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words)
+{
+    entropy_kernel_body<true>(descs, l2_in_lds, window_words);
 }
 
 // Fused path: same prologue as huffman_kernel, then every lane runs the whole
@@ -291,23 +306,8 @@ hipError_t read_ac_stamps(unsigned long long out[4], bool reset)
 }
 #endif
 
-// Extension pipeline for layouts other than 4:2:2 (kernels_body.h): lane per data unit ...
-__global__ void __launch_bounds__(256)
-idct_in_place_kernel(const ImageDesc *__restrict__ descs)
-{
-    __shared__ float quant[3 * kRetained];
-    const ImageDesc &d = descs[blockIdx.y];
-    if (blockIdx.x * blockDim.x >= d.total_dus)
-        return;
-    if (threadIdx.x < 3 * kRetained)
-        quant[threadIdx.x] = d.quant[threadIdx.x / kRetained][threadIdx.x % kRetained];
-    __syncthreads();
-    const uint32_t du = blockIdx.x * blockDim.x + threadIdx.x;
-    if (du < d.total_dus)
-        idct_record_in_place(d, quant, du);
-}
-
-// ... then lane per four pixels of a row.
+// Extension layouts: composite from the sample records entropy_samples_kernel wrote, lane per
+// four pixels of a row.
 __global__ void __launch_bounds__(256)
 composite_generic_kernel(const ImageDesc *__restrict__ descs)
 {
@@ -444,15 +444,28 @@ hipError_t launch_idct_composite(const ImageDesc *descs, uint32_t images, uint32
     return hipGetLastError();
 }
 
-hipError_t launch_generic_transform(const ImageDesc *descs, uint32_t images, uint32_t max_dus, uint32_t max_w,
-                                    uint32_t max_h, hipStream_t stream)
+hipError_t launch_entropy_samples(const ImageDesc *descs, uint32_t images, uint32_t max_intervals,
+                                  const HuffLdsPlan &plan, hipStream_t stream)
 {
-    if (images == 0 || max_dus == 0 || max_w == 0 || max_h == 0)
+    if (images == 0 || max_intervals == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(idct_in_place_kernel, dim3((max_dus + 255) / 256, images, 1), dim3(256), 0, stream, descs);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess)
-        return e;
+    const uint32_t threads = plan.waves_per_block * kWave; // planned like the fused kernel: at most 12 waves
+    dim3 grid((max_intervals + threads - 1) / threads, images, 1);
+    static const hipError_t attr = hipFuncSetAttribute(
+        reinterpret_cast<const void *>(entropy_samples_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        int(kLdsBytesPerCu));
+    if (attr != hipSuccess)
+        return attr;
+    hipLaunchKernelGGL(entropy_samples_kernel, grid, dim3(threads), plan.total_bytes, stream, descs,
+                       plan.l2_entries_in_lds, plan.window_words);
+    return hipGetLastError();
+}
+
+hipError_t launch_generic_composite(const ImageDesc *descs, uint32_t images, uint32_t max_w, uint32_t max_h,
+                                    hipStream_t stream)
+{
+    if (images == 0 || max_w == 0 || max_h == 0)
+        return hipSuccess;
     // y is limited to 65535 rows per launch dimension: more than any baseline JPEG has
     hipLaunchKernelGGL(composite_generic_kernel, dim3(((max_w + 3) / 4 + 255) / 256, max_h, images), dim3(256), 0,
                        stream, descs);

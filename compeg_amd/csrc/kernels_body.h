@@ -1416,10 +1416,26 @@ CG_DEV void records_flush_quad(const ImageDesc &d, const uint8_t *wave_slots, ui
         CG_GLOBAL(int32_t, d.dc)[size_t(interval) * du_count + du_in_interval] = dc;
 }
 
+// The lane's coefficient slot -> the data unit's 64 samples, in the slot (the
+// extension layouts flush samples instead of coefficients: one pass over HBM less).
+CG_DEV void slot_to_samples(const ImageDesc &d, uint32_t comp, uint8_t *slot, int32_t dc)
+{
+    uint32_t rec[kRetained / 2];
+    take_slot(slot, rec);
+    uint32_t px[16];
+    idct_data_unit(rec, dc, d.quant[comp], px);
+    SlotVec *p = reinterpret_cast<SlotVec *>(slot);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        p[i] = SlotVec{px[4 * i], px[4 * i + 1], px[4 * i + 2], px[4 * i + 3]};
+}
+
 #if defined(__HIPCC__)
 // All 64 lanes of a wave call this together (tests/emul drives the same steps
 // lane by lane); lanes past the last interval decode the last one again and
-// only help their quad store.
+// only help their quad store.  SAMPLES: the records carry the IDCT's output
+// instead of its input.
+template <bool SAMPLES>
 CG_DEV void entropy_wave_to_records(const ImageDesc &d, const HuffShared &s, uint32_t interval, uint32_t lane)
 {
     uint8_t *slot = s.du_slots + lane * kDuSlotBytes;
@@ -1436,6 +1452,8 @@ CG_DEV void entropy_wave_to_records(const ImageDesc &d, const HuffShared &s, uin
     for (uint32_t du = 0; du < du_count; du++) {
         const uint32_t comp = (d.comp_of_du >> (2u * k)) & 3u;
         const int32_t dc = entropy_data_unit(e, d, s, comp < 3u ? comp : 2u, slot16);
+        if (SAMPLES)
+            slot_to_samples(d, comp < 3u ? comp : 2u, slot, dc);
         records_flush_quad(d, s.du_slots, lane, interval, du, dc);
         zero_slot(slot);
         k = k + 1u == dpm ? 0u : k + 1u;
@@ -1446,34 +1464,12 @@ CG_DEV void entropy_wave_to_records(const ImageDesc &d, const HuffShared &s, uin
 // ---------------------------------------------------------------------------
 // Layouts other than 4:2:2 (extension): three plain kernels
 // ---------------------------------------------------------------------------
-// entropy_kernel writes coefficient records; then every data unit's 64-byte
-// record is replaced in place by its 64 samples (what the reference's dct pass
-// does with its coefficient buffer, src/dct.wgsl:187-201), and a last pass
-// converts four horizontally adjacent pixels per lane (the reference's finalize
+// entropy_samples_kernel decodes and transforms: every data unit's 64-byte
+// record holds its 64 samples (what the reference's coefficient buffer holds
+// after its dct pass, src/dct.wgsl:187-201), and a last pass converts four horizontally
+// adjacent pixels per lane (the reference's finalize
 // pass, src/dct.wgsl:257-321, continued to 16-row MCUs as orc_finalize_pass
 // states it).
-
-// quant: 3 x 32 quantiser values (component-major)
-CG_DEV void idct_record_in_place(const ImageDesc &d, const float *quant, uint32_t du)
-{
-    const uint32_t k = du % d.dus_per_mcu;
-    const uint32_t comp = (d.comp_of_du >> (2u * k)) & 3u;
-    auto *record = CG_GLOBAL(Vec4u, reinterpret_cast<Vec4u *>(d.ac + size_t(du) * kRetained));
-    uint32_t rec[kRetained / 2];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const Vec4u v = record[i];
-        rec[4 * i + 0] = v.x;
-        rec[4 * i + 1] = v.y;
-        rec[4 * i + 2] = v.z;
-        rec[4 * i + 3] = v.w;
-    }
-    uint32_t px[16];
-    idct_data_unit(rec, CG_GLOBAL(const int32_t, d.dc)[du], quant + (comp < 3u ? comp : 2u) * kRetained, px);
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-        record[i] = Vec4u{px[4 * i], px[4 * i + 1], px[4 * i + 2], px[4 * i + 3]};
-}
 
 // Pixels x0 .. x0+3 (x0 a multiple of 4) of output row y.  Sampling factors
 // are 1 or 2 and MCU sizes 8 or 16, so every division below is a shift.

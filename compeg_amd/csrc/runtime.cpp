@@ -343,15 +343,16 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
                                     : max_wave_span(scan.starts(), scan.nstarts(), scan.nwords(),
                                                     md.total_restart_intervals);
     const bool fused = use_fused_pipeline() && is_422(img);
-    const HuffLdsPlan plan = plan_huffman(md.total_restart_intervals, 1, staged_lut_entries(img), span, fused);
+    // (the extension pipeline's first kernel carries the IDCT: planned like the fused kernel)
+    const HuffLdsPlan plan = plan_huffman(md.total_restart_intervals, 1, staged_lut_entries(img), span,
+                                          fused || !is_422(img));
     last_span = span;
     last_plan = plan;
     if (!is_422(img)) {
         // extension layouts (4:4:4, 4:4:0, 4:2:0): entropy stage, IDCT in place, generic composite
-        CG_HIP(launch_entropy(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals, plan,
-                              stream));
-        CG_HIP(launch_generic_transform(reinterpret_cast<const ImageDesc *>(db), 1, total_dus, out_w, out_h,
-                                        stream));
+        CG_HIP(launch_entropy_samples(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals,
+                                      plan, stream));
+        CG_HIP(launch_generic_composite(reinterpret_cast<const ImageDesc *>(db), 1, out_w, out_h, stream));
         coefficients_valid = false;
     } else if (fused) {
         if (use_pair_kernel(md.total_restart_intervals, 1))
@@ -743,12 +744,12 @@ Status compeg_batch::decode(hipStream_t stream)
     for (uint32_t at = 0; at < n; at += step) {
         const uint32_t m = std::min(step, n - at);
         const bool fused = use_fused_pipeline() && !generic_layout;
-        const HuffLdsPlan plan = plan_huffman(max_intervals, m, max_l2, max_span, fused);
+        const HuffLdsPlan plan = plan_huffman(max_intervals, m, max_l2, max_span, fused || generic_layout);
         if (generic_layout) {
-            CG_HIP(launch_entropy(dd + at, m, max_intervals, plan, stream));
+            CG_HIP(launch_entropy_samples(dd + at, m, max_intervals, plan, stream));
             if (timing && at == 0)
                 CG_HIP(hipEventRecord(ev[1], stream));
-            CG_HIP(launch_generic_transform(dd + at, m, max_dus, max_out_w, max_out_h, stream));
+            CG_HIP(launch_generic_composite(dd + at, m, max_out_w, max_out_h, stream));
             continue;
         }
         if (fused) {

@@ -191,6 +191,9 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
                     for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
                         dcs[lane] = entropy_data_unit(es[lane], d, sh, comp < 3u ? comp : 2u,
                                                       reinterpret_cast<int16_t *>(slots + lane * kDuSlotBytes));
+                    if (fused == 4) // entropy_samples_kernel: the IDCT runs here, the records carry samples
+                        for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
+                            slot_to_samples(d, comp < 3u ? comp : 2u, slots + lane * kDuSlotBytes, dcs[lane]);
                     for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
                         records_flush_quad(d, slots, lane, wave_first + lane, du, dcs[lane]);
                     for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
@@ -210,13 +213,7 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
         memcpy(dc_out, dc.data(), dc.size() * 4);
 
     if (fused == 4) {
-        // ---- idct_in_place_kernel + composite_generic_kernel (extension layouts) ----
-        // coefficient read-back is taken before the records are overwritten by samples
-        std::vector<float> quant(3 * kRetained);
-        for (uint32_t t = 0; t < 3 * kRetained; t++)
-            quant[t] = d.quant[t / kRetained][t % kRetained];
-        for (uint32_t du = 0; du < d.total_dus; du++)
-            idct_record_in_place(d, quant.data(), du);
+        // ---- composite_generic_kernel (extension layouts; the records hold samples) ----
         for (uint32_t y = 0; y < tex_h; y++)
             for (uint32_t x0 = 0; x0 < ((tex_w + 3u) & ~3u) + 8u; x0 += 4) // a few lanes past the row end, like the grid
                 composite_generic_4px(d, x0, y);
