@@ -1297,6 +1297,41 @@ CG_DEV Vec4u rgba_quad(uint32_t yw, uint32_t cb2, uint32_t cr2)
     return o;
 }
 
+// Four pixels with a chroma sample each (cb4 / cr4: one byte per pixel) --
+// the same arithmetic for layouts whose chroma is not shared pairwise.
+CG_DEV Vec4u rgba_quad4(uint32_t yw, uint32_t cb4, uint32_t cr4)
+{
+    Vec4u o;
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    const s2 k45 = {45, 45}, k11 = {11, 11}, k23 = {23, 23}, k113 = {113, 113};
+    const s2 b45 = {-5760, -5760}, b34 = {-4352, -4352}, b113 = {-14464, -14464};
+    const s2 sh5 = {5, 5}, sh6 = {6, 6};
+    // lanes (p0, p2) and (p1, p3) of luma and chroma alike
+    const s2 ya = __builtin_bit_cast(s2, yw & 0x00ff00ffu), yb = __builtin_bit_cast(s2, (yw >> 8) & 0x00ff00ffu);
+    const s2 cba = __builtin_bit_cast(s2, cb4 & 0x00ff00ffu), cbb = __builtin_bit_cast(s2, (cb4 >> 8) & 0x00ff00ffu);
+    const s2 cra = __builtin_bit_cast(s2, cr4 & 0x00ff00ffu), crb = __builtin_bit_cast(s2, (cr4 >> 8) & 0x00ff00ffu);
+    uint32_t ra, ga, ba, rb, gb, bb;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(ra) : "v"(ya + ((cra * k45 + b45) >> sh5)));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(ga) : "v"(ya - ((cba * k11 + (cra * k23 + b34)) >> sh5)));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(ba) : "v"(ya + ((cba * k113 + b113) >> sh6)));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(rb) : "v"(yb + ((crb * k45 + b45) >> sh5)));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(gb) : "v"(yb - ((cbb * k11 + (crb * k23 + b34)) >> sh5)));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(bb) : "v"(yb + ((cbb * k113 + b113) >> sh6)));
+    const uint32_t rga = ga << 16 | ra, rgb = gb << 16 | rb;
+    o.x = __builtin_amdgcn_perm(ba, rga, 0x0d040200u);
+    o.z = __builtin_amdgcn_perm(ba, rga, 0x0d050301u);
+    o.y = __builtin_amdgcn_perm(bb, rgb, 0x0d040200u);
+    o.w = __builtin_amdgcn_perm(bb, rgb, 0x0d050301u);
+#else
+    o.x = ycbcr_to_rgba(yw & 0xffu, cb4 & 0xffu, cr4 & 0xffu);
+    o.y = ycbcr_to_rgba((yw >> 8) & 0xffu, (cb4 >> 8) & 0xffu, (cr4 >> 8) & 0xffu);
+    o.z = ycbcr_to_rgba((yw >> 16) & 0xffu, (cb4 >> 16) & 0xffu, (cr4 >> 16) & 0xffu);
+    o.w = ycbcr_to_rgba(yw >> 24, cb4 >> 24, cr4 >> 24);
+#endif
+    return o;
+}
+
 // px[k][2*row + half]: data unit k (Y0, Y1, Cb, Cr), 4 samples per word.
 //
 // The composite of an MCU (16x8 pixels, 8 rows of 64 bytes) goes out through
@@ -1491,7 +1526,7 @@ CG_DEV void composite_generic_4px(const ImageDesc &d, uint32_t x0, uint32_t y)
         uint32_t lo, hi;
     };
     auto *samples = CG_GLOBAL(const Row8, reinterpret_cast<const Row8 *>(d.ac));
-    uint32_t val[3][4];
+    uint32_t val[3]; // the component's sample of each of the four pixels, one byte per pixel
 #pragma unroll
     for (uint32_t c = 0; c < 3; c++) {
         const uint32_t hs = d.hsample[c], vs = d.vsample[c]; // 1 or 2
@@ -1500,21 +1535,28 @@ CG_DEV void composite_generic_4px(const ImageDesc &d, uint32_t x0, uint32_t y)
         const uint32_t du = d.du_base[c] + ((row * vs) >> hsh) * hs + ((col * hs) >> wsh);
         const Row8 r = samples[(size_t(mcu) * d.dus_per_mcu + du) * 8u + yy];
         const uint64_t bits = uint64_t(r.hi) << 32 | r.lo;
-#pragma unroll
-        for (uint32_t i = 0; i < 4; i++)
-            val[c][i] = uint32_t(bits >> ((((col + i) >> xsh) & 7u) * 8u)) & 0xffu;
+        if (xsh == 0u) {
+            val[c] = uint32_t(bits >> ((col & 7u) * 8u)); // four consecutive samples
+        } else {
+            // two samples, each under two pixels
+            const uint32_t two = uint32_t(bits >> (((col >> 1) & 7u) * 8u));
+            val[c] = (two & 0xffu) * 0x0101u | ((two >> 8) & 0xffu) * 0x01010000u;
+        }
     }
-    auto *p = CG_GLOBAL(uint32_t, reinterpret_cast<uint32_t *>(d.out + size_t(y) * d.out_pitch + size_t(x0) * 4u));
+    const Vec4u o = rgba_quad4(val[0], val[1], val[2]);
+    uint8_t *p = d.out + size_t(y) * d.out_pitch + size_t(x0) * 4u;
     if (x0 + 3u < d.out_w && (d.out_pitch & 15u) == 0u) {
-        store_pixels<true>(d.out + size_t(y) * d.out_pitch + size_t(x0) * 4u,
-                     Vec4u{ycbcr_to_rgba(val[0][0], val[1][0], val[2][0]), ycbcr_to_rgba(val[0][1], val[1][1], val[2][1]),
-                           ycbcr_to_rgba(val[0][2], val[1][2], val[2][2]), ycbcr_to_rgba(val[0][3], val[1][3], val[2][3])});
+        store_pixels<true>(p, o);
         return;
     }
-#pragma unroll
-    for (uint32_t i = 0; i < 4; i++)
-        if (x0 + i < d.out_w)
-            p[i] = ycbcr_to_rgba(val[0][i], val[1][i], val[2][i]);
+    auto *q = CG_GLOBAL(uint32_t, reinterpret_cast<uint32_t *>(p));
+    q[0] = o.x;
+    if (x0 + 1u < d.out_w)
+        q[1] = o.y;
+    if (x0 + 2u < d.out_w)
+        q[2] = o.z;
+    if (x0 + 3u < d.out_w)
+        q[3] = o.w;
 }
 
 // Transformer role: the samples of the MCU being assembled and where it goes.
