@@ -8,6 +8,7 @@ namespace compeg {
 constexpr int kWave = 64;              // CDNA wavefront
 constexpr int kRetained = 32;          // zig-zag positions kept per data unit (metadata.rs:43)
 constexpr int kMaxDusPerMcu = 6;
+constexpr uint32_t kStripMcus = 32;    // MCUs per workgroup of the generic composite
 
 // Direct AC tables (decode-side acceleration, derived from the reference LUTs;
 // not part of the reference's upload format): one u16 per 11-bit code prefix,

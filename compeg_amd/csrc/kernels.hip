@@ -306,14 +306,34 @@ hipError_t read_ac_stamps(unsigned long long out[4], bool reset)
 }
 #endif
 
-// Extension layouts: composite from the sample records entropy_samples_kernel wrote, lane per
-// four pixels of a row.
+// Extension layouts: composite from the sample records entropy_samples_kernel wrote.  A workgroup
+// takes a strip of 32 MCUs of one MCU row: their records (contiguous in memory) go to LDS with
+// 16-byte loads, then every lane converts four pixels of a row at a time, so that a wave-wide
+// store writes 1 KB of one pixel row.
 __global__ void __launch_bounds__(256)
 composite_generic_kernel(const ImageDesc *__restrict__ descs)
 {
+    __shared__ __attribute__((aligned(16))) uint8_t strip[kStripMcus * kMaxDusPerMcu * kRetained * 2];
     const ImageDesc &d = descs[blockIdx.z];
-    const uint32_t x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4u, y = blockIdx.y;
-    composite_generic_4px(d, x0, y);
+    const uint32_t mcu_row = blockIdx.y, first = blockIdx.x * kStripMcus;
+    if (mcu_row * d.mcu_h >= d.out_h || first >= d.width_mcus)
+        return; // uniform for the workgroup
+    const uint32_t in_strip = umin(kStripMcus, d.width_mcus - first);
+    const uint32_t mcu0 = mcu_row * d.width_mcus + first;
+    const uint32_t total_mcus = d.total_intervals * d.restart_interval;
+    const uint32_t decoded = mcu0 < total_mcus ? umin(in_strip, total_mcus - mcu0) : 0u;
+    const uint32_t nvec = decoded * d.dus_per_mcu * 4u; // 16-byte pieces
+    auto *src = CG_GLOBAL(const Vec4u, reinterpret_cast<const Vec4u *>(d.ac + size_t(mcu0) * d.dus_per_mcu * kRetained));
+    for (uint32_t v = threadIdx.x; v < nvec; v += blockDim.x)
+        reinterpret_cast<Vec4u *>(strip)[v] = src[v];
+    __syncthreads();
+    // 4-pixel groups per row of a full strip: 64 (8-pixel MCUs) or 128; rows per pass 4 or 2
+    const uint32_t gsh = d.mcu_w == 16u ? 7u : 6u;
+    const uint32_t xg = threadIdx.x & ((1u << gsh) - 1u), r0 = threadIdx.x >> gsh, rstep = blockDim.x >> gsh;
+    if (xg * 4u >= in_strip * d.mcu_w)
+        return;
+    for (uint32_t r = r0; r < d.mcu_h; r += rstep)
+        composite_generic_4px(d, first * d.mcu_w + xg * 4u, mcu_row * d.mcu_h + r, strip, mcu0);
 }
 
 namespace {
@@ -467,8 +487,9 @@ hipError_t launch_generic_composite(const ImageDesc *descs, uint32_t images, uin
     if (images == 0 || max_w == 0 || max_h == 0)
         return hipSuccess;
     // y is limited to 65535 rows per launch dimension: more than any baseline JPEG has
-    hipLaunchKernelGGL(composite_generic_kernel, dim3(((max_w + 3) / 4 + 255) / 256, max_h, images), dim3(256), 0,
-                       stream, descs);
+    // grid sized for the smallest MCU (8 x 8): workgroups past an image's own strips / MCU rows exit at once
+    hipLaunchKernelGGL(composite_generic_kernel, dim3(((max_w + 7) / 8 + kStripMcus - 1) / kStripMcus, (max_h + 7) / 8, images),
+                       dim3(256), 0, stream, descs);
     return hipGetLastError();
 }
 

@@ -1508,7 +1508,9 @@ CG_DEV void entropy_wave_to_records(const ImageDesc &d, const HuffShared &s, uin
 
 // Pixels x0 .. x0+3 (x0 a multiple of 4) of output row y.  Sampling factors
 // are 1 or 2 and MCU sizes 8 or 16, so every division below is a shift.
-CG_DEV void composite_generic_4px(const ImageDesc &d, uint32_t x0, uint32_t y)
+// samples: the sample records, starting with MCU `mcu0` (the whole buffer with
+// mcu0 = 0, or a strip of it that a workgroup has copied into LDS).
+CG_DEV void composite_generic_4px(const ImageDesc &d, uint32_t x0, uint32_t y, const uint8_t *samples_, uint32_t mcu0)
 {
     if (x0 >= d.out_w || y >= d.out_h)
         return;
@@ -1525,7 +1527,7 @@ CG_DEV void composite_generic_4px(const ImageDesc &d, uint32_t x0, uint32_t y)
     struct alignas(8) Row8 {
         uint32_t lo, hi;
     };
-    auto *samples = CG_GLOBAL(const Row8, reinterpret_cast<const Row8 *>(d.ac));
+    const Row8 *samples = reinterpret_cast<const Row8 *>(samples_);
     uint32_t val[3]; // the component's sample of each of the four pixels, one byte per pixel
 #pragma unroll
     for (uint32_t c = 0; c < 3; c++) {
@@ -1533,7 +1535,7 @@ CG_DEV void composite_generic_4px(const ImageDesc &d, uint32_t x0, uint32_t y)
         const uint32_t xsh = (wsh - 3u) - (hs - 1u), ysh = (hsh - 3u) - (vs - 1u); // log2 of xscale, yscale
         const uint32_t yy = (row >> ysh) & 7u;
         const uint32_t du = d.du_base[c] + ((row * vs) >> hsh) * hs + ((col * hs) >> wsh);
-        const Row8 r = samples[(size_t(mcu) * d.dus_per_mcu + du) * 8u + yy];
+        const Row8 r = samples[(size_t(mcu - mcu0) * d.dus_per_mcu + du) * 8u + yy];
         const uint64_t bits = uint64_t(r.hi) << 32 | r.lo;
         if (xsh == 0u) {
             val[c] = uint32_t(bits >> ((col & 7u) * 8u)); // four consecutive samples

@@ -216,7 +216,7 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
         // ---- composite_generic_kernel (extension layouts; the records hold samples) ----
         for (uint32_t y = 0; y < tex_h; y++)
             for (uint32_t x0 = 0; x0 < ((tex_w + 3u) & ~3u) + 8u; x0 += 4) // a few lanes past the row end, like the grid
-                composite_generic_4px(d, x0, y);
+                composite_generic_4px(d, x0, y, reinterpret_cast<const uint8_t *>(d.ac), 0u);
         delete img;
         return 0;
     }
