@@ -297,7 +297,8 @@ int main(int argc, char **argv)
     auto dump = [](const char *path, const void *p, size_t bytes) {
         FILE *o = fopen(path, "wb");
         if (o) {
-            fwrite(p, 1, bytes, o);
+            if (bytes) // an image without a single complete restart interval has no data units
+                fwrite(p, 1, bytes, o);
             fclose(o);
         }
     };

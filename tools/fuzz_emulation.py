@@ -1,0 +1,42 @@
+"""One-off randomized check (not part of the test suite): random geometry, quality, restart interval, bit flips in
+the scan, both entropy modes, cut-short windows -- the emulated fused and two-kernel pipelines against the oracle.
+    python tools/fuzz_emulation.py [seed] [iterations]   (tests/emul/emul_runner must be built)"""
+import os, subprocess, sys, numpy as np, tempfile
+sys.path.insert(0,'/root/repo')
+from tools import synth
+import oracle.oracle as orc
+RUN='/root/repo/tests/emul/emul_runner'
+tmp=tempfile.mkdtemp()
+def run(jpeg, fused, window=2048, standard=False):
+    p=os.path.join(tmp,'in.jpg'); open(p,'wb').write(jpeg)
+    env=dict(os.environ); env['EMUL_FUSED']=str(fused)
+    if standard: env['EMUL_STANDARD']='1'
+    r=subprocess.run([RUN,p,tmp+'/rgba',tmp+'/ac',tmp+'/dc','1',str(window),'12288'],capture_output=True,text=True,env=env,timeout=600)
+    if r.returncode!=0: return None, r.stdout+r.stderr[-500:]
+    _,w,h,_=r.stdout.split()
+    return np.fromfile(tmp+'/rgba',dtype=np.uint8).reshape(int(h),int(w),4), ''
+rng=np.random.default_rng(int(sys.argv[1]) if len(sys.argv)>1 else 1234)
+bad=0; n=0
+for it in range(int(sys.argv[2]) if len(sys.argv)>2 else 150):
+    w=int(rng.integers(16,300)); h=int(rng.integers(8,120)); kind=int(rng.integers(0,3)); q=int(rng.choice([30,60,85,95,100])); ri=int(rng.integers(0,9))
+    base=synth.make_jpeg(w,h,seed=int(rng.integers(1,1<<30)),kind=kind,quality=q,ri=ri)
+    j=bytearray(base)
+    if it%3!=0:
+        scan_at=j.find(b"\xff\xda")+14
+        for _ in range(int(rng.integers(1,40))):
+            pos=int(rng.integers(scan_at,len(j)-2))
+            if j[pos]!=0xFF and j[pos-1]!=0xFF:
+                j[pos]^=1<<int(rng.integers(0,8))
+                if j[pos]==0xFF: j[pos]=0xFE
+    j=bytes(j)
+    std=bool(it%2)
+    try:
+        want=orc.ImageData(j,standard_entropy=std).decode()
+    except orc.OracleError:
+        continue
+    for fused in (1,3):
+        got,err=run(j,fused,window=int(rng.choice([64,200,2048])),standard=std)
+        n+=1
+        if got is None or not np.array_equal(got,want):
+            bad+=1; print('MISMATCH',it,w,h,kind,q,ri,fused,std,err[:200]); open('/tmp/bad_%d.jpg'%it,'wb').write(j)
+print('runs',n,'bad',bad)
