@@ -23,6 +23,13 @@ void fill_desc(const ImageData &img, ImageDesc &d);
 }
 using namespace compeg;
 
+// EMUL_DUMP_SYMBOLS=path: one line per wave and data unit with the 64 lanes' AC symbol counts (analysis only)
+static FILE *symbol_dump()
+{
+    static FILE *f = getenv("EMUL_DUMP_SYMBOLS") ? fopen(getenv("EMUL_DUMP_SYMBOLS"), "w") : nullptr;
+    return f;
+}
+
 extern "C" __attribute__((visibility("default")))
 int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, uint32_t tex_h,
                 int16_t *ac_out, int32_t *dc_out, uint32_t waves_per_block, uint32_t window_words,
@@ -114,6 +121,8 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
                         dcs[set * kWave + lane] = entropy_data_unit(
                             es[lane], d, sh, comp, reinterpret_cast<int16_t *>(set_slots + lane * kDuSlotBytes));
                         step_max = std::max(step_max, g_emul_stats.lane_symbols);
+                        if (FILE *dump = symbol_dump())
+                            fprintf(dump, "%lu%c", g_emul_stats.lane_symbols, lane == uint32_t(kWave) - 1 ? '\n' : ' ');
                     }
                 g_emul_stats.wave_steps++;
                 g_emul_stats.wave_step_symbols += step_max;
