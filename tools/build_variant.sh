@@ -8,4 +8,4 @@ rm -rf $W && mkdir -p $W/compeg_amd $W/include $ROOT/gpurun_ab
 cp -r $ROOT/compeg_amd/csrc $W/compeg_amd/csrc && rm -rf $W/compeg_amd/csrc/build
 cp $ROOT/include/*.h $W/include/
 make -C $W/compeg_amd/csrc -s OUT=$ROOT/gpurun_ab/lib_$1.so \
-  CXXFLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-signed-zeros -fvisibility=hidden $2"
+  CXXFLAGS="${OPT:--O3} -std=c++17 -fPIC -ffp-contract=off -fno-signed-zeros -fvisibility=hidden $2"
