@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <string>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -133,6 +135,35 @@ bool is_422(const ImageData &img)
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// COMPEG_TRACE=1: one stderr line per enqueue with the host time spent in each step (us)
+struct EnqueueTrace {
+    bool on;
+    std::chrono::steady_clock::time_point last;
+    std::string line;
+    EnqueueTrace()
+    {
+        static const bool enabled = getenv("COMPEG_TRACE") != nullptr;
+        on = enabled;
+        if (on)
+            last = std::chrono::steady_clock::now();
+    }
+    void mark(const char *what)
+    {
+        if (!on)
+            return;
+        const auto now = std::chrono::steady_clock::now();
+        char buf[64];
+        snprintf(buf, sizeof buf, " %s=%.1f", what, std::chrono::duration<double, std::micro>(now - last).count());
+        line += buf;
+        last = now;
+    }
+    ~EnqueueTrace()
+    {
+        if (on)
+            fprintf(stderr, "[compeg] enqueue:%s\n", line.c_str());
+    }
+};
+
 // Per-image LUT blob: [L1 2048 B][L2, padded to 4 B][two 11-bit direct AC tables]
 size_t table_blob_bytes(const ImageData &img)
 {
@@ -215,16 +246,29 @@ Status compeg_decoder::preprocess_on_device(const ImageData &img, hipStream_t st
     s.starts_out = reinterpret_cast<uint32_t *>(da + o_st);
     s.words_out = da + o_w;
     s.result = reinterpret_cast<uint32_t *>(da + o_res);
+    EnqueueTrace trace;
     // descriptor and segment travel in one copy (the descriptor sits in front of the raw bytes)
     memset(hs, 0, o_raw);
     memcpy(hs + o_desc, &s, sizeof s);
-    memcpy(hs + o_raw, img.scan_data(), len);
-    CG_HIP(hipMemcpyAsync(da, hs, o_raw + len, hipMemcpyHostToDevice, stream));
+    // the segment goes through the pinned staging buffer piece by piece, so that the DMA of one
+    // piece runs under the host copy of the next
+    constexpr size_t kPiece = 256u << 10;
+    for (size_t at = 0; at < len || at == 0; at += kPiece) {
+        const size_t n = std::min<size_t>(kPiece, len - at);
+        memcpy(hs + o_raw + at, img.scan_data() + at, n);
+        const size_t from = at ? o_raw + at : 0; // the first piece carries the descriptor
+        CG_HIP(hipMemcpyAsync(da + from, hs + from, o_raw + at + n - from, hipMemcpyHostToDevice, stream));
+        if (len == 0)
+            break;
+    }
+    trace.mark("  stage_and_copy");
     CG_HIP(hipMemsetAsync(da + o_res, 0, 16, stream));
     CG_HIP(launch_scan(reinterpret_cast<const ScanDesc *>(da + o_desc), 1, ntiles, stream));
     uint32_t res[4];
     CG_HIP(hipMemcpyAsync(res, da + o_res, 16, hipMemcpyDeviceToHost, stream));
+    trace.mark("submit");
     CG_HIP(hipStreamSynchronize(stream));
+    trace.mark("sync");
     if ((res[3] & 1u) || res[0] > capacity) {
         fell_back = true; // FF run beyond the kernels' bound, or far more markers than announced
         return Status{};
@@ -247,6 +291,7 @@ Status compeg_decoder::preprocess_on_device(const ImageData &img, hipStream_t st
 // Counterpart of Decoder::enqueue (src/lib.rs:385-477).
 Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *changed)
 {
+    EnqueueTrace trace;
     CG_HIP(hipSetDevice(gpu->device));
     warning.clear();
 
@@ -293,6 +338,7 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
             warning = pre.message; // the reference drops this error (lib.rs:391-394)
         }
     }
+    trace.mark(on_device ? "device_preprocess" : "host_preprocess");
     const size_t n_words = on_device ? dev_nwords : scan.nwords();
     const size_t n_starts = on_device ? dev_nstarts : scan.nstarts();
 
@@ -325,6 +371,7 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     d.out_h = out_h;
     d.out_pitch = uint32_t(out_pitch);
     write_tables(hb + l1_off, img);
+    trace.mark("tables");
 
     CG_HIP(hipMemcpyAsync(db, hb, blob_bytes, hipMemcpyHostToDevice, stream));
     if (!on_device && n_starts)
@@ -336,6 +383,7 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     last_stream = stream;
     last_md = md;
     have_last = true;
+    trace.mark("copies");
 
     if (total_dus == 0)
         return Status{};
@@ -348,6 +396,7 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
                                           fused || !is_422(img));
     last_span = span;
     last_plan = plan;
+    trace.mark("plan");
     if (!is_422(img)) {
         // extension layouts (4:4:4, 4:4:0, 4:2:0): entropy stage, IDCT in place, generic composite
         CG_HIP(launch_entropy_samples(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals,
@@ -368,6 +417,7 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
         CG_HIP(launch_idct_composite(reinterpret_cast<const ImageDesc *>(db), 1, total_dus, stream));
         coefficients_valid = true;
     }
+    trace.mark("launch");
     return Status{};
 }
 

@@ -215,35 +215,74 @@ __global__ void __launch_bounds__(kThreads) marker_kernel(const ScanDesc *descs)
 // (P[count] = kept bytes); start_m = sum_{j<m} ceil(len_j / 4).  The reference
 // stores start m at index (m & mask) of a power-of-two array and keeps
 // min(count, slots) entries (src/scan.rs:46-56,111).
-__global__ void __launch_bounds__(kThreads) interval_scan_kernel(const ScanDesc *descs)
+//
+// A single 4K frame has 16 200 intervals and this block is all that runs, so
+// its latency is the point: 1024 threads, chunks of 8192 intervals; P[] comes
+// in with coalesced loads through LDS, every thread scans 8 consecutive
+// entries (index i lives at i + i / 8: conflict-free for that access), and the
+// starts leave through the same LDS array with coalesced stores.
+constexpr uint32_t kIvThreads = 1024, kIvPerThread = 8, kIvChunk = kIvThreads * kIvPerThread;
+
+__device__ __forceinline__ uint32_t iv_slot(uint32_t i) { return i + i / kIvPerThread; }
+
+__global__ void __launch_bounds__(kIvThreads) interval_scan_kernel(const ScanDesc *descs)
 {
-    __shared__ uint32_t lds[4];
+    __shared__ uint32_t pos[kIvChunk + kIvChunk / kIvPerThread + 2];
+    __shared__ uint32_t wave_total[kIvThreads / 64];
     const ScanDesc &d = descs[blockIdx.x];
     const uint32_t count = min(d.result[0], d.marker_capacity);
     const uint32_t kept = d.result[1];
-    // Every thread owns a contiguous run of intervals: one pass for the run's
-    // word total, one block-wide scan of the totals, one pass for the starts
-    // (a chunk-by-chunk block scan costs two barriers per 256 intervals, which
-    // is what a single 4K frame -- 16 200 intervals, one block -- waits for).
-    const uint32_t per = (count + kThreads - 1u) / kThreads;
-    const uint32_t first = threadIdx.x * per, last = min(first + per, count);
-    uint32_t mine = 0;
-    for (uint32_t m = first; m < last; m++) {
-        const uint32_t lo = d.marker_pos[m], hi = m + 1 < count ? d.marker_pos[m + 1] : kept;
-        mine += (hi - lo + 3u) / 4u;
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    uint32_t carry = 0; // words in front of the chunk
+    for (uint32_t base = 0; base < count; base += kIvChunk) {
+        const uint32_t n = min(kIvChunk, count - base);
+        // P[base .. base + n], the entry behind the last interval being the kept total
+        for (uint32_t i = t; i <= n; i += kIvThreads)
+            pos[iv_slot(i)] = base + i < count ? d.marker_pos[base + i] : kept;
+        __syncthreads();
+        uint32_t p[kIvPerThread + 1];
+        const uint32_t first = t * kIvPerThread;
+        for (uint32_t k = 0; k <= kIvPerThread; k++)
+            p[k] = first + k <= n ? pos[iv_slot(first + k)] : 0u;
+        uint32_t mine = 0;
+        for (uint32_t k = 0; k < kIvPerThread; k++)
+            mine += first + k < n ? (p[k + 1] - p[k] + 3u) / 4u : 0u;
+        // block-wide exclusive scan of the per-thread totals
+        uint32_t x = mine;
+        for (uint32_t o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(x, o);
+            if (lane >= o)
+                x += y;
+        }
+        if (lane == 63)
+            wave_total[wave] = x;
+        __syncthreads(); // also: every thread has read its pos[] entries
+        uint32_t before = 0, total = 0;
+        for (uint32_t w = 0; w < kIvThreads / 64; w++) {
+            const uint32_t v = wave_total[w];
+            before += w < wave ? v : 0u;
+            total += v;
+        }
+        uint32_t start = carry + before + x - mine;
+        for (uint32_t k = 0; k < kIvPerThread; k++) {
+            if (first + k < n) {
+                pos[iv_slot(first + k)] = start;
+                start += (p[k + 1] - p[k] + 3u) / 4u;
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = t; i < n; i += kIvThreads) {
+            const uint32_t m = base + i, s = pos[iv_slot(i)];
+            d.interval_start[m] = s;
+            // the last writer of a slot wins in the reference's sequential loop
+            if (m + d.slots >= count && m != 0)
+                d.starts_out[m & (d.slots - 1u)] = s;
+        }
+        carry += total;
+        __syncthreads(); // pos[] and wave_total[] are reused by the next chunk
     }
-    uint32_t total;
-    uint32_t start = block_exclusive_scan(mine, lds, total);
-    for (uint32_t m = first; m < last; m++) {
-        const uint32_t lo = d.marker_pos[m], hi = m + 1 < count ? d.marker_pos[m + 1] : kept;
-        d.interval_start[m] = start;
-        // the last writer of a slot wins in the reference's sequential loop
-        if (m + d.slots >= count && m != 0)
-            d.starts_out[m & (d.slots - 1u)] = start;
-        start += (hi - lo + 3u) / 4u;
-    }
-    if (threadIdx.x == 0) {
-        d.result[2] = total; // total output words
+    if (t == 0) {
+        d.result[2] = carry; // total output words
         // entry 0 keeps its initial 0 unless a wrapped index (m = k * slots) hit it above
         if (count <= d.slots)
             d.starts_out[0] = 0u;
@@ -361,7 +400,7 @@ hipError_t launch_scan(const ScanDesc *descs, uint32_t images, uint32_t max_tile
     if (max_tiles) {
         hipLaunchKernelGGL(marker_kernel, dim3(max_tiles, images), dim3(kThreads), 0, stream, descs);
     }
-    hipLaunchKernelGGL(interval_scan_kernel, dim3(images), dim3(kThreads), 0, stream, descs);
+    hipLaunchKernelGGL(interval_scan_kernel, dim3(images), dim3(kIvThreads), 0, stream, descs);
     if (max_tiles) {
         hipLaunchKernelGGL(emit_kernel, dim3(max_tiles, images), dim3(kThreads), 0, stream, descs);
     }

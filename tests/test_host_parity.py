@@ -222,6 +222,24 @@ def test_scanbuffer_fuzz():
         data[zero] = 0
         expected = int(rng.integers(0, 12))
         _scan_both(data.tobytes(), expected)
+    # long plain runs (the vector copy of the host loop): sparse FFs, FFs on and around every
+    # 16/32-byte boundary, FF pairs cut by the end of the data
+    for it in range(120):
+        n = int(rng.integers(1, 4000))
+        data = rng.integers(0, 255, n, dtype=np.uint8)       # no FF yet
+        for pos in rng.integers(0, n, int(rng.integers(0, 12))):
+            data[pos] = 0xFF
+            if pos + 1 < n and rng.random() < 0.5:
+                data[pos + 1] = 0
+        if it % 3 == 0:
+            edge = int(rng.integers(1, max(2, n // 16))) * 16 + int(rng.integers(-2, 2))
+            if 0 <= edge < n:
+                data[edge] = 0xFF
+        if it % 5 == 0:
+            data[n - 1] = 0xFF
+        if it % 7 == 0 and n > 2:
+            data[n - 2] = 0xFF
+        _scan_both(data.tobytes(), int(rng.integers(0, 14)))
     _scan_both(b"", 0)
     _scan_both(b"\xff", 1)
     _scan_both(b"\xff\xff\xff", 2)
