@@ -344,10 +344,35 @@ int compeg_decoder_start_decode(compeg_decoder *dec, const compeg_image *img, co
 
 int compeg_decoder_decode_blocking(compeg_decoder *dec, const compeg_image *img, compeg_op **op)
 {
-    int rc = compeg_decoder_start_decode(dec, img, op);
-    if (rc != COMPEG_OK)
-        return rc;
-    return compeg_op_wait(*op);
+    // like start_decode + wait; a blocking decode may run the device-side scan preprocessing
+    // without the read-back in the middle and look at its outcome afterwards
+    return guarded([&] {
+        if (!dec || !img || !op)
+            return fail(COMPEG_E_INVALID_ARG, "NULL argument");
+        *op = nullptr;
+        bool changed = false;
+        Status s = dec->enqueue(*img->data, dec->gpu->stream, &changed, true);
+        if (!s.ok())
+            return fail(s);
+        hipError_t e = hipStreamSynchronize(dec->gpu->stream);
+        if (e != hipSuccess)
+            return fail(hip_status(e, "hipStreamSynchronize"));
+        s = dec->finish_deferred(*img->data, dec->gpu->stream);
+        if (!s.ok())
+            return fail(s);
+        compeg_op *o = new compeg_op();
+        o->device = dec->gpu->device;
+        o->texture_changed = changed;
+        e = hipEventCreateWithFlags(&o->done, hipEventDisableTiming);
+        if (e == hipSuccess)
+            e = hipEventRecord(o->done, dec->gpu->stream);
+        if (e != hipSuccess) {
+            compeg_op_free(o);
+            return fail(hip_status(e, "hipEventRecord"));
+        }
+        *op = o;
+        return ok();
+    });
 }
 
 int compeg_decoder_set_device_preprocess(compeg_decoder *dec, int on)
@@ -460,7 +485,7 @@ int compeg_decoder_read_coefficients(compeg_decoder *dec, int32_t *host, size_t 
             // stage alone into the scratch buffers for this debug read-back
             const HuffLdsPlan plan = plan_huffman(md.total_restart_intervals, 1, dec->last_plan.l2_entries_in_lds,
                                                   dec->last_span, false);
-            e = launch_huffman(static_cast<const ImageDesc *>(dec->dev_blob.ptr), 1,
+            e = launch_huffman(static_cast<const ImageDesc *>(dec->last_desc_dev), 1,
                                md.total_restart_intervals, plan, dec->last_stream);
             if (e == hipSuccess)
                 e = hipStreamSynchronize(dec->last_stream);

@@ -118,6 +118,17 @@ bool use_pair_kernel(uint32_t max_intervals, uint32_t images)
     return waves <= 768;
 }
 
+// Which of the two small-launch kernels: the team kernel (decoder wave + three transformer
+// waves) unless COMPEG_TEAM=0 asks for the paired one.
+bool use_team_kernel()
+{
+    static const bool team = [] {
+        const char *e = getenv("COMPEG_TEAM");
+        return e ? atoi(e) != 0 : false;
+    }();
+    return team;
+}
+
 namespace {
 
 void *pinned_alloc(size_t n)
@@ -205,10 +216,18 @@ compeg_decoder::~compeg_decoder()
 }
 
 // Device-side variant of the preprocess step of enqueue: raw segment to HBM
-// (pinned staging, async copy), scan kernels, then one small synchronous
-// read-back of the result words (interval count, output size, flags).
+// (pinned staging, async copy), scan kernels, then the result words (interval
+// count, output size, flags) come back.  Two ways:
+//  * before_submit empty: one small synchronous read-back here, and the caller
+//    builds the image descriptor from it;
+//  * before_submit given (decode_blocking): no synchronisation.  The callback
+//    uploads the image descriptor once the output addresses are known, the scan
+//    kernels patch the two counts into it (patch_nwords / patch_nstarts), the
+//    result words travel to pinned host memory behind them, and the caller
+//    checks them after the decode (finish_deferred).
 Status compeg_decoder::preprocess_on_device(const ImageData &img, hipStream_t stream, uint32_t &nwords,
-                                            uint32_t &nstarts, uint32_t &span, bool &fell_back)
+                                            uint32_t &nstarts, uint32_t &span, bool &fell_back, size_t blob_bytes,
+                                            const BlobWriter &before_submit)
 {
     fell_back = false;
     if (img.scan_len > 0xfffffff0u) {
@@ -226,10 +245,13 @@ Status compeg_decoder::preprocess_on_device(const ImageData &img, hipStream_t st
         total += align_up(bytes, 256);
         return at;
     };
-    const size_t o_desc = take(sizeof(ScanDesc)), o_raw = take(size_t(len) + 64),
+    // everything the host writes sits in front of the raw bytes and travels with their first piece: the
+    // zeroed result words (first 16 bytes), the scan descriptor and, for a deferred decode, the image's blob
+    const size_t o_res = 0, o_desc = take(sizeof(ScanDesc)), o_blob = take(before_submit ? blob_bytes : 0),
+                 o_raw = take(size_t(len) + 64),
                  o_tk = take(size_t(ntiles) * 4 + 4), o_tm = take(size_t(ntiles) * 4 + 4),
                  o_mp = take(size_t(capacity) * 4), o_is = take(size_t(capacity) * 4),
-                 o_st = take(size_t(slots) * 4), o_w = take(size_t(len) + len / 3 + 64), o_res = take(16);
+                 o_st = take(size_t(slots) * 4), o_w = take(size_t(len) + len / 3 + 64);
     CG_TRY(scan_arena.reserve(total));
     CG_TRY(raw_stage.reserve(o_raw + len + 64));
     uint8_t *da = static_cast<uint8_t *>(scan_arena.ptr), *hs = static_cast<uint8_t *>(raw_stage.ptr);
@@ -246,13 +268,16 @@ Status compeg_decoder::preprocess_on_device(const ImageData &img, hipStream_t st
     s.starts_out = reinterpret_cast<uint32_t *>(da + o_st);
     s.words_out = da + o_w;
     s.result = reinterpret_cast<uint32_t *>(da + o_res);
+    dev_words = da + o_w;
+    dev_starts = da + o_st;
     EnqueueTrace trace;
-    // descriptor and segment travel in one copy (the descriptor sits in front of the raw bytes)
-    memset(hs, 0, o_raw);
+    memset(hs, 0, o_blob);
+    if (before_submit)
+        CG_TRY(before_submit(hs + o_blob, da + o_blob, &s.patch_nwords, &s.patch_nstarts));
     memcpy(hs + o_desc, &s, sizeof s);
     // the segment goes through the pinned staging buffer piece by piece, so that the DMA of one
-    // piece runs under the host copy of the next
-    constexpr size_t kPiece = 256u << 10;
+    // piece runs under the host copy of the next (few pieces: every copy costs the GPU ~6 us)
+    constexpr size_t kPiece = 640u << 10;
     for (size_t at = 0; at < len || at == 0; at += kPiece) {
         const size_t n = std::min<size_t>(kPiece, len - at);
         memcpy(hs + o_raw + at, img.scan_data() + at, n);
@@ -262,34 +287,76 @@ Status compeg_decoder::preprocess_on_device(const ImageData &img, hipStream_t st
             break;
     }
     trace.mark("  stage_and_copy");
-    CG_HIP(hipMemsetAsync(da + o_res, 0, 16, stream));
     CG_HIP(launch_scan(reinterpret_cast<const ScanDesc *>(da + o_desc), 1, ntiles, stream));
-    uint32_t res[4];
-    CG_HIP(hipMemcpyAsync(res, da + o_res, 16, hipMemcpyDeviceToHost, stream));
+    CG_TRY(scan_result.reserve(16));
+    uint32_t *res = static_cast<uint32_t *>(scan_result.ptr);
+    scan_result_dev = da + o_res;
+    deferred_capacity = capacity;
+    deferred_expected = expected;
+    if (!before_submit)
+        CG_HIP(hipMemcpyAsync(res, scan_result_dev, 16, hipMemcpyDeviceToHost, stream));
     trace.mark("submit");
-    CG_HIP(hipStreamSynchronize(stream));
-    trace.mark("sync");
-    if ((res[3] & 1u) || res[0] > capacity) {
-        fell_back = true; // FF run beyond the kernels' bound, or far more markers than announced
+    if (before_submit) {
+        // (the result words are fetched behind the decode kernel: fetch_deferred_result)
+        // the per-wave span is unknown: size the window generously from the largest possible average
+        const uint64_t most_words = (uint64_t(len) + 3u * uint64_t(expected)) / 4u + 1u;
+        const uint64_t avg = expected ? (most_words + expected - 1) / expected : most_words;
+        span = uint32_t(std::min<uint64_t>(2 * avg * kWave + 64, 0x7fffffffu));
+        nwords = nstarts = 0; // patched into the descriptor on the device
+        deferred_check = true;
         return Status{};
     }
+    CG_HIP(hipStreamSynchronize(stream));
+    trace.mark("sync");
+    CG_TRY(check_scan_result(fell_back));
+    if (fell_back)
+        return Status{};
     nwords = res[2];
     nstarts = std::min(res[0], slots);
-    dev_words = da + o_w;
-    dev_starts = da + o_st;
     // the per-wave span is not read back: size the window generously from the average
     const uint64_t avg = expected ? (uint64_t(nwords) + expected - 1) / expected : nwords;
     span = uint32_t(std::min<uint64_t>(2 * avg * kWave + 64, 0x7fffffffu));
-    if (res[0] != expected) {
+    return Status{};
+}
+
+// Reads the scan kernels' result words (in pinned memory, complete once the stream has passed
+// the copy): hand the image back to the host preprocessor, or note a count mismatch.
+Status compeg_decoder::check_scan_result(bool &fell_back)
+{
+    const uint32_t *res = static_cast<const uint32_t *>(scan_result.ptr);
+    fell_back = (res[3] & 1u) || res[0] > deferred_capacity; // FF run beyond the kernels' bound, or far
+                                                              // more markers than announced
+    if (!fell_back && res[0] != deferred_expected) {
         char msg[128];
-        snprintf(msg, sizeof msg, "restart interval count mismatch: counted %u, expected %u", res[0], expected);
+        snprintf(msg, sizeof msg, "restart interval count mismatch: counted %u, expected %u", res[0],
+                 deferred_expected);
         warning = msg; // the reference drops this error (lib.rs:391-394)
     }
     return Status{};
 }
 
+// Second half of a decode whose scan was preprocessed without a read-back: the stream has
+// finished; if the scan kernels gave the image up, decode it again through the host preprocessor.
+Status compeg_decoder::finish_deferred(const ImageData &img, hipStream_t stream)
+{
+    if (!deferred_check)
+        return Status{};
+    deferred_check = false;
+    bool fell_back = false;
+    CG_TRY(check_scan_result(fell_back));
+    if (!fell_back)
+        return Status{};
+    const bool keep = device_preprocess;
+    device_preprocess = false;
+    Status st = enqueue(img, stream, nullptr, false);
+    device_preprocess = keep;
+    CG_TRY(st);
+    CG_HIP(hipStreamSynchronize(stream));
+    return Status{};
+}
+
 // Counterpart of Decoder::enqueue (src/lib.rs:385-477).
-Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *changed)
+Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *changed, bool may_defer)
 {
     EnqueueTrace trace;
     CG_HIP(hipSetDevice(gpu->device));
@@ -323,12 +390,63 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     }
 
     const Metadata &md = img.metadata;
+    deferred_check = false;
+    const uint32_t total_dus = img.total_dus();
+    const size_t blob_bytes = align_up(sizeof(ImageDesc), 256) + table_blob_bytes(img);
+    CG_TRY(host_blob.reserve(blob_bytes));
+    CG_TRY(dev_blob.reserve(blob_bytes));
+    CG_TRY(ac.reserve(size_t(total_dus) * kRetained * 2 + 64));
+    CG_TRY(dc.reserve(size_t(total_dus) * 4 + 64));
+    uint8_t *hb = static_cast<uint8_t *>(host_blob.ptr);
+    uint8_t *db = static_cast<uint8_t *>(dev_blob.ptr);
+    const size_t l1_off = align_up(sizeof(ImageDesc), 256), l2_off = l1_off + COMPEG_HUFFMAN_L1_BYTES;
+
+    // image descriptor + LUTs into the staging blob at hb, as they will sit at db
+    auto write_blob = [&](const void *words_ptr, const void *starts_ptr, size_t n_words, size_t n_starts) {
+        ImageDesc &d = *reinterpret_cast<ImageDesc *>(hb);
+        fill_desc(img, d);
+        d.words = static_cast<const uint32_t *>(words_ptr);
+        d.starts = static_cast<const uint32_t *>(starts_ptr);
+        d.nwords = uint32_t(n_words);
+        d.nstarts = uint32_t(n_starts);
+        d.l1 = reinterpret_cast<const uint16_t *>(db + l1_off);
+        d.l2 = reinterpret_cast<const uint16_t *>(db + l2_off);
+        d.ac = static_cast<int16_t *>(ac.ptr);
+        d.dc = static_cast<int32_t *>(dc.ptr);
+        d.out = static_cast<uint8_t *>(out.ptr);
+        d.out_w = out_w;
+        d.out_h = out_h;
+        d.out_pitch = uint32_t(out_pitch);
+        write_tables(hb + l1_off, img);
+    };
+
     uint32_t dev_nwords = 0, dev_nstarts = 0, dev_span = 0;
     bool on_device = device_preprocess && use_fused_pipeline();
+    bool blob_uploaded = false;
     if (on_device) {
         bool fell_back = false;
-        CG_TRY(preprocess_on_device(img, stream, dev_nwords, dev_nstarts, dev_span, fell_back));
+        BlobWriter before_submit;
+        if (may_defer)
+            before_submit = [&](uint8_t *host_at, uint8_t *dev_at, uint32_t **patch_nwords,
+                                uint32_t **patch_nstarts) -> Status {
+                // the blob rides in front of the raw segment; the scan kernels fill in the two counts
+                // behind that copy, in stream order
+                hb = host_at;
+                db = dev_at;
+                *patch_nwords = reinterpret_cast<uint32_t *>(db + offsetof(ImageDesc, nwords));
+                *patch_nstarts = reinterpret_cast<uint32_t *>(db + offsetof(ImageDesc, nstarts));
+                blob_uploaded = true;
+                write_blob(dev_words, dev_starts, 0, 0);
+                return Status{};
+            };
+        CG_TRY(preprocess_on_device(img, stream, dev_nwords, dev_nstarts, dev_span, fell_back, blob_bytes,
+                                    before_submit));
         on_device = !fell_back;
+        if (fell_back) { // (reported before anything was written)
+            blob_uploaded = false;
+            hb = static_cast<uint8_t *>(host_blob.ptr);
+            db = static_cast<uint8_t *>(dev_blob.ptr);
+        }
     }
     if (!on_device) {
         Status pre = scan.process(img.scan_data(), img.scan_len, md.total_restart_intervals);
@@ -341,39 +459,15 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     trace.mark(on_device ? "device_preprocess" : "host_preprocess");
     const size_t n_words = on_device ? dev_nwords : scan.nwords();
     const size_t n_starts = on_device ? dev_nstarts : scan.nstarts();
-
-    const uint32_t total_dus = img.total_dus();
-    const size_t blob_bytes = align_up(sizeof(ImageDesc), 256) + table_blob_bytes(img);
-    CG_TRY(host_blob.reserve(blob_bytes));
-    CG_TRY(dev_blob.reserve(blob_bytes));
     if (!on_device) {
         CG_TRY(words.reserve(n_words * 4 + 16));
         CG_TRY(starts.reserve(n_starts * 4 + 16));
     }
-    CG_TRY(ac.reserve(size_t(total_dus) * kRetained * 2 + 64));
-    CG_TRY(dc.reserve(size_t(total_dus) * 4 + 64));
-
-    uint8_t *hb = static_cast<uint8_t *>(host_blob.ptr);
-    uint8_t *db = static_cast<uint8_t *>(dev_blob.ptr);
-    const size_t l1_off = align_up(sizeof(ImageDesc), 256), l2_off = l1_off + COMPEG_HUFFMAN_L1_BYTES;
-    ImageDesc &d = *reinterpret_cast<ImageDesc *>(hb);
-    fill_desc(img, d);
-    d.words = static_cast<const uint32_t *>(on_device ? dev_words : words.ptr);
-    d.starts = static_cast<const uint32_t *>(on_device ? dev_starts : starts.ptr);
-    d.nwords = uint32_t(n_words);
-    d.nstarts = uint32_t(n_starts);
-    d.l1 = reinterpret_cast<const uint16_t *>(db + l1_off);
-    d.l2 = reinterpret_cast<const uint16_t *>(db + l2_off);
-    d.ac = static_cast<int16_t *>(ac.ptr);
-    d.dc = static_cast<int32_t *>(dc.ptr);
-    d.out = static_cast<uint8_t *>(out.ptr);
-    d.out_w = out_w;
-    d.out_h = out_h;
-    d.out_pitch = uint32_t(out_pitch);
-    write_tables(hb + l1_off, img);
+    if (!blob_uploaded) {
+        write_blob(on_device ? dev_words : words.ptr, on_device ? dev_starts : starts.ptr, n_words, n_starts);
+        CG_HIP(hipMemcpyAsync(db, hb, blob_bytes, hipMemcpyHostToDevice, stream));
+    }
     trace.mark("tables");
-
-    CG_HIP(hipMemcpyAsync(db, hb, blob_bytes, hipMemcpyHostToDevice, stream));
     if (!on_device && n_starts)
         CG_HIP(hipMemcpyAsync(starts.ptr, scan.starts(), n_starts * 4, hipMemcpyHostToDevice, stream));
     if (!on_device && n_words)
@@ -382,11 +476,15 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     upload_pending = true;
     last_stream = stream;
     last_md = md;
+    last_desc_dev = db;
     have_last = true;
     trace.mark("copies");
 
-    if (total_dus == 0)
+    if (total_dus == 0) {
+        if (deferred_check)
+            CG_HIP(hipMemcpyAsync(scan_result.ptr, scan_result_dev, 16, hipMemcpyDeviceToHost, stream));
         return Status{};
+    }
     const uint32_t span = on_device ? dev_span
                                     : max_wave_span(scan.starts(), scan.nstarts(), scan.nwords(),
                                                     md.total_restart_intervals);
@@ -404,7 +502,10 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
         CG_HIP(launch_generic_composite(reinterpret_cast<const ImageDesc *>(db), 1, out_w, out_h, stream));
         coefficients_valid = false;
     } else if (fused) {
-        if (use_pair_kernel(md.total_restart_intervals, 1))
+        if (use_pair_kernel(md.total_restart_intervals, 1) && use_team_kernel())
+            CG_HIP(launch_team_422(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals,
+                                   md.restart_interval, plan, stream));
+        else if (use_pair_kernel(md.total_restart_intervals, 1))
             CG_HIP(launch_pair_422(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals,
                                    plan, stream));
         else
@@ -417,6 +518,8 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
         CG_HIP(launch_idct_composite(reinterpret_cast<const ImageDesc *>(db), 1, total_dus, stream));
         coefficients_valid = true;
     }
+    if (deferred_check) // behind the decode kernel: no copy engine between the scan kernels and it
+        CG_HIP(hipMemcpyAsync(scan_result.ptr, scan_result_dev, 16, hipMemcpyDeviceToHost, stream));
     trace.mark("launch");
     return Status{};
 }
@@ -803,7 +906,9 @@ Status compeg_batch::decode(hipStream_t stream)
             continue;
         }
         if (fused) {
-            if (use_pair_kernel(max_intervals, m))
+            if (use_pair_kernel(max_intervals, m) && use_team_kernel())
+                CG_HIP(launch_team_422(dd + at, m, max_intervals, 0xffffffffu, plan, stream));
+            else if (use_pair_kernel(max_intervals, m))
                 CG_HIP(launch_pair_422(dd + at, m, max_intervals, plan, stream));
             else
                 CG_HIP(launch_fused_422(dd + at, m, max_intervals, plan, stream));

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <atomic>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -90,9 +91,25 @@ struct compeg_decoder {
 
     compeg_decoder();
     ~compeg_decoder();
-    compeg::Status enqueue(const compeg::ImageData &img, hipStream_t stream, bool *changed);
+    // device preprocessing without a read-back in the middle (decode_blocking): the scan kernels'
+    // result words land here, to be looked at by finish_deferred once the stream is done
+    compeg::PinnedBuffer scan_result;
+    const void *scan_result_dev = nullptr;
+    const void *last_desc_dev = nullptr; // the last decode's image descriptor (dev_blob, or inside scan_arena)
+    bool deferred_check = false;
+    // writes the image's blob (descriptor + LUTs) at host_at as it will sit at dev_at, and says where
+    // the scan kernels should drop nwords / nstarts
+    using BlobWriter = std::function<compeg::Status(uint8_t *host_at, uint8_t *dev_at, uint32_t **patch_nwords,
+                                                    uint32_t **patch_nstarts)>;
+    uint32_t deferred_capacity = 0, deferred_expected = 0;
+
+    // may_defer: the caller will wait for the stream and then call finish_deferred(img)
+    compeg::Status enqueue(const compeg::ImageData &img, hipStream_t stream, bool *changed, bool may_defer = false);
+    compeg::Status finish_deferred(const compeg::ImageData &img, hipStream_t stream);
+    compeg::Status check_scan_result(bool &fell_back);
     compeg::Status preprocess_on_device(const compeg::ImageData &img, hipStream_t stream, uint32_t &nwords,
-                                        uint32_t &nstarts, uint32_t &span, bool &fell_back);
+                                        uint32_t &nstarts, uint32_t &span, bool &fell_back, size_t blob_bytes,
+                                        const BlobWriter &before_submit);
 };
 
 struct compeg_batch {

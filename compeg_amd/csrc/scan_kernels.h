@@ -23,6 +23,10 @@ struct ScanDesc {
     uint32_t *starts_out;    // [slots] the reference's start_positions
     uint8_t *words_out;      // preprocessed scan, (len + len/3 + 4) bytes
     uint32_t *result;        // [4]: intervals counted, kept bytes, output words, flags (bit 0: FF run too long)
+    // optional: where to drop the output word count and the number of start positions kept
+    // (the nwords / nstarts fields of the image descriptor a following decode kernel reads)
+    uint32_t *patch_nwords = nullptr;
+    uint32_t *patch_nstarts = nullptr;
 };
 
 uint32_t scan_tiles(uint32_t len);

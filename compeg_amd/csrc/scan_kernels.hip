@@ -283,6 +283,10 @@ __global__ void __launch_bounds__(kIvThreads) interval_scan_kernel(const ScanDes
     }
     if (t == 0) {
         d.result[2] = carry; // total output words
+        if (d.patch_nwords)
+            *d.patch_nwords = carry;
+        if (d.patch_nstarts)
+            *d.patch_nstarts = min(count, d.slots);
         // entry 0 keeps its initial 0 unless a wrapped index (m = k * slots) hit it above
         if (count <= d.slots)
             d.starts_out[0] = 0u;

@@ -121,3 +121,24 @@ def test_decoder_with_device_preprocess(ca, gpu):
     dec.decode_blocking(ca.ImageData(bytes(j)))
     assert dec.last_warning().startswith("restart interval count mismatch: counted")
     assert np.array_equal(dec.read_texture(128, 32), orc.ImageData(bytes(j)).decode())
+
+
+def test_decoder_device_preprocess_hands_pathological_scans_to_the_host(ca, gpu):
+    """decode_blocking runs the scan kernels without a read-back in the middle and looks at their verdict after
+    the decode: a scan they give up on (an FF run beyond their look-back bound) is decoded again through the
+    host preprocessor, and the next ordinary image takes the device path again."""
+    j = synth.make_jpeg(256, 64, seed=3, ri=2)
+    sd = orc.ImageData(j).scan_data()
+    o = j.find(sd[:16])
+    half = len(sd) // 2
+    bad = j[:o] + sd[:half] + b"\xff" * 70001 + b"\x00" + sd[half:] + j[o + len(sd):]
+    dec = ca.Decoder(gpu)
+    dec.set_device_preprocess(True)
+    for jpeg in (j, bad, j, bad):
+        dec.decode_blocking(ca.ImageData(jpeg))
+        assert np.array_equal(dec.read_texture(256, 64), orc.ImageData(jpeg).decode())
+    # the non-blocking entry point keeps the read-back in the middle: same results
+    for jpeg in (bad, j):
+        op = dec.start_decode(ca.ImageData(jpeg))
+        op.wait()
+        assert np.array_equal(dec.read_texture(256, 64), orc.ImageData(jpeg).decode())

@@ -32,6 +32,13 @@ def main():
         t_wait.sort()
         print(f"device_preprocess={mode}: start_decode median {t_start[10]*1e6:.0f} us, wait median {t_wait[10]*1e6:.0f} us, "
               f"total {1e6*(t_start[10]+t_wait[10]):.0f} us; scan bytes {img.scan_range()[1]}", flush=True)
+        tb = []
+        for _ in range(20):
+            t0 = time.perf_counter()
+            dec.decode_blocking(img)
+            tb.append(time.perf_counter() - t0)
+        tb.sort()
+        print(f"  decode_blocking median {tb[10]*1e6:.0f} us, best {tb[0]*1e6:.0f} us", flush=True)
         sb = compeg_amd.ScanBuffer()
         o, n = img.scan_range()
         import numpy as np
