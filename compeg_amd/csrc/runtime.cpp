@@ -238,7 +238,7 @@ Status compeg_decoder::preprocess_on_device(const ImageData &img, hipStream_t st
     uint32_t slots = 1;
     while (slots < expected)
         slots <<= 1;
-    const uint32_t ntiles = scan_tiles(len), capacity = 2 * expected + 64;
+    const uint32_t ntiles = scan_tiles(len);
     size_t total = 64;
     auto take = [&](size_t bytes) {
         const size_t at = total;
@@ -248,9 +248,7 @@ Status compeg_decoder::preprocess_on_device(const ImageData &img, hipStream_t st
     // everything the host writes sits in front of the raw bytes and travels with their first piece: the
     // zeroed result words (first 16 bytes), the scan descriptor and, for a deferred decode, the image's blob
     const size_t o_res = 0, o_desc = take(sizeof(ScanDesc)), o_blob = take(before_submit ? blob_bytes : 0),
-                 o_raw = take(size_t(len) + 64),
-                 o_tk = take(size_t(ntiles) * 4 + 4), o_tm = take(size_t(ntiles) * 4 + 4),
-                 o_mp = take(size_t(capacity) * 4), o_is = take(size_t(capacity) * 4),
+                 o_raw = take(size_t(len) + 64), o_ts = take(size_t(ntiles) * kScanTileStateBytes + 32),
                  o_st = take(size_t(slots) * 4), o_w = take(size_t(len) + len / 3 + 64);
     CG_TRY(scan_arena.reserve(total));
     CG_TRY(raw_stage.reserve(o_raw + len + 64));
@@ -260,11 +258,7 @@ Status compeg_decoder::preprocess_on_device(const ImageData &img, hipStream_t st
     s.len = len;
     s.ntiles = ntiles;
     s.slots = slots;
-    s.marker_capacity = capacity;
-    s.tile_kept = reinterpret_cast<uint32_t *>(da + o_tk);
-    s.tile_markers = reinterpret_cast<uint32_t *>(da + o_tm);
-    s.marker_pos = reinterpret_cast<uint32_t *>(da + o_mp);
-    s.interval_start = reinterpret_cast<uint32_t *>(da + o_is);
+    s.tile_state = reinterpret_cast<uint32_t *>(da + o_ts);
     s.starts_out = reinterpret_cast<uint32_t *>(da + o_st);
     s.words_out = da + o_w;
     s.result = reinterpret_cast<uint32_t *>(da + o_res);
@@ -291,7 +285,6 @@ Status compeg_decoder::preprocess_on_device(const ImageData &img, hipStream_t st
     CG_TRY(scan_result.reserve(16));
     uint32_t *res = static_cast<uint32_t *>(scan_result.ptr);
     scan_result_dev = da + o_res;
-    deferred_capacity = capacity;
     deferred_expected = expected;
     if (!before_submit)
         CG_HIP(hipMemcpyAsync(res, scan_result_dev, 16, hipMemcpyDeviceToHost, stream));
@@ -324,8 +317,7 @@ Status compeg_decoder::preprocess_on_device(const ImageData &img, hipStream_t st
 Status compeg_decoder::check_scan_result(bool &fell_back)
 {
     const uint32_t *res = static_cast<const uint32_t *>(scan_result.ptr);
-    fell_back = (res[3] & 1u) || res[0] > deferred_capacity; // FF run beyond the kernels' bound, or far
-                                                              // more markers than announced
+    fell_back = (res[3] & 1u) != 0u; // an FF run beyond the kernels' look-back bound
     if (!fell_back && res[0] != deferred_expected) {
         char msg[128];
         snprintf(msg, sizeof msg, "restart interval count mismatch: counted %u, expected %u", res[0],
@@ -536,7 +528,6 @@ Status compeg::ScanBuffer::process_on_gpu(compeg_gpu *gpu, const uint8_t *scan, 
     while (slots < expected)
         slots <<= 1;
     const uint32_t ntiles = scan_tiles(uint32_t(len));
-    const uint32_t capacity = uint32_t(std::min<size_t>(len / 2 + 2, 0x3fffffffu)); // every possible marker
     DeviceBuffer arena, descbuf;
     size_t total = 64;
     auto take = [&](size_t bytes) {
@@ -544,8 +535,7 @@ Status compeg::ScanBuffer::process_on_gpu(compeg_gpu *gpu, const uint8_t *scan, 
         total += align_up(bytes, 256);
         return at;
     };
-    const size_t o_raw = take(len + 64), o_tk = take(size_t(ntiles) * 4 + 4), o_tm = take(size_t(ntiles) * 4 + 4),
-                 o_mp = take(size_t(capacity) * 4), o_is = take(size_t(capacity) * 4),
+    const size_t o_raw = take(len + 64), o_ts = take(size_t(ntiles) * kScanTileStateBytes + 32),
                  o_st = take(size_t(slots) * 4), o_w = take(len + len / 3 + 64), o_res = take(16);
     CG_TRY(arena.reserve(total));
     CG_TRY(descbuf.reserve(sizeof(ScanDesc)));
@@ -558,11 +548,7 @@ Status compeg::ScanBuffer::process_on_gpu(compeg_gpu *gpu, const uint8_t *scan, 
     s.len = uint32_t(len);
     s.ntiles = ntiles;
     s.slots = slots;
-    s.marker_capacity = capacity;
-    s.tile_kept = reinterpret_cast<uint32_t *>(da + o_tk);
-    s.tile_markers = reinterpret_cast<uint32_t *>(da + o_tm);
-    s.marker_pos = reinterpret_cast<uint32_t *>(da + o_mp);
-    s.interval_start = reinterpret_cast<uint32_t *>(da + o_is);
+    s.tile_state = reinterpret_cast<uint32_t *>(da + o_ts);
     s.starts_out = reinterpret_cast<uint32_t *>(da + o_st);
     s.words_out = da + o_w;
     s.result = reinterpret_cast<uint32_t *>(da + o_res);
@@ -736,8 +722,8 @@ Status compeg_batch::upload_device_scan(const ImageData *const *images, size_t n
         return Status::error(COMPEG_E_INVALID_ARG, "at most 65535 images per batch");
 
     struct Layout {
-        size_t raw, tile_kept, tile_markers, marker_pos, interval_start, starts, words, result, tables;
-        uint32_t ntiles, slots, capacity;
+        size_t raw, tile_state, starts, words, result, tables;
+        uint32_t ntiles, slots;
     };
     std::vector<Layout> lay(n);
     size_t total = 0, out_total = 0;
@@ -759,13 +745,9 @@ Status compeg_batch::upload_device_scan(const ImageData *const *images, size_t n
         L.slots = 1;
         while (L.slots < expected)
             L.slots <<= 1;
-        L.capacity = 2 * expected + 64;
         total += 64; // readable bytes in front of the segment
         L.raw = take(size_t(len) + 64);
-        L.tile_kept = take(size_t(L.ntiles) * 4 + 4);
-        L.tile_markers = take(size_t(L.ntiles) * 4 + 4);
-        L.marker_pos = take(size_t(L.capacity) * 4);
-        L.interval_start = take(size_t(L.capacity) * 4);
+        L.tile_state = take(size_t(L.ntiles) * kScanTileStateBytes + 32);
         L.starts = take(size_t(L.slots) * 4);
         L.words = take(size_t(len) + len / 3 + 64);
         L.result = take(16);
@@ -798,11 +780,7 @@ Status compeg_batch::upload_device_scan(const ImageData *const *images, size_t n
         s.len = uint32_t(img.scan_len);
         s.ntiles = L.ntiles;
         s.slots = L.slots;
-        s.marker_capacity = L.capacity;
-        s.tile_kept = reinterpret_cast<uint32_t *>(da + L.tile_kept);
-        s.tile_markers = reinterpret_cast<uint32_t *>(da + L.tile_markers);
-        s.marker_pos = reinterpret_cast<uint32_t *>(da + L.marker_pos);
-        s.interval_start = reinterpret_cast<uint32_t *>(da + L.interval_start);
+        s.tile_state = reinterpret_cast<uint32_t *>(da + L.tile_state);
         s.starts_out = reinterpret_cast<uint32_t *>(da + L.starts);
         s.words_out = da + L.words;
         s.result = reinterpret_cast<uint32_t *>(da + L.result);
@@ -827,9 +805,8 @@ Status compeg_batch::upload_device_scan(const ImageData *const *images, size_t n
         uint32_t nwords = res[2], nstarts = std::min(res[0], L.slots);
         const uint32_t expected = img.metadata.total_restart_intervals;
         starts_host.resize(L.slots);
-        if ((res[3] & 1u) || res[0] > L.capacity) {
-            // pathological FF run or far more markers than announced: the host
-            // preprocessor (same output format) takes this image
+        if (res[3] & 1u) {
+            // pathological FF run: the host preprocessor (same output format) takes this image
             ScanBuffer sb;
             Status s = sb.process(img.scan_data(), img.scan_len, expected);
             if (!s.ok() && s.code != COMPEG_E_COUNT_MISMATCH)

@@ -101,7 +101,7 @@ struct compeg_decoder {
     // the scan kernels should drop nwords / nstarts
     using BlobWriter = std::function<compeg::Status(uint8_t *host_at, uint8_t *dev_at, uint32_t **patch_nwords,
                                                     uint32_t **patch_nstarts)>;
-    uint32_t deferred_capacity = 0, deferred_expected = 0;
+    uint32_t deferred_expected = 0;
 
     // may_defer: the caller will wait for the stream and then call finish_deferred(img)
     compeg::Status enqueue(const compeg::ImageData &img, hipStream_t stream, bool *changed, bool may_defer = false);

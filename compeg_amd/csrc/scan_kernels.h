@@ -15,11 +15,7 @@ struct ScanDesc {
     uint32_t len;
     uint32_t ntiles;         // ceil(len / 4096)
     uint32_t slots;          // next_power_of_two(expected intervals), >= 1
-    uint32_t marker_capacity; // entries of marker_pos / interval_start
-    uint32_t *tile_kept;     // [ntiles] scratch
-    uint32_t *tile_markers;  // [ntiles] scratch
-    uint32_t *marker_pos;    // [marker_capacity] kept bytes in front of marker m (P[0] = 0)
-    uint32_t *interval_start; // [marker_capacity] start word of interval m
+    uint32_t *tile_state;    // [ntiles] x 20 bytes of scratch (kScanTileStateBytes each)
     uint32_t *starts_out;    // [slots] the reference's start_positions
     uint8_t *words_out;      // preprocessed scan, (len + len/3 + 4) bytes
     uint32_t *result;        // [4]: intervals counted, kept bytes, output words, flags (bit 0: FF run too long)
@@ -29,6 +25,7 @@ struct ScanDesc {
     uint32_t *patch_nstarts = nullptr;
 };
 
+constexpr size_t kScanTileStateBytes = 20;
 uint32_t scan_tiles(uint32_t len);
 hipError_t launch_scan(const ScanDesc *descs, uint32_t images, uint32_t max_tiles, hipStream_t stream);
 

@@ -10,11 +10,13 @@
 // length r of the run of FF bytes in front of it (a byte is the second half of
 // an FF xx pair iff r is odd), so all bytes are classified independently:
 //
-//   count_kernel   per 4 KiB tile: kept bytes and markers              (grid: tiles x images)
-//   tile_scan      exclusive prefix over an image's tiles              (one block per image)
-//   marker_kernel  P[m] = number of kept bytes in front of marker m
-//   interval_scan  start word of interval m = sum of ceil(len_j / 4)   (one block per image)
-//   emit_kernel    every kept byte to 4*start[m] + (p - P[m]); padding zeroed
+//   count_kernel   per 4 KiB tile: what it contributes to the layout    (grid: tiles x images)
+//   tile_scan      the same for everything in front of each tile        (one block per image)
+//   emit_kernel    every kept byte to its place; padding zeroed; start positions
+//
+// The layout (which interval a byte belongs to, where that interval starts in
+// the word-aligned output) composes associatively from left to right -- see
+// `Stretch` -- so three launches do: no per-marker arrays, no pass over them.
 //
 // Integer / byte work, HBM-bound (a few bytes of traffic per input byte).
 #include <hip/hip_runtime.h>
@@ -120,30 +122,111 @@ __device__ __forceinline__ void load_classify(const ScanDesc &d, uint32_t g, Chu
     c.marker = lead & ~next_zero & has_next & valid;
 }
 
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *lds, uint32_t &total)
+// ---- the scan's algebra -------------------------------------------------------
+//
+// What a stretch of the segment contributes to the output layout, in a form
+// that composes left to right (associative, not commutative), so that tiles
+// and threads can be summarised independently and then scanned:
+//   markers  restart markers inside the stretch
+//   head     kept bytes in front of its first marker (all of them if it has none)
+//   words    output words of the intervals that begin and end inside it
+//   tail     kept bytes behind its last marker (all of them if it has none)
+//   kept     kept bytes in all
+struct Stretch {
+    uint32_t markers, head, words, tail, kept;
+};
+
+static_assert(sizeof(Stretch) == kScanTileStateBytes, "tile_state stride");
+
+__device__ __forceinline__ Stretch stretch_none() { return Stretch{0u, 0u, 0u, 0u, 0u}; }
+
+__device__ __forceinline__ Stretch join(const Stretch &l, const Stretch &r)
 {
-    // 256 threads: wave-level shuffles, then 4 wave totals through LDS
+    Stretch o;
+    o.kept = l.kept + r.kept;
+    o.markers = l.markers + r.markers;
+    const bool lm = l.markers != 0u, rm = r.markers != 0u;
+    o.head = lm ? l.head : l.head + r.head;
+    o.tail = rm ? r.tail : l.tail + r.tail;
+    // the interval that straddles the seam is complete only with markers on both sides
+    o.words = l.words + r.words + ((lm && rm) ? (l.tail + r.head + 3u) / 4u : 0u);
+    return o;
+}
+
+__device__ __forceinline__ Stretch stretch_shfl_up(const Stretch &x, uint32_t o)
+{
+    return Stretch{__shfl_up(x.markers, o), __shfl_up(x.head, o), __shfl_up(x.words, o), __shfl_up(x.tail, o),
+                   __shfl_up(x.kept, o)};
+}
+
+// Where the output stands in front of a stretch, given everything before it:
+// the open interval's index, its start word and how many bytes it holds so far.
+struct Cursor {
+    uint32_t interval, start_word, bytes;
+};
+
+__device__ __forceinline__ Cursor cursor_behind(const Stretch &before)
+{
+    if (before.markers == 0u)
+        return Cursor{0u, 0u, before.kept};
+    return Cursor{before.markers, (before.head + 3u) / 4u + before.words, before.tail};
+}
+
+// A thread's 16 classified bytes as a stretch.
+__device__ __forceinline__ Stretch stretch_of(const Chunk &c)
+{
+    Stretch s;
+    s.kept = __popc(c.kept);
+    s.markers = __popc(c.marker);
+    s.words = 0u;
+    if (s.markers == 0u) {
+        s.head = s.tail = s.kept;
+        return s;
+    }
+    const uint32_t first = uint32_t(__ffs(int(c.marker))) - 1u, last = 31u - uint32_t(__clz(int(c.marker)));
+    s.head = __popc(c.kept & ((1u << first) - 1u));
+    s.tail = __popc(c.kept & ~((2u << last) - 1u));
+    uint32_t prev = first;
+    for (uint32_t mk = c.marker & (c.marker - 1u); mk; mk &= mk - 1u) { // more than one marker: rare
+        const uint32_t i = uint32_t(__ffs(int(mk))) - 1u;
+        s.words += (__popc(c.kept & ((1u << i) - 1u) & ~((2u << prev) - 1u)) + 3u) / 4u;
+        prev = i;
+    }
+    return s;
+}
+
+// Exclusive scan of the block's 256 stretches (thread order); `total` = all of them.
+__device__ __forceinline__ Stretch block_exclusive_scan(const Stretch &mine, Stretch *lds, Stretch &total)
+{
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t x = v;
+    Stretch x = mine;
     for (uint32_t o = 1; o < 64; o <<= 1) {
-        const uint32_t y = __shfl_up(x, o);
+        const Stretch y = stretch_shfl_up(x, o);
         if (lane >= o)
-            x += y;
+            x = join(y, x);
     }
     if (lane == 63)
         lds[wave] = x;
     __syncthreads();
-    uint32_t base = 0;
-    for (uint32_t w = 0; w < wave; w++)
-        base += lds[w];
-    total = lds[0] + lds[1] + lds[2] + lds[3];
+    Stretch before = stretch_none();
+    total = stretch_none();
+    for (uint32_t w = 0; w < kThreads / 64u; w++) {
+        const Stretch t = lds[w];
+        if (w < wave)
+            before = join(before, t);
+        total = join(total, t);
+    }
     __syncthreads();
-    return base + x - v;
+    Stretch prev = stretch_shfl_up(x, 1);
+    if (lane == 0)
+        prev = stretch_none();
+    return join(before, prev);
 }
 
+// per tile: its stretch
 __global__ void __launch_bounds__(kThreads) count_kernel(const ScanDesc *descs)
 {
-    __shared__ uint32_t lds[4];
+    __shared__ Stretch lds[kThreads / 64u];
     const ScanDesc &d = descs[blockIdx.y];
     const uint32_t tile = blockIdx.x;
     if (tile >= d.ntiles)
@@ -151,145 +234,44 @@ __global__ void __launch_bounds__(kThreads) count_kernel(const ScanDesc *descs)
     const uint32_t g = tile * kTileBytes + threadIdx.x * kBytesPerThread;
     Chunk c;
     load_classify(d, g, c);
-    const uint32_t kept = __popc(c.kept), markers = __popc(c.marker);
-    uint32_t tk, tm;
-    block_exclusive_scan(kept, lds, tk);
-    block_exclusive_scan(markers, lds, tm);
-    if (threadIdx.x == 0) {
-        d.tile_kept[tile] = tk;
-        d.tile_markers[tile] = tm;
-    }
+    Stretch total;
+    block_exclusive_scan(stretch_of(c), lds, total);
+    if (threadIdx.x == 0)
+        reinterpret_cast<Stretch *>(d.tile_state)[tile] = total;
 }
 
-// One block per image: exclusive prefix over the image's tiles (in place) and
-// the totals.  result[0] = number of intervals counted (markers + 1),
-// result[1] = kept bytes.
+// One block per image: every tile's stretch is replaced by the stretch of all
+// tiles in front of it.  result[0] = number of intervals counted (markers + 1),
+// result[1] = kept bytes, result[2] = output words.
 __global__ void __launch_bounds__(kThreads) tile_scan_kernel(const ScanDesc *descs)
 {
-    __shared__ uint32_t lds[4];
+    __shared__ Stretch lds[kThreads / 64u];
     const ScanDesc &d = descs[blockIdx.x];
-    uint32_t carry_k = 0, carry_m = 0;
+    Stretch *tiles = reinterpret_cast<Stretch *>(d.tile_state);
+    Stretch carry = stretch_none();
     for (uint32_t base = 0; base < d.ntiles; base += kThreads) {
         const uint32_t i = base + threadIdx.x;
-        const uint32_t k = i < d.ntiles ? d.tile_kept[i] : 0u, m = i < d.ntiles ? d.tile_markers[i] : 0u;
-        uint32_t tk, tm;
-        const uint32_t ek = block_exclusive_scan(k, lds, tk), em = block_exclusive_scan(m, lds, tm);
-        if (i < d.ntiles) {
-            d.tile_kept[i] = carry_k + ek;
-            d.tile_markers[i] = carry_m + em;
-        }
-        carry_k += tk;
-        carry_m += tm;
+        const Stretch mine = i < d.ntiles ? tiles[i] : stretch_none();
+        Stretch total;
+        const Stretch before = block_exclusive_scan(mine, lds, total);
+        if (i < d.ntiles)
+            tiles[i] = join(carry, before);
+        carry = join(carry, total);
     }
     if (threadIdx.x == 0) {
-        d.result[0] = carry_m + 1u;
-        d.result[1] = carry_k;
-        d.marker_pos[0] = 0u;
-    }
-}
-
-// P[m] for every marker: kept bytes in front of it (m counts from 1).
-__global__ void __launch_bounds__(kThreads) marker_kernel(const ScanDesc *descs)
-{
-    __shared__ uint32_t lds[4];
-    const ScanDesc &d = descs[blockIdx.y];
-    const uint32_t tile = blockIdx.x;
-    if (tile >= d.ntiles)
-        return;
-    const uint32_t g = tile * kTileBytes + threadIdx.x * kBytesPerThread;
-    Chunk c;
-    load_classify(d, g, c);
-    const uint32_t kept = __popc(c.kept), markers = __popc(c.marker);
-    uint32_t tk, tm;
-    uint32_t p = d.tile_kept[tile] + block_exclusive_scan(kept, lds, tk);
-    uint32_t m = d.tile_markers[tile] + block_exclusive_scan(markers, lds, tm) + 1u;
-    for (uint32_t mk = c.marker; mk; mk &= mk - 1u) { // markers are rare: visit only those
-        const uint32_t i = uint32_t(__ffs(int(mk))) - 1u;
-        if (m < d.marker_capacity)
-            d.marker_pos[m] = p + __popc(c.kept & ((1u << i) - 1u));
-        m++;
-    }
-}
-
-// One block per image: start word of every interval.  len_m = P[m+1] - P[m]
-// (P[count] = kept bytes); start_m = sum_{j<m} ceil(len_j / 4).  The reference
-// stores start m at index (m & mask) of a power-of-two array and keeps
-// min(count, slots) entries (src/scan.rs:46-56,111).
-//
-// A single 4K frame has 16 200 intervals and this block is all that runs, so
-// its latency is the point: 1024 threads, chunks of 8192 intervals; P[] comes
-// in with coalesced loads through LDS, every thread scans 8 consecutive
-// entries (index i lives at i + i / 8: conflict-free for that access), and the
-// starts leave through the same LDS array with coalesced stores.
-constexpr uint32_t kIvThreads = 1024, kIvPerThread = 8, kIvChunk = kIvThreads * kIvPerThread;
-
-__device__ __forceinline__ uint32_t iv_slot(uint32_t i) { return i + i / kIvPerThread; }
-
-__global__ void __launch_bounds__(kIvThreads) interval_scan_kernel(const ScanDesc *descs)
-{
-    __shared__ uint32_t pos[kIvChunk + kIvChunk / kIvPerThread + 2];
-    __shared__ uint32_t wave_total[kIvThreads / 64];
-    const ScanDesc &d = descs[blockIdx.x];
-    const uint32_t count = min(d.result[0], d.marker_capacity);
-    const uint32_t kept = d.result[1];
-    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    uint32_t carry = 0; // words in front of the chunk
-    for (uint32_t base = 0; base < count; base += kIvChunk) {
-        const uint32_t n = min(kIvChunk, count - base);
-        // P[base .. base + n], the entry behind the last interval being the kept total
-        for (uint32_t i = t; i <= n; i += kIvThreads)
-            pos[iv_slot(i)] = base + i < count ? d.marker_pos[base + i] : kept;
-        __syncthreads();
-        uint32_t p[kIvPerThread + 1];
-        const uint32_t first = t * kIvPerThread;
-        for (uint32_t k = 0; k <= kIvPerThread; k++)
-            p[k] = first + k <= n ? pos[iv_slot(first + k)] : 0u;
-        uint32_t mine = 0;
-        for (uint32_t k = 0; k < kIvPerThread; k++)
-            mine += first + k < n ? (p[k + 1] - p[k] + 3u) / 4u : 0u;
-        // block-wide exclusive scan of the per-thread totals
-        uint32_t x = mine;
-        for (uint32_t o = 1; o < 64; o <<= 1) {
-            const uint32_t y = __shfl_up(x, o);
-            if (lane >= o)
-                x += y;
-        }
-        if (lane == 63)
-            wave_total[wave] = x;
-        __syncthreads(); // also: every thread has read its pos[] entries
-        uint32_t before = 0, total = 0;
-        for (uint32_t w = 0; w < kIvThreads / 64; w++) {
-            const uint32_t v = wave_total[w];
-            before += w < wave ? v : 0u;
-            total += v;
-        }
-        uint32_t start = carry + before + x - mine;
-        for (uint32_t k = 0; k < kIvPerThread; k++) {
-            if (first + k < n) {
-                pos[iv_slot(first + k)] = start;
-                start += (p[k + 1] - p[k] + 3u) / 4u;
-            }
-        }
-        __syncthreads();
-        for (uint32_t i = t; i < n; i += kIvThreads) {
-            const uint32_t m = base + i, s = pos[iv_slot(i)];
-            d.interval_start[m] = s;
-            // the last writer of a slot wins in the reference's sequential loop
-            if (m + d.slots >= count && m != 0)
-                d.starts_out[m & (d.slots - 1u)] = s;
-        }
-        carry += total;
-        __syncthreads(); // pos[] and wave_total[] are reused by the next chunk
-    }
-    if (t == 0) {
-        d.result[2] = carry; // total output words
+        const uint32_t count = carry.markers + 1u;
+        const Cursor end = cursor_behind(carry);
+        const uint32_t words = end.start_word + (end.bytes + 3u) / 4u;
+        d.result[0] = count;
+        d.result[1] = carry.kept;
+        d.result[2] = words;
         if (d.patch_nwords)
-            *d.patch_nwords = carry;
+            *d.patch_nwords = words;
         if (d.patch_nstarts)
             *d.patch_nstarts = min(count, d.slots);
-        // entry 0 keeps its initial 0 unless a wrapped index (m = k * slots) hit it above
-        if (count <= d.slots)
-            d.starts_out[0] = 0u;
+        // entry 0 of the start positions keeps its initial 0 unless a wrapped index
+        // (m = k * slots) overwrites it in emit_kernel
+        d.starts_out[0] = 0u;
     }
 }
 
@@ -297,37 +279,39 @@ __global__ void __launch_bounds__(kIvThreads) interval_scan_kernel(const ScanDes
 // bytes behind each of its (at most 2048) markers.
 constexpr uint32_t kOutStageBytes = kTileBytes + 3u * (kTileBytes / 2u) + 32u;
 
+// Every kept byte to 4 * start_word + bytes of its interval's cursor; a marker
+// closes the interval (the gap up to the next word stays zero) and notes the
+// next one's start.  The reference stores start m at index (m & mask) of a
+// power-of-two array and keeps min(count, slots) entries, the last writer of a
+// slot winning (src/scan.rs:46-56,111): only the last `slots` markers write.
 __global__ void __launch_bounds__(kThreads) emit_kernel(const ScanDesc *descs)
 {
-    __shared__ uint32_t lds[4];
+    __shared__ Stretch lds[kThreads / 64u];
     __shared__ uint32_t span[2];
     __shared__ __attribute__((aligned(16))) uint8_t stage[kOutStageBytes];
     const ScanDesc &d = descs[blockIdx.y];
     const uint32_t tile = blockIdx.x;
     if (tile >= d.ntiles)
         return;
-    const uint32_t count = min(d.result[0], d.marker_capacity);
+    const uint32_t count = d.result[0];
     const uint32_t g = tile * kTileBytes + threadIdx.x * kBytesPerThread;
     Chunk c;
     load_classify(d, g, c);
-    const uint32_t kept = __popc(c.kept), markers = __popc(c.marker);
-    uint32_t tk, tm;
-    uint32_t p = d.tile_kept[tile] + block_exclusive_scan(kept, lds, tk);
-    uint32_t m = d.tile_markers[tile] + block_exclusive_scan(markers, lds, tm); // current interval
+    Stretch total;
+    const Stretch in_tile = block_exclusive_scan(stretch_of(c), lds, total);
+    Cursor at = cursor_behind(join(reinterpret_cast<const Stretch *>(d.tile_state)[tile], in_tile));
 
     // zero what this tile can touch: its kept bytes, 3 padding bytes per marker, alignment slack
-    const uint32_t zero_dwords = min((tk + 3u * tm + 11u) / 4u, kOutStageBytes / 4u);
+    const uint32_t zero_dwords = min((total.kept + 3u * total.markers + 11u) / 4u, kOutStageBytes / 4u);
     for (uint32_t i = threadIdx.x; i < zero_dwords; i += kThreads)
         reinterpret_cast<uint32_t *>(stage)[i] = 0u; // padding bytes are zeros
-    // absolute output offset of a kept byte: 4 * start[m] + (p - P[m])
-    uint32_t pm = m < count ? d.marker_pos[m] : 0u, sm = m < count ? d.interval_start[m] : 0u;
+    uint32_t end = at.start_word * 4u + at.bytes; // absolute output offset of the thread's next kept byte
     if (threadIdx.x == 0)
-        span[0] = sm * 4u + (p - pm); // where this tile's output begins
+        span[0] = end; // where this tile's output begins
     __syncthreads();
     const uint32_t lo = span[0];
     const uint32_t origin = lo & ~3u; // staging words line up with the output's words
-    uint32_t end = sm * 4u + (p - pm);
-    if (m < count && c.kept == 0xffffu) {
+    if (c.kept == 0xffffu) {
         // common case, 16 plain bytes: OR them into the (zeroed) staging words at
         // whatever byte alignment the output position has
         const uint32_t o = end - origin, sh = (o & 3u) * 8u;
@@ -342,19 +326,19 @@ __global__ void __launch_bounds__(kThreads) emit_kernel(const ScanDesc *descs)
             atomicOr(&dst[4], c.w[3] >> (32u - sh));
         }
         end += 16u;
-    } else if (m < count) {
+    } else {
         for (uint32_t i = 0; i < kBytesPerThread; i++) {
             if (c.kept >> i & 1u) {
                 stage[end - origin] = uint8_t(byte_of(c.w, i)); // an FF 00 pair emits its FF
-                p++;
+                at.bytes++;
                 end++;
             } else if (c.marker >> i & 1u) {
-                m++;
-                if (m >= count)
-                    break;
-                pm = d.marker_pos[m];
-                sm = d.interval_start[m];
-                end = sm * 4u + (p - pm); // next word boundary: the gap stays zero
+                at.interval++;
+                at.start_word += (at.bytes + 3u) / 4u;
+                at.bytes = 0u;
+                end = at.start_word * 4u; // next word boundary: the gap stays zero
+                if (at.interval + d.slots >= count)
+                    d.starts_out[at.interval & (d.slots - 1u)] = at.start_word;
             }
         }
     }
@@ -401,10 +385,6 @@ hipError_t launch_scan(const ScanDesc *descs, uint32_t images, uint32_t max_tile
         hipLaunchKernelGGL(count_kernel, dim3(max_tiles, images), dim3(kThreads), 0, stream, descs);
     }
     hipLaunchKernelGGL(tile_scan_kernel, dim3(images), dim3(kThreads), 0, stream, descs);
-    if (max_tiles) {
-        hipLaunchKernelGGL(marker_kernel, dim3(max_tiles, images), dim3(kThreads), 0, stream, descs);
-    }
-    hipLaunchKernelGGL(interval_scan_kernel, dim3(images), dim3(kIvThreads), 0, stream, descs);
     if (max_tiles) {
         hipLaunchKernelGGL(emit_kernel, dim3(max_tiles, images), dim3(kThreads), 0, stream, descs);
     }
