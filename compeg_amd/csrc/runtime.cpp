@@ -129,6 +129,17 @@ bool use_team_kernel()
     return team;
 }
 
+// Single-image device preprocessing: the raw segment is fetched from the pinned staging buffer by a
+// kernel (COMPEG_PULL=0: by the copy engine).
+bool pull_copies()
+{
+    static const bool pull = [] {
+        const char *e = getenv("COMPEG_PULL");
+        return e ? atoi(e) != 0 : true;
+    }();
+    return pull;
+}
+
 namespace {
 
 void *pinned_alloc(size_t n)
@@ -276,7 +287,10 @@ Status compeg_decoder::preprocess_on_device(const ImageData &img, hipStream_t st
         const size_t n = std::min<size_t>(kPiece, len - at);
         memcpy(hs + o_raw + at, img.scan_data() + at, n);
         const size_t from = at ? o_raw + at : 0; // the first piece carries the descriptor
-        CG_HIP(hipMemcpyAsync(da + from, hs + from, o_raw + at + n - from, hipMemcpyHostToDevice, stream));
+        if (pull_copies())
+            CG_HIP(launch_pull(da + from, hs + from, o_raw + at + n - from, stream));
+        else
+            CG_HIP(hipMemcpyAsync(da + from, hs + from, o_raw + at + n - from, hipMemcpyHostToDevice, stream));
         if (len == 0)
             break;
     }

@@ -27,6 +27,9 @@ struct ScanDesc {
 
 constexpr size_t kScanTileStateBytes = 20;
 uint32_t scan_tiles(uint32_t len);
+// dst (device) <- pinned_src (pinned host memory), both 16-byte aligned and readable / writable up to the
+// next multiple of 16 bytes; the copy is a kernel on `stream`
+hipError_t launch_pull(void *dst, const void *pinned_src, size_t bytes, hipStream_t stream);
 hipError_t launch_scan(const ScanDesc *descs, uint32_t images, uint32_t max_tiles, hipStream_t stream);
 
 } // namespace compeg

@@ -21,6 +21,8 @@
 // Integer / byte work, HBM-bound (a few bytes of traffic per input byte).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "scan_kernels.h"
 
 namespace compeg {
@@ -370,7 +372,34 @@ __global__ void __launch_bounds__(kThreads) emit_kernel(const ScanDesc *descs)
         out32[i] = stage32[i - origin / 4u];
 }
 
+// Host-to-device copy done by the compute queue itself: `src` is pinned host
+// memory, read over PCIe with 16-byte loads.  Used for the single-image path,
+// where a copy-engine transfer costs more in hand-over between the engines
+// than in bytes (measured: 35 GB/s either way, but no gaps between the pieces
+// and the kernels behind them; more loads in flight per lane did not help).
+typedef uint32_t PullVec __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(kThreads) pull_kernel(PullVec *__restrict__ dst, const PullVec *__restrict__ src,
+                                                        uint32_t n16)
+{
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n16; i += gridDim.x * kThreads)
+        dst[i] = __builtin_nontemporal_load(src + i);
+}
+
 } // namespace
+
+hipError_t launch_pull(void *dst, const void *pinned_src, size_t bytes, hipStream_t stream)
+{
+    const size_t n16 = (bytes + 15) / 16;
+    if (n16 == 0)
+        return hipSuccess;
+    if (n16 > 0xffffffffu)
+        return hipErrorInvalidValue;
+    const uint32_t blocks = uint32_t(std::min<size_t>((n16 + kThreads - 1) / kThreads, 2048));
+    hipLaunchKernelGGL(pull_kernel, dim3(blocks), dim3(kThreads), 0, stream, static_cast<PullVec *>(dst),
+                       static_cast<const PullVec *>(pinned_src), uint32_t(n16));
+    return hipGetLastError();
+}
 
 uint32_t scan_tiles(uint32_t len)
 {
