@@ -400,7 +400,7 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     const uint32_t total_dus = img.total_dus();
     const size_t blob_bytes = align_up(sizeof(ImageDesc), 256) + table_blob_bytes(img);
     CG_TRY(host_blob.reserve(blob_bytes));
-    CG_TRY(dev_blob.reserve(blob_bytes));
+    CG_TRY(dev_blob.reserve(blob_bytes + 16));
     CG_TRY(ac.reserve(size_t(total_dus) * kRetained * 2 + 64));
     CG_TRY(dc.reserve(size_t(total_dus) * 4 + 64));
     uint8_t *hb = static_cast<uint8_t *>(host_blob.ptr);
@@ -454,8 +454,26 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
             db = static_cast<uint8_t *>(dev_blob.ptr);
         }
     }
+    size_t shipped = 0; // bytes of the preprocessed scan already on their way
     if (!on_device) {
-        Status pre = scan.process(img.scan_data(), img.scan_len, md.total_restart_intervals);
+        // the output's worst case (scan.rs:38-44), so that pieces can leave while the scan is running
+        const size_t out_cap = ((img.scan_len + img.scan_len / 3 + 3) / 4) * 4;
+        uint32_t slots = 1;
+        while (slots < md.total_restart_intervals)
+            slots <<= 1;
+        CG_TRY(words.reserve(out_cap + 64));
+        CG_TRY(starts.reserve(size_t(slots) * 4 + 16));
+        hipError_t ship_error = hipSuccess;
+        ScanBuffer::Progress ship;
+        if (pull_copies())
+            ship = [&](size_t final_bytes) {
+                if (final_bytes > shipped && ship_error == hipSuccess)
+                    ship_error = launch_pull(static_cast<uint8_t *>(words.ptr) + shipped, scan.data() + shipped,
+                                             final_bytes - shipped, stream);
+                shipped = std::max(shipped, final_bytes);
+            };
+        Status pre = scan.process(img.scan_data(), img.scan_len, md.total_restart_intervals, ship, 384u << 10);
+        CG_HIP(ship_error);
         if (!pre.ok()) {
             if (pre.code != COMPEG_E_COUNT_MISMATCH)
                 return pre;
@@ -465,19 +483,26 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     trace.mark(on_device ? "device_preprocess" : "host_preprocess");
     const size_t n_words = on_device ? dev_nwords : scan.nwords();
     const size_t n_starts = on_device ? dev_nstarts : scan.nstarts();
-    if (!on_device) {
-        CG_TRY(words.reserve(n_words * 4 + 16));
-        CG_TRY(starts.reserve(n_starts * 4 + 16));
-    }
+    const bool pull = !on_device && pull_copies(); // everything the host path uploads sits in pinned memory
     if (!blob_uploaded) {
         write_blob(on_device ? dev_words : words.ptr, on_device ? dev_starts : starts.ptr, n_words, n_starts);
-        CG_HIP(hipMemcpyAsync(db, hb, blob_bytes, hipMemcpyHostToDevice, stream));
+        if (pull)
+            CG_HIP(launch_pull(db, hb, blob_bytes, stream));
+        else
+            CG_HIP(hipMemcpyAsync(db, hb, blob_bytes, hipMemcpyHostToDevice, stream));
     }
     trace.mark("tables");
-    if (!on_device && n_starts)
-        CG_HIP(hipMemcpyAsync(starts.ptr, scan.starts(), n_starts * 4, hipMemcpyHostToDevice, stream));
-    if (!on_device && n_words)
-        CG_HIP(hipMemcpyAsync(words.ptr, scan.words(), n_words * 4, hipMemcpyHostToDevice, stream));
+    if (pull) {
+        CG_HIP(launch_pull(starts.ptr, scan.starts(), n_starts * 4, stream));
+        if (n_words * 4 > shipped)
+            CG_HIP(launch_pull(static_cast<uint8_t *>(words.ptr) + shipped, scan.data() + shipped,
+                               n_words * 4 - shipped, stream));
+    } else if (!on_device) {
+        if (n_starts)
+            CG_HIP(hipMemcpyAsync(starts.ptr, scan.starts(), n_starts * 4, hipMemcpyHostToDevice, stream));
+        if (n_words)
+            CG_HIP(hipMemcpyAsync(words.ptr, scan.words(), n_words * 4, hipMemcpyHostToDevice, stream));
+    }
     CG_HIP(hipEventRecord(upload_done, stream));
     upload_pending = true;
     last_stream = stream;

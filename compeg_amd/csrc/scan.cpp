@@ -44,6 +44,7 @@ namespace {
 // one vector and returns the bit mask of its FF bytes.
 #define COMPEG_SCAN_LOOP(VECTOR_BYTES, COPY_MASK)                                                      \
     size_t wp = 0, ri = 1, rp = 0;                                                                     \
+    size_t report_at = progress ? progress_step : ~size_t(0);                                          \
     for (;;) {                                                                                         \
         while (rp + (VECTOR_BYTES) <= len) {                                                           \
             const uint32_t ffs = COPY_MASK(scan + rp, out + wp);                                       \
@@ -73,6 +74,10 @@ namespace {
         slot = stuffing ? slot : uint32_t(next / 4);                                                   \
         ri += stuffing ? 0 : 1;                                                                        \
         wp = next;                                                                                     \
+        if (wp >= report_at) { /* everything below wp is final */                                     \
+            progress(wp & ~size_t(15));                                                                \
+            report_at = wp + progress_step;                                                            \
+        }                                                                                              \
     }                                                                                                  \
     end.wp = wp;                                                                                       \
     end.ri = ri;
@@ -99,19 +104,22 @@ inline uint32_t copy_mask_sse2(const uint8_t *src, uint8_t *dst)
 }
 
 __attribute__((target("avx2"))) void scan_avx2(const uint8_t *scan, size_t len, uint8_t *out, uint32_t *starts,
-                                               size_t mask, ScanEnd &end)
+                                               size_t mask, ScanEnd &end, const ScanBuffer::Progress &progress,
+                                               size_t progress_step)
 {
     COMPEG_SCAN_LOOP(32, copy_mask_avx2)
 }
 
-void scan_sse2(const uint8_t *scan, size_t len, uint8_t *out, uint32_t *starts, size_t mask, ScanEnd &end)
+void scan_sse2(const uint8_t *scan, size_t len, uint8_t *out, uint32_t *starts, size_t mask, ScanEnd &end,
+               const ScanBuffer::Progress &progress, size_t progress_step)
 {
     COMPEG_SCAN_LOOP(16, copy_mask_sse2)
 }
 #else
 inline uint32_t copy_mask_none(const uint8_t *, uint8_t *) { return 0; }
 
-void scan_bytes(const uint8_t *scan, size_t len, uint8_t *out, uint32_t *starts, size_t mask, ScanEnd &end)
+void scan_bytes(const uint8_t *scan, size_t len, uint8_t *out, uint32_t *starts, size_t mask, ScanEnd &end,
+                const ScanBuffer::Progress &progress, size_t progress_step)
 {
     COMPEG_SCAN_LOOP(len + 1, copy_mask_none)
 }
@@ -119,7 +127,8 @@ void scan_bytes(const uint8_t *scan, size_t len, uint8_t *out, uint32_t *starts,
 
 } // namespace
 
-Status ScanBuffer::process(const uint8_t *scan, size_t len, uint32_t expected)
+Status ScanBuffer::process(const uint8_t *scan, size_t len, uint32_t expected, const Progress &progress,
+                           size_t progress_step)
 {
     // Worst case: a 1-byte interval behind a 2-byte marker occupies a whole
     // word, i.e. 4 bytes out for 3 in (scan.rs:38-44).
@@ -138,11 +147,11 @@ Status ScanBuffer::process(const uint8_t *scan, size_t len, uint32_t expected)
 #if defined(__x86_64__)
     static const bool avx2 = __builtin_cpu_supports("avx2");
     if (avx2)
-        scan_avx2(scan, len, out, starts, mask, end);
+        scan_avx2(scan, len, out, starts, mask, end, progress, progress_step);
     else
-        scan_sse2(scan, len, out, starts, mask, end);
+        scan_sse2(scan, len, out, starts, mask, end, progress, progress_step);
 #else
-    scan_bytes(scan, len, out, starts, mask, end);
+    scan_bytes(scan, len, out, starts, mask, end, progress, progress_step);
 #endif
     size_t wp = end.wp;
     const size_t ri = end.ri;

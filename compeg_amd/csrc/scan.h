@@ -6,6 +6,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <functional>
 
 #include "front.h"
 
@@ -38,7 +39,12 @@ class ScanBuffer {
 
     // COMPEG_E_COUNT_MISMATCH leaves the truncated result in place, like the
     // reference (scan.rs:55-63).
-    Status process(const uint8_t *scan, size_t len, uint32_t expected_intervals);
+    // progress (optional) is called from inside the loop whenever about `progress_step` more
+    // output bytes are final, with the number of final bytes (a multiple of 16): the decoder
+    // ships them to the GPU while the rest of the segment is still being scanned.
+    using Progress = std::function<void(size_t final_bytes)>;
+    Status process(const uint8_t *scan, size_t len, uint32_t expected_intervals, const Progress &progress = {},
+                   size_t progress_step = 0);
     // Same buffers, filled by the device-side scan kernels (runtime.cpp).
     Status process_on_gpu(struct ::compeg_gpu *gpu, const uint8_t *scan, size_t len,
                           uint32_t expected_intervals);
