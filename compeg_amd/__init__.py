@@ -130,6 +130,10 @@ class ScanBuffer:
         a = _host_view(scan_data)
         check(lib.compeg_scanbuffer_process(self._h, a.ctypes.data, a.nbytes, expected_restart_intervals))
 
+    def set_threads(self, threads):
+        """Extension: threads that share one process() call (same output)."""
+        check(lib.compeg_scanbuffer_set_threads(self._h, threads))
+
     def process_on_gpu(self, gpu, scan_data, expected_restart_intervals):
         """Same buffers, filled by the device-side scan kernels (extension)."""
         a = _host_view(scan_data)
@@ -226,6 +230,10 @@ class Decoder:
     def set_device_preprocess(self, on=True):
         """Extension: preprocess scans with the device-side scan kernels instead of on the host."""
         check(lib.compeg_decoder_set_device_preprocess(self._h, 1 if on else 0))
+
+    def set_scan_threads(self, threads):
+        """Extension: threads of this decoder's host scan preprocessor."""
+        check(lib.compeg_decoder_set_scan_threads(self._h, threads))
 
     def texture(self):
         p, w, h, pitch = C.c_void_p(), C.c_uint32(), C.c_uint32(), C.c_size_t()

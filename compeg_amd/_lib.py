@@ -53,6 +53,7 @@ def _load():
         "compeg_scanbuffer_free": (None, [vp]),
         "compeg_scanbuffer_process": (i, [vp, vp, sz, u32]),
         "compeg_scanbuffer_process_on_gpu": (i, [vp, vp, vp, sz, u32]),
+        "compeg_scanbuffer_set_threads": (i, [vp, C.c_uint]),
         "compeg_scanbuffer_data": (vp, [vp, psz]),
         "compeg_scanbuffer_start_positions": (vp, [vp, psz]),
         "compeg_decoder_new": (i, [vp, pvp]),
@@ -62,6 +63,7 @@ def _load():
         "compeg_decoder_decode_blocking": (i, [vp, vp, pvp]),
         "compeg_decoder_last_warning": (C.c_char_p, [vp]),
         "compeg_decoder_set_device_preprocess": (i, [vp, i]),
+        "compeg_decoder_set_scan_threads": (i, [vp, C.c_uint]),
         "compeg_op_wait": (i, [vp]),
         "compeg_op_texture_changed": (i, [vp]),
         "compeg_op_free": (None, [vp]),

@@ -252,6 +252,16 @@ int compeg_scanbuffer_process(compeg_scanbuffer *sb, const uint8_t *scan, size_t
     });
 }
 
+int compeg_scanbuffer_set_threads(compeg_scanbuffer *sb, unsigned threads)
+{
+    return guarded([&] {
+        if (!sb || threads < 1 || threads > 16)
+            return fail(COMPEG_E_INVALID_ARG, "threads must be 1..16");
+        sb->buf.set_threads(threads);
+        return ok();
+    });
+}
+
 int compeg_scanbuffer_process_on_gpu(compeg_scanbuffer *sb, compeg_gpu *gpu, const uint8_t *scan,
                                      size_t len, uint32_t expected_restart_intervals)
 {
@@ -381,6 +391,16 @@ int compeg_decoder_set_device_preprocess(compeg_decoder *dec, int on)
         return fail(COMPEG_E_INVALID_ARG, "dec is NULL");
     dec->device_preprocess = on != 0;
     return ok();
+}
+
+int compeg_decoder_set_scan_threads(compeg_decoder *dec, unsigned threads)
+{
+    return guarded([&] {
+        if (!dec || threads < 1 || threads > 16)
+            return fail(COMPEG_E_INVALID_ARG, "threads must be 1..16");
+        dec->scan.set_threads(threads);
+        return ok();
+    });
 }
 
 const char *compeg_decoder_last_warning(const compeg_decoder *dec)

@@ -4,6 +4,12 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <vector>
+
 #if defined(__x86_64__)
 #include <immintrin.h>
 #endif
@@ -45,6 +51,7 @@ namespace {
 #define COMPEG_SCAN_LOOP(VECTOR_BYTES, COPY_MASK)                                                      \
     size_t wp = 0, ri = 1, rp = 0;                                                                     \
     size_t report_at = progress ? progress_step : ~size_t(0);                                          \
+    size_t head = ~size_t(0);                                                                          \
     for (;;) {                                                                                         \
         while (rp + (VECTOR_BYTES) <= len) {                                                           \
             const uint32_t ffs = COPY_MASK(scan + rp, out + wp);                                       \
@@ -72,6 +79,7 @@ namespace {
         const size_t next = stuffing ? wp + 1 : (wp + 3) & ~size_t(3);                                 \
         uint32_t &slot = starts[ri & mask];                                                            \
         slot = stuffing ? slot : uint32_t(next / 4);                                                   \
+        head = (!stuffing && ri == 1) ? wp : head;                                                     \
         ri += stuffing ? 0 : 1;                                                                        \
         wp = next;                                                                                     \
         if (wp >= report_at) { /* everything below wp is final */                                     \
@@ -80,10 +88,12 @@ namespace {
         }                                                                                              \
     }                                                                                                  \
     end.wp = wp;                                                                                       \
-    end.ri = ri;
+    end.ri = ri;                                                                                       \
+    end.head = head == ~size_t(0) ? wp : head;
 
 struct ScanEnd {
     size_t wp, ri;
+    size_t head; // kept bytes in front of the first marker (all of them if there is none)
 };
 
 inline void store_u32(uint8_t *p, uint32_t v) { memcpy(p, &v, 4); }
@@ -125,7 +135,202 @@ void scan_bytes(const uint8_t *scan, size_t len, uint8_t *out, uint32_t *starts,
 }
 #endif
 
+void scan_range(const uint8_t *scan, size_t len, uint8_t *out, uint32_t *starts, size_t mask, ScanEnd &end,
+                const ScanBuffer::Progress &progress, size_t progress_step)
+{
+#if defined(__x86_64__)
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2)
+        scan_avx2(scan, len, out, starts, mask, end, progress, progress_step);
+    else
+        scan_sse2(scan, len, out, starts, mask, end, progress, progress_step);
+#else
+    scan_bytes(scan, len, out, starts, mask, end, progress, progress_step);
+#endif
+}
+
+// Spin-wait step.  No PAUSE: inside a virtual machine a loop of PAUSEs is what the hypervisor watches
+// for to take the CPU away (pause-loop exiting), and a helper that lost its CPU is late by a
+// scheduling quantum, not by a cache miss.
+inline void cpu_relax()
+{
+    std::atomic_signal_fence(std::memory_order_seq_cst);
+}
+
 } // namespace
+
+// ---- several threads on one segment ------------------------------------------
+//
+// The segment is cut into one piece per thread.  A piece cannot know where its
+// output goes (every interval is padded to a word, so positions depend on
+// everything in front), but it can be preprocessed on its own into a private
+// buffer: the bytes in front of its first marker (its head), then whole
+// word-aligned intervals, then the unpadded bytes behind its last marker.  A
+// serial step of a few instructions per piece turns the pieces' sizes into
+// output positions, and the threads copy their pieces into place.  Whether the
+// first byte of a piece is the second half of an FF xx pair follows from the
+// length of the FF run in front of it (odd: yes), as in the device kernels.
+struct ScanTeam {
+    struct Piece {
+        size_t begin = 0, end = 0;  // byte range of the segment
+        std::vector<uint8_t> out;   // private output
+        std::vector<uint32_t> starts; // entry j: word offset (in `out`) of the interval the piece's marker j opens, j >= 1
+        ScanEnd done{0, 1, 0};
+        bool overflow = false;      // more markers than `starts` holds
+        // where the piece's output begins: open interval, its start word, bytes it holds so far
+        size_t interval = 0, start_word = 0, bytes = 0;
+    };
+    std::vector<Piece> pieces;
+    std::vector<std::thread> workers;
+    std::mutex m;
+    std::condition_variable cv;
+    std::atomic<uint64_t> generation{0};
+    std::atomic<unsigned> pending{0};
+    std::atomic<bool> stop{false};
+    const std::function<void(unsigned)> *job = nullptr;
+
+    explicit ScanTeam(unsigned threads) : pieces(threads)
+    {
+        for (unsigned k = 1; k < threads; k++)
+            workers.emplace_back([this, k] { work(k); });
+    }
+    ~ScanTeam()
+    {
+        {
+            std::lock_guard<std::mutex> l(m);
+            stop = true;
+        }
+        cv.notify_all();
+        for (std::thread &t : workers)
+            t.join();
+    }
+    void work(unsigned k)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            // a decoder fed frame after frame finds its helpers still spinning; otherwise they sleep
+            for (unsigned spins = 0; generation.load(std::memory_order_acquire) == seen && !stop; spins++) {
+                if (spins < 400000) {
+                    cpu_relax();
+                } else {
+                    std::unique_lock<std::mutex> l(m);
+                    cv.wait(l, [&] { return generation.load() != seen || stop; });
+                }
+            }
+            if (stop)
+                return;
+            seen = generation.load(std::memory_order_acquire);
+            (*job)(k);
+            pending.fetch_sub(1, std::memory_order_release);
+        }
+    }
+    // job(k) on every thread, k = 0 on the caller's
+    void run(const std::function<void(unsigned)> &j)
+    {
+        job = &j;
+        pending.store(unsigned(workers.size()), std::memory_order_relaxed);
+        {
+            std::lock_guard<std::mutex> l(m);
+            generation.fetch_add(1, std::memory_order_release);
+        }
+        cv.notify_all();
+        j(0);
+        while (pending.load(std::memory_order_acquire))
+            cpu_relax();
+    }
+};
+
+ScanBuffer::ScanBuffer() = default;
+ScanBuffer::ScanBuffer(HostArena::AllocFn a, HostArena::FreeFn f) : words_(a, f), starts_(a, f) {}
+ScanBuffer::~ScanBuffer() = default;
+
+void ScanBuffer::set_threads(unsigned threads)
+{
+    threads = threads < 1 ? 1 : (threads > 16 ? 16 : threads);
+    if (team_ && team_->pieces.size() == threads)
+        return;
+    team_.reset();
+    if (threads > 1)
+        team_.reset(new ScanTeam(threads));
+}
+
+// false: not worth it or not possible (the caller takes the one-thread loop)
+bool ScanBuffer::process_with_team(const uint8_t *scan, size_t len, uint32_t expected, uint8_t *out, uint32_t *starts,
+                                   size_t slots, size_t &wp_out, size_t &ri_out)
+{
+    ScanTeam &team = *team_;
+    const size_t n = team.pieces.size();
+    if (len < n * (64u << 10))
+        return false;
+    // cut; a piece begins behind the partner byte if the cut fell inside an FF xx pair
+    for (size_t k = 0; k <= n; k++) {
+        size_t at = k == n ? len : len / n * k;
+        if (k > 0 && k < n) {
+            size_t run = 0;
+            while (run < at && scan[at - 1 - run] == 0xff)
+                run++;
+            at += run & 1u;
+        }
+        if (k < n)
+            team.pieces[k].begin = at;
+        if (k > 0)
+            team.pieces[k - 1].end = at;
+    }
+    size_t per_piece_starts = 1024;
+    while (per_piece_starts < size_t(expected) / n * 4 + 1024)
+        per_piece_starts <<= 1;
+    team.run([&](unsigned k) {
+        ScanTeam::Piece &p = team.pieces[k];
+        const size_t range = p.end - p.begin;
+        if (p.out.size() < range + range / 3 + 80)
+            p.out.resize(range + range / 3 + 80);
+        if (p.starts.size() < per_piece_starts)
+            p.starts.resize(per_piece_starts);
+        p.done = ScanEnd{0, 1, 0};
+        scan_range(scan + p.begin, range, p.out.data(), p.starts.data(), per_piece_starts - 1, p.done, {}, 0);
+        p.overflow = p.done.ri > per_piece_starts; // marker indices wrapped around
+    });
+    // positions
+    size_t interval = 0, start_word = 0, bytes = 0;
+    for (ScanTeam::Piece &p : team.pieces) {
+        if (p.overflow)
+            return false;
+        p.interval = interval;
+        p.start_word = start_word;
+        p.bytes = bytes;
+        const size_t markers = p.done.ri - 1;
+        if (markers == 0) {
+            bytes += p.done.head;
+        } else {
+            const size_t first = p.starts[1], last = p.starts[markers & (per_piece_starts - 1)];
+            interval += markers;
+            start_word += (bytes + p.done.head + 3) / 4 + (last - first);
+            bytes = p.done.wp - last * 4;
+        }
+    }
+    const size_t count = interval + 1, mask = slots - 1;
+    team.run([&](unsigned k) {
+        const ScanTeam::Piece &p = team.pieces[k];
+        const size_t markers = p.done.ri - 1;
+        uint8_t *dst = out + p.start_word * 4 + p.bytes;
+        memcpy(dst, p.out.data(), p.done.head);
+        if (markers == 0)
+            return;
+        const size_t seam_end = p.start_word * 4 + p.bytes + p.done.head, body = (seam_end + 3) & ~size_t(3);
+        memset(out + seam_end, 0, body - seam_end);
+        const size_t first = p.starts[1];
+        memcpy(out + body, p.out.data() + first * 4, p.done.wp - first * 4);
+        // the reference keeps the last writer of every slot (scan.rs:46-56,111): the last `slots` markers
+        for (size_t j = 1; j <= markers; j++) {
+            const size_t global = p.interval + j;
+            if (global + slots >= count)
+                starts[global & mask] = uint32_t(body / 4 + (p.starts[j] - first));
+        }
+    });
+    wp_out = start_word * 4 + bytes;
+    ri_out = count;
+    return true;
+}
 
 Status ScanBuffer::process(const uint8_t *scan, size_t len, uint32_t expected, const Progress &progress,
                            size_t progress_step)
@@ -143,18 +348,14 @@ Status ScanBuffer::process(const uint8_t *scan, size_t len, uint32_t expected, c
     memset(starts, 0, slots * 4);
     const size_t mask = slots - 1;
 
-    ScanEnd end{0, 1};
-#if defined(__x86_64__)
-    static const bool avx2 = __builtin_cpu_supports("avx2");
-    if (avx2)
-        scan_avx2(scan, len, out, starts, mask, end, progress, progress_step);
-    else
-        scan_sse2(scan, len, out, starts, mask, end, progress, progress_step);
-#else
-    scan_bytes(scan, len, out, starts, mask, end, progress, progress_step);
-#endif
-    size_t wp = end.wp;
-    const size_t ri = end.ri;
+    size_t wp = 0, ri = 1;
+    if (!team_ || !process_with_team(scan, len, expected, out, starts, slots, wp, ri)) {
+        memset(starts, 0, slots * 4); // (a team that gave up may have written some)
+        ScanEnd end{0, 1, 0};
+        scan_range(scan, len, out, starts, mask, end, progress, progress_step);
+        wp = end.wp;
+        ri = end.ri;
+    }
     const size_t nwords = (wp + 3) / 4;
     store_u32(out + wp, 0u);
     wp = nwords * 4;

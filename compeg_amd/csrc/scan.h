@@ -7,6 +7,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <functional>
+#include <memory>
 
 #include "front.h"
 
@@ -32,10 +33,17 @@ struct HostArena {
     bool reserve(size_t bytes); // contents are not preserved
 };
 
+struct ScanTeam;
+
 class ScanBuffer {
   public:
-    ScanBuffer() = default;
-    ScanBuffer(HostArena::AllocFn a, HostArena::FreeFn f) : words_(a, f), starts_(a, f) {}
+    ScanBuffer();
+    ScanBuffer(HostArena::AllocFn a, HostArena::FreeFn f);
+    ~ScanBuffer();
+
+    // Threads that share the work of one process() call on segments of 64 KiB per thread and more
+    // (1 = the calling thread alone, the default).  The helpers live as long as the buffer.
+    void set_threads(unsigned threads);
 
     // COMPEG_E_COUNT_MISMATCH leaves the truncated result in place, like the
     // reference (scan.rs:55-63).
@@ -57,8 +65,11 @@ class ScanBuffer {
     size_t nstarts() const { return nstarts_; }
 
   private:
+    bool process_with_team(const uint8_t *scan, size_t len, uint32_t expected, uint8_t *out, uint32_t *starts,
+                           size_t slots, size_t &wp, size_t &ri);
     HostArena words_, starts_;
     size_t nwords_ = 0, nstarts_ = 0;
+    std::unique_ptr<ScanTeam> team_;
 };
 
 } // namespace compeg

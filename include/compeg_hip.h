@@ -118,6 +118,9 @@ void compeg_scanbuffer_free(compeg_scanbuffer *sb);
  * the (truncated) result, as in the reference. */
 int compeg_scanbuffer_process(compeg_scanbuffer *sb, const uint8_t *scan, size_t len,
                               uint32_t expected_restart_intervals);
+/* Extension: `threads` threads (1..16, default 1) share the work of every following process() call on
+ * segments of 64 KiB per thread and more; same output.  The helper threads live as long as the buffer. */
+int compeg_scanbuffer_set_threads(compeg_scanbuffer *sb, unsigned threads);
 /* Same result, computed by the device-side scan kernels: the
  * segment is copied to HBM, preprocessed there and the two buffers are copied
  * back.  Inputs the kernels hand back (FF runs longer than 64 KiB) are
@@ -152,6 +155,10 @@ const char *compeg_decoder_last_warning(const compeg_decoder *dec);
  * kernels; the raw entropy-coded segment is uploaded instead of the
  * preprocessed one.  Results are identical. */
 int compeg_decoder_set_device_preprocess(compeg_decoder *dec, int on);
+/* Extension: threads the host scan preprocessor of this decoder uses for one image (see
+ * compeg_scanbuffer_set_threads).  Default: 8 on hosts with 32 hardware threads or more, 4 with 8 or more, else 1;
+ * the environment variable COMPEG_SCAN_THREADS overrides the default. */
+int compeg_decoder_set_scan_threads(compeg_decoder *dec, unsigned threads);
 
 /* `DecodeOp` (lib.rs:541-574).  compeg_op_wait replaces polling the
  * SubmissionIndex.  Ops are freed by the caller. */

@@ -46,6 +46,7 @@ extern "C" {
     pub fn compeg_scanbuffer_new() -> *mut compeg_scanbuffer;
     pub fn compeg_scanbuffer_free(sb: *mut compeg_scanbuffer);
     pub fn compeg_scanbuffer_process(sb: *mut compeg_scanbuffer, scan: *const u8, len: usize, expected: u32) -> c_int;
+    pub fn compeg_scanbuffer_set_threads(sb: *mut compeg_scanbuffer, threads: c_uint) -> c_int;
     pub fn compeg_scanbuffer_process_on_gpu(sb: *mut compeg_scanbuffer, gpu: *mut compeg_gpu, scan: *const u8,
                                             len: usize, expected: u32) -> c_int;
     pub fn compeg_scanbuffer_data(sb: *const compeg_scanbuffer, nbytes: *mut usize) -> *const u8;
@@ -62,6 +63,7 @@ extern "C" {
                                           op: *mut *mut compeg_op) -> c_int;
     pub fn compeg_decoder_last_warning(dec: *const compeg_decoder) -> *const c_char;
     pub fn compeg_decoder_set_device_preprocess(dec: *mut compeg_decoder, on: c_int) -> c_int;
+    pub fn compeg_decoder_set_scan_threads(dec: *mut compeg_decoder, threads: c_uint) -> c_int;
     pub fn compeg_op_wait(op: *mut compeg_op) -> c_int;
     pub fn compeg_op_texture_changed(op: *const compeg_op) -> c_int;
     pub fn compeg_op_free(op: *mut compeg_op);

@@ -237,6 +237,12 @@ impl Decoder {
             .expect("compeg_decoder_set_device_preprocess");
     }
 
+    /// Extension: threads of this decoder's host scan preprocessor (1..=16).
+    pub fn set_scan_threads(&mut self, threads: u32) {
+        check(unsafe { ffi::compeg_decoder_set_scan_threads(self.raw.as_ptr(), threads as std::os::raw::c_uint) })
+            .expect("compeg_decoder_set_scan_threads");
+    }
+
     /// Preprocesses, uploads and records the decode on `stream` without
     /// waiting; returns whether the output was reallocated (always on the
     /// first call).  The reference records into a `CommandEncoder` here.

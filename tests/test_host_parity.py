@@ -245,6 +245,42 @@ def test_scanbuffer_fuzz():
     _scan_both(b"\xff\xff\xff", 2)
 
 
+def test_scanbuffer_with_threads_gives_the_same_buffers():
+    """Extension: several threads share one process() call (pieces preprocessed privately, then put in place)."""
+    rng = np.random.default_rng(23)
+    cases = []
+    for it in range(10):
+        n = int(rng.integers(200_000, 700_000))
+        data = rng.integers(0, 256, n, dtype=np.uint8)
+        if it % 2:
+            data[rng.random(n) < 0.02] = 0xFF                 # FF runs, markers every few dozen bytes
+        data[rng.random(n) < 0.01] = 0
+        for cut in (n // 2, n // 3, 2 * (n // 3), n // 4, 3 * (n // 4)):   # FF pairs and FF runs across the cuts
+            k = int(rng.integers(0, 6))
+            data[max(0, cut - k):cut + int(rng.integers(0, 6))] = 0xFF
+        cases.append((data.tobytes(), int(rng.integers(1, 40000))))
+    cases.append((read_golden("scan", "scan.dat"), 42876))     # ref benches/bench.rs:9-19
+    cases.append((bytes([0x55]) * 300_000, 1))                  # no marker at all: every piece is all head
+    cases.append((bytes([0xFF, 0xD0]) * 150_000, 150_001))      # nothing but markers
+    for threads in (2, 3, 4):
+        sb = ca.ScanBuffer()
+        sb.set_threads(threads)
+        for data, expected in cases:
+            ref = orc.ScanBuffer()
+            try:
+                ref.process(data, expected)
+            except orc.OracleError:
+                pass
+            try:
+                sb.process(data, expected)
+            except ca.Error as e:
+                assert e.code == ca.E_COUNT_MISMATCH
+            assert sb.processed_scan_data() == ref.processed_scan_data(), (threads, len(data))
+            assert sb.start_positions() == ref.start_positions(), (threads, len(data))
+        sb.process(bytes([1, 2, 0xFF, 0xD0, 3]), 2)             # small segments stay on the calling thread
+        assert sb.processed_scan_data() == bytes([1, 2, 0, 0, 3, 0, 0, 0])
+
+
 def test_scanbuffer_reuse_gives_fresh_buffer_output():
     """Quirk Q7: we always produce what the reference produces on a fresh buffer."""
     sb = ca.ScanBuffer()
