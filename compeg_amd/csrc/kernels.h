@@ -28,9 +28,6 @@ hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t ma
 // Latency variant: one decoder wave + one transformer wave per 64 intervals.
 hipError_t launch_pair_422(const ImageDesc *descs, uint32_t images, uint32_t max_intervals,
                            const HuffLdsPlan &plan, hipStream_t stream);
-// Latency variant: one decoder wave + three transformer waves per 64 intervals, slot ring in LDS.
-hipError_t launch_team_422(const ImageDesc *descs, uint32_t images, uint32_t max_intervals, uint32_t restart_interval,
-                           const HuffLdsPlan &plan, hipStream_t stream);
 hipError_t launch_idct_composite(const ImageDesc *descs, uint32_t images, uint32_t max_dus,
                                  hipStream_t stream);
 

@@ -247,158 +247,6 @@ decode_pair_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, 
     }
 }
 
-// Team kernel for launches that cannot fill the chip (one 4K frame is 254 x 64
-// intervals for 256 CUs): the critical path of such a launch is one wave's
-// instruction stream, so the work of 64 intervals is spread over a decoder wave
-// and kTeamTransformers transformer waves on the other SIMDs of the CU.  The
-// decoder writes data unit after data unit into a ring of slot sets (whole
-// MCUs, `ring_mcus` of them); transformer t takes MCUs t, t + T, t + 2T, ...
-// (IDCT of each data unit as soon as it is there, then the composite).
-// Hand-over through two kinds of LDS counters, release / acquire at workgroup
-// scope: produced (data units written) and done[t] (MCUs transformer t has
-// finished, i.e. ring entries free again).  All waves of a workgroup are
-// resident together, the decoder never waits for anything but ring space, and
-// every wait is bounded (a wave that gives up flags the image and runs on), so
-// the grid always drains.
-#ifndef CG_TEAM_EXP
-#define CG_TEAM_EXP 0
-#endif
-constexpr uint32_t kTeamTransformers = 3;
-constexpr uint32_t kTeamSpinLimit = 1u << 22;
-
-__device__ __forceinline__ void team_wait(const uint32_t *counter, uint32_t above)
-{
-    for (uint32_t spins = 0; spins < kTeamSpinLimit; spins++) {
-        // (the same word for every lane: keep the loop scalar)
-        const uint32_t seen = __hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (uint32_t(__builtin_amdgcn_readfirstlane(int(seen))) > above)
-            return;
-        __builtin_amdgcn_s_sleep(1);
-    }
-}
-
-__device__ __forceinline__ void team_publish(uint32_t *counter, uint32_t value)
-{
-    __hip_atomic_store(counter, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-__global__ void __launch_bounds__((1 + kTeamTransformers) * kWave)
-decode_team_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words,
-                       uint32_t ring_mcus)
-{
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const ImageDesc &d = descs[blockIdx.y];
-    const uint32_t first_interval = blockIdx.x * kWave;
-    if (first_interval >= d.total_intervals)
-        return;
-#if defined(CG_STAMPS) // diagnostic build: wall-clock (100 MHz) stamps per workgroup into the unused dc buffer
-    uint64_t *stamps = reinterpret_cast<uint64_t *>(d.dc) + size_t(blockIdx.x) * 8u;
-    const uint64_t stamp_entry = wall_clock64();
-#endif
-
-    const uint32_t ring = ring_mcus * 4u; // slot sets
-    uint16_t *l1 = reinterpret_cast<uint16_t *>(smem);
-    uint16_t *l2 = l1 + kL1Entries;
-    uint8_t *area = smem + align16((kL1Entries + l2_in_lds) * 2u);
-    uint32_t *win = reinterpret_cast<uint32_t *>(area);
-    uint8_t *slots = area + align16(window_words * 4u);
-    int32_t *dcs = reinterpret_cast<int32_t *>(slots + ring * kWave * kDuSlotBytes);
-    uint32_t *counters = reinterpret_cast<uint32_t *>(dcs + ring * kWave); // produced, done[T]
-
-    stage_luts(d, l1, l2, l2_in_lds, threadIdx.x, blockDim.x);
-    const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x / kWave))), lane = threadIdx.x % kWave;
-    uint32_t win_base = 0, win_len = 0;
-    wave_window(d, first_interval, window_words, win_base, win_len);
-    for (uint32_t i = threadIdx.x; i < win_len; i += blockDim.x)
-        win[i] = win_base + i < d.nwords ? bswap32(CG_GLOBAL(const uint32_t, d.words)[win_base + i]) : 0u;
-    for (uint32_t i = threadIdx.x; i < ring * kWave * kDuSlotBytes / 4u; i += blockDim.x)
-        reinterpret_cast<slot_word_t *>(slots)[i] = 0u;
-    if (threadIdx.x <= kTeamTransformers)
-        counters[threadIdx.x] = 0u;
-    __syncthreads();
-#if defined(CG_STAMPS)
-    if (threadIdx.x == 0) {
-        stamps[0] = stamp_entry;
-        stamps[1] = wall_clock64();
-    }
-    const uint64_t cycles0 = clock64();
-#endif
-
-    const uint32_t interval = first_interval + lane;
-    const bool active = interval < d.total_intervals;
-    const uint32_t mcus = d.restart_interval;
-
-    HuffShared s;
-    s.l1 = l1;
-    s.l2 = l2;
-    s.l2_staged = umin(l2_in_lds, d.fast_off + 2u * kFastEntries);
-    s.win = win;
-    s.win_base = win_base;
-    s.win_len = win_len;
-    s.du_slots = slots;
-
-    if (wave == 0) {
-        EntropyState e;
-        if (active)
-            entropy_init(e, d, s, interval);
-        uint32_t set = 0;
-#pragma unroll 1
-        for (uint32_t m = 0; m < mcus; m++) {
-            if (m >= ring_mcus) { // ring entry of MCU m - ring_mcus must be free again
-                const uint32_t old = m - ring_mcus;
-                team_wait(&counters[1u + old % kTeamTransformers], old / kTeamTransformers);
-            }
-#pragma unroll 1
-            for (uint32_t k = 0; k < 4u; k++) {
-                const uint32_t comp = k < 2u ? 0u : k - 1u;
-#if CG_TEAM_EXP != 2 // diagnostic build 2: no entropy decode
-                if (active) {
-                    uint8_t *slot = slots + (set * kWave + lane) * kDuSlotBytes;
-                    dcs[set * kWave + lane] = entropy_data_unit(e, d, s, comp, reinterpret_cast<int16_t *>(slot));
-                }
-#endif
-                team_publish(&counters[0], m * 4u + k + 1u);
-                set = set + 1u == ring ? 0u : set + 1u;
-            }
-        }
-#if defined(CG_STAMPS)
-        if (lane == 0) {
-            stamps[2] = wall_clock64();
-            stamps[6] = clock64() - cycles0;
-        }
-#endif
-    } else {
-        const uint32_t t = wave - 1u;
-        PixelState px;
-        pixel_init(px, d, active ? interval : 0u, active);
-        for (uint32_t i = 0; i < t; i++)
-            pixel_next_mcu(px, d);
-#pragma unroll 1
-        for (uint32_t m = t; m < mcus; m += kTeamTransformers) {
-            const uint32_t set0 = (m % ring_mcus) * 4u;
-#pragma unroll 1
-            for (uint32_t k = 0; k < 4u; k++) {
-                const uint32_t comp = k < 2u ? 0u : k - 1u, set = set0 + k;
-                team_wait(&counters[0], m * 4u + k);
-#if CG_TEAM_EXP != 1 // diagnostic build 1: no transform, no composite
-                if (active)
-                    pixel_transform(px, d, comp, slots + (set * kWave + lane) * kDuSlotBytes, dcs[set * kWave + lane]);
-#endif
-            }
-#if CG_TEAM_EXP != 1
-            composite_mcus_422<false>(px, d, slots + (set0 + 3u) * kWave * kDuSlotBytes, lane); // moves on one MCU
-#endif
-            for (uint32_t i = 1; i < kTeamTransformers; i++)
-                pixel_next_mcu(px, d);
-            team_publish(&counters[1u + t], m / kTeamTransformers + 1u);
-        }
-#if defined(CG_STAMPS)
-        if (lane == 0)
-            stamps[3u + t] = wall_clock64();
-#endif
-    }
-}
-
 // One lane per data unit for the IDCT, then the same lanes regroup (through
 // LDS) so that every wave-wide store writes 16 MCUs x 64 contiguous bytes.
 __global__ void __launch_bounds__(256)
@@ -603,42 +451,6 @@ hipError_t launch_pair_422(const ImageDesc *descs, uint32_t images, uint32_t max
                          2u * kWave * 4u;
     hipLaunchKernelGGL(decode_pair_422_kernel, grid, dim3(2 * kWave), lds, stream, descs,
                        plan.l2_entries_in_lds, plan.window_words);
-    return hipGetLastError();
-}
-
-uint32_t team_ring_mcus(const HuffLdsPlan &plan, uint32_t restart_interval, uint64_t waves)
-{
-    // whole MCUs of slot sets: all of the interval's when one workgroup per CU is all there is,
-    // fewer when several workgroups should share a CU's LDS
-    const uint32_t tables = (((kL1Entries + plan.l2_entries_in_lds) * 2u) + 15u) & ~15u;
-    const uint32_t fixed = tables + ((plan.window_words * 4u + 15u) & ~15u) + 64u;
-    const uint32_t per_mcu = 4u * kWave * (kDuSlotBytes + 4u);
-    const uint32_t groups_per_cu = uint32_t((waves + 255u) / 256u);
-    const uint32_t budget = kLdsBytesPerCu / (groups_per_cu ? groups_per_cu : 1u);
-    uint32_t ring = budget > fixed + per_mcu ? (budget - fixed) / per_mcu : 1u;
-    if (ring > restart_interval)
-        ring = restart_interval;
-    if (ring > 8u)
-        ring = 8u;
-    return ring ? ring : 1u;
-}
-
-hipError_t launch_team_422(const ImageDesc *descs, uint32_t images, uint32_t max_intervals, uint32_t restart_interval,
-                           const HuffLdsPlan &plan, hipStream_t stream)
-{
-    if (images == 0 || max_intervals == 0)
-        return hipSuccess;
-    dim3 grid((max_intervals + kWave - 1) / kWave, images, 1);
-    const uint32_t ring = team_ring_mcus(plan, restart_interval, uint64_t(grid.x) * images);
-    const uint32_t tables = (((kL1Entries + plan.l2_entries_in_lds) * 2u) + 15u) & ~15u;
-    const uint32_t lds = tables + ((plan.window_words * 4u + 15u) & ~15u) + ring * 4u * kWave * (kDuSlotBytes + 4u) + 64u;
-    static const hipError_t attr = hipFuncSetAttribute(
-        reinterpret_cast<const void *>(decode_team_422_kernel),
-        hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsBytesPerCu));
-    if (attr != hipSuccess)
-        return attr;
-    hipLaunchKernelGGL(decode_team_422_kernel, grid, dim3((1 + kTeamTransformers) * kWave), lds, stream, descs,
-                       plan.l2_entries_in_lds, plan.window_words, ring);
     return hipGetLastError();
 }
 

@@ -118,17 +118,6 @@ bool use_pair_kernel(uint32_t max_intervals, uint32_t images)
     return waves <= 768;
 }
 
-// Which of the two small-launch kernels: the team kernel (decoder wave + three transformer
-// waves) unless COMPEG_TEAM=0 asks for the paired one.
-bool use_team_kernel()
-{
-    static const bool team = [] {
-        const char *e = getenv("COMPEG_TEAM");
-        return e ? atoi(e) != 0 : false;
-    }();
-    return team;
-}
-
 // Single-image device preprocessing: the raw segment is fetched from the pinned staging buffer by a
 // kernel (COMPEG_PULL=0: by the copy engine).
 bool pull_copies()
@@ -541,10 +530,7 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
         CG_HIP(launch_generic_composite(reinterpret_cast<const ImageDesc *>(db), 1, out_w, out_h, stream));
         coefficients_valid = false;
     } else if (fused) {
-        if (use_pair_kernel(md.total_restart_intervals, 1) && use_team_kernel())
-            CG_HIP(launch_team_422(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals,
-                                   md.restart_interval, plan, stream));
-        else if (use_pair_kernel(md.total_restart_intervals, 1))
+        if (use_pair_kernel(md.total_restart_intervals, 1))
             CG_HIP(launch_pair_422(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals,
                                    plan, stream));
         else
@@ -930,9 +916,7 @@ Status compeg_batch::decode(hipStream_t stream)
             continue;
         }
         if (fused) {
-            if (use_pair_kernel(max_intervals, m) && use_team_kernel())
-                CG_HIP(launch_team_422(dd + at, m, max_intervals, 0xffffffffu, plan, stream));
-            else if (use_pair_kernel(max_intervals, m))
+            if (use_pair_kernel(max_intervals, m))
                 CG_HIP(launch_pair_422(dd + at, m, max_intervals, plan, stream));
             else
                 CG_HIP(launch_fused_422(dd + at, m, max_intervals, plan, stream));
