@@ -1,0 +1,21 @@
+// Test infrastructure: the host scan preprocessor with 2, 3 and 5 threads against the one-thread loop on
+// random segments, built with -fsanitize=thread (tests/emul/Makefile) and run by tests/test_kernel_emulation.py.
+#include "scan.h"
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <vector>
+using namespace compeg;
+int main(){
+  std::mt19937 rng(5);
+  int bad=0;
+  for(int it=0;it<12;it++){
+    size_t n=300000+rng()%400000; std::vector<uint8_t> d(n);
+    for(auto&b:d){uint32_t r=rng(); b=(r&0xff); if((r>>8)%50==0)b=0xff; if((r>>16)%90==0)b=0;}
+    uint32_t exp=1+rng()%20000;
+    ScanBuffer ref; ref.process(d.data(),n,exp);
+    for(unsigned T:{2u,3u,5u}){ ScanBuffer sb; sb.set_threads(T); sb.process(d.data(),n,exp); sb.process(d.data(),n,exp);
+      if(sb.nwords()!=ref.nwords()||sb.nstarts()!=ref.nstarts()||memcmp(sb.data(),ref.data(),ref.nwords()*4)||memcmp(sb.starts(),ref.starts(),ref.nstarts()*4)){bad++; printf("DIFF it %d T %u\n",it,T);} }
+  }
+  printf("bad %d\n",bad); return bad;
+}

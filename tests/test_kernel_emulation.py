@@ -168,3 +168,11 @@ def test_emulated_rare_paths_were_reached():
     assert STATS.get("exact_dus", 0) > 100
     for key in ("left_window", "left_underflow", "dc_cut", "escapes"):
         assert STATS.get(key, 0) > 0, (key, STATS)
+
+
+def test_threaded_host_scan_under_the_thread_sanitizer(runner):
+    """compeg_amd/csrc/scan.cpp with helper threads: same buffers as the one-thread loop, no data race."""
+    exe = os.path.join(EMUL_DIR, "scan_threads_check")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "bad 0" in r.stdout and "ThreadSanitizer" not in r.stderr
