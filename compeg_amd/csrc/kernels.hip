@@ -194,13 +194,15 @@ decode_pair_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, 
     uint8_t *slots = area + align16(window_words * 4u);          // 2 x 64 slots
     int32_t *dcs = reinterpret_cast<int32_t *>(slots + 2u * kWave * kDuSlotBytes); // 2 x 64 DC terms
 
-    stage_luts(d, l1, l2, l2_in_lds, threadIdx.x, blockDim.x);
     const uint32_t wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
     uint32_t win_base = 0, win_len = 0;
     wave_window(d, first_interval, window_words, win_base, win_len);
-    // both waves stage the window: 128 threads, interleaved
-    for (uint32_t i = threadIdx.x; i < win_len; i += blockDim.x)
-        win[i] = win_base + i < d.nwords ? bswap32(CG_GLOBAL(const uint32_t, d.words)[win_base + i]) : 0u;
+    // the decoder wave issues the window's loads (16 bytes per lane, eight in flight) and both waves
+    // copy the LUTs under their latency: one memory round trip behind the start positions
+    if (wave == 0)
+        stage_luts_and_window(d, l1, l2, l2_in_lds, threadIdx.x, blockDim.x, win, win_base, win_len, lane);
+    else
+        stage_luts(d, l1, l2, l2_in_lds, threadIdx.x, blockDim.x);
     for (uint32_t i = threadIdx.x; i < 2u * kWave * kDuSlotBytes / 4u; i += blockDim.x)
         reinterpret_cast<slot_word_t *>(slots)[i] = 0u;
     __syncthreads();
