@@ -242,7 +242,7 @@ decode_pair_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, 
             __syncthreads(); // data unit `du` is complete
             uint8_t *set_slots = slots + set * kWave * kDuSlotBytes;
             if (active)
-                pixel_transform(t, d, comp, set_slots + lane * kDuSlotBytes, dcs[set * kWave + lane]);
+                pixel_transform(t, d, comp, k, set_slots + lane * kDuSlotBytes, dcs[set * kWave + lane]);
             if (k == 3u)
                 composite_mcus_422<false>(t, d, set_slots, lane);
         }

@@ -1563,7 +1563,7 @@ CG_DEV void composite_generic_4px(const ImageDesc &d, uint32_t x0, uint32_t y, c
 
 // Transformer role: the samples of the MCU being assembled and where it goes.
 struct PixelState {
-    uint32_t px[4][16]; // 4-deep shift chain: after Cr it holds Y0 Y1 Cb Cr
+    uint32_t px[4][16]; // the MCU's four data units (Y0 Y1 Cb Cr), 4 samples per word
     uint32_t mx, my;
     bool active;        // false: a lane past the image's last interval; it only helps its quad store
 };
@@ -1581,17 +1581,22 @@ CG_DEV void pixel_init(PixelState &t, const ImageDesc &d, uint32_t interval, boo
     t.active = active;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CG_PLACE_MARK(text) asm volatile(text)
+#else
+#define CG_PLACE_MARK(text) do { } while (0)
+#endif
+
 // One data unit: coefficients out of `slot` (cleared for reuse) and IDCT.
-CG_DEV void pixel_transform(PixelState &t, const ImageDesc &d, uint32_t comp, uint8_t *slot, int32_t dc)
+// k = 0..3: Y0 Y1 Cb Cr; at the end of the MCU px[k] holds data unit k.  One
+// copy of the IDCT in the instruction stream: it leaves its 16 words in px[3],
+// and the first three data units are moved to their place afterwards (16 moves
+// behind a wave-uniform branch; a shift chain through all four arrays would
+// move 48 words per data unit).
+CG_DEV void pixel_transform(PixelState &t, const ImageDesc &d, uint32_t comp, uint32_t k, uint8_t *slot, int32_t dc)
 {
     uint32_t rec[kRetained / 2];
     take_slot(slot, rec);
-#pragma unroll
-    for (int w = 0; w < 16; w++) {
-        t.px[0][w] = t.px[1][w];
-        t.px[1][w] = t.px[2][w];
-        t.px[2][w] = t.px[3][w];
-    }
 #if CG_EXP == 4 // diagnostic build: no IDCT (same data flow)
 #pragma unroll
     for (int w = 0; w < 16; w++)
@@ -1599,6 +1604,24 @@ CG_DEV void pixel_transform(PixelState &t, const ImageDesc &d, uint32_t comp, ui
 #else
     idct_data_unit(rec, dc, d.quant[comp], t.px[3]);
 #endif
+    // (an empty asm statement of its own in every branch: without it the three blocks are merged into one
+    // store through a computed index, and px leaves the register file)
+    if (k == 0u) {
+#pragma unroll
+        for (int w = 0; w < 16; w++)
+            t.px[0][w] = t.px[3][w];
+        CG_PLACE_MARK("; data unit 0 in place");
+    } else if (k == 1u) {
+#pragma unroll
+        for (int w = 0; w < 16; w++)
+            t.px[1][w] = t.px[3][w];
+        CG_PLACE_MARK("; data unit 1 in place");
+    } else if (k == 2u) {
+#pragma unroll
+        for (int w = 0; w < 16; w++)
+            t.px[2][w] = t.px[3][w];
+        CG_PLACE_MARK("; data unit 2 in place");
+    }
 }
 
 // Where the MCU the lane has just finished goes.
@@ -1725,8 +1748,7 @@ CG_DEV void decode_wave_fused_422(const ImageDesc &d, const HuffShared &s, uint3
 #define CG_STAMP(acc) do { } while (0)
 #endif
     // The four data units of an MCU pass through one loop body (one copy of
-    // the IDCT in the instruction stream, bounded register pressure); their
-    // sample words ride a 4-deep register shift chain px[0..3].
+    // the IDCT in the instruction stream, bounded register pressure).
     const uint32_t du_total = d.restart_interval * 4u;
 #pragma unroll 1
     for (uint32_t du = 0; du < du_total; du++) {
@@ -1739,7 +1761,7 @@ CG_DEV void decode_wave_fused_422(const ImageDesc &d, const HuffShared &s, uint3
         const int32_t dc = entropy_data_unit(e, d, s, comp, slot16);
         CG_STAMP(t_ac);
         __builtin_amdgcn_s_setprio(CG_PRIO_IDCT);
-        pixel_transform(t, d, comp, slot, dc);
+        pixel_transform(t, d, comp, k, slot, dc);
         CG_STAMP(t_idct);
         if (k == 3u) {
             __builtin_amdgcn_s_setprio(CG_PRIO_COMPOSITE);

@@ -128,7 +128,7 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
                 g_emul_stats.wave_step_symbols += step_max;
                 for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
                     if (ps[lane].active)
-                        pixel_transform(ps[lane], d, comp, set_slots + lane * kDuSlotBytes, dcs[set * kWave + lane]);
+                        pixel_transform(ps[lane], d, comp, k, set_slots + lane * kDuSlotBytes, dcs[set * kWave + lane]);
                 if (k != 3u)
                     continue;
                 // composite_mcus_422, phase by phase
