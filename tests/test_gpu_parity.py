@@ -399,6 +399,16 @@ def test_corrupt_streams_and_hostile_tables_on_the_gpu(ca, gpu):
     for j, want in variants:
         _, _, got = _decode(ca, gpu, j)
         _assert_equal(got, want)
+    # the same streams with the scan preprocessed by the device kernels (blocking decode: no read-back between
+    # the scan kernels and the decode kernel, window sized from an upper bound) and on one host thread
+    for device, threads in ((True, 4), (False, 1)):
+        dec = ca.Decoder(gpu)
+        dec.set_device_preprocess(device)
+        dec.set_scan_threads(threads)
+        for j, want in variants:
+            data = ca.ImageData(j)
+            dec.decode_blocking(data)
+            _assert_equal(dec.read_texture(data.width(), data.height()), want)
     images = [ca.ImageData(j) for j, _ in variants]
     n = 800
     assert sum((images[i % len(images)].parallelism() + 63) // 64 for i in range(n)) > 768
