@@ -277,12 +277,13 @@ Status compeg_decoder::preprocess_on_device(const ImageData &img, hipStream_t st
     if (before_submit)
         CG_TRY(before_submit(hs + o_blob, da + o_blob, &s.patch_nwords, &s.patch_nstarts));
     memcpy(hs + o_desc, &s, sizeof s);
-    // the segment goes through the pinned staging buffer piece by piece, so that the DMA of one
-    // piece runs under the host copy of the next (few pieces: every copy costs the GPU ~6 us)
-    constexpr size_t kPiece = 640u << 10;
-    for (size_t at = 0; at < len || at == 0; at += kPiece) {
-        const size_t n = std::min<size_t>(kPiece, len - at);
-        memcpy(hs + o_raw + at, img.scan_data() + at, n);
+    // the segment goes through the pinned staging buffer: copied by the scan buffer's threads if it
+    // has helpers (then one transfer follows), else piece by piece, so that the transfer of one piece
+    // runs under the host copy of the next (few pieces: every transfer has a fixed cost)
+    const size_t piece = scan.threads() > 1 ? size_t(len) + 1 : size_t(640u << 10);
+    for (size_t at = 0; at < len || at == 0; at += piece) {
+        const size_t n = std::min<size_t>(piece, len - at);
+        scan.copy(hs + o_raw + at, img.scan_data() + at, n);
         const size_t from = at ? o_raw + at : 0; // the first piece carries the descriptor
         if (pull_copies())
             CG_HIP(launch_pull(da + from, hs + from, o_raw + at + n - from, stream));

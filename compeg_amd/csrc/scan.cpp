@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
@@ -252,6 +253,24 @@ void ScanBuffer::set_threads(unsigned threads)
     team_.reset();
     if (threads > 1)
         team_.reset(new ScanTeam(threads));
+}
+
+unsigned ScanBuffer::threads() const { return team_ ? unsigned(team_->pieces.size()) : 1u; }
+
+void ScanBuffer::copy(void *dst, const void *src, size_t bytes)
+{
+    const size_t n = team_ ? team_->pieces.size() : 1;
+    if (n < 2 || bytes < n * (64u << 10)) {
+        memcpy(dst, src, bytes);
+        return;
+    }
+    const size_t per = (bytes / n + 63) & ~size_t(63);
+    team_->run([&](unsigned k) {
+        const size_t at = per * k;
+        if (at < bytes)
+            memcpy(static_cast<uint8_t *>(dst) + at, static_cast<const uint8_t *>(src) + at,
+                   std::min(per, bytes - at));
+    });
 }
 
 // false: not worth it or not possible (the caller takes the one-thread loop)

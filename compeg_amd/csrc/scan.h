@@ -44,6 +44,9 @@ class ScanBuffer {
     // Threads that share the work of one process() call on segments of 64 KiB per thread and more
     // (1 = the calling thread alone, the default).  The helpers live as long as the buffer.
     void set_threads(unsigned threads);
+    // memcpy shared by the same threads (the decoder stages raw segments with it)
+    void copy(void *dst, const void *src, size_t bytes);
+    unsigned threads() const;
 
     // COMPEG_E_COUNT_MISMATCH leaves the truncated result in place, like the
     // reference (scan.rs:55-63).

@@ -375,8 +375,8 @@ __global__ void __launch_bounds__(kThreads) emit_kernel(const ScanDesc *descs)
 // Host-to-device copy done by the compute queue itself: `src` is pinned host
 // memory, read over PCIe with 16-byte loads.  Used for the single-image path,
 // where a copy-engine transfer costs more in hand-over between the engines
-// than in bytes (measured: 35 GB/s either way, but no gaps between the pieces
-// and the kernels behind them; more loads in flight per lane did not help).
+// than in bytes (no gaps between the pieces and the kernels behind them; more
+// loads in flight per lane did not help, fewer workgroups did).
 typedef uint32_t PullVec __attribute__((ext_vector_type(4)));
 
 __global__ void __launch_bounds__(kThreads) pull_kernel(PullVec *__restrict__ dst, const PullVec *__restrict__ src,
@@ -395,7 +395,9 @@ hipError_t launch_pull(void *dst, const void *pinned_src, size_t bytes, hipStrea
         return hipSuccess;
     if (n16 > 0xffffffffu)
         return hipErrorInvalidValue;
-    const uint32_t blocks = uint32_t(std::min<size_t>((n16 + kThreads - 1) / kThreads, 2048));
+    // few workgroups: 32-64 of them move 1.6 MB in 42 us (launch and wait included), 2048 in 55 us,
+    // the copy engine in 38 us (tools/probes/pcie_pull.hip)
+    const uint32_t blocks = uint32_t(std::min<size_t>((n16 + kThreads - 1) / kThreads, 48));
     hipLaunchKernelGGL(pull_kernel, dim3(blocks), dim3(kThreads), 0, stream, static_cast<PullVec *>(dst),
                        static_cast<const PullVec *>(pinned_src), uint32_t(n16));
     return hipGetLastError();
