@@ -281,6 +281,22 @@ def test_scanbuffer_with_threads_gives_the_same_buffers():
         assert sb.processed_scan_data() == bytes([1, 2, 0, 0, 3, 0, 0, 0])
 
 
+def test_scanbuffer_thread_count_is_validated_and_can_change():
+    sb = ca.ScanBuffer()
+    for bad in (0, 17, 1000):
+        with pytest.raises(ca.Error) as e:
+            sb.set_threads(bad)
+        assert e.value.code == ca.E_INVALID_ARG
+    data = read_golden("scan", "scan.dat")
+    ref = orc.ScanBuffer()
+    ref.process(data, 42876)
+    for threads in (3, 1, 2, 2):               # helpers are replaced / dropped / kept
+        sb.set_threads(threads)
+        sb.process(data, 42876)
+        assert sb.processed_scan_data() == ref.processed_scan_data()
+        assert sb.start_positions() == ref.start_positions()
+
+
 def test_scanbuffer_reuse_gives_fresh_buffer_output():
     """Quirk Q7: we always produce what the reference produces on a fresh buffer."""
     sb = ca.ScanBuffer()
