@@ -69,7 +69,7 @@ class ScanBuffer {
 
   private:
     bool process_with_team(const uint8_t *scan, size_t len, uint32_t expected, uint8_t *out, uint32_t *starts,
-                           size_t slots, size_t &wp, size_t &ri);
+                           size_t slots, size_t &wp, size_t &ri, const Progress &progress);
     HostArena words_, starts_;
     size_t nwords_ = 0, nstarts_ = 0;
     std::unique_ptr<ScanTeam> team_;

@@ -10,12 +10,17 @@ int main(){
   std::mt19937 rng(5);
   int bad=0;
   for(int it=0;it<12;it++){
-    size_t n=300000+rng()%400000; std::vector<uint8_t> d(n);
+    size_t n=300000+rng()%900000; std::vector<uint8_t> d(n);
     for(auto&b:d){uint32_t r=rng(); b=(r&0xff); if((r>>8)%50==0)b=0xff; if((r>>16)%90==0)b=0;}
     uint32_t exp=1+rng()%20000;
     ScanBuffer ref; ref.process(d.data(),n,exp);
     for(unsigned T:{2u,3u,5u}){ ScanBuffer sb; sb.set_threads(T); sb.process(d.data(),n,exp); sb.process(d.data(),n,exp);
-      if(sb.nwords()!=ref.nwords()||sb.nstarts()!=ref.nstarts()||memcmp(sb.data(),ref.data(),ref.nwords()*4)||memcmp(sb.starts(),ref.starts(),ref.nstarts()*4)){bad++; printf("DIFF it %d T %u\n",it,T);} }
+      if(sb.nwords()!=ref.nwords()||sb.nstarts()!=ref.nstarts()||memcmp(sb.data(),ref.data(),ref.nwords()*4)||memcmp(sb.starts(),ref.starts(),ref.nstarts()*4)){bad++; printf("DIFF it %d T %u\n",it,T);}
+      // with a progress callback (rounds): what is reported as final must already equal the final bytes
+      size_t reported=0, calls=0; bool early_ok=true;
+      sb.process(d.data(),n,exp,[&](size_t fin){ calls++; if(fin<reported||fin%16||fin>ref.nwords()*4||memcmp(sb.data(),ref.data(),fin)) early_ok=false; reported=fin; },0);
+      if(!early_ok||sb.nwords()!=ref.nwords()||memcmp(sb.data(),ref.data(),ref.nwords()*4)||memcmp(sb.starts(),ref.starts(),ref.nstarts()*4)){bad++; printf("DIFF with progress it %d T %u calls %zu\n",it,T,calls);}
+      if(it==0) printf("T %u: %zu progress calls, %zu of %zu bytes reported early\n",T,calls,reported,ref.nwords()*4); }
   }
   printf("bad %d\n",bad); return bad;
 }
