@@ -642,30 +642,10 @@ Status compeg_batch::upload(const ImageData *const *images, size_t n, int thread
     if (n > 65535)
         return Status::error(COMPEG_E_INVALID_ARG, "at most 65535 images per batch");
 
-    // host front-end: preprocess every scan (independent, so spread over threads)
-    std::vector<ScanBuffer> scans(n);
-    std::vector<Status> results(n);
-    unsigned nthreads = threads > 0 ? unsigned(threads) : std::max(1u, std::thread::hardware_concurrency());
-    nthreads = unsigned(std::min<size_t>(nthreads, std::max<size_t>(n, 1)));
-    auto work = [&](unsigned t) {
-        for (size_t i = t; i < n; i += nthreads)
-            results[i] = scans[i].process(images[i]->scan_data(), images[i]->scan_len,
-                                          images[i]->metadata.total_restart_intervals);
-    };
-    if (nthreads <= 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < nthreads; t++)
-            pool.emplace_back(work, t);
-        for (auto &th : pool)
-            th.join();
-    }
-    for (size_t i = 0; i < n; i++)
-        if (!results[i].ok() && results[i].code != COMPEG_E_COUNT_MISMATCH)
-            return results[i];
-
-    // lay out one input arena: per image [L1][L2][starts][words], 256-byte aligned
+    // One input arena, per image [L1][L2 + direct tables][start positions][words], 256-byte aligned, laid
+    // out for the worst case of every scan (scan.rs:38-44) so that nothing depends on another image's size:
+    // the threads preprocess straight into the pinned staging copy of the arena and send every image off as
+    // soon as it is done -- the transfers run under the preprocessing of the images that follow.
     descs.assign(n, ImageDesc{});
     out_offset.assign(n, 0);
     std::vector<size_t> in_off(n);
@@ -676,7 +656,8 @@ Status compeg_batch::upload(const ImageData *const *images, size_t n, int thread
     for (size_t i = 0; i < n; i++) {
         const ImageData &img = *images[i];
         in_off[i] = in_total;
-        in_total += align_up(table_blob_bytes(img) + scans[i].nstarts() * 4 + scans[i].nwords() * 4 + 16, 256);
+        in_total += align_up(table_blob_bytes(img) + ScanBuffer::start_slots(img.metadata.total_restart_intervals) * 4 +
+                                 ScanBuffer::output_capacity(img.scan_len) + 16, 256);
         out_offset[i] = out_total;
         out_total += align_up(size_t(img.width) * 4 * img.height, 256);
         ac_total += size_t(img.total_dus()) * kRetained * 2;
@@ -684,11 +665,6 @@ Status compeg_batch::upload(const ImageData *const *images, size_t n, int thread
         max_intervals = std::max(max_intervals, img.metadata.total_restart_intervals);
         max_dus = std::max(max_dus, img.total_dus());
         max_l2 = std::max<uint32_t>(max_l2, staged_lut_entries(img));
-        max_span = std::max(max_span, max_wave_span(scans[i].starts(), scans[i].nstarts(), scans[i].nwords(),
-                                                    img.metadata.total_restart_intervals));
-        algorithmic_bytes += 4ull * scans[i].nwords() + 4ull * img.metadata.total_restart_intervals +
-                             COMPEG_METADATA_BYTES + COMPEG_HUFFMAN_L1_BYTES + img.l2.size() * 2 +
-                             4ull * img.width * img.height;
         pixels += uint64_t(img.width) * img.height;
     }
 
@@ -702,43 +678,90 @@ Status compeg_batch::upload(const ImageData *const *images, size_t n, int thread
         CG_TRY(dc.reserve(dc_total + 256));
     }
     CG_TRY(out.reserve(out_total + 256));
-    CG_HIP(hipMemset(out.ptr, 0, out.capacity));
+    hipStream_t st = gpu->stream;
+    CG_HIP(hipMemsetAsync(out.ptr, 0, out.capacity, st)); // (the card does this while the host preprocesses)
     CG_TRY(dev_descs.reserve(n * sizeof(ImageDesc) + 256));
-
-    PinnedBuffer stage;
     CG_TRY(stage.reserve(in_total + 256));
     uint8_t *hs = static_cast<uint8_t *>(stage.ptr);
     uint8_t *di = static_cast<uint8_t *>(inputs.ptr);
-    size_t ac_at = 0, dc_at = 0;
-    for (size_t i = 0; i < n; i++) {
-        const ImageData &img = *images[i];
-        ImageDesc &d = descs[i];
-        fill_desc(img, d);
-        size_t o = in_off[i];
-        write_tables(hs + o, img);
-        d.l1 = reinterpret_cast<const uint16_t *>(di + o);
-        d.l2 = reinterpret_cast<const uint16_t *>(di + o + COMPEG_HUFFMAN_L1_BYTES);
-        o += table_blob_bytes(img);
-        if (scans[i].nstarts())
-            memcpy(hs + o, scans[i].starts(), scans[i].nstarts() * 4);
-        d.starts = reinterpret_cast<const uint32_t *>(di + o);
-        d.nstarts = uint32_t(scans[i].nstarts());
-        o += scans[i].nstarts() * 4;
-        if (scans[i].nwords())
-            memcpy(hs + o, scans[i].words(), scans[i].nwords() * 4);
-        d.words = reinterpret_cast<const uint32_t *>(di + o);
-        d.nwords = uint32_t(scans[i].nwords());
-        d.ac = fused ? nullptr : reinterpret_cast<int16_t *>(static_cast<uint8_t *>(ac.ptr) + ac_at);
-        d.dc = (fused && !stamps) ? nullptr : reinterpret_cast<int32_t *>(static_cast<uint8_t *>(dc.ptr) + dc_at);
-        ac_at += size_t(img.total_dus()) * kRetained * 2;
-        dc_at += size_t(img.total_dus()) * 4;
-        d.out = static_cast<uint8_t *>(out.ptr) + out_offset[i];
-        d.out_w = img.width;
-        d.out_h = img.height;
-        d.out_pitch = img.width * 4;
+    std::vector<size_t> ac_at(n), dc_at(n);
+    for (size_t i = 0, a = 0, c = 0; i < n; i++) {
+        ac_at[i] = a;
+        dc_at[i] = c;
+        a += size_t(images[i]->total_dus()) * kRetained * 2;
+        c += size_t(images[i]->total_dus()) * 4;
     }
-    CG_HIP(hipMemcpy(inputs.ptr, hs, in_total, hipMemcpyHostToDevice));
-    CG_HIP(hipMemcpy(dev_descs.ptr, descs.data(), n * sizeof(ImageDesc), hipMemcpyHostToDevice));
+
+    std::vector<Status> results(n);
+    std::vector<uint32_t> spans(n, 0);
+    std::vector<uint64_t> alg(n, 0);
+    std::atomic<int> hip_error{int(hipSuccess)};
+    unsigned nthreads = threads > 0 ? unsigned(threads) : std::max(1u, std::thread::hardware_concurrency());
+    nthreads = unsigned(std::min<size_t>(nthreads, std::max<size_t>(n, 1)));
+    const int device = gpu->device;
+    auto work = [&](unsigned t) {
+        if (hipSetDevice(device) != hipSuccess) {
+            hip_error = int(hipErrorInvalidDevice);
+            return;
+        }
+        for (size_t i = t; i < n; i += nthreads) {
+            const ImageData &img = *images[i];
+            ImageDesc &d = descs[i];
+            fill_desc(img, d);
+            size_t o = in_off[i];
+            write_tables(hs + o, img);
+            d.l1 = reinterpret_cast<const uint16_t *>(di + o);
+            d.l2 = reinterpret_cast<const uint16_t *>(di + o + COMPEG_HUFFMAN_L1_BYTES);
+            o += table_blob_bytes(img);
+            const size_t slots = ScanBuffer::start_slots(img.metadata.total_restart_intervals);
+            uint32_t *starts_at = reinterpret_cast<uint32_t *>(hs + o);
+            uint8_t *words_at = hs + o + slots * 4;
+            size_t nwords = 0, nstarts = 0;
+            results[i] = ScanBuffer::process_to(img.scan_data(), img.scan_len, img.metadata.total_restart_intervals,
+                                                words_at, starts_at, nwords, nstarts);
+            if (!results[i].ok() && results[i].code != COMPEG_E_COUNT_MISMATCH)
+                continue;
+            d.starts = reinterpret_cast<const uint32_t *>(di + o);
+            d.nstarts = uint32_t(nstarts);
+            d.words = reinterpret_cast<const uint32_t *>(di + o + slots * 4);
+            d.nwords = uint32_t(nwords);
+            d.ac = fused ? nullptr : reinterpret_cast<int16_t *>(static_cast<uint8_t *>(ac.ptr) + ac_at[i]);
+            d.dc = (fused && !stamps) ? nullptr : reinterpret_cast<int32_t *>(static_cast<uint8_t *>(dc.ptr) + dc_at[i]);
+            d.out = static_cast<uint8_t *>(out.ptr) + out_offset[i];
+            d.out_w = img.width;
+            d.out_h = img.height;
+            d.out_pitch = img.width * 4;
+            spans[i] = max_wave_span(starts_at, nstarts, nwords, img.metadata.total_restart_intervals);
+            alg[i] = 4ull * nwords + 4ull * img.metadata.total_restart_intervals + COMPEG_METADATA_BYTES +
+                     COMPEG_HUFFMAN_L1_BYTES + img.l2.size() * 2 + 4ull * img.width * img.height;
+            // this image's part of the arena, as far as it is used
+            const size_t used = table_blob_bytes(img) + slots * 4 + nwords * 4;
+            const hipError_t e = hipMemcpyAsync(di + in_off[i], hs + in_off[i], used, hipMemcpyHostToDevice, st);
+            if (e != hipSuccess)
+                hip_error = int(e);
+        }
+    };
+    if (nthreads <= 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nthreads; t++)
+            pool.emplace_back(work, t);
+        for (auto &th : pool)
+            th.join();
+    }
+    CG_HIP(hipError_t(hip_error.load()));
+    for (size_t i = 0; i < n; i++) {
+        if (!results[i].ok() && results[i].code != COMPEG_E_COUNT_MISMATCH) {
+            (void)hipStreamSynchronize(st);
+            return results[i];
+        }
+        max_span = std::max(max_span, spans[i]);
+        algorithmic_bytes += alg[i];
+    }
+    CG_HIP(hipMemcpyAsync(dev_descs.ptr, descs.data(), n * sizeof(ImageDesc), hipMemcpyHostToDevice, st));
+    CG_HIP(hipStreamSynchronize(st)); // descs (pageable) and the staging arena may be reused from here on
+    last_stream = st;
     count = n;
     decodes_timed = 0;
     return Status{};

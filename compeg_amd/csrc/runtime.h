@@ -117,6 +117,7 @@ struct compeg_batch {
     size_t count = 0;
     std::vector<compeg::ImageDesc> descs; // host copy (device pointers inside)
     compeg::DeviceBuffer dev_descs, inputs, ac, dc, out;
+    compeg::PinnedBuffer stage; // host copy of the input arena (kept between uploads: pinning is slow)
     std::vector<size_t> out_offset;
     uint32_t max_intervals = 0, max_dus = 0, max_l2 = 0, max_span = 0;
     // some image is not 4:2:2 (extension): the whole batch takes the three-kernel pipeline

@@ -368,6 +368,39 @@ bool ScanBuffer::process_with_team(const uint8_t *scan, size_t len, uint32_t exp
     return true;
 }
 
+size_t ScanBuffer::output_capacity(size_t len)
+{
+    // Worst case: a 1-byte interval behind a 2-byte marker occupies a whole
+    // word, i.e. 4 bytes out for 3 in (scan.rs:38-44); plus the vector loop's slack.
+    return ((len + len / 3 + 3) / 4) * 4 + 72;
+}
+
+size_t ScanBuffer::start_slots(uint32_t expected)
+{
+    size_t slots = 1;
+    while (slots < expected)
+        slots <<= 1;
+    return slots;
+}
+
+Status ScanBuffer::process_to(const uint8_t *scan, size_t len, uint32_t expected, uint8_t *out, uint32_t *starts,
+                              size_t &nwords, size_t &nstarts)
+{
+    const size_t slots = start_slots(expected);
+    memset(starts, 0, slots * 4);
+    ScanEnd end{0, 1, 0};
+    scan_range(scan, len, out, starts, slots - 1, end, {}, 0);
+    nwords = (end.wp + 3) / 4;
+    store_u32(out + end.wp, 0u);
+    nstarts = end.ri < slots ? end.ri : slots;
+    if (end.ri != expected) {
+        char msg[128];
+        snprintf(msg, sizeof msg, "restart interval count mismatch: counted %zu, expected %u", end.ri, expected);
+        return Status::error(COMPEG_E_COUNT_MISMATCH, msg);
+    }
+    return Status{};
+}
+
 Status ScanBuffer::process(const uint8_t *scan, size_t len, uint32_t expected, const Progress &progress,
                            size_t progress_step)
 {

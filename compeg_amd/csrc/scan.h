@@ -56,6 +56,12 @@ class ScanBuffer {
     using Progress = std::function<void(size_t final_bytes)>;
     Status process(const uint8_t *scan, size_t len, uint32_t expected_intervals, const Progress &progress = {},
                    size_t progress_step = 0);
+    // The same result in memory of the caller's (one thread, no helpers): `out` holds
+    // output_capacity(len) bytes, `starts` start_slots(expected) words.
+    static size_t output_capacity(size_t len);
+    static size_t start_slots(uint32_t expected_intervals);
+    static Status process_to(const uint8_t *scan, size_t len, uint32_t expected_intervals, uint8_t *out,
+                             uint32_t *starts, size_t &nwords, size_t &nstarts);
     // Same buffers, filled by the device-side scan kernels (runtime.cpp).
     Status process_on_gpu(struct ::compeg_gpu *gpu, const uint8_t *scan, size_t len,
                           uint32_t expected_intervals);
