@@ -570,7 +570,7 @@ Status compeg::ScanBuffer::process_on_gpu(compeg_gpu *gpu, const uint8_t *scan, 
         return at;
     };
     const size_t o_raw = take(len + 64), o_ts = take(size_t(ntiles) * kScanTileStateBytes + 32),
-                 o_st = take(size_t(slots) * 4), o_w = take(len + len / 3 + 64), o_res = take(16);
+                 o_st = take(size_t(slots) * 4), o_w = take(len + len / 3 + 64), o_res = take(kScanResultBytes);
     CG_TRY(arena.reserve(total));
     CG_TRY(descbuf.reserve(sizeof(ScanDesc)));
     uint8_t *da = static_cast<uint8_t *>(arena.ptr);
@@ -634,7 +634,7 @@ Status compeg_batch::upload(const ImageData *const *images, size_t n, int thread
         if (generic_layout)
             return Status::error(COMPEG_E_UNSUPPORTED,
                                  "device preprocessing of a batch supports 4:2:2 images only");
-        return upload_device_scan(images, n);
+        return upload_device_scan(images, n, threads);
     }
     CG_HIP(hipSetDevice(gpu->device));
     CG_HIP(hipStreamSynchronize(last_stream));
@@ -770,7 +770,7 @@ Status compeg_batch::upload(const ImageData *const *images, size_t n, int thread
 // Device-side preprocessing: raw entropy-coded segments go to HBM as they are
 // and the scan kernels (scan_kernels.hip) produce words / start positions in
 // the reference layout.
-Status compeg_batch::upload_device_scan(const ImageData *const *images, size_t n)
+Status compeg_batch::upload_device_scan(const ImageData *const *images, size_t n, int threads)
 {
     CG_HIP(hipSetDevice(gpu->device));
     CG_HIP(hipStreamSynchronize(last_stream));
@@ -778,12 +778,15 @@ Status compeg_batch::upload_device_scan(const ImageData *const *images, size_t n
     if (n > 65535)
         return Status::error(COMPEG_E_INVALID_ARG, "at most 65535 images per batch");
 
+    // Device arena per image: [64 readable bytes][raw segment][LUTs] -- what the host sends, one transfer --
+    // then the scan kernels' scratch and output.  The pinned staging arena holds the first part only.
     struct Layout {
-        size_t raw, tile_state, starts, words, result, tables;
+        size_t sent, raw, tables, sent_bytes, tile_state, starts, words; // `sent`: start of the transferred part
+        size_t staged;                                                     // the same part in the staging arena
         uint32_t ntiles, slots;
     };
     std::vector<Layout> lay(n);
-    size_t total = 0, out_total = 0;
+    size_t total = 0, staged_total = 0, out_total = 0;
     max_tiles = 0;
     max_intervals = max_dus = max_l2 = max_span = 0;
     algorithmic_bytes = pixels = 0;
@@ -792,6 +795,7 @@ Status compeg_batch::upload_device_scan(const ImageData *const *images, size_t n
         total += align_up(bytes, 256);
         return at;
     };
+    const size_t o_results = take(n * kScanResultBytes);
     for (size_t i = 0; i < n; i++) {
         const ImageData &img = *images[i];
         if (img.scan_len > 0xfffffff0u)
@@ -799,16 +803,17 @@ Status compeg_batch::upload_device_scan(const ImageData *const *images, size_t n
         Layout &L = lay[i];
         const uint32_t len = uint32_t(img.scan_len), expected = img.metadata.total_restart_intervals;
         L.ntiles = scan_tiles(len);
-        L.slots = 1;
-        while (L.slots < expected)
-            L.slots <<= 1;
-        total += 64; // readable bytes in front of the segment
-        L.raw = take(size_t(len) + 64);
+        L.slots = uint32_t(ScanBuffer::start_slots(expected));
+        const size_t raw_bytes = align_up(size_t(len) + 64, 16);
+        L.sent_bytes = 64 + raw_bytes + table_blob_bytes(img);
+        L.sent = take(L.sent_bytes);
+        L.raw = L.sent + 64;
+        L.tables = L.raw + raw_bytes;
         L.tile_state = take(size_t(L.ntiles) * kScanTileStateBytes + 32);
         L.starts = take(size_t(L.slots) * 4);
         L.words = take(size_t(len) + len / 3 + 64);
-        L.result = take(16);
-        L.tables = take(table_blob_bytes(img));
+        L.staged = staged_total;
+        staged_total += align_up(L.sent_bytes, 256);
         out_total += align_up(size_t(img.width) * 4 * img.height, 256);
         max_tiles = std::max(max_tiles, L.ntiles);
         max_intervals = std::max(max_intervals, expected);
@@ -819,50 +824,76 @@ Status compeg_batch::upload_device_scan(const ImageData *const *images, size_t n
     CG_TRY(scan_arena.reserve(total + 256));
     CG_TRY(scan_descs.reserve(n * sizeof(ScanDesc) + 256));
     CG_TRY(out.reserve(out_total + 256));
-    CG_HIP(hipMemset(out.ptr, 0, out.capacity));
-    CG_TRY(dev_descs.reserve(n * sizeof(ImageDesc) + 256));
-
-    PinnedBuffer stage;
-    CG_TRY(stage.reserve(total + 256));
-    uint8_t *hs = static_cast<uint8_t *>(stage.ptr), *da = static_cast<uint8_t *>(scan_arena.ptr);
-    memset(hs, 0, total);
-    std::vector<ScanDesc> sd(n);
-    for (size_t i = 0; i < n; i++) {
-        const ImageData &img = *images[i];
-        const Layout &L = lay[i];
-        memcpy(hs + L.raw, img.scan_data(), img.scan_len);
-        write_tables(hs + L.tables, img);
-        ScanDesc &s = sd[i];
-        s.raw = da + L.raw;
-        s.len = uint32_t(img.scan_len);
-        s.ntiles = L.ntiles;
-        s.slots = L.slots;
-        s.tile_state = reinterpret_cast<uint32_t *>(da + L.tile_state);
-        s.starts_out = reinterpret_cast<uint32_t *>(da + L.starts);
-        s.words_out = da + L.words;
-        s.result = reinterpret_cast<uint32_t *>(da + L.result);
-    }
-    CG_HIP(hipMemcpy(da, hs, total, hipMemcpyHostToDevice));
-    CG_HIP(hipMemcpy(scan_descs.ptr, sd.data(), n * sizeof(ScanDesc), hipMemcpyHostToDevice));
     hipStream_t st = gpu->stream;
-    CG_HIP(launch_scan(static_cast<const ScanDesc *>(scan_descs.ptr), uint32_t(n), max_tiles, st));
-    CG_HIP(hipStreamSynchronize(st));
+    CG_HIP(hipMemsetAsync(out.ptr, 0, out.capacity, st));
+    CG_TRY(dev_descs.reserve(n * sizeof(ImageDesc) + 256));
+    CG_TRY(stage.reserve(staged_total + 256));
+    uint8_t *hs = static_cast<uint8_t *>(stage.ptr), *da = static_cast<uint8_t *>(scan_arena.ptr);
+    CG_HIP(hipMemsetAsync(da + o_results, 0, n * kScanResultBytes, st));
 
-    // read the per-image results back once: sizes for the decode descriptors
+    // the threads stage segment and LUTs of an image and send them off at once
+    std::vector<ScanDesc> sd(n);
+    std::atomic<int> hip_error{int(hipSuccess)};
+    unsigned nthreads = threads > 0 ? unsigned(threads) : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    nthreads = unsigned(std::min<size_t>(nthreads, std::max<size_t>(n, 1)));
+    const int device = gpu->device;
+    auto work = [&](unsigned t) {
+        if (hipSetDevice(device) != hipSuccess) {
+            hip_error = int(hipErrorInvalidDevice);
+            return;
+        }
+        for (size_t i = t; i < n; i += nthreads) {
+            const ImageData &img = *images[i];
+            const Layout &L = lay[i];
+            uint8_t *h = hs + L.staged;
+            memset(h, 0, 64);
+            memcpy(h + 64, img.scan_data(), img.scan_len);
+            memset(h + 64 + img.scan_len, 0, L.tables - L.raw - img.scan_len);
+            write_tables(h + (L.tables - L.sent), img);
+            const hipError_t e = hipMemcpyAsync(da + L.sent, h, L.sent_bytes, hipMemcpyHostToDevice, st);
+            if (e != hipSuccess)
+                hip_error = int(e);
+            ScanDesc &s = sd[i];
+            s.raw = da + L.raw;
+            s.len = uint32_t(img.scan_len);
+            s.ntiles = L.ntiles;
+            s.slots = L.slots;
+            s.expected = img.metadata.total_restart_intervals;
+            s.tile_state = reinterpret_cast<uint32_t *>(da + L.tile_state);
+            s.starts_out = reinterpret_cast<uint32_t *>(da + L.starts);
+            s.words_out = da + L.words;
+            s.result = reinterpret_cast<uint32_t *>(da + o_results + i * kScanResultBytes);
+        }
+    };
+    if (nthreads <= 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nthreads; t++)
+            pool.emplace_back(work, t);
+        for (auto &th : pool)
+            th.join();
+    }
+    CG_HIP(hipError_t(hip_error.load()));
+    CG_HIP(hipMemcpyAsync(scan_descs.ptr, sd.data(), n * sizeof(ScanDesc), hipMemcpyHostToDevice, st));
+    CG_HIP(launch_scan(static_cast<const ScanDesc *>(scan_descs.ptr), uint32_t(n), max_tiles, st, true));
+    // all results in one read-back: sizes and window spans for the decode descriptors
+    std::vector<uint32_t> res(n * (kScanResultBytes / 4));
+    CG_HIP(hipMemcpyAsync(res.data(), da + o_results, n * kScanResultBytes, hipMemcpyDeviceToHost, st));
+    CG_HIP(hipStreamSynchronize(st));
+    last_stream = st;
+
     descs.assign(n, ImageDesc{});
     out_offset.assign(n, 0);
     host_fallbacks = 0;
     size_t out_at = 0;
-    std::vector<uint32_t> starts_host;
     for (size_t i = 0; i < n; i++) {
         const ImageData &img = *images[i];
         const Layout &L = lay[i];
-        uint32_t res[4];
-        CG_HIP(hipMemcpy(res, da + L.result, 16, hipMemcpyDeviceToHost));
-        uint32_t nwords = res[2], nstarts = std::min(res[0], L.slots);
+        const uint32_t *r = &res[i * (kScanResultBytes / 4)];
+        uint32_t nwords = r[2], nstarts = std::min(r[0], L.slots), span = r[4];
         const uint32_t expected = img.metadata.total_restart_intervals;
-        starts_host.resize(L.slots);
-        if (res[3] & 1u) {
+        if (r[3] & 1u) {
             // pathological FF run: the host preprocessor (same output format) takes this image
             ScanBuffer sb;
             Status s = sb.process(img.scan_data(), img.scan_len, expected);
@@ -874,10 +905,8 @@ Status compeg_batch::upload_device_scan(const ImageData *const *images, size_t n
                 CG_HIP(hipMemcpy(da + L.words, sb.words(), size_t(nwords) * 4, hipMemcpyHostToDevice));
             if (nstarts)
                 CG_HIP(hipMemcpy(da + L.starts, sb.starts(), size_t(nstarts) * 4, hipMemcpyHostToDevice));
-            memcpy(starts_host.data(), sb.starts(), size_t(nstarts) * 4);
+            span = max_wave_span(sb.starts(), nstarts, nwords, expected);
             host_fallbacks++;
-        } else if (nstarts) {
-            CG_HIP(hipMemcpy(starts_host.data(), da + L.starts, size_t(nstarts) * 4, hipMemcpyDeviceToHost));
         }
         ImageDesc &d = descs[i];
         fill_desc(img, d);
@@ -895,7 +924,7 @@ Status compeg_batch::upload_device_scan(const ImageData *const *images, size_t n
         d.out_w = img.width;
         d.out_h = img.height;
         d.out_pitch = img.width * 4;
-        max_span = std::max(max_span, max_wave_span(starts_host.data(), nstarts, nwords, expected));
+        max_span = std::max(max_span, span);
         algorithmic_bytes += 4ull * nwords + 4ull * expected + COMPEG_METADATA_BYTES +
                              COMPEG_HUFFMAN_L1_BYTES + img.l2.size() * 2 + 4ull * img.width * img.height;
     }

@@ -142,6 +142,6 @@ struct compeg_batch {
 
     ~compeg_batch();
     compeg::Status upload(const compeg::ImageData *const *images, size_t n, int threads);
-    compeg::Status upload_device_scan(const compeg::ImageData *const *images, size_t n);
+    compeg::Status upload_device_scan(const compeg::ImageData *const *images, size_t n, int threads);
     compeg::Status decode(hipStream_t stream);
 };

@@ -18,7 +18,9 @@ struct ScanDesc {
     uint32_t *tile_state;    // [ntiles] x 20 bytes of scratch (kScanTileStateBytes each)
     uint32_t *starts_out;    // [slots] the reference's start_positions
     uint8_t *words_out;      // preprocessed scan, (len + len/3 + 4) bytes
-    uint32_t *result;        // [4]: intervals counted, kept bytes, output words, flags (bit 0: FF run too long)
+    uint32_t expected = 0;   // restart intervals the frame header announces (span_kernel only)
+    uint32_t *result;        // [8]: intervals counted, kept bytes, output words, flags (bit 0: FF run too long),
+                             // widest 64-interval span in words (span_kernel), 3 unused
     // optional: where to drop the output word count and the number of start positions kept
     // (the nwords / nstarts fields of the image descriptor a following decode kernel reads)
     uint32_t *patch_nwords = nullptr;
@@ -30,6 +32,10 @@ uint32_t scan_tiles(uint32_t len);
 // dst (device) <- pinned_src (pinned host memory), both 16-byte aligned and readable / writable up to the
 // next multiple of 16 bytes; the copy is a kernel on `stream`
 hipError_t launch_pull(void *dst, const void *pinned_src, size_t bytes, hipStream_t stream);
-hipError_t launch_scan(const ScanDesc *descs, uint32_t images, uint32_t max_tiles, hipStream_t stream);
+// with_span: one more small kernel leaves in result[4] what max_wave_span() computes on the host (the decode
+// kernels' LDS window is sized from it)
+hipError_t launch_scan(const ScanDesc *descs, uint32_t images, uint32_t max_tiles, hipStream_t stream,
+                       bool with_span = false);
+constexpr size_t kScanResultBytes = 32;
 
 } // namespace compeg

@@ -372,6 +372,30 @@ __global__ void __launch_bounds__(kThreads) emit_kernel(const ScanDesc *descs)
         out32[i] = stage32[i - origin / 4u];
 }
 
+// One block per image: the widest stretch of words that 64 consecutive intervals (one decoder wave) cover,
+// exactly what max_wave_span() (desc.cpp) computes from the start positions on the host.
+__global__ void __launch_bounds__(kThreads) span_kernel(const ScanDesc *descs)
+{
+    __shared__ uint32_t best;
+    const ScanDesc &d = descs[blockIdx.x];
+    const uint32_t nstarts = min(d.result[0], d.slots), nwords = d.result[2], intervals = d.expected;
+    if (threadIdx.x == 0)
+        best = 0u;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t first = threadIdx.x * 64u; first < intervals; first += kThreads * 64u) {
+        const uint32_t lo = first < nstarts ? d.starts_out[first] : 0u;
+        const uint32_t after = first + 64u;
+        const uint32_t hi = (after < intervals && after < nstarts) ? d.starts_out[after] : nwords;
+        if (hi > lo)
+            mine = max(mine, hi - lo);
+    }
+    atomicMax(&best, mine);
+    __syncthreads();
+    if (threadIdx.x == 0)
+        d.result[4] = best;
+}
+
 // Host-to-device copy done by the compute queue itself: `src` is pinned host
 // memory, read over PCIe with 16-byte loads.  Used for the single-image path,
 // where a copy-engine transfer costs more in hand-over between the engines
@@ -408,7 +432,7 @@ uint32_t scan_tiles(uint32_t len)
     return (len + kTileBytes - 1) / kTileBytes;
 }
 
-hipError_t launch_scan(const ScanDesc *descs, uint32_t images, uint32_t max_tiles, hipStream_t stream)
+hipError_t launch_scan(const ScanDesc *descs, uint32_t images, uint32_t max_tiles, hipStream_t stream, bool with_span)
 {
     if (images == 0)
         return hipSuccess;
@@ -419,6 +443,8 @@ hipError_t launch_scan(const ScanDesc *descs, uint32_t images, uint32_t max_tile
     if (max_tiles) {
         hipLaunchKernelGGL(emit_kernel, dim3(max_tiles, images), dim3(kThreads), 0, stream, descs);
     }
+    if (with_span)
+        hipLaunchKernelGGL(span_kernel, dim3(images), dim3(kThreads), 0, stream, descs);
     return hipGetLastError();
 }
 
