@@ -178,6 +178,20 @@ def main():
         if not verified:
             raise SystemExit("bench: GPU output differs from the oracle -- refusing to report a number")
 
+    # the same batch from host memory: upload (preprocess + PCIe) + decode, steady state (the staging arena is
+    # pinned by now) -- the PCIe/host-inclusive rate, reported beside `value`, never as it
+    inclusive = None
+    if rank == 0 and world == 1:
+        t_i = time.perf_counter()
+        batch.upload(images, host_threads=threads)
+        batch.decode()
+        batch.wait()
+        t_i = time.perf_counter() - t_i
+        batch.timing(reset=True)
+        inclusive = {"ms_per_batch": round(t_i * 1e3, 2), "mpix_s": round(batch.pixels() / t_i / 1e6, 1),
+                     "what": "compeg_batch_upload (%s preprocessing, %d host threads, PCIe) + compeg_batch_decode + wait"
+                             % (args.preprocess, threads)}
+
     # single-frame latency (BASELINE config 2: one 4K frame), device-only and end-to-end
     single = None
     if rank == 0:
@@ -286,6 +300,7 @@ def main():
             },
             "cpu_baseline": base,
             "single_frame": single,
+            "pcie_inclusive": inclusive,
             "verified_bit_exact_vs_oracle": verified,
             "setup_s": {"synthesize": round(t_gen, 2), "host_preprocess_and_upload": round(t_up, 2)},
             "device": gpu.name(),
