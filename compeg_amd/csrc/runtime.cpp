@@ -455,12 +455,8 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     size_t shipped = 0; // bytes of the preprocessed scan already on their way
     if (!on_device) {
         // the output's worst case (scan.rs:38-44), so that pieces can leave while the scan is running
-        const size_t out_cap = ((img.scan_len + img.scan_len / 3 + 3) / 4) * 4;
-        uint32_t slots = 1;
-        while (slots < md.total_restart_intervals)
-            slots <<= 1;
-        CG_TRY(words.reserve(out_cap + 64));
-        CG_TRY(starts.reserve(size_t(slots) * 4 + 16));
+        CG_TRY(words.reserve(ScanBuffer::output_capacity(img.scan_len)));
+        CG_TRY(starts.reserve(ScanBuffer::start_slots(md.total_restart_intervals) * 4 + 16));
         hipError_t ship_error = hipSuccess;
         ScanBuffer::Progress ship;
         if (pull_copies())
