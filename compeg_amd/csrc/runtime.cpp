@@ -692,7 +692,7 @@ Status compeg_batch::upload(const ImageData *const *images, size_t n, int thread
     std::vector<uint32_t> spans(n, 0);
     std::vector<uint64_t> alg(n, 0);
     std::atomic<int> hip_error{int(hipSuccess)};
-    unsigned nthreads = threads > 0 ? unsigned(threads) : std::max(1u, std::thread::hardware_concurrency());
+    unsigned nthreads = threads > 0 ? unsigned(threads) : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     nthreads = unsigned(std::min<size_t>(nthreads, std::max<size_t>(n, 1)));
     const int device = gpu->device;
     auto work = [&](unsigned t) {
