@@ -198,8 +198,9 @@ int compeg_decoder_read_coefficients(compeg_decoder *dec, int32_t *host_coeffici
  * device allocation. */
 int compeg_batch_new(compeg_gpu *gpu, compeg_batch **out);
 void compeg_batch_free(compeg_batch *batch);
-/* Host front-end for all images (preprocess, may use `host_threads` threads,
- * 0 = one per core) + upload; replaces any previous content. */
+/* Host front-end for all images (preprocess or stage on `host_threads` threads,
+ * 0 = one per core, at most 16) + upload, every image sent off as soon as it is
+ * ready; replaces any previous content. */
 int compeg_batch_upload(compeg_batch *batch, const compeg_image *const *images, size_t count,
                         int host_threads);
 /* Records the decode of every uploaded image on hip_stream (NULL = the gpu's
