@@ -359,6 +359,11 @@ impl ScanBuffer {
         })
     }
 
+    /// Extension: `threads` threads (1..=16) share every following `process` call; same bytes.
+    pub fn set_threads(&mut self, threads: u32) -> Result<()> {
+        check(unsafe { ffi::compeg_scanbuffer_set_threads(self.raw.as_ptr(), threads as std::os::raw::c_uint) })
+    }
+
     /// Extension: the same bytes, computed by the device-side scan kernels.
     pub fn process_on_gpu(&mut self, gpu: &Gpu, scan_data: &[u8], expected_restart_intervals: u32) -> Result<()> {
         check(unsafe {
