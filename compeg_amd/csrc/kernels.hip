@@ -18,6 +18,7 @@
 // instruction issue of the serial entropy decode and by HBM writes.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 
@@ -366,19 +367,22 @@ HuffLdsPlan plan_huffman(uint32_t max_intervals, uint32_t images, uint32_t max_l
     p.window_words = (w + 3u) & ~3u;
     const uint32_t wave_area = ((p.window_words * 4u + 15u) & ~15u) + slots;
 
-    // Workgroup shape.  A launch with few waves (one 4K frame with DRI=4 is
-    // 254 waves for 256 CUs) uses one wave per workgroup so that every wave
-    // gets a CU of its own.  Once the chip is oversubscribed, one workgroup
-    // fills a CU: as many waves as the LDS holds, at most 12 (3 per SIMD).
+    // Workgroup shape.  As many waves per workgroup as one CU's share of the launch (256 CUs), so that a
+    // launch that fits the chip runs in one round with one workgroup per CU (one 4K frame with DRI=4 is 254
+    // waves: one wave per workgroup, a CU each); at most what the LDS holds and 12 (3 per SIMD) -- a launch
+    // that oversubscribes the chip fills every CU with one such workgroup at a time.
     const uint64_t total_waves = uint64_t((max_intervals + kWave - 1) / kWave) * images;
-    uint32_t wpb = 1;
-    if (total_waves > 2048) {
-        const uint32_t fit = (kLdsBytesPerCu - tables) / wave_area;
-        wpb = fit < 1u ? 1u : fit;
-        const uint32_t cap = fused ? kMaxWavesFused : kMaxWavesSplit;
-        if (wpb > cap)
-            wpb = cap;
-    }
+    const uint32_t fit = (kLdsBytesPerCu - tables) / wave_area;
+    const uint32_t most = std::max(1u, std::min(fit, fused ? kMaxWavesFused : kMaxWavesSplit));
+    const uint64_t per_cu = (total_waves + 255u) / 256u;
+    uint32_t wpb = uint32_t(std::min<uint64_t>(std::max<uint64_t>(per_cu, 1u), most));
+    // (every image rounds up to whole workgroups: a few more waves per workgroup can save a second round)
+    auto groups = [&](uint32_t w) { return uint64_t((max_intervals + w * kWave - 1) / (w * kWave)) * images; };
+    auto groups_per_cu = [&](uint32_t w) {
+        return std::max(1u, std::min(kLdsBytesPerCu / (tables + w * wave_area), most / w));
+    };
+    while (wpb < most && groups(wpb) > 256u * groups_per_cu(wpb))
+        wpb++;
     if (const char *e = getenv("COMPEG_WPB")) // experiment knob
         wpb = uint32_t(atoi(e));
     p.waves_per_block = wpb;
