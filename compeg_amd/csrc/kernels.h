@@ -23,8 +23,9 @@ hipError_t launch_huffman(const ImageDesc *descs, uint32_t images, uint32_t max_
 // Same outputs as launch_huffman (coefficient records + DC terms) from the fast-mode decoder.
 hipError_t launch_entropy(const ImageDesc *descs, uint32_t images, uint32_t max_intervals,
                           const HuffLdsPlan &plan, hipStream_t stream);
+// uniform: all images have max_intervals intervals and byte-identical LUTs (workgroups may then span images)
 hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t max_intervals,
-                            const HuffLdsPlan &plan, hipStream_t stream);
+                            const HuffLdsPlan &plan, hipStream_t stream, bool uniform = false);
 // Latency variant: one decoder wave + one transformer wave per 64 intervals.
 hipError_t launch_pair_422(const ImageDesc *descs, uint32_t images, uint32_t max_intervals,
                            const HuffLdsPlan &plan, hipStream_t stream);

@@ -133,32 +133,47 @@ entropy_samples_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, 
 // Fused path: same prologue as huffman_kernel, then every lane runs the whole
 // decode of its interval (entropy decode -> IDCT -> composite), so neither
 // coefficients nor samples ever touch HBM.
+//
+// Two grid shapes.  waves_per_image == 0: grid (workgroups per image, images); the last workgroup of an image
+// is filled only as far as the image's intervals go (one 4K frame: 21 workgroups of 12 waves and one of 2).
+// waves_per_image != 0, for batches whose images all have that many waves and byte-identical LUTs (frames of
+// one stream): a one-dimensional grid over the waves of all images, workgroups span image boundaries (every
+// wave works from its own image's descriptor; the LUTs are staged from whichever images the workgroup's
+// threads belong to -- the same bytes), and only the batch's last workgroup is short.
 __global__ void __launch_bounds__(768)
-decode_fused_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words)
+decode_fused_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words,
+                        uint32_t waves_per_image, uint32_t images)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const ImageDesc &d = descs[blockIdx.y];
-    const uint32_t first_interval = blockIdx.x * blockDim.x;
-    if (first_interval >= d.total_intervals)
-        return;
+    const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x / kWave))), lane = threadIdx.x % kWave;
+    uint32_t image = blockIdx.y, wave_first = (blockIdx.x * (blockDim.x / kWave) + wave) * kWave;
+    bool has_work = true;
+    if (waves_per_image) {
+        const uint32_t flat = blockIdx.x * (blockDim.x / kWave) + wave; // wave-uniform
+        image = flat / waves_per_image;
+        wave_first = (flat % waves_per_image) * kWave;
+        has_work = image < images;
+        image = has_work ? image : images - 1u; // (it still helps staging the LUTs)
+    }
+    const ImageDesc &d = descs[image];
+    if (!waves_per_image && blockIdx.x * blockDim.x >= d.total_intervals)
+        return; // the whole workgroup
+    has_work = has_work && wave_first < d.total_intervals;
 
     uint16_t *l1 = reinterpret_cast<uint16_t *>(smem);
     uint16_t *l2 = l1 + kL1Entries;
     const uint32_t wave_area = align16(window_words * 4u) + kWave * kDuSlotBytes;
     uint8_t *wave_base = smem + align16((kL1Entries + l2_in_lds) * 2u);
-
-    const uint32_t wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
     uint32_t *win = reinterpret_cast<uint32_t *>(wave_base + wave * wave_area);
     uint8_t *slots = reinterpret_cast<uint8_t *>(win) + align16(window_words * 4u);
 
-    const uint32_t wave_first = first_interval + wave * kWave;
     uint32_t win_base = 0, win_len = 0;
-    if (wave_first < d.total_intervals)
+    if (has_work)
         wave_window(d, wave_first, window_words, win_base, win_len);
     stage_luts_and_window(d, l1, l2, l2_in_lds, threadIdx.x, blockDim.x, win, win_base, win_len, lane);
     __syncthreads();
 
-    if (wave_first >= d.total_intervals)
+    if (!has_work)
         return; // the whole wave; lanes past the last interval of a partly used wave stay (quad exchange)
 
     HuffShared s;
@@ -430,19 +445,29 @@ hipError_t launch_entropy(const ImageDesc *descs, uint32_t images, uint32_t max_
 }
 
 hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t max_intervals,
-                            const HuffLdsPlan &plan, hipStream_t stream)
+                            const HuffLdsPlan &plan, hipStream_t stream, bool uniform)
 {
     if (images == 0 || max_intervals == 0)
         return hipSuccess;
     const uint32_t threads = plan.waves_per_block * kWave;
+    // uniform: every image has max_intervals intervals and the same LUT bytes -> workgroups may span images
+    static const bool flat_allowed = [] {
+        const char *e = getenv("COMPEG_FLAT"); // experiment knob: 0 = always one grid row per image
+        return e ? atoi(e) != 0 : true;
+    }();
+    const uint32_t waves_per_image = (uniform && flat_allowed) ? (max_intervals + kWave - 1) / kWave : 0u;
+    const uint64_t flat_groups = (uint64_t(waves_per_image) * images + plan.waves_per_block - 1) / plan.waves_per_block;
     dim3 grid((max_intervals + threads - 1) / threads, images, 1);
+    if (waves_per_image && flat_groups <= 0x7fffffffu)
+        grid = dim3(uint32_t(flat_groups), 1, 1);
     static const hipError_t attr = hipFuncSetAttribute(
         reinterpret_cast<const void *>(decode_fused_422_kernel),
         hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsBytesPerCu));
     if (attr != hipSuccess)
         return attr;
     hipLaunchKernelGGL(decode_fused_422_kernel, grid, dim3(threads), plan.total_bytes, stream, descs,
-                       plan.l2_entries_in_lds, plan.window_words);
+                       plan.l2_entries_in_lds, plan.window_words, grid.y == 1 && waves_per_image ? waves_per_image : 0u,
+                       images);
     return hipGetLastError();
 }
 

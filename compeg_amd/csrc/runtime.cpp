@@ -619,10 +619,16 @@ Status compeg_batch::upload(const ImageData *const *images, size_t n, int thread
 {
     generic_layout = false;
     max_out_w = max_out_h = 0;
+    // frames of one stream: the same number of restart intervals and byte-identical LUTs in every image
+    // (the fused kernel's workgroups may then span image boundaries)
+    uniform = n > 0;
     for (size_t i = 0; i < n; i++) {
-        generic_layout = generic_layout || !is_422(*images[i]);
-        max_out_w = std::max(max_out_w, images[i]->width);
-        max_out_h = std::max(max_out_h, images[i]->height);
+        const ImageData &img = *images[i], &first = *images[0];
+        generic_layout = generic_layout || !is_422(img);
+        max_out_w = std::max(max_out_w, img.width);
+        max_out_h = std::max(max_out_h, img.height);
+        uniform = uniform && img.metadata.total_restart_intervals == first.metadata.total_restart_intervals &&
+                  img.l2 == first.l2 && img.ac_fast == first.ac_fast && memcmp(img.l1, first.l1, sizeof img.l1) == 0;
     }
     if (preprocess_mode != 0) {
         if (!use_fused_pipeline())
@@ -968,7 +974,7 @@ Status compeg_batch::decode(hipStream_t stream)
             if (use_pair_kernel(max_intervals, m))
                 CG_HIP(launch_pair_422(dd + at, m, max_intervals, plan, stream));
             else
-                CG_HIP(launch_fused_422(dd + at, m, max_intervals, plan, stream));
+                CG_HIP(launch_fused_422(dd + at, m, max_intervals, plan, stream, uniform));
             if (timing && at == 0)
                 CG_HIP(hipEventRecord(ev[1], stream));
             continue;

@@ -122,6 +122,7 @@ struct compeg_batch {
     uint32_t max_intervals = 0, max_dus = 0, max_l2 = 0, max_span = 0;
     // some image is not 4:2:2 (extension): the whole batch takes the three-kernel pipeline
     bool generic_layout = false;
+    bool uniform = false; // same interval count and LUT bytes in every image (set by upload)
     uint32_t max_out_w = 0, max_out_h = 0;
     uint64_t algorithmic_bytes = 0, pixels = 0;
     uint32_t chunk = 0; // images per launch pair, 0 = all

@@ -225,6 +225,31 @@ def test_fused_kernel_ragged_batch(ca, gpu):
         assert np.array_equal(dev.read_output(i), batch.read_output(i))
 
 
+def test_uniform_batch_spans_images_with_its_workgroups(ca, gpu):
+    """Frames of one stream (same interval count, same LUT bytes): the throughput kernel runs a one-dimensional
+    grid over the waves of all images; 112.5 waves per image, so workgroups and even the image's last wave are
+    shared out unevenly.  A batch with one odd image takes the per-image grid; both equal the oracle."""
+    jpegs = [synth.make_jpeg(1280, 720, seed=500 + i, kind=i % 3, quality=85, ri=1) for i in range(10)]
+    wants = [orc.ImageData(j).decode() for j in jpegs]
+    images = [ca.ImageData(j) for j in jpegs]
+    assert sum((im.parallelism() + 63) // 64 for im in images) > 768
+    batch = ca.Batch(gpu)
+    batch.upload(images)
+    batch.decode()
+    batch.wait()
+    for i, want in enumerate(wants):
+        _assert_equal(batch.read_output(i), want)
+    odd = synth.make_jpeg(1280, 720, seed=77, kind=1, quality=60, ri=1)      # other quantisers, same LUTs: still uniform
+    other = synth.make_jpeg(640, 360, seed=78, kind=0, quality=85, ri=1)     # other interval count: not uniform
+    for extra in (odd, other):
+        batch.upload(images + [ca.ImageData(extra)])
+        batch.decode()
+        batch.wait()
+        for i, want in enumerate(wants):
+            _assert_equal(batch.read_output(i), want)
+        _assert_equal(batch.read_output(len(images)), orc.ImageData(extra).decode())
+
+
 def test_restart_interval_changes_pixels_only_where_the_reference_does(ca, gpu):
     """The restart interval only changes where the DC predictors are reset and how the scan is
     cut into lanes -- except for the reference's quirk Q1: its reader is not refilled in front
