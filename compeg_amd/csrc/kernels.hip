@@ -396,7 +396,15 @@ HuffLdsPlan plan_huffman(uint32_t max_intervals, uint32_t images, uint32_t max_l
     auto groups_per_cu = [&](uint32_t w) {
         return std::max(1u, std::min(kLdsBytesPerCu / (tables + w * wave_area), most / w));
     };
-    while (wpb < most && groups(wpb) > 256u * groups_per_cu(wpb))
+    uint64_t rounds = 1;
+    if (per_cu > most) {
+        // two or three rounds: split the waves evenly over them (16 4K frames are 15.9 waves per CU: two
+        // rounds of 8 rather than one of 12 and one of 4 that takes as long as a full one)
+        rounds = (per_cu + most - 1) / most;
+        if (rounds <= 3)
+            wpb = uint32_t(std::min<uint64_t>((per_cu + rounds - 1) / rounds, most));
+    }
+    while (wpb < most && groups(wpb) > 256u * rounds * groups_per_cu(wpb))
         wpb++;
     if (const char *e = getenv("COMPEG_WPB")) // experiment knob
         wpb = uint32_t(atoi(e));
