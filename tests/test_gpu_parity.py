@@ -199,16 +199,16 @@ def test_full_size_8k_dri1_roundtrip_properties(ca, gpu):
 
 
 def test_fused_kernel_ragged_batch(ca, gpu):
-    """A batch big enough for the throughput kernel (more than 768 waves) of images whose
+    """A batch big enough for the throughput kernel (more than 1024 waves) of images whose
     geometry exercises its corner cases: MCUs cut by the right and bottom edge (stored by
     their own lane), a last wave with unused lanes (they only help their quad store), an
     interval count that is not a multiple of the restart interval."""
     shapes = [(1000, 1000, 3), (1016, 990, 5), (1000, 1004, 4)]
     jpegs = [synth.make_jpeg(w, h, seed=200 + i, kind=i % 3, quality=80, ri=ri)
-             for i, (w, h, ri) in enumerate(shapes * 8)]
+             for i, (w, h, ri) in enumerate(shapes * 11)]
     images = [ca.ImageData(j) for j in jpegs]
     waves = sum((im.parallelism() + 63) // 64 for im in images)
-    assert waves > 768
+    assert waves > 1024
     batch = ca.Batch(gpu)
     batch.upload(images)
     batch.decode()
@@ -232,7 +232,7 @@ def test_uniform_batch_spans_images_with_its_workgroups(ca, gpu):
     jpegs = [synth.make_jpeg(1280, 720, seed=500 + i, kind=i % 3, quality=85, ri=1) for i in range(10)]
     wants = [orc.ImageData(j).decode() for j in jpegs]
     images = [ca.ImageData(j) for j in jpegs]
-    assert sum((im.parallelism() + 63) // 64 for im in images) > 768
+    assert sum((im.parallelism() + 63) // 64 for im in images) > 1024
     batch = ca.Batch(gpu)
     batch.upload(images)
     batch.decode()
@@ -409,7 +409,7 @@ def _hostile_table_variants(n):
 def test_corrupt_streams_and_hostile_tables_on_the_gpu(ca, gpu):
     """The rare paths of the entropy decoder (cut DC codes, reader underflow -> exact mode, escapes,
     reads past the window and past the scan) as the GPU executes them -- through the paired kernel
-    (single decodes) and through the throughput kernel (one batch of more than 768 waves) --
+    (single decodes) and through the throughput kernel (one batch of more than 1024 waves) --
     byte-equal to the oracle.  tests/test_kernel_emulation.py runs the same inputs under ASan."""
     variants = []
     for j in _corrupt_variants(12) + _hostile_table_variants(10):
@@ -435,8 +435,8 @@ def test_corrupt_streams_and_hostile_tables_on_the_gpu(ca, gpu):
             dec.decode_blocking(data)
             _assert_equal(dec.read_texture(data.width(), data.height()), want)
     images = [ca.ImageData(j) for j, _ in variants]
-    n = 800
-    assert sum((images[i % len(images)].parallelism() + 63) // 64 for i in range(n)) > 768
+    n = 1100
+    assert sum((images[i % len(images)].parallelism() + 63) // 64 for i in range(n)) > 1024
     batch = ca.Batch(gpu)
     batch.upload([images[i % len(images)] for i in range(n)])
     batch.decode()
@@ -459,13 +459,14 @@ def test_standard_entropy_extension(ca, gpu):
         outs.append(got)
     for other in outs[1:]:
         assert np.array_equal(outs[0], other)
-    # throughput kernel (more than 768 waves) and a 4:2:0 image, both with the switch
-    jpegs = [synth.make_jpeg(1000, 1000, seed=210 + i, kind=i % 2, quality=92, ri=3) for i in range(20)]
+    # throughput kernel (more than 1024 waves) and a 4:2:0 image, both with the switch
+    jpegs = [synth.make_jpeg(1000, 1000, seed=210 + i, kind=i % 2, quality=92, ri=3) for i in range(26)]
     batch = ca.Batch(gpu)
     batch.upload([ca.ImageData(j, standard_entropy=True) for j in jpegs])
     batch.decode()
     batch.wait()
-    for i in (0, 1, 19):
+    assert sum((2625 + 63) // 64 for _ in jpegs) > 1024
+    for i in (0, 1, 25):
         _assert_equal(batch.read_output(i), orc.ImageData(jpegs[i], standard_entropy=True).decode())
     j420 = synth.make_jpeg(640, 360, seed=230, kind=0, quality=95, ri=2, sampling=(2, 2))
     dec = ca.Decoder(gpu)
