@@ -155,6 +155,9 @@ decode_fused_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds,
         has_work = image < images;
         image = has_work ? image : images - 1u; // (it still helps staging the LUTs)
     }
+    // (wave-uniform by construction; said explicitly so that the descriptor is read through scalar loads)
+    image = uint32_t(__builtin_amdgcn_readfirstlane(int(image)));
+    wave_first = uint32_t(__builtin_amdgcn_readfirstlane(int(wave_first)));
     const ImageDesc &d = descs[image];
     if (!waves_per_image && blockIdx.x * blockDim.x >= d.total_intervals)
         return; // the whole workgroup
