@@ -208,9 +208,12 @@ compeg_decoder::compeg_decoder() : scan(pinned_alloc, pinned_free)
     // helpers for the host scan preprocessor (one image is all a Decoder has to be parallel over)
     const unsigned hw = std::thread::hardware_concurrency();
     unsigned threads = hw >= 32 ? 8 : (hw >= 8 ? 4 : 1);
-    if (const char *e = getenv("COMPEG_SCAN_THREADS"))
+    bool asked = false;
+    if (const char *e = getenv("COMPEG_SCAN_THREADS")) {
         threads = unsigned(std::max(1, std::min(16, atoi(e))));
-    scan.set_threads(threads);
+        asked = true;
+    }
+    scan.set_threads(threads, !asked); // a default nobody asked for checks itself on first use
 }
 
 compeg_decoder::~compeg_decoder()

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -245,12 +246,15 @@ ScanBuffer::ScanBuffer() = default;
 ScanBuffer::ScanBuffer(HostArena::AllocFn a, HostArena::FreeFn f) : words_(a, f), starts_(a, f) {}
 ScanBuffer::~ScanBuffer() = default;
 
-void ScanBuffer::set_threads(unsigned threads)
+void ScanBuffer::set_threads(unsigned threads, bool self_check)
 {
     threads = threads < 1 ? 1 : (threads > 16 ? 16 : threads);
-    if (team_ && team_->pieces.size() == threads)
+    if (team_ && team_->pieces.size() == threads) {
+        team_checked_ = team_checked_ || !self_check;
         return;
+    }
     team_.reset();
+    team_checked_ = !self_check;
     if (threads > 1)
         team_.reset(new ScanTeam(threads));
 }
@@ -418,6 +422,28 @@ Status ScanBuffer::process(const uint8_t *scan, size_t len, uint32_t expected, c
     const size_t mask = slots - 1;
 
     size_t wp = 0, ri = 1;
+    // The first segment large enough for the helpers is also timed on one thread: where threads are scarce or
+    // slow to wake (a small CPU quota, some virtual machines) sharing the work costs more than it saves, and
+    // the buffer then keeps to the calling thread.
+    if (team_ && !team_checked_ && len >= team_->pieces.size() * (64u << 10)) {
+        team_checked_ = true;
+        using clock = std::chrono::steady_clock;
+        const auto t0 = clock::now();
+        ScanEnd alone{0, 1, 0};
+        scan_range(scan, len, out, starts, mask, alone, {}, 0);
+        const auto t1 = clock::now();
+        memset(starts, 0, slots * 4);
+        size_t twp = 0, tri = 1;
+        // (once to wake the helpers and touch their buffers, once for the clock)
+        bool shared = process_with_team(scan, len, expected, out, starts, slots, twp, tri, {});
+        const auto t2 = clock::now();
+        memset(starts, 0, slots * 4);
+        shared = shared && process_with_team(scan, len, expected, out, starts, slots, twp, tri, {});
+        const auto t3 = clock::now();
+        if (!shared || (t3 - t2) > (t1 - t0))
+            team_.reset();
+        memset(starts, 0, slots * 4);
+    }
     if (!team_ || !process_with_team(scan, len, expected, out, starts, slots, wp, ri, progress)) {
         memset(starts, 0, slots * 4); // (a team that gave up may have written some)
         ScanEnd end{0, 1, 0};

@@ -43,7 +43,9 @@ class ScanBuffer {
 
     // Threads that share the work of one process() call on segments of 64 KiB per thread and more
     // (1 = the calling thread alone, the default).  The helpers live as long as the buffer.
-    void set_threads(unsigned threads);
+    // self_check: the first such call is timed both ways and the helpers are dropped if sharing the
+    // work is slower than the calling thread alone (for thread counts nobody asked for explicitly).
+    void set_threads(unsigned threads, bool self_check = false);
     // memcpy shared by the same threads (the decoder stages raw segments with it)
     void copy(void *dst, const void *src, size_t bytes);
     unsigned threads() const;
@@ -79,6 +81,7 @@ class ScanBuffer {
     HostArena words_, starts_;
     size_t nwords_ = 0, nstarts_ = 0;
     std::unique_ptr<ScanTeam> team_;
+    bool team_checked_ = false; // the helpers have been timed against the calling thread alone
 };
 
 } // namespace compeg

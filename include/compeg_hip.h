@@ -157,7 +157,8 @@ const char *compeg_decoder_last_warning(const compeg_decoder *dec);
 int compeg_decoder_set_device_preprocess(compeg_decoder *dec, int on);
 /* Extension: threads the host scan preprocessor of this decoder uses for one image (see
  * compeg_scanbuffer_set_threads).  Default: 8 on hosts with 32 hardware threads or more, 4 with 8 or more, else 1;
- * the environment variable COMPEG_SCAN_THREADS overrides the default. */
+ * the environment variable COMPEG_SCAN_THREADS overrides the default.  The default (only) checks itself:
+ * the first large segment is timed on one thread and on all, and the helpers are dropped if they lose. */
 int compeg_decoder_set_scan_threads(compeg_decoder *dec, unsigned threads);
 
 /* `DecodeOp` (lib.rs:541-574).  compeg_op_wait replaces polling the

@@ -18,7 +18,7 @@ int main(){
       if(sb.nwords()!=ref.nwords()||sb.nstarts()!=ref.nstarts()||memcmp(sb.data(),ref.data(),ref.nwords()*4)||memcmp(sb.starts(),ref.starts(),ref.nstarts()*4)){bad++; printf("DIFF it %d T %u\n",it,T);}
       // with a progress callback (rounds): what is reported as final must already equal the final bytes
       size_t reported=0, calls=0; bool early_ok=true;
-      sb.process(d.data(),n,exp,[&](size_t fin){ calls++; if(fin<reported||fin%16||fin>ref.nwords()*4||memcmp(sb.data(),ref.data(),fin)) early_ok=false; reported=fin; },0);
+      sb.process(d.data(),n,exp,[&](size_t fin){ calls++; if(fin<reported||fin%16||fin>ref.nwords()*4||memcmp(sb.data(),ref.data(),fin)) early_ok=false; reported=fin; },64u<<10);
       if(!early_ok||sb.nwords()!=ref.nwords()||memcmp(sb.data(),ref.data(),ref.nwords()*4)||memcmp(sb.starts(),ref.starts(),ref.nstarts()*4)){bad++; printf("DIFF with progress it %d T %u calls %zu\n",it,T,calls);}
       if(it==0) printf("T %u: %zu progress calls, %zu of %zu bytes reported early\n",T,calls,reported,ref.nwords()*4); }
   }
