@@ -1,3 +1,5 @@
+// Host scan preprocessor (see scan.h): the reference's byte-serial loop (src/scan.rs:33-128) as a
+// vector copy between 0xFF bytes, optionally shared by several threads; byte-identical output.
 #include "scan.h"
 
 #include <cstdio>
