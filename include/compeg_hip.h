@@ -147,7 +147,10 @@ int compeg_decoder_enqueue(compeg_decoder *dec, const compeg_image *img, void *h
                            int *texture_changed);
 /* `start_decode` (lib.rs:483-499): enqueue on the gpu's own stream + submit. */
 int compeg_decoder_start_decode(compeg_decoder *dec, const compeg_image *img, compeg_op **op);
-/* `decode_blocking` (lib.rs:508-529): start_decode + wait. */
+/* `decode_blocking` (lib.rs:508-529): start_decode + wait.  (With device-side scan preprocessing the
+ * blocking call does without the read-back between the scan kernels and the decode kernel: it looks at the
+ * scan kernels' verdict after the decode and, for the rare segment they hand back, decodes again through
+ * the host preprocessor before returning.) */
 int compeg_decoder_decode_blocking(compeg_decoder *dec, const compeg_image *img, compeg_op **op);
 const char *compeg_decoder_last_warning(const compeg_decoder *dec);
 /* Extension: on != 0 moves the scan preprocessing of every following decode
