@@ -146,6 +146,21 @@ bool is_422(const ImageData &img)
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// work(t) for t = 0 .. nthreads-1, each on a thread of its own (the caller's for a single one)
+template <typename Work>
+void run_on_threads(unsigned nthreads, Work &work)
+{
+    if (nthreads <= 1) {
+        work(0);
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nthreads; t++)
+        pool.emplace_back([&work, t] { work(t); });
+    for (std::thread &th : pool)
+        th.join();
+}
+
 // COMPEG_TRACE=1: one stderr line per enqueue with the host time spent in each step (us)
 struct EnqueueTrace {
     bool on;
@@ -746,15 +761,7 @@ Status compeg_batch::upload(const ImageData *const *images, size_t n, int thread
                 hip_error = int(e);
         }
     };
-    if (nthreads <= 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < nthreads; t++)
-            pool.emplace_back(work, t);
-        for (auto &th : pool)
-            th.join();
-    }
+    run_on_threads(nthreads, work);
     CG_HIP(hipError_t(hip_error.load()));
     for (size_t i = 0; i < n; i++) {
         if (!results[i].ok() && results[i].code != COMPEG_E_COUNT_MISMATCH) {
@@ -870,15 +877,7 @@ Status compeg_batch::upload_device_scan(const ImageData *const *images, size_t n
             s.result = reinterpret_cast<uint32_t *>(da + o_results + i * kScanResultBytes);
         }
     };
-    if (nthreads <= 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < nthreads; t++)
-            pool.emplace_back(work, t);
-        for (auto &th : pool)
-            th.join();
-    }
+    run_on_threads(nthreads, work);
     CG_HIP(hipError_t(hip_error.load()));
     CG_HIP(hipMemcpyAsync(scan_descs.ptr, sd.data(), n * sizeof(ScanDesc), hipMemcpyHostToDevice, st));
     CG_HIP(launch_scan(static_cast<const ScanDesc *>(scan_descs.ptr), uint32_t(n), max_tiles, st, true));
