@@ -239,6 +239,12 @@ def test_uniform_batch_spans_images_with_its_workgroups(ca, gpu):
     batch.wait()
     for i, want in enumerate(wants):
         _assert_equal(batch.read_output(i), want)
+    # 64 such frames are more than two rounds of workgroups over the chip
+    batch.upload([images[i % 10] for i in range(64)])
+    batch.decode()
+    batch.wait()
+    for i in range(64):
+        _assert_equal(batch.read_output(i), wants[i % 10])
     odd = synth.make_jpeg(1280, 720, seed=77, kind=1, quality=60, ri=1)      # other quantisers, same LUTs: still uniform
     other = synth.make_jpeg(640, 360, seed=78, kind=0, quality=85, ri=1)     # other interval count: not uniform
     for extra in (odd, other):
