@@ -172,9 +172,17 @@ def main():
     if not args.no_verify and rank == 0:
         import numpy as np
         from oracle import oracle as orc
-        got = batch.read_output(0)
-        want = orc.ImageData(jpegs[0], allow_sampling=ext).decode()
-        verified = bool(np.array_equal(got, want))
+        # a spread of output slots (first, last, middle ones) against the oracle output of each slot's source;
+        # tests/test_gpu_parity.py::test_full_size_batch_* check every slot of this workload
+        slots = sorted({0, args.batch - 1, args.batch // 2, args.batch // 3, (2 * args.batch) // 3})
+        wants = {}
+        verified = True
+        for i in slots:
+            srci = i % distinct
+            if srci not in wants:
+                wants[srci] = orc.ImageData(jpegs[srci], allow_sampling=ext).decode()
+            verified = verified and bool(np.array_equal(batch.read_output(i), wants[srci]))
+        verified_slots = slots
         if not verified:
             raise SystemExit("bench: GPU output differs from the oracle -- refusing to report a number")
 
@@ -302,6 +310,7 @@ def main():
             "single_frame": single,
             "pcie_inclusive": inclusive,
             "verified_bit_exact_vs_oracle": verified,
+            "verified_slots": None if verified is None else verified_slots,
             "setup_s": {"synthesize": round(t_gen, 2), "host_preprocess_and_upload": round(t_up, 2)},
             "device": gpu.name(),
         }

@@ -359,7 +359,7 @@ composite_generic_kernel(const ImageDesc *__restrict__ descs)
 
 namespace {
 constexpr uint32_t kLdsBytesPerCu = 160u * 1024u;
-constexpr uint32_t kMaxWavesFused = 12; // 3 per SIMD: what 147 VGPRs allow
+constexpr uint32_t kMaxWavesFused = 12; // 3 per SIMD: what 168 VGPRs allow
 constexpr uint32_t kMaxWavesSplit = 16; // entropy_kernel: 4 per SIMD
 } // namespace
 

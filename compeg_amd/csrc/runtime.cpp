@@ -237,6 +237,8 @@ compeg_decoder::~compeg_decoder()
         (void)hipStreamSynchronize(last_stream);
     if (upload_done)
         (void)hipEventDestroy(upload_done);
+    if (decode_done)
+        (void)hipEventDestroy(decode_done);
     if (gpu)
         compeg_gpu_release(gpu);
 }
@@ -384,6 +386,14 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     CG_HIP(hipSetDevice(gpu->device));
     warning.clear();
 
+    // One decoder, one set of device buffers (descriptor, LUTs, scan words, output): a decode recorded on
+    // another stream than the previous one must not overwrite them while that one may still be running.
+    // The reference gets this ordering from wgpu's queue; here the new stream waits for the old decode.
+    if (!decode_done)
+        CG_HIP(hipEventCreateWithFlags(&decode_done, hipEventDisableTiming));
+    if (decode_pending && stream != last_stream)
+        CG_HIP(hipStreamWaitEvent(stream, decode_done, 0));
+
     // DynamicTexture::reserve (dynamic.rs:214-248): recreate at exactly the
     // requested size when either dimension is too small.
     bool realloc_out = false;
@@ -393,9 +403,10 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
         bool fresh = false;
         CG_TRY(out.reserve(std::max<size_t>(pitch * img.height, 256), &fresh));
         // wgpu zero-initialises new textures; texels no MCU covers (a truncated
-        // last restart interval, lib.rs:785) therefore read as 0 in the reference
-        if (fresh)
-            CG_HIP(hipMemsetAsync(out.ptr, 0, out.capacity, stream));
+        // last restart interval, lib.rs:785) therefore read as 0 in the reference --
+        // also when the new logical texture lands in an allocation that is already there
+        (void)fresh;
+        CG_HIP(hipMemsetAsync(out.ptr, 0, std::min(out.capacity, std::max<size_t>(pitch * img.height, 256)), stream));
         out_w = img.width;
         out_h = img.height;
         out_pitch = pitch;
@@ -526,6 +537,8 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     if (total_dus == 0) {
         if (deferred_check)
             CG_HIP(hipMemcpyAsync(scan_result.ptr, scan_result_dev, 16, hipMemcpyDeviceToHost, stream));
+        CG_HIP(hipEventRecord(decode_done, stream));
+        decode_pending = true;
         return Status{};
     }
     const uint32_t span = on_device ? dev_span
@@ -560,6 +573,8 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     }
     if (deferred_check) // behind the decode kernel: no copy engine between the scan kernels and it
         CG_HIP(hipMemcpyAsync(scan_result.ptr, scan_result_dev, 16, hipMemcpyDeviceToHost, stream));
+    CG_HIP(hipEventRecord(decode_done, stream));
+    decode_pending = true;
     trace.mark("launch");
     return Status{};
 }

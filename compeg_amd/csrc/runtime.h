@@ -73,6 +73,8 @@ struct compeg_decoder {
     size_t out_pitch = 0;
     hipEvent_t upload_done = nullptr; // host staging may be rewritten after this
     bool upload_pending = false;
+    hipEvent_t decode_done = nullptr; // the device buffers may be rewritten after this (enqueue on another stream waits for it)
+    bool decode_pending = false;
     hipStream_t last_stream = nullptr;
     std::string warning;
     // what read_coefficients needs to rebuild the reference's buffer

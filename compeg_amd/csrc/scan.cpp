@@ -180,7 +180,6 @@ struct ScanTeam {
         std::vector<uint8_t> out;   // private output
         std::vector<uint32_t> starts; // entry j: word offset (in `out`) of the interval the piece's marker j opens, j >= 1
         ScanEnd done{0, 1, 0};
-        bool overflow = false;      // more markers than `starts` holds
         // where the piece's output begins: open interval, its start word, bytes it holds so far
         size_t interval = 0, start_word = 0, bytes = 0;
     };
@@ -192,6 +191,7 @@ struct ScanTeam {
     std::atomic<unsigned> pending{0};
     std::atomic<bool> stop{false};
     const std::function<void(unsigned)> *job = nullptr;
+    int claimed = 0; // helpers counted against the process-wide budget of default (unasked-for) helpers
 
     explicit ScanTeam(unsigned threads) : pieces(threads)
     {
@@ -207,7 +207,12 @@ struct ScanTeam {
         cv.notify_all();
         for (std::thread &t : workers)
             t.join();
+        g_default_helpers.fetch_sub(claimed);
     }
+    // Helper threads that decoders start by default, all decoders of the process together: never more than
+    // the machine has spare hardware threads ("any number of decoders per gpu" must not mean any number of
+    // spinning helpers).  Thread counts asked for explicitly are not limited.
+    static std::atomic<int> g_default_helpers;
     void work(unsigned k)
     {
         uint64_t seen = 0;
@@ -244,6 +249,8 @@ struct ScanTeam {
     }
 };
 
+std::atomic<int> ScanTeam::g_default_helpers{0};
+
 ScanBuffer::ScanBuffer() = default;
 ScanBuffer::ScanBuffer(HostArena::AllocFn a, HostArena::FreeFn f) : words_(a, f), starts_(a, f) {}
 ScanBuffer::~ScanBuffer() = default;
@@ -257,8 +264,20 @@ void ScanBuffer::set_threads(unsigned threads, bool self_check)
     }
     team_.reset();
     team_checked_ = !self_check;
-    if (threads > 1)
+    int claim = 0;
+    if (self_check && threads > 1) {
+        const int spare = int(std::thread::hardware_concurrency()) - 1;
+        const int want = int(threads) - 1;
+        const int before = ScanTeam::g_default_helpers.fetch_add(want);
+        claim = std::max(0, std::min(want, spare - before));
+        if (claim < want)
+            ScanTeam::g_default_helpers.fetch_sub(want - claim);
+        threads = unsigned(claim) + 1u;
+    }
+    if (threads > 1) {
         team_.reset(new ScanTeam(threads));
+        team_->claimed = claim;
+    }
 }
 
 unsigned ScanBuffer::threads() const { return team_ ? unsigned(team_->pieces.size()) : 1u; }
@@ -303,9 +322,7 @@ bool ScanBuffer::process_with_team(const uint8_t *scan, size_t len, uint32_t exp
             run++;
         return at + (run & 1u);
     };
-    size_t per_piece_starts = 1024;
-    while (per_piece_starts < size_t(expected) / (n * rounds) * 4 + 1024)
-        per_piece_starts <<= 1;
+    (void)expected;
     const size_t mask = slots - 1;
     size_t interval = 0, start_word = 0, bytes = 0; // the output's cursor: open interval, its start word, bytes in it
     for (size_t r = 0; r < rounds; r++) {
@@ -322,17 +339,21 @@ bool ScanBuffer::process_with_team(const uint8_t *scan, size_t len, uint32_t exp
             const size_t range = p.end - p.begin;
             if (p.out.size() < range + range / 3 + 80)
                 p.out.resize(range + range / 3 + 80);
-            if (p.starts.size() < per_piece_starts)
-                p.starts.resize(per_piece_starts);
+            // a marker takes two bytes, so a piece holds at most range / 2 of them: its private table is sized
+            // for that and the marker index can never wrap.  (A table sized from the expected count could, on
+            // segments whose markers crowd into one piece, and giving up then -- after an earlier round's output
+            // had been reported and was perhaps being shipped -- would have had the one-thread loop rewrite
+            // reported bytes with its look-ahead stores.)
+            size_t cap = 1024;
+            while (cap < range / 2 + 2)
+                cap <<= 1;
+            if (p.starts.size() < cap)
+                p.starts.resize(cap);
             p.done = ScanEnd{0, 1, 0};
-            scan_range(scan + p.begin, range, p.out.data(), p.starts.data(), per_piece_starts - 1, p.done, {}, 0);
-            p.overflow = p.done.ri > per_piece_starts; // marker indices wrapped around
+            scan_range(scan + p.begin, range, p.out.data(), p.starts.data(), cap - 1, p.done, {}, 0);
         });
         // positions
         for (ScanTeam::Piece &p : team.pieces) {
-            if (p.overflow)
-                return false; // (the caller starts over on one thread; what was reported so far stays valid:
-                              // the one-thread loop writes the same bytes)
             p.interval = interval;
             p.start_word = start_word;
             p.bytes = bytes;
@@ -340,7 +361,7 @@ bool ScanBuffer::process_with_team(const uint8_t *scan, size_t len, uint32_t exp
             if (markers == 0) {
                 bytes += p.done.head;
             } else {
-                const size_t first = p.starts[1], last = p.starts[markers & (per_piece_starts - 1)];
+                const size_t first = p.starts[1], last = p.starts[markers];
                 interval += markers;
                 start_word += (bytes + p.done.head + 3) / 4 + (last - first);
                 bytes = p.done.wp - last * 4;

@@ -31,7 +31,11 @@ namespace {
 constexpr uint32_t kTileBytes = 4096;
 constexpr uint32_t kThreads = 256;
 constexpr uint32_t kBytesPerThread = kTileBytes / kThreads; // 16
-constexpr uint32_t kMaxLookBack = 1u << 16;
+// A thread whose chunk follows an FF walks back byte by byte to find the run's length.  Entropy-coded data
+// holds FF 00, FF RSTn and at most a few fill FFs, so real runs are a few bytes long; the bound keeps a
+// hostile segment (megabytes of FF) from costing every one of its chunks tens of thousands of dependent
+// loads before the image is handed to the host anyway.
+constexpr uint32_t kMaxLookBack = 512;
 
 // What a thread knows about its 16 bytes after classification.
 struct Chunk {

@@ -123,7 +123,7 @@ int compeg_scanbuffer_process(compeg_scanbuffer *sb, const uint8_t *scan, size_t
 int compeg_scanbuffer_set_threads(compeg_scanbuffer *sb, unsigned threads);
 /* Same result, computed by the device-side scan kernels: the
  * segment is copied to HBM, preprocessed there and the two buffers are copied
- * back.  Inputs the kernels hand back (FF runs longer than 64 KiB) are
+ * back.  Inputs the kernels hand back (FF runs longer than 512 bytes) are
  * processed on the host. */
 int compeg_scanbuffer_process_on_gpu(compeg_scanbuffer *sb, compeg_gpu *gpu, const uint8_t *scan,
                                      size_t len, uint32_t expected_restart_intervals);

@@ -9,9 +9,15 @@ using namespace compeg;
 int main(){
   std::mt19937 rng(5);
   int bad=0;
-  for(int it=0;it<12;it++){
+  for(int it=0;it<16;it++){
     size_t n=300000+rng()%900000; std::vector<uint8_t> d(n);
-    for(auto&b:d){uint32_t r=rng(); b=(r&0xff); if((r>>8)%50==0)b=0xff; if((r>>16)%90==0)b=0;}
+    // iterations 12..15: skewed segments -- markers crowd into the last sixteenth (12, 13) or the second half
+    // (14, 15) and are rare elsewhere, so that one piece of one round holds almost all of them; every
+    // callback still has to find the whole reported prefix final
+    const size_t dense_from = it<12 ? 0 : (it<14 ? n-n/16 : n/2);
+    for(size_t i=0;i<n;i++){uint8_t&b=d[i]; uint32_t r=rng(); b=(r&0xff); if(b==0xff)b=0x7f;
+      const uint32_t every = it<12 ? 50 : (i>=dense_from ? 3 : 20000);
+      if((r>>8)%every==0)b=0xff; if((r>>16)%90==0)b=0;}
     uint32_t exp=1+rng()%20000;
     ScanBuffer ref; ref.process(d.data(),n,exp);
     for(unsigned T:{2u,3u,5u}){ ScanBuffer sb; sb.set_threads(T); sb.process(d.data(),n,exp); sb.process(d.data(),n,exp);

@@ -55,6 +55,20 @@ def test_reference_reftest_images(ca, gpu, name):
         "30d5ae4c2ae877f80b33d923736c97f164e424ab7bb21bb23a26d0c707a944c6"
 
 
+def test_reference_444_fixture_through_the_extension(ca, gpu):
+    """ref src/tests.rs:137-142 (`#[ignore]`d there): the reference's own 4:4:4 fixture, accepted through
+    compeg_image_parse_ext; bit-exact against the oracle's extension, which tests/test_oracle_pinning.py
+    pins to the reference's 64x8.png within its +-3.  The default parse keeps the reference's rejection."""
+    jpeg = read_golden("refs", "64x8-Hi1-Vi1.jpg")
+    with pytest.raises(ca.Error) as e:
+        ca.ImageData(jpeg)
+    assert "invalid sampling factors 1x1 for Y component" in str(e.value)
+    dec = ca.Decoder(gpu)
+    data = ca.ImageData(jpeg, allow_sampling=True)
+    dec.decode_blocking(data)
+    _assert_equal(dec.read_texture(data.width(), data.height()), orc.ImageData(jpeg, allow_sampling=True).decode())
+
+
 def test_reference_mjpeg_fixture(ca, gpu):
     """960x720 webcam MJPEG frame, DRI=10, no DHT (Annex-K tables), contains ZRL runs."""
     jpeg = read_golden("parser", "mjpeg.jpg")
@@ -478,3 +492,62 @@ def test_standard_entropy_extension(ca, gpu):
     dec = ca.Decoder(gpu)
     dec.decode_blocking(ca.ImageData(j420, allow_sampling=True, standard_entropy=True))
     _assert_equal(dec.read_texture(640, 360), orc.ImageData(j420, allow_sampling=True, standard_entropy=True).decode())
+
+
+def _full_size_batch(ca, gpu, w, h, n=256, distinct=8, ri=4):
+    """n frames of distinct synthetic sources through compeg_batch_*; EVERY output slot is read back and compared
+    with the oracle's output of its source (slot i holds source (3 i + i // distinct) % distinct, so that
+    neighbouring slots, and slots a workgroup may share, come from different sources)."""
+    jpegs = [synth.make_jpeg(w, h, seed=0xC0FFEE + i, kind=0, quality=85, ri=ri) for i in range(distinct)]
+    wants = [orc.ImageData(j).decode() for j in jpegs]
+    images = [ca.ImageData(j) for j in jpegs]
+    src = [(3 * i + i // distinct) % distinct for i in range(n)]
+    assert len(set(src)) == distinct
+    batch = ca.Batch(gpu)
+    batch.upload([images[s] for s in src])
+    assert batch.count() == n and batch.pixels() == n * w * h
+    batch.decode()
+    batch.wait()
+    for i, s in enumerate(src):
+        got = batch.read_output(i)
+        if not np.array_equal(got, wants[s]):
+            _assert_equal(got, wants[s])
+    # a second decode into the same outputs (what a benchmark step is) changes nothing: first, middle, last slot
+    batch.decode()
+    batch.wait()
+    for i in (0, n // 2 - 1, n - 1):
+        _assert_equal(batch.read_output(i), wants[src[i]])
+    return batch, images, src, wants
+
+
+def test_full_size_batch_256_x_1080p(ca, gpu):
+    """BASELINE configs[2] at size: a batch of 256 1920x1080 4:2:2 DRI=4 JPEGs in one launch, every slot checked."""
+    batch, images, src, wants = _full_size_batch(ca, gpu, 1920, 1080)
+    # the same batch with the scan preprocessed by the device kernels inside every decode
+    dev = ca.Batch(gpu)
+    dev.set_device_preprocess(2)
+    dev.upload([images[s] for s in src])
+    dev.decode()
+    dev.wait()
+    assert dev.host_fallbacks() == 0
+    for i in range(0, 256, 17):
+        _assert_equal(dev.read_output(i), wants[src[i]])
+
+
+def test_full_size_batch_256_x_4k(ca, gpu):
+    """BASELINE configs[3], one GPU's share at size: 256 3840x2160 4:2:2 DRI=4 JPEGs (8.5 GB of RGBA) in one
+    launch -- the workload bench.py times -- every slot checked against the oracle output of its source."""
+    _full_size_batch(ca, gpu, 3840, 2160)
+
+
+def test_bounded_gpu_fuzz_seed(ca, gpu):
+    """A bounded seed of tools/fuzz_gpu.py (random geometry / quality / DRI / sampling / bit flips / both entropy
+    modes; host preprocessor on 1 and 4 threads and the device scan kernels, blocking and non-blocking, plus
+    batches): every decode equal to the oracle.  The device-only instruction sequences (inline-asm LDS reads,
+    sbfe, the rounding-mode block) are not seen by the sanitised emulation, so they get random inputs here."""
+    from tools import fuzz_gpu
+    lines = []
+    runs, bad, skipped = fuzz_gpu.run(seed=20260, iters=60, budget_s=20.0,
+                                      log=lambda *a, **k: lines.append(" ".join(str(x) for x in a)))
+    assert bad == 0, "\n".join(lines[-20:])
+    assert runs >= 60, (runs, skipped)

@@ -131,14 +131,17 @@ def test_decoder_device_preprocess_hands_pathological_scans_to_the_host(ca, gpu)
     sd = orc.ImageData(j).scan_data()
     o = j.find(sd[:16])
     half = len(sd) // 2
-    bad = j[:o] + sd[:half] + b"\xff" * 70001 + b"\x00" + sd[half:] + j[o + len(sd):]
     dec = ca.Decoder(gpu)
     dec.set_device_preprocess(True)
-    for jpeg in (j, bad, j, bad):
-        dec.decode_blocking(ca.ImageData(jpeg))
-        assert np.array_equal(dec.read_texture(256, 64), orc.ImageData(jpeg).decode())
-    # the non-blocking entry point keeps the read-back in the middle: same results
-    for jpeg in (bad, j):
-        op = dec.start_decode(ca.ImageData(jpeg))
-        op.wait()
-        assert np.array_equal(dec.read_texture(256, 64), orc.ImageData(jpeg).decode())
+    # runs below the bound (the kernels handle them), just above it, and of a megabyte (every chunk of which
+    # would otherwise walk back to the bound: the walk is short, so this takes milliseconds)
+    for run in (301, 513, 70001, (1 << 20) + 1):
+        bad = j[:o] + sd[:half] + b"\xff" * run + b"\x00" + sd[half:] + j[o + len(sd):]
+        for jpeg in (j, bad, j, bad):
+            dec.decode_blocking(ca.ImageData(jpeg))
+            assert np.array_equal(dec.read_texture(256, 64), orc.ImageData(jpeg).decode()), run
+        # the non-blocking entry point keeps the read-back in the middle: same results
+        for jpeg in (bad, j):
+            op = dec.start_decode(ca.ImageData(jpeg))
+            op.wait()
+            assert np.array_equal(dec.read_texture(256, 64), orc.ImageData(jpeg).decode()), run

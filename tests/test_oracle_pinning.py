@@ -275,6 +275,21 @@ def test_reftest_444_rejected():
     assert "invalid sampling factors 1x1 for Y component" in str(e.value)
 
 
+def test_reftest_444_extension_within_the_reference_tolerance():
+    """The reference keeps a 4:4:4 fixture for the day its front-end accepts it (src/tests.rs:137-142,
+    `#[ignore]`d: same 64x8.png, same ABS_TOLERANCE).  The oracle's sampling extension
+    (orc_image_parse_ext: what the reference's shaders do once the front-end lets the layout through)
+    decodes it today: that pins the extension to a reference-held vector, +-3 per channel like the
+    reference's own comparison (measured: max 2)."""
+    ref = _read_png_rgb(read_golden("refs", "64x8.png"))
+    img = orc.ImageData(read_golden("refs", "64x8-Hi1-Vi1.jpg"), allow_sampling=True)
+    assert (img.width(), img.height()) == (ref.shape[1], ref.shape[0])
+    rgba = img.decode()
+    diff = np.abs(rgba[:, :, :3].astype(np.int32) - ref.astype(np.int32))
+    assert diff.max() <= 3  # ABS_TOLERANCE, src/tests.rs:18
+    assert np.all(rgba[:, :, 3] == 255)
+
+
 def test_cross_check_against_survey_probe_hashes():
     """SURVEY.md section 8c records SHA-256 values from an independent NumPy emulation
     of the WGSL semantics; two independent restatements must agree."""

@@ -1,4 +1,4 @@
-"""One-off randomized check on the GPU (not part of the test suite): random geometry, quality, restart interval,
+"""Randomized check on the GPU (tests/test_gpu_parity.py runs a bounded seed of it; longer runs by hand): random geometry, quality, restart interval,
 sampling, bit flips in the scan, both entropy modes -- single decodes through every way of getting the scan to the
 card (host preprocessor on 1 / 4 threads, device scan kernels; blocking and non-blocking), and batches (host and
 device preprocessing) -- against the oracle.
@@ -14,9 +14,11 @@ import oracle.oracle as orc
 from tools import synth
 
 
-def main():
-    rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 4321)
-    iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+def run(seed=4321, iters=200, budget_s=None, log=print):
+    """Returns (decodes compared, mismatches, inputs the oracle rejects); stops early after budget_s seconds."""
+    import time
+    t_end = time.monotonic() + budget_s if budget_s else None
+    rng = np.random.default_rng(seed)
     gpu = ca.Gpu.open()
     decs = []
     for device, threads in ((False, 1), (False, 4), (True, 4)):
@@ -27,6 +29,9 @@ def main():
     bad = runs = skipped = 0
     pool = []
     for it in range(iters):
+        if t_end and time.monotonic() > t_end:
+            iters = it
+            break
         big = it % 10 == 0                      # now and then a scan large enough for the threaded host path
         w = int(rng.integers(600, 2600)) if big else int(rng.integers(16, 420))
         h = int(rng.integers(300, 1300)) if big else int(rng.integers(8, 200))
@@ -71,7 +76,7 @@ def main():
                 runs += 1
                 if not np.array_equal(got[mask], want[mask]):
                     bad += 1
-                    print("MISMATCH", it, w, h, kind, q, ri, sampling, std, name, "blocking" if blocking else "async", flush=True)
+                    log("MISMATCH", it, w, h, kind, q, ri, sampling, std, name, "blocking" if blocking else "async", flush=True)
                     open("/tmp/bad_gpu_%d.jpg" % it, "wb").write(j)
         pool.append((img, want))
         if len(pool) == 24 or it == iters - 1:
@@ -91,11 +96,26 @@ def main():
                         runs += 1
                         if not np.array_equal(b.read_output(i), wnt):
                             bad += 1
-                            print("MISMATCH in batch, preprocess mode", mode, "entry", i, flush=True)
+                            log("MISMATCH in batch, preprocess mode", mode, "entry", i, flush=True)
             pool = []
         if it % 20 == 0:
-            print("iteration", it, "runs", runs, "bad", bad, flush=True)
-    print("runs", runs, "bad", bad, "skipped (oracle rejects)", skipped)
+            log("iteration", it, "runs", runs, "bad", bad, flush=True)
+    if pool:  # (a run cut short by its budget: the images still waiting for their batch)
+        b = ca.Batch(gpu)
+        b.upload([im for im, _ in pool])
+        b.decode()
+        b.wait()
+        for i, (_, wnt) in enumerate(pool):
+            runs += 1
+            if not np.array_equal(b.read_output(i), wnt):
+                bad += 1
+                log("MISMATCH in the final batch, entry", i, flush=True)
+    log("runs", runs, "bad", bad, "skipped (oracle rejects)", skipped)
+    return runs, bad, skipped
+
+
+def main():
+    runs, bad, _ = run(int(sys.argv[1]) if len(sys.argv) > 1 else 4321, int(sys.argv[2]) if len(sys.argv) > 2 else 200)
     return 1 if bad else 0
 
 
