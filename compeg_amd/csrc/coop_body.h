@@ -1,0 +1,1004 @@
+// Per-lane bodies of the cooperative kernel (decode_coop_422_kernel): the lanes of a wave split the bitstream
+// of each restart interval among themselves.
+//
+// The reference decodes a restart interval with one thread (src/huffman.wgsl:118-204), and so do the other
+// kernels here (one lane per interval).  A launch that has few intervals -- one 4K frame with DRI = 4 is
+// 16 200 of them -- then leaves most of the chip idle while every lane walks ~170 dependent symbols.  Here a
+// wave takes only as many intervals as have 64 data units together (4 with DRI = 4) and spends its lanes inside
+// them:
+//
+//  1. Chase.  What is serial in an interval is only *where each data unit begins*: bit position, and the
+//     reference reader's `left` there (quirk Q1).  Lane 0 of an interval walks the symbols from the
+//     interval's start (lengths and zig-zag advances only, no values).  The other lanes start at word
+//     boundaries further into the interval ("subsequences") WITHOUT knowing the decoder state there: each
+//     assumes it is inside the AC part of data unit k of an MCU, one lane per k = 0..3, and walks on from
+//     that guess.  Huffman streams re-synchronise: after a few symbols a wrong start lands on a true symbol
+//     boundary, and from the next end-of-block on it walks the true sequence of data units (if its k was the
+//     right one).  Every lane lists the data-unit starts it passes (bit position, reference `left`, k).
+//  2. Validate.  A lane walks a little beyond the end of its subsequence.  If one of the data-unit starts it
+//     lists there equals -- same bit position, same `left`, same k -- an entry of a lane of the next
+//     subsequence, the two walks are identical from that point on (the state is the whole state), so the
+//     successor's list continues the predecessor's.  Following these links from lane 0, whose start state is
+//     known, yields the start state of every data unit of the interval.  A link that is missing (no
+//     synchronisation within the overlap) is not an error: the last validated lane simply walks on through
+//     the next subsequence, and validation runs again.  Nothing is ever assumed: a state is used only if the
+//     chain from the interval's start proves it.
+//  3. Decode.  One lane per DATA UNIT: the proven fast-mode decoder of the fused kernel (fast_dc / fast_ac,
+//     exact path behind it) started at the data unit's state, coefficients into the lane's LDS slot, then DC
+//     prediction (a sum over the interval's earlier data units of the component), IDCT and composite with
+//     all 64 lanes busy.
+//
+// Quirk Q1 in this scheme: an underflow of the reference reader at a DC code depends on (bit position, size of
+// the previous symbol) only, so the chase sees it; behind it the reference reads zeros for the rest of the
+// interval, and those data units decode to a per-component constant that the host front-end computes with the
+// exact-path reader (ImageDesc::zero_du).  Anything else out of the ordinary (a walk that leaves the LDS
+// window on a corrupt stream, DC categories above 15 from a hostile table) sends the interval to one lane
+// running the interval-serial decoder the other kernels use.
+#pragma once
+
+#include "kernels_body.h"
+
+namespace compeg {
+
+#if defined(CG_EMUL_STATS)
+struct CoopStats {
+    unsigned long intervals, rounds, continued, serial, dead, zero, chase_steps, wave_steps, true_steps, true_max, hist[16], link_tries, link_ok, link_full_ok, link_none;
+};
+inline CoopStats g_coop_stats{};
+#define CG_COOP_COUNT(field, n) (g_coop_stats.field += (n))
+#else
+#define CG_COOP_COUNT(field, n) ((void)0)
+#endif
+
+constexpr uint32_t kCoopListCap = 20;      // state words per chasing lane (64 x 20 words = the slot area)
+constexpr uint32_t kCoopMaxEntries = 19;   // ... of which the last is scratch (the entry being built)
+#ifndef CG_COOP_MARGIN
+#define CG_COOP_MARGIN 64
+#endif
+constexpr uint32_t kCoopMargin = CG_COOP_MARGIN; // bits a lane walks on beyond the end of its subsequence
+constexpr uint32_t kCoopHead = 3;          // leading entries of a successor's list that a link may point at
+constexpr uint32_t kCoopTail = 3;          // trailing entries of a lane's own list that may carry the link
+constexpr uint32_t kCoopMaxWindow = 2040;  // words: bit positions inside the wave's window fit 16 bits
+constexpr uint32_t kCoopMaxRestart = 16;   // MCUs per interval: 64 data units, one per lane
+constexpr uint32_t kCoopQuantStride = 36;  // floats between the components' quantiser rows in LDS
+
+// Data-unit start state: bits 0..15 bit position inside the wave's window, 16..20 size of the symbol in front
+// of it (with the position it fixes the reference reader's `left` at the DC code, quirk Q1).  The third part of
+// the state, the data unit's index inside its MCU, is not stored: entry i of a list belongs to index
+// (index of entry 0 + i) mod 4.  Two states are equal iff these 21 bits and that index are.
+constexpr uint32_t kCoopStateMask = 0x001fffffu;
+constexpr uint32_t kCoopZero = 1u << 25;   // (decode phase) the data unit lies behind a dead one: zero-stream levels
+constexpr uint32_t kCoopSerial = 1u << 26; // (decode phase) its interval is decoded by one lane, serially
+constexpr uint32_t kCoopUnset = 1u << 27;  // (decode phase) no state: nothing to decode
+
+constexpr uint32_t kStopAnomaly = 2u;      // the walk cannot go on (window exhausted, hostile table)
+
+// Wave-uniform values of the image the lanes select from by component / data-unit index.
+struct CoopTables {
+    const uint16_t *ac_fast; // the two direct AC tables (LDS)
+    const uint16_t *dc_fast; // the two direct DC tables (LDS)
+    uint32_t acsel, dcsel;   // byte k: offset of the table data unit k of an MCU uses, in KiB from ac_fast
+    uint32_t ac_off[3], dc_off[3]; // per component: offset of its L1 tables (escapes)
+    uint32_t fast_base[3];
+    uint32_t dc_quant[3];
+    uint32_t zrl;            // 17 (the reference, quirk Q2) or 16
+    bool standard;
+};
+
+// The wave's share of LDS.
+struct CoopShared {
+    HuffShared h;        // tables, window, the 64 data-unit slots
+    uint32_t *lists;     // 64 x kCoopListCap state words: the same bytes as the slots (lists die before slots live)
+    uint32_t *du_state;  // [64] start state of every data unit of the wave
+    uint32_t *lane_n;    // [64] chasing lanes: entries listed | stop reason << 8
+    uint32_t *link;      // [64] chasing lanes: 1 | successor lane << 8 | its entry << 16 | own entry << 24, or 0
+    uint32_t *seg;       // [16] this round's stretches of every interval's sequence (see coop_follow)
+    uint32_t *verdict;   // [16] per interval: kVerdict* | lane << 8 | data units settled << 16
+    uint32_t *nseg;      // [16] per interval: stretches in seg
+    uint32_t *dead_from; // [16] per interval: first data unit whose DC code underflows the reference reader
+    int32_t *diffs;      // [64] DC differences
+    const float *quant;  // 3 rows of quantisers (workgroup-wide)
+};
+constexpr uint32_t kCoopMiscWords = 4 * 64 + 4 * 16; // du_state, lane_n, link, diffs; seg, verdict, nseg, dead_from
+
+constexpr uint32_t kVerdictDone = 1u, kVerdictContinue = 2u, kVerdictSerial = 3u;
+
+struct CoopGeom {
+    uint32_t R, dpi, ipw;    // MCUs and data units per interval, intervals per wave (all powers of two)
+    uint32_t dpi_shift;      // log2(dpi)
+    uint32_t count;          // subsequences per interval: 1 + the speculative ones (a power of two)
+    uint32_t count_shift;
+    uint32_t first_interval; // of this wave
+    uint32_t intervals;      // that exist (0..ipw)
+};
+
+CG_DEV uint32_t ilog2(uint32_t v)
+{
+    uint32_t r = 0;
+    while ((1u << r) < v)
+        r++;
+    return r;
+}
+
+CG_DEV void coop_geom(const ImageDesc &d, uint32_t wave_index, CoopGeom &g)
+{
+    g.R = d.restart_interval; // 1, 2, 4, 8 or 16 (ImageDesc::coop_ok)
+    g.dpi = 4u * g.R;
+    g.dpi_shift = ilog2(g.dpi);
+    g.ipw = uint32_t(kWave) >> g.dpi_shift;
+    g.count = 1u + (g.dpi - 1u) / 4u; // lane 0, then four lanes per speculative subsequence: 1, 2, 4, 8, 16
+    g.count_shift = ilog2(g.count);
+    g.first_interval = wave_index * g.ipw;
+    const uint32_t left = d.total_intervals > g.first_interval ? d.total_intervals - g.first_interval : 0u;
+    g.intervals = left < g.ipw ? left : g.ipw;
+}
+
+CG_DEV uint32_t sel3(uint32_t c, uint32_t a0, uint32_t a1, uint32_t a2)
+{
+    return c == 0u ? a0 : (c == 1u ? a1 : a2);
+}
+
+CG_DEV uint32_t comp_of_k(uint32_t k) { return k < 2u ? 0u : k - 1u; } // Y0 Y1 Cb Cr
+
+CG_DEV void coop_tables(const ImageDesc &d, const HuffShared &s, CoopTables &t)
+{
+    t.ac_fast = s.l2 + d.fast_off;
+    t.dc_fast = t.ac_fast + 2u * kFastEntries;
+    t.acsel = t.dcsel = 0u;
+    for (uint32_t k = 0; k < 4u; k++) {
+        const uint32_t c = comp_of_k(k);
+        // direct AC tables: 4 KiB each; the direct DC tables, 1 KiB each, follow them
+        t.acsel |= ((d.fast_table[c] & 1u) * (kFastEntries * 2u / 1024u)) << (8u * k);
+        t.dcsel |= (2u * (kFastEntries * 2u / 1024u) + (d.dc_fast_table[c] & 1u) * (kDcFastEntries * 2u / 1024u)) << (8u * k);
+    }
+    for (uint32_t c = 0; c < 3u; c++) {
+        t.ac_off[c] = d.ac_table[c] * 256u;
+        t.dc_off[c] = d.dc_table[c] * 256u;
+        t.fast_base[c] = d.fast_off + d.fast_table[c] * kFastEntries;
+        t.dc_quant[c] = d.dc_quant[c];
+    }
+    t.standard = d.standard_entropy != 0u;
+    t.zrl = t.standard ? 16u : 17u;
+}
+
+// The window of the wave's intervals: their contiguous words plus the reader's slack.
+CG_DEV void coop_window(const ImageDesc &d, const CoopGeom &g, uint32_t window_words, uint32_t &base, uint32_t &len)
+{
+    const uint32_t first = g.first_interval, after = first + g.ipw;
+    base = first < d.nstarts ? CG_GLOBAL(const uint32_t, d.starts)[first] : 0u;
+    uint32_t end = (after < d.total_intervals && after < d.nstarts) ? CG_GLOBAL(const uint32_t, d.starts)[after] : d.nwords;
+    // (+ 2: the reader keeps up to two words in hand, so at the start of the last data units of the wave's last
+    // interval its position is that far beyond the interval's end -- still inside the window with these)
+    end = umin(end, d.nwords) + kDuWordSlack + 2u;
+    base = umin(base, d.nwords);
+    len = end > base ? umin(end - base, window_words) : 0u;
+}
+
+// First bit position at which a walk may not begin another data unit (it could leave the window).
+CG_DEV uint32_t coop_hard_end(const HuffShared &s)
+{
+    return s.win_len > kDuWordSlack ? 32u * (s.win_len - kDuWordSlack) : 0u;
+}
+
+// ---------------------------------------------------------------------------
+// 1. Chase
+// ---------------------------------------------------------------------------
+
+struct ChaseState {
+    uint32_t p;        // bit position of the coming symbol, window-relative
+    uint32_t s;        // 0: a DC code comes next; else 1 + zig-zag position of the coefficient decoded last
+    uint32_t k8;       // 8 x (data units completed + the index inside its MCU the walk began in)
+    uint32_t *lp;      // the list's next free slot
+    uint32_t *lp_max;  // the walk ends when the list has grown to here
+    uint32_t stop_p;   // ... or when a data unit is complete at or beyond this position
+    uint32_t sub_end;  // bit position where this lane's own stretch ends: entries from here on may carry a link
+    uint32_t next_sub; // the subsequence whose lanes may continue this lane's list (>= count: none)
+    uint32_t k0;       // index (inside its MCU) of the data unit that entry 0 of the list starts
+    uint32_t flags;    // kStopAnomaly
+    bool used;         // this lane walks at all
+    bool active;
+};
+
+// The walk: a per-lane loop (lanes that are done drop out of it, the wave leaves it when the last one has).
+// The reader is a bit position: the two stream words around it come from the window, the symbol's size
+// and zig-zag advance from the direct table of the state the lane is in.  The state word of "the data unit
+// that would begin behind this symbol" is written to the list's next free slot every time; it stays there when
+// the symbol does end a data unit (no branch around the store).
+//
+// On the GPU the loop is hand-written: it is where a small launch spends most of its time, and the compiler's
+// version of it carried twenty instructions of mask bookkeeping per symbol.  34 instructions per symbol; lanes
+// that are done leave through EXEC.  Codes longer than the direct tables' prefix are rare: when a lane meets one
+// the block hands the step to the C++ below (two-level tables) and is entered again at "apply".
+CG_DEV void chase_run(ChaseState &c, const ImageDesc &d, const HuffShared &s, const CoopTables &t, unsigned long &steps)
+{
+    uint32_t p = c.p, st = c.s, k8 = c.k8;
+    uint32_t *lp = c.lp;
+    (void)steps;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CG_COOP_NO_ASM)
+    uint32_t alive = c.active ? 1u : 0u, ent = 0u, cur = 0u, resume = 0u, code = 0u;
+    uint32_t lpa = uint32_t(reinterpret_cast<uintptr_t>(lp));
+    const uint32_t lpmax = uint32_t(reinterpret_cast<uintptr_t>(c.lp_max));
+    const uint32_t win = uint32_t(reinterpret_cast<uintptr_t>(s.win)), tab = uint32_t(reinterpret_cast<uintptr_t>(t.ac_fast));
+    const uint32_t acsel = t.acsel, dcsel = t.dcsel; // (vector copies: one scalar operand per instruction)
+    if (__builtin_amdgcn_ballot_w64(alive != 0u) != 0u)
+        for (;;) {
+            asm volatile(
+                "s_mov_b64 s[74:75], exec\n\t"
+                "v_cmp_ne_u32 vcc, 0, %[alive]\n\t"
+                "s_and_b64 exec, exec, vcc\n\t"
+                "s_cbranch_execz 4f\n\t"
+                "s_cmp_lg_u32 %[resume], 0\n\t"
+                "s_cbranch_scc1 2f\n"
+                "1:\n\t" // ---- fetch the stream bits at p, look the symbol up
+                "v_lshrrev_b32 v40, 5, %[p]\n\t"
+                "v_lshl_add_u32 v40, v40, 2, %[win]\n\t"
+                "ds_read2_b32 v[42:43], v40 offset0:1 offset1:0\n\t" // v43 = word at p, v42 = the next one
+                "v_and_b32 v44, 31, %[p]\n\t"
+                "v_cmp_eq_u32 vcc, 0, %[st]\n\t"                      // a DC code comes next
+                "v_cndmask_b32 v46, %[acsel], %[dcsel], vcc\n\t"
+                "v_bfe_u32 v46, v46, %[k8], 8\n\t"                    // the table's offset in KiB
+                "v_cndmask_b32_e64 v45, 21, 23, vcc\n\t"              // 32 - index bits
+                "v_lshl_add_u32 v46, v46, 10, %[tab]\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_lshlrev_b64 v[42:43], v44, v[42:43]\n\t"           // v43 = the next 32 stream bits
+                "v_lshrrev_b32 v45, v45, v43\n\t"
+                "v_lshl_add_u32 v46, v45, 1, v46\n\t"
+                "ds_read_u16 %[ent], v46\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_cmp_le_u32 vcc, 0xfe00, %[ent]\n\t"                // kFastEscape
+                "s_cbranch_vccnz 3f\n"
+                "2:\n\t" // ---- apply: advance, note the state behind the symbol, end of data unit?
+                "v_bfe_u32 v40, %[ent], 4, 5\n\t"                     // size
+                "v_lshrrev_b32 v44, 9, %[ent]\n\t"                    // zig-zag advance
+                "v_add_u32 %[p], %[p], v40\n\t"
+                "v_add_u32 %[st], %[st], v44\n\t"
+                "v_lshl_or_b32 v40, v40, 16, %[p]\n\t"
+                "ds_write_b32 %[lp], v40\n\t"
+                "v_cmp_lt_u32 vcc, 63, %[st]\n\t"                     // the data unit is complete
+                "v_cndmask_b32_e64 v44, 0, 1, vcc\n\t"
+                "v_lshl_add_u32 %[lp], v44, 2, %[lp]\n\t"
+                "v_lshl_add_u32 %[k8], v44, 3, %[k8]\n\t"
+                "v_cndmask_b32_e64 %[st], %[st], 0, vcc\n\t"
+                "v_cmp_ge_u32 s[70:71], %[p], %[stopp]\n\t"
+                "v_cmp_ge_u32 s[72:73], %[lp], %[lpmax]\n\t"
+                "s_or_b64 s[70:71], s[70:71], s[72:73]\n\t"
+                "s_and_b64 s[70:71], s[70:71], vcc\n\t"               // lanes whose walk ends here
+                "s_andn2_b64 exec, exec, s[70:71]\n\t"
+                "s_cbranch_execnz 1b\n\t"
+                "s_mov_b32 %[code], 0\n\t"
+                "s_branch 5f\n"
+                "3:\n\t" // ---- a lane met a long code: out, with the bits it looked at
+                "v_mov_b32 %[cur], v43\n\t"
+                "s_mov_b32 %[code], 1\n\t"
+                "s_branch 5f\n"
+                "4:\n\t"
+                "s_mov_b32 %[code], 0\n"
+                "5:\n\t"
+                "s_mov_b64 s[72:73], exec\n\t"                        // lanes still walking
+                "s_mov_b64 exec, s[74:75]\n\t"
+                "v_cndmask_b32_e64 %[alive], 0, 1, s[72:73]\n\t"
+                : [p] "+v"(p), [st] "+v"(st), [k8] "+v"(k8), [lp] "+v"(lpa), [ent] "+v"(ent), [cur] "+v"(cur),
+                  [alive] "+v"(alive), [code] "=s"(code)
+                : [resume] "s"(resume), [win] "s"(win), [tab] "s"(tab), [acsel] "v"(acsel), [dcsel] "v"(dcsel),
+                  [stopp] "v"(c.stop_p), [lpmax] "v"(lpmax)
+                : "memory", "vcc", "scc", "v40", "v42", "v43", "v44", "v45", "v46", "s70", "s71", "s72", "s73", "s74", "s75");
+            if (code == 0u)
+                break;
+            if (alive != 0u && ent >= kFastEscape) {
+                // longer than the direct table's prefix: through the reference's two-level tables
+                const uint32_t comp = comp_of_k((k8 >> 3) & 3u);
+                if (st == 0u) {
+                    const uint32_t e2 = lut_lookup<true>(d, s, sel3(comp, t.dc_off[0], t.dc_off[1], t.dc_off[2]), cur);
+                    const uint32_t len = e2 >> 8, cat = e2 & 0xffu;
+                    const bool bad = cat > 15u || len + cat > 31u; // only a hostile table has such categories
+                    ent = bad ? 0u : (1u << 9) | ((len + cat) << 4) | cat;
+                    c.flags |= bad ? kStopAnomaly : 0u;
+                    alive = bad ? 0u : alive;
+                } else {
+                    ent = fast_entry(lut_lookup<true>(d, s, sel3(comp, t.ac_off[0], t.ac_off[1], t.ac_off[2]), cur), t.zrl);
+                }
+            }
+            resume = 1u;
+        }
+    lp = c.lp + (lpa - uint32_t(reinterpret_cast<uintptr_t>(c.lp))) / 4u;
+#else
+    if (c.active)
+        for (;;) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+            steps++;
+#endif
+            const uint32_t *wp = s.win + (p >> 5);
+            const uint32_t w0 = wp[0], w1 = wp[1];
+            const uint32_t cur = uint32_t(((uint64_t(w0) << 32 | w1) << (p & 31u)) >> 32);
+            const bool dc = st == 0u;
+            // (the selectors repeat every four data units: the byte offset is taken modulo 32 on its own)
+            const uint32_t kib = ((dc ? t.dcsel : t.acsel) >> (k8 & 31u)) & 0xffu;
+            const uint16_t *tab = t.ac_fast + kib * 512u;
+            uint32_t ent = tab[cur >> (dc ? 32u - kDcFastBits : 32u - kFastBits)];
+            if (ent >= kFastEscape) {
+                // longer than the direct table's prefix: through the reference's two-level tables
+                CG_COUNT(escapes);
+                const uint32_t comp = comp_of_k((k8 >> 3) & 3u);
+                if (dc) {
+                    const uint32_t e2 = lut_lookup<true>(d, s, sel3(comp, t.dc_off[0], t.dc_off[1], t.dc_off[2]), cur);
+                    const uint32_t len = e2 >> 8, cat = e2 & 0xffu;
+                    if (cat > 15u || len + cat > 31u) { // only a hostile table has such categories
+                        c.flags |= kStopAnomaly;
+                        break;
+                    }
+                    ent = (1u << 9) | ((len + cat) << 4) | cat;
+                } else {
+                    ent = fast_entry(lut_lookup<true>(d, s, sel3(comp, t.ac_off[0], t.ac_off[1], t.ac_off[2]), cur), t.zrl);
+                }
+            }
+            const uint32_t tot = (ent >> 4) & 31u;
+            p += tot;
+            const uint32_t s_new = st + (ent >> 9);
+            const bool du_end = s_new >= 64u;
+            *lp = p | (tot << 16);
+            const uint32_t one = du_end ? 1u : 0u;
+            lp += one;
+            k8 += one << 3;
+            st = du_end ? 0u : s_new;
+            if (du_end && (p >= c.stop_p || lp >= c.lp_max))
+                break;
+        }
+#endif
+    c.p = p;
+    c.s = st;
+    c.k8 = k8;
+    c.lp = lp;
+    c.active = false;
+}
+
+// Word offset (inside the interval) at which subsequence j of `count` (a power of two) begins.
+CG_DEV uint32_t coop_sub_start(uint32_t len_words, uint32_t j, const CoopGeom &g)
+{
+    return j >= g.count ? len_words : (len_words * j) >> g.count_shift;
+}
+
+// The first subsequence behind j that begins further into the interval than j does (count: none).
+CG_DEV uint32_t coop_next_sub(uint32_t len_words, uint32_t j, const CoopGeom &g)
+{
+    const uint32_t here = coop_sub_start(len_words, j, g);
+    uint32_t n = j + 1u;
+    while (n < g.count && coop_sub_start(len_words, n, g) == here)
+        n++;
+    return n;
+}
+
+// Where a walk that covers the stretch up to subsequence `next_sub` ends.
+CG_DEV void chase_set_end(ChaseState &c, const HuffShared &s, const CoopGeom &g, uint32_t start_rel, uint32_t len_words)
+{
+    c.sub_end = 32u * (start_rel + coop_sub_start(len_words, c.next_sub, g));
+    // a lane with a successor walks a little further, so that their lists overlap; the last one stops at the end
+    const uint32_t want = c.next_sub < g.count ? c.sub_end + kCoopMargin : c.sub_end;
+    c.stop_p = umin(want, coop_hard_end(s));
+}
+
+// What lane `tl` of an interval does in the first round.  Lane 0 walks from the interval's start; lanes
+// 1 + 4 (j - 1) + h, j = 1..count-1, walk subsequence j assuming data unit h.
+// start_rel / len_words: the interval's first word inside the window, and its length.
+CG_DEV void chase_assign(ChaseState &c, const HuffShared &s, const CoopGeom &g, uint32_t tl, uint32_t start_rel,
+                         uint32_t len_words, bool exists, uint32_t *list)
+{
+    uint32_t j = 0u, h = 0u;
+    bool used = exists && tl == 0u;
+    if (tl >= 1u && tl <= 4u * (g.count - 1u)) {
+        j = 1u + (tl - 1u) / 4u;
+        h = (tl - 1u) & 3u;
+        used = exists;
+    }
+    const uint32_t begin = coop_sub_start(len_words, j, g);
+    // subsequences that begin where the one before them begins (a tiny interval) are not walked twice
+    if (j > 0u && begin == coop_sub_start(len_words, j - 1u, g))
+        used = false;
+    // a start outside the window (corrupt start positions) is nobody's to walk: the interval goes serial
+    const bool inside = start_rel + begin + kDuWordSlack <= s.win_len;
+    c.p = inside && used ? 32u * (start_rel + begin) : 0u;
+    c.k8 = 8u * h;
+    c.lp = list;
+    c.lp_max = list;
+    c.flags = used && !inside ? kStopAnomaly : 0u;
+    c.next_sub = g.count;
+    c.sub_end = c.stop_p = 0u;
+    c.used = used && inside;
+    c.active = false;
+    c.s = 1u;
+    c.k0 = 0u;
+    if (!c.used)
+        return;
+    c.next_sub = coop_next_sub(len_words, j, g);
+    chase_set_end(c, s, g, start_rel, len_words);
+    c.active = true;
+    if (j == 0u) {
+        // lane 0 stands at the start of data unit 0, and needs the starts of the interval's data units only
+        c.s = 0u;
+        list[0] = c.p;
+        c.lp = list + 1;
+        c.lp_max = list + umin(kCoopMaxEntries, g.dpi);
+        c.active = c.lp < c.lp_max;
+    } else {
+        // inside the AC part of data unit h, by assumption: its first entry starts data unit h + 1
+        c.k0 = (h + 1u) & 3u;
+        c.lp_max = list + kCoopMaxEntries;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// 2. Validate
+// ---------------------------------------------------------------------------
+
+// Lane index (inside the interval) of the walk of subsequence j under assumption h
+CG_DEV uint32_t coop_spec_lane(uint32_t j, uint32_t h) { return 1u + 4u * (j - 1u) + h; }
+
+CG_DEV void coop_publish(const ChaseState &c, const CoopShared &cs, uint32_t lane)
+{
+    const uint32_t anomaly = c.flags | ((c.used && c.p >= coop_hard_end(cs.h)) ? kStopAnomaly : 0u);
+    const uint32_t n = uint32_t(c.lp - (cs.lists + lane * kCoopListCap));
+    cs.lane_n[lane] = n | (anomaly << 8) | (c.k0 << 16);
+    cs.link[lane] = 0u;
+}
+
+// Every chasing lane looks among its last entries, at or beyond the end of its own stretch, for one that a lane
+// of the next subsequence lists too (among its first entries).  lane0: first lane of the interval.
+CG_DEV void coop_find_link(const ChaseState &c, const CoopShared &cs, const CoopGeom &g, uint32_t lane, uint32_t lane0)
+{
+    const uint32_t *mine = cs.lists + lane * kCoopListCap;
+    const uint32_t n = uint32_t(c.lp - mine);
+    if (n == 0u || c.next_sub >= g.count)
+        return;
+    const uint32_t first = n > kCoopTail ? n - kCoopTail : 0u;
+    uint32_t own[kCoopTail];
+    bool own_ok[kCoopTail];
+#pragma unroll
+    for (uint32_t a = 0; a < kCoopTail; a++) {
+        own[a] = mine[first + a] & kCoopStateMask; // (first + a <= n <= kCoopMaxEntries: inside the list)
+        own_ok[a] = first + a < n && (own[a] & 0xffffu) >= c.sub_end;
+    }
+    uint32_t best = 0u;
+#pragma unroll
+    for (uint32_t h = 0; h < 4u; h++) {
+        const uint32_t other = lane0 + coop_spec_lane(c.next_sub, h);
+        const uint32_t info = cs.lane_n[other];
+        const uint32_t n_other = umin(info & 0xffu, kCoopHead), k_other = (info >> 16) & 3u;
+        const uint32_t *theirs = cs.lists + other * kCoopListCap;
+#pragma unroll
+        for (uint32_t q = 0; q < kCoopHead; q++) {
+            const uint32_t e = theirs[q] & kCoopStateMask;
+#pragma unroll
+            for (uint32_t a = 0; a < kCoopTail; a++) {
+                // same position, same symbol in front, same index inside the MCU
+                const bool hit = q < n_other && own_ok[a] && own[a] == e && ((c.k0 + first + a - k_other - q) & 3u) == 0u;
+                // the earliest of the lane's own entries wins
+                if (hit && (best == 0u || first + a < (best >> 24)))
+                    best = 1u | (other << 8) | (q << 16) | ((first + a) << 24);
+            }
+        }
+    }
+    cs.link[lane] = best;
+#if defined(CG_EMUL_STATS)
+    if (lane == lane0 || true) {
+        // (statistics only) would any of the lane's entries have matched any entry of a successor?
+        bool full = false;
+        for (uint32_t h = 0; h < 4u && !full; h++) {
+            const uint32_t other = lane0 + coop_spec_lane(c.next_sub, h);
+            const uint32_t info = cs.lane_n[other];
+            const uint32_t n_o = info & 0xffu, k_o = (info >> 16) & 3u;
+            for (uint32_t q = 0; q < n_o && !full; q++)
+                for (uint32_t i = 0; i < n && !full; i++)
+                    full = (mine[i] & kCoopStateMask) == (cs.lists[other * kCoopListCap + q] & kCoopStateMask) &&
+                           ((c.k0 + i - k_o - q) & 3u) == 0u && (mine[i] & 0xffffu) >= c.sub_end;
+        }
+        if (lane == lane0) {
+            CG_COOP_COUNT(link_tries, 1);
+            CG_COOP_COUNT(link_ok, best ? 1 : 0);
+            CG_COOP_COUNT(link_full_ok, (!best && full) ? 1 : 0);
+            CG_COOP_COUNT(link_none, (!best && !full) ? 1 : 0);
+        }
+    }
+#endif
+}
+
+// First lane of every interval that is not settled yet: follows the links from the chain's current head
+// (itself at first; later the lane that walked on) and notes, for this round, which entries of which lane
+// continue the interval's sequence of data units -- one word per stretch: lane | first entry << 6 |
+// entries << 11 | index of the first data unit << 16 -- and how the interval stands.
+//   head: the lane the chain continues with; from: its first entry that has not been noted yet;
+//   du: data units whose start has been noted so far
+CG_DEV void coop_follow(const CoopShared &cs, const CoopGeom &g, uint32_t il, uint32_t head, uint32_t from, uint32_t du)
+{
+    uint32_t x = head, nseg = 0u;
+    uint32_t *seg = cs.seg + il * g.count;
+    uint32_t v = kVerdictSerial;
+    for (uint32_t hops = 0; hops < g.count; hops++) {
+        const uint32_t info = cs.lane_n[x], n = info & 0xffu, stop = info >> 8;
+        const uint32_t l = cs.link[x];
+        const bool linked = (l & 1u) && (l >> 24) >= from;
+        const uint32_t upto = linked ? l >> 24 : (n > from ? n : from);
+        seg[nseg++] = x | (from << 6) | ((upto - from) << 11) | (du << 16);
+        du += upto - from;
+        if (du >= g.dpi) {
+            v = kVerdictDone;
+            break;
+        }
+        if (!linked) {
+            // the chain ends with lane x: it walks on, unless it cannot
+            v = ((stop & kStopAnomaly) || du == 0u) ? kVerdictSerial : (kVerdictContinue | (x << 8) | (du << 16));
+            break;
+        }
+        x = (l >> 8) & 0xffu;
+        from = (l >> 16) & 0xffu;
+    }
+    cs.nseg[il] = nseg;
+    cs.verdict[il] = v;
+}
+
+// Every lane fetches the start state of its own data unit, if this round's stretches hold it.
+CG_DEV void coop_emit(const CoopShared &cs, const CoopGeom &g, uint32_t il, uint32_t tl, uint32_t lane)
+{
+    const uint32_t nseg = cs.nseg[il];
+    const uint32_t *seg = cs.seg + il * g.count;
+    for (uint32_t i = 0; i < nseg; i++) {
+        const uint32_t sg = seg[i];
+        const uint32_t x = sg & 63u, from = (sg >> 6) & 31u, cnt = (sg >> 11) & 31u, du0 = sg >> 16;
+        if (tl >= du0 && tl - du0 < cnt)
+            cs.du_state[lane] = cs.lists[x * kCoopListCap + from + (tl - du0)] & kCoopStateMask;
+    }
+}
+
+// A lane whose interval's verdict names it walks on, through the next subsequence.  It stands at the state of
+// its last entry (noted already): that entry becomes entry 0 of its new list, the ones it lists now follow.
+// Every other lane rests.
+CG_DEV void coop_continue(ChaseState &c, const CoopShared &cs, const CoopGeom &g, uint32_t il, uint32_t lane,
+                          uint32_t start_rel, uint32_t len_words, uint32_t *list)
+{
+    const uint32_t v = cs.verdict[il];
+    c.active = false;
+    if ((v & 0xffu) != kVerdictContinue || ((v >> 8) & 0xffu) != lane || c.lp == list)
+        return;
+    const uint32_t settled = v >> 16;
+    const uint32_t n = uint32_t(c.lp - list);
+    list[0] = list[n - 1u] & kCoopStateMask;
+    c.k0 = (c.k0 + n - 1u) & 3u;
+    c.lp = list + 1;
+    if (c.next_sub < g.count)
+        c.next_sub = coop_next_sub(len_words, c.next_sub, g);
+    chase_set_end(c, cs.h, g, start_rel, len_words);
+    c.lp_max = list + umin(kCoopMaxEntries, 1u + (g.dpi - settled));
+    c.active = c.lp < c.lp_max && c.p < coop_hard_end(cs.h);
+}
+
+// ---------------------------------------------------------------------------
+// 3. Decode: one lane per data unit
+// ---------------------------------------------------------------------------
+
+CG_DEV void lds_read_done(uint32_t &a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)::"memory");
+#else
+    (void)a;
+#endif
+}
+
+CG_DEV void copy_zero_levels(const ImageDesc &d, uint32_t comp, int16_t *slot16)
+{
+    auto *z = CG_GLOBAL(const int16_t, &d.zero_du[0][0]) + comp * kRetained;
+    for (int i = 1; i < kRetained; i++)
+        slot16[i] = z[i];
+}
+
+CG_DEV int32_t zero_diff(const ImageDesc &d, uint32_t comp)
+{
+    return CG_GLOBAL(const int16_t, &d.zero_du[0][0])[comp * kRetained];
+}
+
+// The data unit whose start state is `state`, of component comp, into the lane's zeroed slot; returns its DC
+// difference.  The decoder is the fused kernel's: fast mode, with the exact reader behind it.  underflow: the
+// reference reader runs dry inside this data unit's DC code (quirk Q1) -- the difference then comes from what
+// is left of its buffer and the AC levels from zeros, and every later data unit of the interval decodes from
+// zeros too (the caller sees to that).
+// hostile: what the reference's reader finds at the underflowing DC code is a category above 15 (only a hostile
+// table has one): its shifts wrap modulo 32 and the buffer does not run empty -- the interval has to go through
+// the serial decoder, which follows the reference's reader literally.
+CG_DEV int32_t coop_decode_du(const ImageDesc &d, const HuffShared &s, const CoopTables &t, uint32_t state, uint32_t comp,
+                              int16_t *slot16, bool &underflow, bool &hostile)
+{
+    underflow = hostile = false;
+    if (state & (kCoopSerial | kCoopUnset))
+        return 0;
+    const uint32_t p = state & 0xffffu, rel = p >> 5, sh = p & 31u, tl = (state >> 16) & 31u;
+    EntropyState e;
+    e.r.buf = uint64_t(s.win[rel] << sh) << 32;
+    e.r.left = 32u - sh;
+    e.r.next_word = 0u;
+    e.wptr = s.win + rel + 1u;
+    e.r.pre = *e.wptr;
+    e.fast = true;
+    e.ref_left = 32u + ((tl - p) & 31u) - tl; // the reference reader's `left` here (see fast_ac)
+    e.pred0 = e.pred1 = e.pred2 = 0;
+    fast_refill(e);
+    lds_read_done(e.r.pre);
+    const uint32_t dc_off = sel3(comp, t.dc_off[0], t.dc_off[1], t.dc_off[2]);
+    const uint32_t ac_off = sel3(comp, t.ac_off[0], t.ac_off[1], t.ac_off[2]);
+    int32_t diff = 0;
+    if (fast_dc(e, d, s, dc_off, diff)) {
+        fast_ac(e, d, s, ac_off, sel3(comp, t.fast_base[0], t.fast_base[1], t.fast_base[2]), slot16);
+        CG_COUNT(fast_dus);
+        return diff;
+    }
+    {
+        // the code the reference sees: its buffer holds ref_left bits, zeros behind them (see fast_dc)
+        const uint32_t seen = e.ref_left < 32u ? e.ref_left : 32u;
+        const uint32_t cut = reader_cur(e.r) & ~uint32_t(uint64_t(0xffffffffu) >> seen);
+        hostile = t.standard || (lut_lookup<true>(d, s, dc_off, cut) & 0xffu) > 15u;
+    }
+    if (hostile)
+        return 0;
+    CG_COUNT(left_underflow);
+    CG_COUNT(exact_dus);
+    underflow = true;
+    leave_fast_mode(e, d, s);
+    diff = decode_dc_diff(e.r, d, s, dc_off);
+    copy_zero_levels(d, comp, slot16);
+    return diff;
+}
+
+// An interval that the chase gave up on (corrupt stream / hostile table): its first lane decodes it the way the
+// other kernels do, data unit after data unit; DC terms come out dequantised.
+CG_DEV void coop_decode_serial(const ImageDesc &d, const HuffShared &s, uint32_t interval, uint32_t dpi,
+                               uint8_t *first_slot, int32_t *dcs)
+{
+    EntropyState e;
+    entropy_init(e, d, s, interval);
+    for (uint32_t du = 0; du < dpi; du++)
+        dcs[du] = entropy_data_unit(e, d, s, comp_of_k(du & 3u), reinterpret_cast<int16_t *>(first_slot + du * kDuSlotBytes));
+}
+
+// DC prediction (src/huffman.wgsl:137,170): the sum of the differences of the component's data units up to this
+// one, inside the interval; i32 wrap like the reference.  diffs: the interval's differences, du: this lane's.
+CG_DEV int32_t coop_dc_term(const CoopTables &t, const int32_t *diffs, uint32_t du)
+{
+    const uint32_t k = du & 3u, m = du >> 2;
+    uint32_t sum = 0u;
+    for (uint32_t i = 0; i < m; i++)
+        sum += k < 2u ? uint32_t(diffs[4u * i]) + uint32_t(diffs[4u * i + 1u]) : uint32_t(diffs[4u * i + k]);
+    sum += k == 1u ? uint32_t(diffs[4u * m]) + uint32_t(diffs[4u * m + 1u]) : uint32_t(diffs[4u * m + k]);
+    return int32_t(sum * sel3(comp_of_k(k), t.dc_quant[0], t.dc_quant[1], t.dc_quant[2]));
+}
+
+// The slot's coefficients without clearing it (the slots are not used again).
+CG_DEV void read_slot(const uint8_t *slot, uint32_t (&rec)[kRetained / 2])
+{
+    const SlotVec *p = reinterpret_cast<const SlotVec *>(slot);
+#pragma unroll
+    for (int i = 0; i < kRetained / 8; i++) {
+        const SlotVec v = p[i];
+        rec[4 * i + 0] = v.x;
+        rec[4 * i + 1] = v.y;
+        rec[4 * i + 2] = v.z;
+        rec[4 * i + 3] = v.w;
+    }
+}
+
+// Lane j composites pixel columns 4 (j % 4) .. +3 of MCU first_mcu + j / 4, all 8 rows: a wave-wide 16-byte
+// store covers 64 contiguous bytes per MCU (1 KB of a pixel row when the 16 MCUs lie side by side).
+// px: the wave's 64 sample records, kPxSlotWords apart, record i = data unit i of the wave.
+CG_DEV void coop_composite(const ImageDesc &d, const uint32_t *px, uint32_t first_mcu, uint32_t mcus, uint32_t j)
+{
+    const uint32_t m = j >> 2, q = j & 3u;
+    if (m >= mcus)
+        return;
+    const uint32_t mcu = first_mcu + m;
+    const uint32_t mx = mcu % d.width_mcus, my = mcu / d.width_mcus;
+    const uint32_t x0 = mx * 16u + q * 4u;
+    if (x0 >= d.out_w)
+        return;
+    const uint32_t *ydu = px + (m * 4u + (q >> 1)) * kPxSlotWords;
+    const uint32_t *cbdu = px + (m * 4u + 2u) * kPxSlotWords;
+    const uint32_t *crdu = px + (m * 4u + 3u) * kPxSlotWords;
+    const bool whole = x0 + 3u < d.out_w && (d.out_pitch & 15u) == 0u;
+#pragma unroll
+    for (uint32_t row = 0; row < 8; row++) {
+        const uint32_t y = my * 8u + row;
+        if (y >= d.out_h)
+            break;
+        const Vec4u o = rgba_quad(ydu[row * 2u + (q & 1u)], cbdu[row * 2u + (q >> 1)] >> ((q & 1u) * 16u),
+                                  crdu[row * 2u + (q >> 1)] >> ((q & 1u) * 16u));
+        uint8_t *p = d.out + size_t(y) * d.out_pitch + size_t(x0) * 4u;
+        if (whole) {
+            store_pixels<true>(p, o);
+        } else {
+            auto *w = CG_GLOBAL(uint32_t, reinterpret_cast<uint32_t *>(p));
+            w[0] = o.x;
+            if (x0 + 1u < d.out_w)
+                w[1] = o.y;
+            if (x0 + 2u < d.out_w)
+                w[2] = o.z;
+            if (x0 + 3u < d.out_w)
+                w[3] = o.w;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The wave: phases in which the lanes work side by side, LDS in between
+// ---------------------------------------------------------------------------
+// One body for the GPU and for tests/emul: LANES = 1 on the GPU, where the function runs in every lane of the
+// wave with `my_lane` = its index and the "for every lane" loops below run once; LANES = 64 in the emulation,
+// where one call plays the whole wave, lane after lane, phase by phase.
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// lanes of a wave exchange data through LDS between two phases: the hardware keeps a wave's LDS operations in
+// order, the compiler has to as well
+#define CG_WAVE_SYNC()                                                                                 \
+    do {                                                                                               \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                         \
+        __builtin_amdgcn_wave_barrier();                                                               \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                         \
+    } while (0)
+#else
+#define CG_WAVE_SYNC() do { } while (0)
+#endif
+
+struct CoopLane {
+    uint32_t lane, il, tl, lane0; // index in the wave; interval of the wave; index inside it; the interval's first lane
+    bool exists;                  // the interval exists (the image's last wave may have fewer)
+    uint32_t start_rel, len_words; // the interval's first word inside the window, its length
+};
+
+CG_DEV void coop_lane(const ImageDesc &d, const HuffShared &s, const CoopGeom &g, uint32_t lane, CoopLane &L)
+{
+    L.lane = lane;
+    L.il = lane >> g.dpi_shift;
+    L.tl = lane & (g.dpi - 1u);
+    L.lane0 = L.il << g.dpi_shift;
+    L.exists = L.il < g.intervals;
+    const uint32_t interval = g.first_interval + (L.exists ? L.il : 0u);
+    const uint32_t ws = interval < d.nstarts ? CG_GLOBAL(const uint32_t, d.starts)[interval] : 0u;
+    const uint32_t we = (interval + 1u < d.total_intervals && interval + 1u < d.nstarts)
+                            ? CG_GLOBAL(const uint32_t, d.starts)[interval + 1u] : d.nwords;
+    L.start_rel = ws >= s.win_base ? umin(ws - s.win_base, 0x7fffffu) : 0x7fffffu; // (outside the window: no walk)
+    L.len_words = we > ws ? umin(we - ws, kCoopMaxWindow) : 0u;
+}
+
+#if defined(CG_COOP_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+#define CG_COOP_STAMP(i) do { const uint64_t now_ = __builtin_readcyclecounter(); stamp_[i] += now_ - tprev_; tprev_ = now_; } while (0)
+#else
+#define CG_COOP_STAMP(i) do { } while (0)
+#endif
+
+template <int LANES>
+CG_DEV bool coop_any(const bool (&flag)[LANES])
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ballot_w64(flag[0]) != 0u;
+#else
+    bool any = false;
+    for (int i = 0; i < LANES; i++)
+        any = any || flag[i];
+    return any;
+#endif
+}
+
+// 64 data units' worth of restart intervals (CoopGeom), from bitstream to pixels.
+template <int LANES>
+CG_DEV void coop_wave_422(const ImageDesc &d, const CoopShared &cs, const CoopTables &t, const CoopGeom &g,
+                          uint32_t my_lane, uint32_t wave_index)
+{
+    const HuffShared &s = cs.h;
+    CoopLane L[LANES];
+    ChaseState c[LANES];
+    bool active[LANES];
+#if defined(CG_COOP_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+    uint64_t tprev_ = __builtin_readcyclecounter(), stamp_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    (void)wave_index;
+#define CG_EACH_LANE for (int li = 0; li < LANES; li++)
+    CG_EACH_LANE
+    {
+        coop_lane(d, s, g, LANES == 1 ? my_lane : uint32_t(li), L[li]);
+        const uint32_t lane = L[li].lane;
+        cs.du_state[lane] = kCoopUnset;
+        if (lane < 16u) {
+            cs.verdict[lane] = 0u;
+            cs.nseg[lane] = 0u;
+            cs.dead_from[lane] = 0xffffu;
+        }
+        chase_assign(c[li], s, g, L[li].tl, L[li].start_rel, L[li].len_words, L[li].exists, cs.lists + lane * kCoopListCap);
+        active[li] = c[li].active;
+    }
+    if (LANES != 1)
+        CG_COOP_COUNT(intervals, g.intervals);
+    CG_COOP_STAMP(0);
+
+    // ---- 1 + 2: walk, link, follow; lanes that have to walk on do so, until every interval is settled ----
+    for (uint32_t round = 0; round <= g.dpi + 1u; round++) {
+        if (!coop_any<LANES>(active))
+            break;
+        if (LANES != 1)
+            CG_COOP_COUNT(rounds, 1);
+        {
+            unsigned long most = 0, most_true = 0;
+            CG_EACH_LANE
+            {
+                unsigned long steps = 0;
+                chase_run(c[li], d, s, t, steps);
+                CG_COOP_COUNT(chase_steps, steps);
+                most = steps > most ? steps : most;
+                if (L[li].tl == 0u) {
+                    CG_COOP_COUNT(true_steps, steps);
+                    most_true = steps > most_true ? steps : most_true;
+                }
+                if (steps)
+                    CG_COOP_COUNT(hist[steps / 16 < 15 ? steps / 16 : 15], 1);
+            }
+            CG_COOP_COUNT(wave_steps, most);
+            CG_COOP_COUNT(true_max, most_true);
+            (void)most_true;
+        }
+        CG_COOP_STAMP(1);
+        CG_EACH_LANE coop_publish(c[li], cs, L[li].lane);
+        CG_WAVE_SYNC();
+        CG_EACH_LANE coop_find_link(c[li], cs, g, L[li].lane, L[li].lane0);
+        CG_WAVE_SYNC();
+        CG_EACH_LANE
+        {
+            if (L[li].tl != 0u || !L[li].exists)
+                continue;
+            const uint32_t v = cs.verdict[L[li].il];
+            if (v == 0u)
+                coop_follow(cs, g, L[li].il, L[li].lane, 0u, 0u);
+            else if ((v & 0xffu) == kVerdictContinue)
+                coop_follow(cs, g, L[li].il, (v >> 8) & 0xffu, 1u, v >> 16);
+            else
+                cs.nseg[L[li].il] = 0u;
+        }
+        CG_WAVE_SYNC();
+        CG_EACH_LANE
+        {
+            if (L[li].exists)
+                coop_emit(cs, g, L[li].il, L[li].tl, L[li].lane);
+        }
+        CG_WAVE_SYNC();
+        CG_EACH_LANE
+        {
+            if (L[li].exists)
+                coop_continue(c[li], cs, g, L[li].il, L[li].lane, L[li].start_rel, L[li].len_words,
+                              cs.lists + L[li].lane * kCoopListCap);
+            else
+                c[li].active = false;
+            active[li] = c[li].active;
+            if (LANES != 1 && active[li])
+                CG_COOP_COUNT(continued, 1);
+        }
+        CG_WAVE_SYNC();
+        CG_COOP_STAMP(2);
+    }
+
+    // ---- 3: one lane per data unit ----
+    uint32_t state[LANES];
+    int32_t dc[LANES];
+    CG_EACH_LANE
+    {
+        uint32_t st = kCoopUnset;
+        if (L[li].exists) {
+            st = cs.du_state[L[li].lane];
+            // (an interval still waiting for a walk after the last round goes the same way as one given up on)
+            if ((cs.verdict[L[li].il] & 0xffu) != kVerdictDone || (st & kCoopUnset))
+                st = kCoopSerial;
+        }
+        state[li] = st;
+    }
+    CG_WAVE_SYNC(); // the lists have been read for the last time: their bytes become the data units' slots
+    CG_EACH_LANE zero_slot(s.du_slots + L[li].lane * kDuSlotBytes);
+    CG_WAVE_SYNC();
+    bool under[LANES];
+    CG_EACH_LANE
+    {
+        const uint32_t lane = L[li].lane;
+        bool hostile = false;
+        const int32_t diff = coop_decode_du(d, s, t, state[li], comp_of_k(L[li].tl & 3u),
+                                            reinterpret_cast<int16_t *>(s.du_slots + lane * kDuSlotBytes), under[li], hostile);
+        cs.diffs[lane] = diff;
+        if (hostile)
+            cs.verdict[L[li].il] = kVerdictSerial; // (every lane that says so says the same)
+        if (under[li]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            atomicMin(&cs.dead_from[L[li].il], L[li].tl);
+#else
+            cs.dead_from[L[li].il] = umin(cs.dead_from[L[li].il], L[li].tl);
+#endif
+        }
+    }
+    CG_WAVE_SYNC();
+    CG_COOP_STAMP(3);
+    CG_EACH_LANE
+    {
+        // an interval that turned out to need the serial decoder after all: what its lanes decoded is dropped
+        if (L[li].exists && !(state[li] & (kCoopSerial | kCoopUnset)) && (cs.verdict[L[li].il] & 0xffu) == kVerdictSerial) {
+            state[li] = kCoopSerial;
+            under[li] = false;
+            zero_slot(s.du_slots + L[li].lane * kDuSlotBytes);
+        }
+    }
+    CG_WAVE_SYNC();
+    if (coop_any<LANES>(under)) {
+        // quirk Q1: behind the first data unit whose DC code underflows the reference reader, the interval decodes
+        // from zeros -- whatever those lanes have decoded from the walk's states is replaced
+        CG_EACH_LANE
+        {
+            if (!L[li].exists || (state[li] & (kCoopSerial | kCoopUnset)))
+                continue;
+            const uint32_t first_dead = cs.dead_from[L[li].il];
+            if (LANES != 1 && L[li].tl == first_dead)
+                CG_COOP_COUNT(dead, 1);
+            if (L[li].tl <= first_dead)
+                continue;
+            const uint32_t comp = comp_of_k(L[li].tl & 3u);
+            uint8_t *slot = s.du_slots + L[li].lane * kDuSlotBytes;
+            zero_slot(slot);
+            copy_zero_levels(d, comp, reinterpret_cast<int16_t *>(slot));
+            cs.diffs[L[li].lane] = zero_diff(d, comp);
+            state[li] |= kCoopZero;
+            if (LANES != 1)
+                CG_COOP_COUNT(zero, 1);
+        }
+        CG_WAVE_SYNC();
+    }
+    CG_EACH_LANE
+    {
+        if ((state[li] & kCoopSerial) && L[li].tl == 0u) {
+            coop_decode_serial(d, s, g.first_interval + L[li].il, g.dpi, s.du_slots + L[li].lane * kDuSlotBytes,
+                               cs.diffs + L[li].lane);
+            if (LANES != 1)
+                CG_COOP_COUNT(serial, 1);
+        }
+    }
+    CG_WAVE_SYNC();
+    CG_COOP_STAMP(4);
+#if defined(CG_EMUL_STATS)
+    if (getenv("EMUL_COOP_DEBUG")) {
+        CG_EACH_LANE
+            if (L[li].exists)
+                fprintf(stderr, "dbg wave %u lane %u il %u tl %u state %08x verdict %08x dead_from %u diff %d under %d\n", wave_index,
+                        L[li].lane, L[li].il, L[li].tl, state[li], cs.verdict[L[li].il], cs.dead_from[L[li].il], cs.diffs[L[li].lane], int(under[li]));
+    }
+#endif
+    uint32_t px[LANES][16];
+    CG_EACH_LANE
+    {
+        const uint32_t lane = L[li].lane;
+        if (state[li] & kCoopUnset)
+            continue;
+        dc[li] = (state[li] & kCoopSerial) ? cs.diffs[lane] : coop_dc_term(t, cs.diffs + L[li].lane0, L[li].tl);
+        uint32_t rec[kRetained / 2];
+        read_slot(s.du_slots + lane * kDuSlotBytes, rec);
+        idct_data_unit(rec, dc[li], cs.quant + comp_of_k(L[li].tl & 3u) * kCoopQuantStride, px[li]);
+    }
+    CG_WAVE_SYNC(); // every slot has been read: the area now holds the samples, kPxSlotWords apart
+    CG_COOP_STAMP(5);
+    uint32_t *samples = reinterpret_cast<uint32_t *>(s.du_slots);
+    CG_EACH_LANE
+    {
+        if (state[li] & kCoopUnset)
+            continue;
+#pragma unroll
+        for (int w = 0; w < 16; w++)
+            reinterpret_cast<slot_word_t *>(samples)[L[li].lane * kPxSlotWords + w] = px[li][w];
+    }
+    CG_WAVE_SYNC();
+    CG_EACH_LANE coop_composite(d, samples, g.first_interval * g.R, g.intervals * g.R, L[li].lane);
+    CG_COOP_STAMP(6);
+#if defined(CG_COOP_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+    if (my_lane == 0u && d.dc) { // diagnostic build only: per-wave phase cycles into the (otherwise unused) dc buffer
+        uint64_t *o = reinterpret_cast<uint64_t *>(d.dc) + size_t(wave_index) * 8u;
+        for (int i = 0; i < 8; i++)
+            o[i] = stamp_[i];
+    }
+#endif
+#undef CG_EACH_LANE
+}
+
+} // namespace compeg

@@ -3,14 +3,17 @@
 // used by the sanitizer tests).
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "device_types.h"
 #include "front.h"
+#include "kernels_body.h" // (host compile of the lane bodies: the exact-path reader, for the zero-stream data units)
 
 namespace compeg {
 
 void fill_desc(const ImageData &img, ImageDesc &d);
-uint32_t max_wave_span(const uint32_t *starts, size_t nstarts, size_t nwords, uint32_t intervals);
+void fill_coop(const ImageData &img, ImageDesc &d);
+uint32_t max_wave_span(const uint32_t *starts, size_t nstarts, size_t nwords, uint32_t intervals, uint32_t group);
 
 void fill_desc(const ImageData &img, ImageDesc &d)
 {
@@ -42,16 +45,74 @@ void fill_desc(const ImageData &img, ImageDesc &d)
         d.vsample[c] = cm.vsample;
         for (int z = 0; z < kRetained; z++)
             d.quant[c][z] = float(md.qtables[cm.qtable & 3][z]);
+        d.dc_fast_table[c] = (cm.dchuff == 0 || cm.dchuff == 2) ? cm.dchuff >> 1 : 2;
     }
+    fill_coop(img, d);
+}
+
+// What the cooperative kernel needs to know beyond the tables (coop_body.h): whether the image qualifies, and
+// the "zero-stream" data unit of every component.  Once the reference's reader has underflown at a DC code
+// (quirk Q1) its buffer is all zeros and is never topped up again, so every later data unit of the interval
+// decodes from zeros -- always the same levels.  They are computed here by the very reader the kernels' exact
+// path uses, on a reader in that state, so that host and device cannot disagree.
+void fill_coop(const ImageData &img, ImageDesc &d)
+{
+    const Metadata &md = img.metadata;
+    d.coop_ok = 0;
+    memset(d.zero_du, 0, sizeof d.zero_du);
+    const bool is422 = md.dus_per_mcu == 4 && md.components[0].hsample == 2 && md.components[0].vsample == 1 &&
+                       md.components[1].hsample == 1 && md.components[1].vsample == 1 &&
+                       md.components[2].hsample == 1 && md.components[2].vsample == 1;
+    // (1, 2, 4, 8 or 16 MCUs per interval: the wave's lane arithmetic is shifts)
+    if (!is422 || md.restart_interval == 0 || md.restart_interval > 16 || (md.restart_interval & (md.restart_interval - 1)))
+        return;
+    for (uint32_t c = 0; c < 3; c++)
+        if (d.fast_table[c] >= 2 || d.dc_fast_table[c] >= 2)
+            return;
+    // the tables as a kernel sees them: five L1 tables (the last one all zero), the whole L2 LUT "staged"
+    std::vector<uint16_t> l1(kL1Entries, 0);
+    memcpy(l1.data(), img.l1, sizeof img.l1);
+    const uint32_t none[4] = {0, 0, 0, 0};
+    ImageDesc t = d;
+    t.l2 = img.l2.data();
+    t.words = nullptr;
+    t.nwords = 0;
+    HuffShared s{};
+    s.l1 = l1.data();
+    s.l2 = img.l2.empty() ? l1.data() : img.l2.data();
+    s.l2_staged = uint32_t(img.l2.size());
+    s.win = none;
+    s.win_base = 0;
+    s.win_len = 4;
+    for (uint32_t c = 0; c < 3; c++) {
+        PrefetchReader r;
+        r.buf = 0;
+        r.left = 0x80000000u; // wrapped below zero: never topped up again
+        r.next_word = 0;
+        r.pre = 0;
+        ImageDesc tq = t;
+        tq.standard_entropy = 0;
+        const int32_t diff = decode_dc_diff(r, tq, s, d.dc_table[c] * 256u);
+        if (diff < -32767 || diff > 32767)
+            return; // (a category above 15 for the all-zero prefix: hostile table)
+        int16_t slot[kDuSlotBytes / 2] = {0};
+        decode_ac_loop<false>(r, tq, s, d.ac_table[c] * 256u, slot);
+        d.zero_du[c][0] = int16_t(diff);
+        for (int z = 1; z < kRetained; z++)
+            d.zero_du[c][z] = slot[z];
+    }
+    d.coop_ok = 1;
 }
 
 
-uint32_t max_wave_span(const uint32_t *starts, size_t nstarts, size_t nwords, uint32_t intervals)
+uint32_t max_wave_span(const uint32_t *starts, size_t nstarts, size_t nwords, uint32_t intervals, uint32_t group)
 {
     uint32_t best = 0;
-    for (size_t first = 0; first < intervals; first += kWave) {
+    if (group == 0)
+        group = kWave;
+    for (size_t first = 0; first < intervals; first += group) {
         const uint64_t lo = first < nstarts ? starts[first] : 0;
-        const size_t after = first + kWave;
+        const size_t after = first + group;
         const uint64_t hi = (after < intervals && after < nstarts) ? starts[after] : nwords;
         if (hi > lo && hi - lo > best)
             best = uint32_t(hi - lo > 0xffffffffu ? 0xffffffffu : hi - lo);

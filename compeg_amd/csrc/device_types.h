@@ -30,6 +30,12 @@ constexpr uint32_t fast_entry(uint32_t ref, uint32_t zrl_advance)
            ((((ref >> 8) & 31u) + (ref & 15u)) << 4) | (ref & 15u);
 }
 
+// Direct DC tables (cooperative kernel): one u16 per 9-bit code prefix in the same format -- bits 0..3 the
+// category (magnitude bits), bits 4..8 code length + category, advance 1 -- or kFastEscape when the code is
+// longer than 9 bits or the category larger than 15.  Stored behind the direct AC tables.
+constexpr uint32_t kDcFastBits = 9;
+constexpr uint32_t kDcFastEntries = 1u << kDcFastBits;
+
 // LDS slot of one lane's data unit while it is being decoded: 32 int16 in
 // zig-zag order + one dummy position (coefficients >= 32 are dropped there).
 // 80 bytes per lane: 16-byte aligned, so that the slot is read back, cleared
@@ -55,6 +61,12 @@ struct ImageDesc {
     uint32_t fast_table[3]; // per component: 0 / 1, or 2 = none (out-of-range selector)
     // COMPEG_PARSE_STANDARD_ENTROPY: refill in front of DC codes, ZRL advances 16 (else 0: the reference)
     uint32_t standard_entropy;
+    // cooperative kernel (coop_body.h): per component the direct DC table (0 / 1, 2 = none); whether the image
+    // qualifies at all; and what a data unit decodes to once the reference's reader has underflown (quirk Q1:
+    // it then reads zeros for the rest of the interval): [c][0] the DC difference, [c][1..31] the AC levels
+    uint32_t dc_fast_table[3];
+    uint32_t coop_ok;
+    int16_t zero_du[3][kRetained];
     // geometry
     uint32_t total_intervals;
     uint32_t restart_interval; // MCUs per interval

@@ -502,6 +502,32 @@ Status ImageData::parse(const uint8_t *jpeg, size_t len, bool copy, ImageData **
         }
     }
 
+    // Direct DC tables for the cooperative kernel, same idea: 9-bit prefixes of the two DC tables.
+    img->dc_fast.assign(2 * kDcFastEntries, uint16_t(kFastEscape));
+    for (int t = 0; t < 2; t++) {
+        const uint16_t *l1 = img->l1 + (2 * t) * 256;
+        for (uint32_t x = 0; x < kDcFastEntries; x++) {
+            const uint16_t e1 = l1[x >> (kDcFastBits - 8)];
+            uint16_t v = e1;
+            bool usable = !(e1 & 0x8000);
+            if (!usable) {
+                // all 16-bit continuations of this prefix must agree
+                const uint32_t lowbits = 16 - kDcFastBits;
+                const size_t first = size_t(e1 & 0x7fff) + ((x << lowbits) & 0xff);
+                v = first < img->l2.size() ? img->l2[first] : 0;
+                usable = true;
+                for (uint32_t i = 1; i < (1u << lowbits) && usable; i++) {
+                    const size_t idx = first + i;
+                    usable = (idx < img->l2.size() ? img->l2[idx] : 0) == v;
+                }
+                usable = usable && (v >> 8) <= kDcFastBits;
+            }
+            const uint32_t len = v >> 8, cat = v & 0xffu;
+            if (usable && cat <= 15u && len + cat <= 31u)
+                img->dc_fast[size_t(t) * kDcFastEntries + x] = uint16_t((1u << 9) | ((len + cat) << 4) | cat);
+        }
+    }
+
     guard.p = nullptr;
     *out = img;
     return Status{};

@@ -63,6 +63,7 @@ struct ImageData {
     // reference's upload format): for each of the two AC tables, one entry per
     // 11-bit prefix in the format device_types.h describes.
     std::vector<uint16_t> ac_fast; // 2 x kFastEntries
+    std::vector<uint16_t> dc_fast; // 2 x kDcFastEntries, for the two DC tables (device_types.h)
     unsigned flags = 0;            // COMPEG_PARSE_* this image was parsed with
     std::vector<uint8_t> owned; // Cow::Owned
     const uint8_t *jpeg = nullptr;

@@ -14,7 +14,8 @@ namespace compeg {
 HuffLdsPlan plan_huffman(uint32_t max_intervals, uint32_t images, uint32_t max_l2,
                          uint32_t max_wave_words, bool fused);
 // Largest word span covered by any group of 64 consecutive restart intervals.
-uint32_t max_wave_span(const uint32_t *starts, size_t nstarts, size_t nwords, uint32_t intervals);
+uint32_t max_wave_span(const uint32_t *starts, size_t nstarts, size_t nwords, uint32_t intervals,
+                       uint32_t group = kWave);
 
 // descs: device array of `images` descriptors.  Grid = (blocks for the
 // largest image, images); blocks past an image's own extent exit at once.
@@ -29,6 +30,17 @@ hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t ma
 // Latency variant: one decoder wave + one transformer wave per 64 intervals.
 hipError_t launch_pair_422(const ImageDesc *descs, uint32_t images, uint32_t max_intervals,
                            const HuffLdsPlan &plan, hipStream_t stream);
+// Cooperative kernel (coop_body.h) for launches too small to fill the chip with a lane per restart interval.
+struct CoopPlan {
+    bool usable;
+    uint32_t intervals_per_wave, waves_per_block, window_words, l2_entries_in_lds, total_bytes, total_waves;
+};
+// max_group_words: largest word span of any group of intervals_per_wave consecutive intervals
+// (max_wave_span with that group size), or an upper estimate of it
+CoopPlan plan_coop(uint32_t max_intervals, uint32_t images, uint32_t restart_interval, uint32_t max_l2,
+                   uint32_t max_group_words);
+hipError_t launch_coop_422(const ImageDesc *descs, uint32_t images, uint32_t max_intervals, const CoopPlan &plan,
+                           hipStream_t stream);
 hipError_t launch_idct_composite(const ImageDesc *descs, uint32_t images, uint32_t max_dus,
                                  hipStream_t stream);
 

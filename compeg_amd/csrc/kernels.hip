@@ -23,9 +23,12 @@
 #include <cstdlib>
 
 #include "kernels_body.h"
+#include "coop_body.h"
 #include "kernels.h"
 
 namespace compeg {
+
+constexpr uint32_t kLdsBytesPerCu = 160u * 1024u;
 
 // LDS layout (dynamic, 16-byte aligned carve-outs):
 //   [L1: 5*256 u16][L2: l2_in_lds u16][per wave: window_words u32 | 64 DU slots]
@@ -268,6 +271,71 @@ decode_pair_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, 
     }
 }
 
+// Cooperative kernel (coop_body.h): launches that cannot fill the chip with one lane per restart interval.
+// A wave takes as many consecutive intervals as have 64 data units together and splits their bitstreams
+// among its lanes; a workgroup is a handful of such waves sharing one copy of the tables.
+// LDS: [L1][L2 + direct AC + direct DC tables][quantisers 3 x 36 f32][per wave: window | 64 slots | bookkeeping]
+constexpr uint32_t kCoopWaveMisc = kCoopMiscWords * 4u;
+
+__device__ __forceinline__ uint32_t coop_wave_area(uint32_t window_words)
+{
+    return align16(window_words * 4u) + kWave * kDuSlotBytes + kCoopWaveMisc;
+}
+
+__global__ void __launch_bounds__(512)
+decode_coop_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const ImageDesc &d = descs[blockIdx.y];
+    const uint32_t waves = blockDim.x / kWave;
+    const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x / kWave))), lane = threadIdx.x % kWave;
+    CoopGeom g;
+    coop_geom(d, blockIdx.x * waves + wave, g);
+    if (blockIdx.x * waves * g.ipw >= d.total_intervals)
+        return; // the whole workgroup
+
+    uint16_t *l1 = reinterpret_cast<uint16_t *>(smem);
+    uint16_t *l2 = l1 + kL1Entries;
+    float *quant = reinterpret_cast<float *>(smem + align16((kL1Entries + l2_in_lds) * 2u));
+    uint8_t *wave_base = reinterpret_cast<uint8_t *>(quant + 3u * kCoopQuantStride) + wave * coop_wave_area(window_words);
+    uint32_t *win = reinterpret_cast<uint32_t *>(wave_base);
+    uint8_t *slots = wave_base + align16(window_words * 4u);
+    uint32_t *misc = reinterpret_cast<uint32_t *>(slots + kWave * kDuSlotBytes);
+
+    uint32_t win_base = 0, win_len = 0;
+    if (g.intervals)
+        coop_window(d, g, window_words, win_base, win_len);
+    stage_luts_and_window(d, l1, l2, l2_in_lds, threadIdx.x, blockDim.x, win, win_base, win_len, lane, 2u * kDcFastEntries);
+    if (threadIdx.x < 3u * kRetained)
+        quant[(threadIdx.x / kRetained) * kCoopQuantStride + threadIdx.x % kRetained] =
+            d.quant[threadIdx.x / kRetained][threadIdx.x % kRetained];
+    __syncthreads();
+    if (!g.intervals)
+        return; // the whole wave
+
+    CoopShared cs;
+    cs.h.l1 = l1;
+    cs.h.l2 = l2;
+    cs.h.l2_staged = umin(l2_in_lds, d.fast_off + 2u * kFastEntries + 2u * kDcFastEntries);
+    cs.h.win = win;
+    cs.h.win_base = win_base;
+    cs.h.win_len = win_len;
+    cs.h.du_slots = slots;
+    cs.lists = reinterpret_cast<uint32_t *>(slots);
+    cs.du_state = misc;
+    cs.lane_n = misc + 64;
+    cs.link = misc + 128;
+    cs.diffs = reinterpret_cast<int32_t *>(misc + 192);
+    cs.seg = misc + 256;
+    cs.verdict = misc + 272;
+    cs.nseg = misc + 288;
+    cs.dead_from = misc + 304;
+    cs.quant = quant;
+    CoopTables t;
+    coop_tables(d, cs.h, t);
+    coop_wave_422<1>(d, cs, t, g, lane, blockIdx.x * waves + wave);
+}
+
 // One lane per data unit for the IDCT, then the same lanes regroup (through
 // LDS) so that every wave-wide store writes 16 MCUs x 64 contiguous bytes.
 __global__ void __launch_bounds__(256)
@@ -358,7 +426,6 @@ composite_generic_kernel(const ImageDesc *__restrict__ descs)
 }
 
 namespace {
-constexpr uint32_t kLdsBytesPerCu = 160u * 1024u;
 constexpr uint32_t kMaxWavesFused = 12; // 3 per SIMD: what 168 VGPRs allow
 constexpr uint32_t kMaxWavesSplit = 16; // entropy_kernel: 4 per SIMD
 } // namespace
@@ -492,6 +559,58 @@ hipError_t launch_pair_422(const ImageDesc *descs, uint32_t images, uint32_t max
     const uint32_t lds = tables + ((plan.window_words * 4u + 15u) & ~15u) + 2u * kWave * kDuSlotBytes +
                          2u * kWave * 4u;
     hipLaunchKernelGGL(decode_pair_422_kernel, grid, dim3(2 * kWave), lds, stream, descs,
+                       plan.l2_entries_in_lds, plan.window_words);
+    return hipGetLastError();
+}
+
+// window_words: plan_coop's.  Every image of the launch must have ImageDesc::coop_ok and the same restart interval.
+CoopPlan plan_coop(uint32_t max_intervals, uint32_t images, uint32_t restart_interval, uint32_t max_l2,
+                   uint32_t max_group_words)
+{
+    CoopPlan p{};
+    const uint32_t dpi = 4u * restart_interval;
+    if (restart_interval == 0 || restart_interval > kCoopMaxRestart)
+        return p;
+    p.intervals_per_wave = uint32_t(kWave) / dpi;
+    p.l2_entries_in_lds = (max_l2 + 2u * kDcFastEntries + 1u) & ~1u;
+    uint32_t w = max_group_words + kDuWordSlack + 4u;
+    w = std::max(w, 128u);
+    w = std::min(w, kCoopMaxWindow);
+    p.window_words = (w + 3u) & ~3u;
+    const uint32_t tables = ((((kL1Entries + p.l2_entries_in_lds) * 2u) + 15u) & ~15u) + 3u * kCoopQuantStride * 4u;
+    const uint32_t wave_area = ((p.window_words * 4u + 15u) & ~15u) + kWave * kDuSlotBytes + kCoopWaveMisc;
+    // as many waves per workgroup as share one copy of the tables without costing residency: two workgroups per CU
+    uint32_t wpb = 8;
+    if (const char *e = getenv("COMPEG_COOP_WPB"))
+        wpb = uint32_t(std::max(1, std::min(8, atoi(e))));
+    while (wpb > 1 && tables + wpb * wave_area > kLdsBytesPerCu / 2u)
+        wpb--;
+    if (tables + wpb * wave_area > kLdsBytesPerCu)
+        return p; // (tables too large for LDS: the other kernels read the rest from global memory)
+    p.waves_per_block = wpb;
+    p.total_bytes = tables + wpb * wave_area;
+    const uint64_t waves = uint64_t((max_intervals + p.intervals_per_wave - 1) / p.intervals_per_wave) * images;
+    p.total_waves = waves > 0xffffffffu ? 0xffffffffu : uint32_t(waves);
+    p.usable = true;
+    if (getenv("COMPEG_VERBOSE"))
+        fprintf(stderr, "[compeg] coop plan: images=%u intervals=%u per wave=%u waves/block=%u window=%u words lds=%u B waves=%u\n",
+                images, max_intervals, p.intervals_per_wave, p.waves_per_block, p.window_words, p.total_bytes, p.total_waves);
+    return p;
+}
+
+hipError_t launch_coop_422(const ImageDesc *descs, uint32_t images, uint32_t max_intervals, const CoopPlan &plan,
+                           hipStream_t stream)
+{
+    if (images == 0 || max_intervals == 0)
+        return hipSuccess;
+    const uint32_t per_block = plan.intervals_per_wave * plan.waves_per_block;
+    dim3 grid((max_intervals + per_block - 1) / per_block, images, 1);
+    static const hipError_t attr = hipFuncSetAttribute(
+        reinterpret_cast<const void *>(decode_coop_422_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        int(kLdsBytesPerCu));
+    if (attr != hipSuccess)
+        return attr;
+    hipLaunchKernelGGL(decode_coop_422_kernel, grid, dim3(plan.waves_per_block * kWave), plan.total_bytes, stream, descs,
                        plan.l2_entries_in_lds, plan.window_words);
     return hipGetLastError();
 }

@@ -224,14 +224,15 @@ CG_DEV void copy_words_to_lds(uint32_t *dst, const uint32_t *src_, uint32_t n, u
         reinterpret_cast<slot_word_t *>(dst)[k] = src[k];
 }
 
+// extra: entries behind the direct AC tables that are wanted too (the cooperative kernel's direct DC tables)
 CG_DEV void stage_luts(const ImageDesc &d, uint16_t *l1, uint16_t *l2, uint32_t l2_in_lds,
-                       uint32_t tid, uint32_t nthreads)
+                       uint32_t tid, uint32_t nthreads, uint32_t extra = 0u)
 {
     uint32_t *dst = reinterpret_cast<uint32_t *>(l1);
     copy_words_to_lds(dst, reinterpret_cast<const uint32_t *>(d.l1), 4 * 128, tid, nthreads);
     for (uint32_t i = tid; i < 128; i += nthreads)
         reinterpret_cast<slot_word_t *>(dst)[4 * 128 + i] = 0u;
-    const uint32_t n2 = umin(l2_in_lds, d.fast_off + 2u * kFastEntries);
+    const uint32_t n2 = umin(l2_in_lds, d.fast_off + 2u * kFastEntries + extra);
     copy_words_to_lds(reinterpret_cast<uint32_t *>(l2), reinterpret_cast<const uint32_t *>(d.l2),
                       (n2 + 1) / 2, tid, nthreads);
 }
@@ -247,7 +248,9 @@ CG_DEV void wave_window(const ImageDesc &d, uint32_t wave_first, uint32_t window
     uint32_t end = (after < d.total_intervals && after < d.nstarts) ? CG_GLOBAL(const uint32_t, d.starts)[after] : d.nwords;
     // the slack lets the last intervals of the wave pass the fast mode's in-window
     // test; positions past the end of the scan are staged as zeros
-    end = umin(end, d.nwords) + kDuWordSlack;
+    // (+ 2: the reader keeps up to two words in hand, so at the start of the last data units of the wave's last
+    // interval its position is that far beyond the interval's end -- still inside the window with these)
+    end = umin(end, d.nwords) + kDuWordSlack + 2u;
     base = umin(base, d.nwords);
     len = end > base ? umin(end - base, window_words) : 0u;
 }
@@ -311,11 +314,11 @@ CG_DEV void stage_window(const ImageDesc &d, uint32_t *win, uint32_t base, uint3
 // issued first, the LUT copy runs under their latency.
 CG_DEV void stage_luts_and_window(const ImageDesc &d, uint16_t *l1, uint16_t *l2, uint32_t l2_in_lds,
                                   uint32_t tid, uint32_t nthreads, uint32_t *win, uint32_t base, uint32_t len,
-                                  uint32_t lane)
+                                  uint32_t lane, uint32_t extra = 0u)
 {
     SlotVec w[8];
     window_load_round(d, base, len, lane, w);
-    stage_luts(d, l1, l2, l2_in_lds, tid, nthreads);
+    stage_luts(d, l1, l2, l2_in_lds, tid, nthreads, extra);
     window_store_round(win, len, lane, w);
     const uint32_t nvec = (len + 3u) / 4u;
     for (uint32_t v0 = lane + 8u * kWave; v0 < nvec; v0 += 8u * kWave) {

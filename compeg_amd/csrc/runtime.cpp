@@ -118,6 +118,20 @@ bool use_pair_kernel(uint32_t max_intervals, uint32_t images)
     return waves <= 1024; // (measured: four 4K frames, 1016 waves, 89 us paired / 101 us fused; five: 133 / 116)
 }
 
+// ... and of those, the ones whose images qualify (ImageDesc::coop_ok, one restart interval for the whole
+// launch) take the cooperative kernel, which spends the idle lanes inside the intervals (coop_body.h).
+bool use_coop_kernel(uint32_t max_intervals, uint32_t images)
+{
+    static const int forced = [] {
+        const char *e = getenv("COMPEG_COOP"); // experiment knob: 0 / 1
+        return e ? atoi(e) : -1;
+    }();
+    if (forced >= 0)
+        return forced != 0;
+    const uint64_t waves = uint64_t((max_intervals + kWave - 1) / kWave) * images;
+    return waves <= 1024;
+}
+
 // Single-image device preprocessing: the raw segment is fetched from the pinned staging buffer by a
 // kernel (COMPEG_PULL=0: by the copy engine).
 bool pull_copies()
@@ -193,7 +207,7 @@ struct EnqueueTrace {
 // Per-image LUT blob: [L1 2048 B][L2, padded to 4 B][two 11-bit direct AC tables]
 size_t table_blob_bytes(const ImageData &img)
 {
-    return COMPEG_HUFFMAN_L1_BYTES + align_up(img.l2.size() * 2, 4) + img.ac_fast.size() * 2;
+    return COMPEG_HUFFMAN_L1_BYTES + align_up(img.l2.size() * 2, 4) + img.ac_fast.size() * 2 + img.dc_fast.size() * 2;
 }
 
 void write_tables(uint8_t *dst, const ImageData &img)
@@ -205,6 +219,7 @@ void write_tables(uint8_t *dst, const ImageData &img)
     if (!img.l2.empty())
         memcpy(l2, img.l2.data(), img.l2.size() * 2);
     memcpy(l2 + l2_bytes, img.ac_fast.data(), img.ac_fast.size() * 2);
+    memcpy(l2 + l2_bytes + img.ac_fast.size() * 2, img.dc_fast.data(), img.dc_fast.size() * 2);
 }
 
 // LUT entries a kernel should stage in LDS behind L1: the L2 LUT and the direct AC tables
@@ -558,7 +573,17 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
         CG_HIP(launch_generic_composite(reinterpret_cast<const ImageDesc *>(db), 1, out_w, out_h, stream));
         coefficients_valid = false;
     } else if (fused) {
-        if (use_pair_kernel(md.total_restart_intervals, 1))
+        CoopPlan coop{};
+        if (reinterpret_cast<const ImageDesc *>(hb)->coop_ok && use_coop_kernel(md.total_restart_intervals, 1)) {
+            const uint32_t ipw = uint32_t(kWave) / (4u * md.restart_interval);
+            const uint32_t group_span = on_device ? uint32_t(std::min<uint64_t>(uint64_t(dev_span) * ipw / kWave + 64, 0x7fffffffu))
+                                                  : max_wave_span(scan.starts(), scan.nstarts(), scan.nwords(),
+                                                                  md.total_restart_intervals, ipw);
+            coop = plan_coop(md.total_restart_intervals, 1, md.restart_interval, staged_lut_entries(img), group_span);
+        }
+        if (coop.usable)
+            CG_HIP(launch_coop_422(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals, coop, stream));
+        else if (use_pair_kernel(md.total_restart_intervals, 1))
             CG_HIP(launch_pair_422(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals,
                                    plan, stream));
         else
@@ -661,7 +686,7 @@ Status compeg_batch::upload(const ImageData *const *images, size_t n, int thread
         max_out_w = std::max(max_out_w, img.width);
         max_out_h = std::max(max_out_h, img.height);
         uniform = uniform && img.metadata.total_restart_intervals == first.metadata.total_restart_intervals &&
-                  img.l2 == first.l2 && img.ac_fast == first.ac_fast && memcmp(img.l1, first.l1, sizeof img.l1) == 0;
+                  img.l2 == first.l2 && img.ac_fast == first.ac_fast && img.dc_fast == first.dc_fast && memcmp(img.l1, first.l1, sizeof img.l1) == 0;
     }
     if (preprocess_mode != 0) {
         if (!use_fused_pipeline())
@@ -728,7 +753,7 @@ Status compeg_batch::upload(const ImageData *const *images, size_t n, int thread
     }
 
     std::vector<Status> results(n);
-    std::vector<uint32_t> spans(n, 0);
+    std::vector<uint32_t> spans(n, 0), group_spans(n, 0);
     std::vector<uint64_t> alg(n, 0);
     std::atomic<int> hip_error{int(hipSuccess)};
     unsigned nthreads = threads > 0 ? unsigned(threads) : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
@@ -767,6 +792,9 @@ Status compeg_batch::upload(const ImageData *const *images, size_t n, int thread
             d.out_h = img.height;
             d.out_pitch = img.width * 4;
             spans[i] = max_wave_span(starts_at, nstarts, nwords, img.metadata.total_restart_intervals);
+            if (d.coop_ok)
+                group_spans[i] = max_wave_span(starts_at, nstarts, nwords, img.metadata.total_restart_intervals,
+                                               uint32_t(kWave) / (4u * img.metadata.restart_interval));
             alg[i] = 4ull * nwords + 4ull * img.metadata.total_restart_intervals + COMPEG_METADATA_BYTES +
                      COMPEG_HUFFMAN_L1_BYTES + img.l2.size() * 2 + 4ull * img.width * img.height;
             // this image's part of the arena, as far as it is used
@@ -785,6 +813,13 @@ Status compeg_batch::upload(const ImageData *const *images, size_t n, int thread
         }
         max_span = std::max(max_span, spans[i]);
         algorithmic_bytes += alg[i];
+    }
+    coop_r = n ? images[0]->metadata.restart_interval : 0;
+    coop_span = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (!descs[i].coop_ok || images[i]->metadata.restart_interval != coop_r)
+            coop_r = 0;
+        coop_span = std::max(coop_span, group_spans[i]);
     }
     CG_HIP(hipMemcpyAsync(dev_descs.ptr, descs.data(), n * sizeof(ImageDesc), hipMemcpyHostToDevice, st));
     CG_HIP(hipStreamSynchronize(st)); // descs (pageable) and the staging arena may be reused from here on
@@ -944,6 +979,18 @@ Status compeg_batch::upload_device_scan(const ImageData *const *images, size_t n
         d.out_h = img.height;
         d.out_pitch = img.width * 4;
         max_span = std::max(max_span, span);
+        if (i == 0) {
+            coop_r = img.metadata.restart_interval;
+            coop_span = 0;
+        }
+        if (!d.coop_ok || img.metadata.restart_interval != coop_r) {
+            coop_r = 0;
+        } else {
+            // (the kernels report the span of 64 intervals only: four times the average for a wave's group;
+            // a group that is longer than that still decodes, its intervals one lane each)
+            const uint64_t ipw = uint64_t(kWave) / (4u * coop_r), avg = expected ? (uint64_t(nwords) + expected - 1) / expected : nwords;
+            coop_span = std::max(coop_span, uint32_t(std::min<uint64_t>(std::min<uint64_t>(span, 4 * avg * ipw + 64), 0x7fffffffu)));
+        }
         algorithmic_bytes += 4ull * nwords + 4ull * expected + COMPEG_METADATA_BYTES +
                              COMPEG_HUFFMAN_L1_BYTES + img.l2.size() * 2 + 4ull * img.width * img.height;
     }
@@ -988,7 +1035,12 @@ Status compeg_batch::decode(hipStream_t stream)
             continue;
         }
         if (fused) {
-            if (use_pair_kernel(max_intervals, m))
+            CoopPlan coop{};
+            if (coop_r && use_coop_kernel(max_intervals, m))
+                coop = plan_coop(max_intervals, m, coop_r, max_l2, coop_span);
+            if (coop.usable)
+                CG_HIP(launch_coop_422(dd + at, m, max_intervals, coop, stream));
+            else if (use_pair_kernel(max_intervals, m))
                 CG_HIP(launch_pair_422(dd + at, m, max_intervals, plan, stream));
             else
                 CG_HIP(launch_fused_422(dd + at, m, max_intervals, plan, stream, uniform));

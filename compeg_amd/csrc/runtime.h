@@ -23,6 +23,7 @@ namespace compeg {
 Status hip_status(hipError_t e, const char *what);
 bool use_fused_pipeline();
 bool use_pair_kernel(uint32_t max_intervals, uint32_t images);
+bool use_coop_kernel(uint32_t max_intervals, uint32_t images);
 
 // Grow-only device allocation; contents are not preserved across growth
 // (every user rewrites the buffer in full before reading it).
@@ -125,6 +126,9 @@ struct compeg_batch {
     // some image is not 4:2:2 (extension): the whole batch takes the three-kernel pipeline
     bool generic_layout = false;
     bool uniform = false; // same interval count and LUT bytes in every image (set by upload)
+    // cooperative kernel: the restart interval all images share if every one of them qualifies (else 0), and the
+    // largest word span of a wave's group of intervals
+    uint32_t coop_r = 0, coop_span = 0;
     uint32_t max_out_w = 0, max_out_h = 0;
     uint64_t algorithmic_bytes = 0, pixels = 0;
     uint32_t chunk = 0; // images per launch pair, 0 = all

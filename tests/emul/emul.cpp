@@ -16,10 +16,12 @@
 #include "../../compeg_amd/csrc/device_types.h"
 #include "../../compeg_amd/csrc/front.h"
 #include "../../compeg_amd/csrc/kernels_body.h"
+#include "../../compeg_amd/csrc/coop_body.h"
 #include "../../compeg_amd/csrc/scan.h"
 
 namespace compeg {
 void fill_desc(const ImageData &img, ImageDesc &d);
+uint32_t max_wave_span(const uint32_t *starts, size_t nstarts, size_t nwords, uint32_t intervals, uint32_t group);
 }
 using namespace compeg;
 
@@ -60,6 +62,7 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
     if (l2.size() & 1)
         l2.push_back(0);
     l2.insert(l2.end(), img->ac_fast.begin(), img->ac_fast.end());
+    l2.insert(l2.end(), img->dc_fast.begin(), img->dc_fast.end());
     std::vector<int16_t> ac(size_t(d.total_dus) * kRetained);
     std::vector<int32_t> dc(d.total_dus);
     d.words = words.data();
@@ -74,6 +77,64 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
     d.out_w = tex_w;
     d.out_h = tex_h;
     d.out_pitch = tex_w * 4;
+
+    if (fused == 5) {
+        // ---- decode_coop_422_kernel: coop_wave_422 plays a whole wave, lane after lane, phase by phase ----
+        if (!d.coop_ok) {
+            snprintf(err, errlen, "image does not qualify for the cooperative kernel");
+            delete img;
+            return -5;
+        }
+        l2_in_lds = (uint32_t(l2.size()) + 1u) & ~1u;
+        const uint32_t ipw = uint32_t(kWave) / (4u * d.restart_interval);
+        if (window_words == 0) { // as the runtime plans it
+            window_words = max_wave_span(starts.data(), starts.size(), words.size(), d.total_intervals, ipw) + kDuWordSlack + 4u;
+            window_words = std::min(std::max(window_words, 128u), kCoopMaxWindow);
+        }
+        window_words = (window_words + 3u) & ~3u;
+        const uint32_t misc_words = kCoopMiscWords;
+        const uint32_t lds_bytes = align16((kL1Entries + l2_in_lds) * 2u) + 3u * kCoopQuantStride * 4u +
+                                   align16(window_words * 4u) + kWave * kDuSlotBytes + misc_words * 4u;
+        const uint32_t nwaves = (d.total_intervals + ipw - 1) / ipw;
+        for (uint32_t wave = 0; wave < nwaves; wave++) {
+            uint8_t *smem = static_cast<uint8_t *>(aligned_alloc(16, align16(lds_bytes)));
+            memset(smem, 0xa5, lds_bytes); // LDS is not zero-initialised
+            uint16_t *sl1 = reinterpret_cast<uint16_t *>(smem);
+            uint16_t *sl2 = sl1 + kL1Entries;
+            float *quant = reinterpret_cast<float *>(smem + align16((kL1Entries + l2_in_lds) * 2u));
+            uint32_t *win = reinterpret_cast<uint32_t *>(quant + 3u * kCoopQuantStride);
+            uint8_t *slots = reinterpret_cast<uint8_t *>(win) + align16(window_words * 4u);
+            uint32_t *misc = reinterpret_cast<uint32_t *>(slots + kWave * kDuSlotBytes);
+            for (uint32_t tid = 0; tid < 128; tid++)
+                stage_luts(d, sl1, sl2, l2_in_lds, tid, 128, 2u * kDcFastEntries);
+            for (uint32_t t = 0; t < 3u * kRetained; t++)
+                quant[(t / kRetained) * kCoopQuantStride + t % kRetained] = d.quant[t / kRetained][t % kRetained];
+            CoopGeom g;
+            coop_geom(d, wave, g);
+            uint32_t wb = 0, wl = 0;
+            coop_window(d, g, window_words, wb, wl);
+            for (uint32_t i = 0; i < wl; i++)
+                win[i] = wb + i < d.nwords ? bswap32(d.words[wb + i]) : 0u;
+            CoopShared cs;
+            cs.h = HuffShared{sl1, sl2, umin(l2_in_lds, d.fast_off + 2u * kFastEntries + 2u * kDcFastEntries), win, wb, wl, slots};
+            cs.lists = reinterpret_cast<uint32_t *>(slots);
+            cs.du_state = misc;
+            cs.lane_n = misc + 64;
+            cs.link = misc + 128;
+            cs.diffs = reinterpret_cast<int32_t *>(misc + 192);
+            cs.seg = misc + 256;
+            cs.verdict = misc + 272;
+            cs.nseg = misc + 288;
+            cs.dead_from = misc + 304;
+            cs.quant = quant;
+            CoopTables t;
+            coop_tables(d, cs.h, t);
+            coop_wave_422<kWave>(d, cs, t, g, 0, wave);
+            free(smem);
+        }
+        delete img;
+        return 0;
+    }
 
     if (fused == 1 || fused == 2) {
         // ---- decode_fused_422_kernel (one slot set) / decode_pair_422_kernel (two sets, decoder role and
@@ -316,6 +377,17 @@ int main(int argc, char **argv)
     dump(argv[4], dc.data(), dc.size() * 4);
     printf("ok %u %u %u\n", tex_w, tex_h, dus);
     const EmulStats &st = g_emul_stats;
+    const CoopStats &cst = g_coop_stats;
+    if (cst.intervals)
+        fprintf(stderr, "coop intervals=%lu rounds=%lu continued=%lu serial=%lu dead=%lu zero=%lu chase_steps=%lu wave_steps=%lu\n", cst.intervals,
+                cst.rounds, cst.continued, cst.serial, cst.dead, cst.zero, cst.chase_steps, cst.wave_steps);
+    if (cst.intervals && getenv("EMUL_COOP_HIST")) {
+        fprintf(stderr, "cooplinks (first lane of each interval) tries=%lu ok=%lu only_full_match=%lu none=%lu\n", cst.link_tries, cst.link_ok, cst.link_full_ok, cst.link_none);
+        fprintf(stderr, "coophist true_steps=%lu true_max=%lu hist(16 steps per bin):", cst.true_steps, cst.true_max);
+        for (int i = 0; i < 16; i++)
+            fprintf(stderr, " %lu", cst.hist[i]);
+        fprintf(stderr, "\n");
+    }
     fprintf(stderr, "stats fast_dus=%lu exact_dus=%lu left_window=%lu left_underflow=%lu dc_cut=%lu escapes=%lu symbols=%lu wave_steps=%lu wave_step_symbols=%lu\n",
             st.fast_dus, st.exact_dus, st.left_window, st.left_underflow, st.dc_cut, st.escapes, st.symbols, st.wave_steps,
             st.wave_step_symbols);

@@ -35,13 +35,16 @@ def _run(runner, tmp_path, jpeg, fused, waves=1, window=2048, l2=12288, standard
     if standard:
         env["EMUL_STANDARD"] = "1"
     if fused:
-        env["EMUL_FUSED"] = str(int(fused))   # 1 = fused kernel, 2 = paired-wave kernel, 3 = entropy + IDCT kernels
+        # 1 = fused kernel, 2 = paired-wave kernel, 3 = entropy + IDCT kernels, 5 = cooperative kernel
+        env["EMUL_FUSED"] = str(int(fused))
     r = subprocess.run([runner, str(p), str(tmp_path / "rgba"), str(tmp_path / "ac"), str(tmp_path / "dc"),
                         str(waves), str(window), str(l2)], capture_output=True, text=True, env=env, timeout=600)
+    if fused == 5 and "does not qualify for the cooperative kernel" in r.stdout:
+        return None   # (no restart interval of 1..16 MCUs, or tables the direct tables cannot hold)
     assert r.returncode == 0, r.stdout + r.stderr[-2000:]
     _, w, h, _ = r.stdout.split()
     for line in r.stderr.splitlines():
-        if line.startswith("stats "):
+        if line.startswith("stats ") or line.startswith("coop "):
             for kv in line.split()[1:]:
                 k, v = kv.split("=")
                 STATS[k] = STATS.get(k, 0) + int(v)
@@ -53,6 +56,12 @@ def _check(runner, tmp_path, jpeg, **kw):
     for fused in (1, 2, 3, 0):   # fused kernel, paired-wave kernel, two-kernel pipeline, reference-style split kernels
         got = _run(runner, tmp_path, jpeg, fused, **kw)
         assert np.array_equal(got, want), f"fused={fused}: {(got != want).any(axis=2).sum()} pixels differ"
+    # the cooperative kernel, with the window the runtime would plan and with the test's (possibly cut short: the
+    # walks that leave it hand their interval to the serial decoder)
+    for window in sorted({0, kw.get("window", 0)}):
+        got = _run(runner, tmp_path, jpeg, 5, window=window)
+        if got is not None:
+            assert np.array_equal(got, want), f"cooperative kernel, window {window}: {(got != want).any(axis=2).sum()} pixels differ"
 
 
 CASES = [
@@ -119,6 +128,24 @@ def test_emulated_hostile_huffman_tables(runner, tmp_path):
         _check(runner, tmp_path, base[:sos] + seg + base[sos:], window=128)
 
 
+def test_emulated_cooperative_kernel_on_the_gpu_suite_inputs(runner, tmp_path):
+    """The corrupt / hostile inputs of tests/test_gpu_parity.py through the emulated cooperative kernel (one of
+    them -- an underflow of the reference reader at a DC code whose cut-off bits select a category above 15 --
+    was first caught on the GPU: such an interval must go to the serial decoder, not to the zero-stream shortcut)."""
+    import test_gpu_parity as gp
+    checked = 0
+    for j in gp._corrupt_variants(12) + gp._hostile_table_variants(10):
+        try:
+            want = orc.ImageData(j).decode()
+        except orc.OracleError:
+            continue
+        got = _run(runner, tmp_path, j, 5, window=0)
+        if got is not None:
+            assert np.array_equal(got, want), f"{(got != want).any(axis=2).sum()} pixels differ"
+            checked += 1
+    assert checked >= 10
+
+
 def test_emulated_count_mismatch_and_truncated_interval(runner, tmp_path):
     j = bytearray(synth.make_jpeg(128, 32, seed=40, ri=2))
     i = j.find(b"\xff\xdd")
@@ -132,6 +159,20 @@ def test_emulated_long_codes_and_dense_blocks(runner, tmp_path):
     which the reference reader reaches a DC code with few buffered bits (quirk Q1)."""
     for seed in (51, 52):
         _check(runner, tmp_path, synth.make_jpeg(96, 32, seed=seed, kind=1, quality=100, ri=3))
+
+
+def test_emulated_reference_reader_underflow_on_valid_streams(runner, tmp_path):
+    """Quirk Q1 on VALID streams: noise at quality 100 whose data units now and then end on a long code right
+    in front of a large DC difference, at a bit alignment that leaves the reference's un-refilled reader short
+    of bits (found by search; about one image in fifty of this kind has such a data unit).  Everything behind
+    the underflow decodes from zeros in the reference.  In the cooperative kernel that is a dead data unit
+    (DC difference from what is left of the reader, AC levels from the host's zero-stream record) and
+    zero-stream data units behind it; in the other kernels the lane's switch to the exact reader."""
+    for (w, h, seed) in [(256, 64, 77), (512, 128, 86), (512, 128, 163)]:
+        before = STATS.get("dead", 0), STATS.get("zero", 0), STATS.get("left_underflow", 0)
+        _check(runner, tmp_path, synth.make_jpeg(w, h, seed=seed, kind=1, quality=100, ri=4))
+        assert STATS.get("dead", 0) > before[0] and STATS.get("left_underflow", 0) > before[2]
+    assert STATS.get("zero", 0) > 0
 
 
 @pytest.mark.parametrize("sampling", [(1, 1), (2, 1), (1, 2), (2, 2)])
@@ -150,13 +191,16 @@ def test_emulated_standard_entropy_extension(runner, tmp_path):
     oracle with the same switch, on content where the reference's reader underflows (noise at
     quality 100) and with cut-short windows (exact-mode path)."""
     for (w, h, kind, q, ri, seed, window) in [(96, 32, 1, 100, 3, 51, 2048), (320, 64, 1, 92, 2, 11, 80),
-                                              (250, 70, 0, 50, 3, 4, 2048), (320, 200, 0, 95, 4, 5, 2048)]:
+                                              (250, 70, 0, 50, 3, 4, 2048), (320, 200, 0, 95, 4, 5, 2048),
+                                              (96, 32, 1, 100, 4, 51, 2048)]:
         jpeg = synth.make_jpeg(w, h, seed=seed, kind=kind, quality=q, ri=ri)
         want = orc.ImageData(jpeg, standard_entropy=True).decode()
         if kind == 0:
             assert not np.array_equal(want, orc.ImageData(jpeg).decode())   # the switch matters on this input
-        for fused in (1, 2, 3, 0):
+        for fused in (1, 2, 3, 0, 5):
             got = _run(runner, tmp_path, jpeg, fused, window=window, standard=True)
+            if got is None:
+                continue   # (the cooperative kernel takes restart intervals of 1, 2, 4, 8, 16 MCUs)
             assert np.array_equal(got, want), f"fused={fused} {w}x{h}: {(got != want).any(axis=2).sum()} pixels differ"
 
 
@@ -167,6 +211,11 @@ def test_emulated_rare_paths_were_reached():
     assert STATS.get("fast_dus", 0) > 10000
     assert STATS.get("exact_dus", 0) > 100
     for key in ("left_window", "left_underflow", "dc_cut", "escapes"):
+        assert STATS.get(key, 0) > 0, (key, STATS)
+    # ... and of the cooperative kernel: intervals settled in one round and in several, lanes that walked on,
+    # reference-reader underflows (dead data units, zero-stream data units behind them), serial hand-overs
+    assert STATS.get("intervals", 0) > 1000
+    for key in ("continued", "dead", "zero", "serial"):
         assert STATS.get(key, 0) > 0, (key, STATS)
 
 

@@ -1,0 +1,31 @@
+"""Diagnostic: per-phase cycles inside decode_coop_422_kernel.  Needs a library built with -DCG_COOP_STAMPS
+(tools/build_variant.sh coopstamps "-DCG_COOP_STAMPS", COMPEG_LIB=gpurun_ab/lib_coopstamps.so); never quote
+this build's run time."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import compeg_amd as ca
+from compeg_amd._lib import lib
+from tools import synth
+
+lib.compeg_debug_read_dc.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+gpu = ca.Gpu.open(0)
+w, h, ri = (int(v) for v in (sys.argv[1:4] if len(sys.argv) > 3 else (3840, 2160, 4)))
+jpeg = synth.make_jpeg(w, h, seed=0xC0FFEE, ri=ri)
+img = ca.ImageData(jpeg)
+dec = ca.Decoder(gpu)
+for _ in range(3):
+    dec.decode_blocking(img)
+ipw = 64 // (4 * ri)
+waves = (img.parallelism() + ipw - 1) // ipw
+buf = np.zeros((waves, 8), dtype=np.uint64)
+assert lib.compeg_debug_read_dc(dec._h, buf.ctypes.data, buf.nbytes) == 0
+tot = buf.sum(axis=1)
+print("waves", waves, "cycles/wave mean %.0f max %.0f p99 %.0f" % (tot.mean(), tot.max(), np.percentile(tot, 99)))
+names = ("setup", "chase", "validate", "decode", "fixups", "dc+idct", "composite", "-")
+for name, col in zip(names, buf.T):
+    print("  %-10s %8.0f cycles/wave (max %8.0f)  %5.1f %%" % (name, col.mean(), col.max(), 100 * col.sum() / max(tot.sum(), 1)))
