@@ -120,13 +120,15 @@ CG_DEV uint32_t ilog2(uint32_t v)
     return r;
 }
 
-CG_DEV void coop_geom(const ImageDesc &d, uint32_t wave_index, CoopGeom &g)
+// spec_shift: experiment knob -- the number of subsequences is divided by 2^spec_shift (0: as many as lanes allow)
+CG_DEV void coop_geom(const ImageDesc &d, uint32_t wave_index, CoopGeom &g, uint32_t spec_shift = 0u)
 {
     g.R = d.restart_interval; // 1, 2, 4, 8 or 16 (ImageDesc::coop_ok)
     g.dpi = 4u * g.R;
     g.dpi_shift = ilog2(g.dpi);
     g.ipw = uint32_t(kWave) >> g.dpi_shift;
     g.count = 1u + (g.dpi - 1u) / 4u; // lane 0, then four lanes per speculative subsequence: 1, 2, 4, 8, 16
+    g.count = g.count >> spec_shift ? g.count >> spec_shift : 1u;
     g.count_shift = ilog2(g.count);
     g.first_interval = wave_index * g.ipw;
     const uint32_t left = d.total_intervals > g.first_interval ? d.total_intervals - g.first_interval : 0u;
@@ -258,12 +260,12 @@ CG_DEV void chase_run(ChaseState &c, const ImageDesc &d, const HuffShared &s, co
                 "v_cndmask_b32_e64 v44, 0, 1, vcc\n\t"
                 "v_lshl_add_u32 %[lp], v44, 2, %[lp]\n\t"
                 "v_lshl_add_u32 %[k8], v44, 3, %[k8]\n\t"
+                "v_cndmask_b32_e64 v45, 0, %[p], vcc\n\t"             // its end position, or 0 inside a data unit
                 "v_cndmask_b32_e64 %[st], %[st], 0, vcc\n\t"
-                "v_cmp_ge_u32 s[70:71], %[p], %[stopp]\n\t"
                 "v_cmp_ge_u32 s[72:73], %[lp], %[lpmax]\n\t"
-                "s_or_b64 s[70:71], s[70:71], s[72:73]\n\t"
-                "s_and_b64 s[70:71], s[70:71], vcc\n\t"               // lanes whose walk ends here
-                "s_andn2_b64 exec, exec, s[70:71]\n\t"
+                "v_cndmask_b32_e64 v46, %[stopp], 1, s[72:73]\n\t"    // where the walk ends: nowhere further if the list is full
+                "v_cmp_ge_u32 vcc, v45, v46\n\t"                      // lanes whose walk ends here
+                "s_andn2_b64 exec, exec, vcc\n\t"
                 "s_cbranch_execnz 1b\n\t"
                 "s_mov_b32 %[code], 0\n\t"
                 "s_branch 5f\n"
@@ -373,7 +375,8 @@ CG_DEV void chase_set_end(ChaseState &c, const HuffShared &s, const CoopGeom &g,
     c.sub_end = 32u * (start_rel + coop_sub_start(len_words, c.next_sub, g));
     // a lane with a successor walks a little further, so that their lists overlap; the last one stops at the end
     const uint32_t want = c.next_sub < g.count ? c.sub_end + kCoopMargin : c.sub_end;
-    c.stop_p = umin(want, coop_hard_end(s));
+    const uint32_t stop = umin(want, coop_hard_end(s));
+    c.stop_p = stop ? stop : 1u; // (never 0: the hand-written loop tests "end position >= stop_p" with 0 for "no end here")
 }
 
 // What lane `tl` of an interval does in the first round.  Lane 0 walks from the interval's start; lanes
@@ -523,6 +526,23 @@ CG_DEV void coop_follow(const CoopShared &cs, const CoopGeom &g, uint32_t il, ui
             break;
         }
         if (!linked) {
+#if defined(CG_EMUL_STATS)
+            if (getenv("EMUL_COOP_FAILS")) {
+                // (analysis only) the failed boundary: the chain lane's last entries and the successors' first ones
+                fprintf(stderr, "fail il %u lane %u n %u du %u :", il, x, n, du);
+                for (uint32_t i = n > 4 ? n - 4 : 0; i < n; i++)
+                    fprintf(stderr, " %u/%u", cs.lists[x * kCoopListCap + i] & 0xffffu, (cs.lists[x * kCoopListCap + i] >> 16) & 31u);
+                const uint32_t lane0 = (x >> g.dpi_shift) << g.dpi_shift;
+                const uint32_t j = x == lane0 ? 0u : 1u + (x - lane0 - 1u) / 4u;
+                for (uint32_t h = 0; h < 4u && j + 1u < g.count; h++) {
+                    const uint32_t o = lane0 + coop_spec_lane(j + 1u, h);
+                    fprintf(stderr, " | h%u k0=%u n=%u:", h, (cs.lane_n[o] >> 16) & 3u, cs.lane_n[o] & 0xffu);
+                    for (uint32_t q = 0; q < (cs.lane_n[o] & 0xffu) && q < 6u; q++)
+                        fprintf(stderr, " %u/%u", cs.lists[o * kCoopListCap + q] & 0xffffu, (cs.lists[o * kCoopListCap + q] >> 16) & 31u);
+                }
+                fprintf(stderr, "\n");
+            }
+#endif
             // the chain ends with lane x: it walks on, unless it cannot
             v = ((stop & kStopAnomaly) || du == 0u) ? kVerdictSerial : (kVerdictContinue | (x << 8) | (du << 16));
             break;

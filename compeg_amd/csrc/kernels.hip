@@ -283,14 +283,14 @@ __device__ __forceinline__ uint32_t coop_wave_area(uint32_t window_words)
 }
 
 __global__ void __launch_bounds__(512)
-decode_coop_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words)
+decode_coop_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words, uint32_t spec_shift)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const ImageDesc &d = descs[blockIdx.y];
     const uint32_t waves = blockDim.x / kWave;
     const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x / kWave))), lane = threadIdx.x % kWave;
     CoopGeom g;
-    coop_geom(d, blockIdx.x * waves + wave, g);
+    coop_geom(d, blockIdx.x * waves + wave, g, spec_shift);
     if (blockIdx.x * waves * g.ipw >= d.total_intervals)
         return; // the whole workgroup
 
@@ -589,6 +589,8 @@ CoopPlan plan_coop(uint32_t max_intervals, uint32_t images, uint32_t restart_int
         return p; // (tables too large for LDS: the other kernels read the rest from global memory)
     p.waves_per_block = wpb;
     p.total_bytes = tables + wpb * wave_area;
+    if (const char *e = getenv("COMPEG_LDS_PAD")) // experiment knob: lowers occupancy
+        p.total_bytes = std::min(kLdsBytesPerCu, p.total_bytes + uint32_t(atoi(e)));
     const uint64_t waves = uint64_t((max_intervals + p.intervals_per_wave - 1) / p.intervals_per_wave) * images;
     p.total_waves = waves > 0xffffffffu ? 0xffffffffu : uint32_t(waves);
     p.usable = true;
@@ -610,8 +612,12 @@ hipError_t launch_coop_422(const ImageDesc *descs, uint32_t images, uint32_t max
         int(kLdsBytesPerCu));
     if (attr != hipSuccess)
         return attr;
+    static const uint32_t spec_shift = [] {
+        const char *e = getenv("COMPEG_COOP_SPEC_SHIFT"); // experiment knob: fewer speculative subsequences
+        return e ? uint32_t(atoi(e)) : 0u;
+    }();
     hipLaunchKernelGGL(decode_coop_422_kernel, grid, dim3(plan.waves_per_block * kWave), plan.total_bytes, stream, descs,
-                       plan.l2_entries_in_lds, plan.window_words);
+                       plan.l2_entries_in_lds, plan.window_words, spec_shift);
     return hipGetLastError();
 }
 

@@ -128,8 +128,12 @@ bool use_coop_kernel(uint32_t max_intervals, uint32_t images)
     }();
     if (forced >= 0)
         return forced != 0;
-    const uint64_t waves = uint64_t((max_intervals + kWave - 1) / kWave) * images;
-    return waves <= 1024;
+    // Measured (one frame, DRI = 4, kernel time paired / cooperative): 640x360 57 / 50 us, 1280x720 59 / 53,
+    // 1920x1080 56 / 54, 3840x2160 59 / 72 -- the cooperative kernel wins while its waves (four intervals
+    // each with DRI = 4) find a SIMD of their own, and loses once four of them share one: its walks are
+    // bound by the latency of their dependent chain, and the slowest wave of a launch (the one whose lanes
+    // had to walk on twice) then takes too long.
+    return uint64_t(max_intervals) * images <= 6000;
 }
 
 // Single-image device preprocessing: the raw segment is fetched from the pinned staging buffer by a

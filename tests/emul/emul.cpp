@@ -110,7 +110,7 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
             for (uint32_t t = 0; t < 3u * kRetained; t++)
                 quant[(t / kRetained) * kCoopQuantStride + t % kRetained] = d.quant[t / kRetained][t % kRetained];
             CoopGeom g;
-            coop_geom(d, wave, g);
+            coop_geom(d, wave, g, getenv("EMUL_COOP_SPEC_SHIFT") ? uint32_t(atoi(getenv("EMUL_COOP_SPEC_SHIFT"))) : 0u);
             uint32_t wb = 0, wl = 0;
             coop_window(d, g, window_words, wb, wl);
             for (uint32_t i = 0; i < wl; i++)
