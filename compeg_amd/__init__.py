@@ -227,6 +227,13 @@ class Decoder:
     def last_warning(self):
         return lib.compeg_decoder_last_warning(self._h).decode()
 
+    def last_stage_times(self):
+        """Host microseconds of the last decode's stages: the reference's three trace timers
+        (t_preprocess, t_enqueue_writes, t_poll: src/lib.rs:391-396,452-475,516-522)."""
+        t = (C.c_double * 3)()
+        check(lib.compeg_decoder_last_stage_times(self._h, t))
+        return {"preprocess_us": t[0], "enqueue_writes_us": t[1], "poll_us": t[2]}
+
     def set_device_preprocess(self, on=True):
         """Extension: preprocess scans with the device-side scan kernels instead of on the host."""
         check(lib.compeg_decoder_set_device_preprocess(self._h, 1 if on else 0))

@@ -62,6 +62,7 @@ def _load():
         "compeg_decoder_start_decode": (i, [vp, vp, pvp]),
         "compeg_decoder_decode_blocking": (i, [vp, vp, pvp]),
         "compeg_decoder_last_warning": (C.c_char_p, [vp]),
+        "compeg_decoder_last_stage_times": (C.c_int, [vp, vp]),
         "compeg_decoder_set_device_preprocess": (i, [vp, i]),
         "compeg_decoder_set_scan_threads": (i, [vp, C.c_uint]),
         "compeg_op_wait": (i, [vp]),

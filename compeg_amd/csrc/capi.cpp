@@ -1,6 +1,7 @@
 // extern "C" surface of libcompeg_hip (include/compeg_hip.h).
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <string>
@@ -364,12 +365,16 @@ int compeg_decoder_decode_blocking(compeg_decoder *dec, const compeg_image *img,
         Status s = dec->enqueue(*img->data, dec->gpu->stream, &changed, true);
         if (!s.ok())
             return fail(s);
+        const auto t_poll = std::chrono::steady_clock::now();
         hipError_t e = hipStreamSynchronize(dec->gpu->stream);
         if (e != hipSuccess)
             return fail(hip_status(e, "hipStreamSynchronize"));
+        const compeg_stage_times first = dec->stage_times; // (a re-decode through the host path would reset them)
         s = dec->finish_deferred(*img->data, dec->gpu->stream);
         if (!s.ok())
             return fail(s);
+        dec->stage_times = first;
+        dec->stage_times.poll_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_poll).count();
         compeg_op *o = new compeg_op();
         o->device = dec->gpu->device;
         o->texture_changed = changed;
@@ -406,6 +411,14 @@ int compeg_decoder_set_scan_threads(compeg_decoder *dec, unsigned threads)
 const char *compeg_decoder_last_warning(const compeg_decoder *dec)
 {
     return dec ? dec->warning.c_str() : "";
+}
+
+int compeg_decoder_last_stage_times(const compeg_decoder *dec, compeg_stage_times *out)
+{
+    if (!dec || !out)
+        return fail(COMPEG_E_INVALID_ARG, "NULL argument");
+    *out = dec->stage_times;
+    return ok();
 }
 
 int compeg_op_wait(compeg_op *op)

@@ -191,6 +191,10 @@ struct EnqueueTrace {
         if (on)
             last = std::chrono::steady_clock::now();
     }
+    static double us_since(std::chrono::steady_clock::time_point t0)
+    {
+        return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    }
     void mark(const char *what)
     {
         if (!on)
@@ -402,6 +406,20 @@ Status compeg_decoder::finish_deferred(const ImageData &img, hipStream_t stream)
 Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *changed, bool may_defer)
 {
     EnqueueTrace trace;
+    const auto t_enter = std::chrono::steady_clock::now();
+    stage_times = compeg_stage_times{0.0, 0.0, 0.0};
+    double preprocess_us = 0.0;
+    // (every way out of this function leaves the split in stage_times)
+    struct Closer {
+        compeg_decoder *self;
+        std::chrono::steady_clock::time_point t0;
+        const double *pre;
+        ~Closer()
+        {
+            self->stage_times.preprocess_us = *pre;
+            self->stage_times.enqueue_writes_us = EnqueueTrace::us_since(t0) - *pre;
+        }
+    } closer{this, t_enter, &preprocess_us};
     CG_HIP(hipSetDevice(gpu->device));
     warning.clear();
 
@@ -475,6 +493,7 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     uint32_t dev_nwords = 0, dev_nstarts = 0, dev_span = 0;
     bool on_device = device_preprocess && use_fused_pipeline();
     bool blob_uploaded = false;
+    const auto t_pre = std::chrono::steady_clock::now();
     if (on_device) {
         bool fell_back = false;
         BlobWriter before_submit;
@@ -522,6 +541,7 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
             warning = pre.message; // the reference drops this error (lib.rs:391-394)
         }
     }
+    preprocess_us = EnqueueTrace::us_since(t_pre);
     trace.mark(on_device ? "device_preprocess" : "host_preprocess");
     const size_t n_words = on_device ? dev_nwords : scan.nwords();
     const size_t n_starts = on_device ? dev_nstarts : scan.nstarts();

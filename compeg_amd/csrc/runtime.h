@@ -78,6 +78,7 @@ struct compeg_decoder {
     bool decode_pending = false;
     hipStream_t last_stream = nullptr;
     std::string warning;
+    compeg_stage_times stage_times{0.0, 0.0, 0.0}; // host time of the last decode's stages (lib.rs:391-396,452-475,516-522)
     // what read_coefficients needs to rebuild the reference's buffer
     compeg::Metadata last_md{};
     bool have_last = false;

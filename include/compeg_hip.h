@@ -153,6 +153,19 @@ int compeg_decoder_start_decode(compeg_decoder *dec, const compeg_image *img, co
  * the host preprocessor before returning.) */
 int compeg_decoder_decode_blocking(compeg_decoder *dec, const compeg_image *img, compeg_op **op);
 const char *compeg_decoder_last_warning(const compeg_decoder *dec);
+/* Host time of the stages of the decoder's last decode, in microseconds -- the three timers the reference
+ * traces (`t_preprocess` lib.rs:391-396, `t_enqueue_writes` lib.rs:452-475, `t_poll` lib.rs:516-522):
+ *   preprocess_us      scan preprocessing on the host (ScanBuffer::process), or staging the raw segment and
+ *                      submitting the scan kernels when preprocessing runs on the device;
+ *   enqueue_writes_us  everything else `enqueue` does: tables and descriptor, uploads, kernel launch;
+ *   poll_us            the wait for the device in decode_blocking (0 after enqueue / start_decode).
+ * Plain data, C layout; all zeros before the first decode. */
+typedef struct compeg_stage_times {
+    double preprocess_us;
+    double enqueue_writes_us;
+    double poll_us;
+} compeg_stage_times;
+int compeg_decoder_last_stage_times(const compeg_decoder *dec, compeg_stage_times *out);
 /* Extension: on != 0 moves the scan preprocessing of every following decode
  * from the host (the reference's data flow, default) to the device-side scan
  * kernels; the raw entropy-coded segment is uploaded instead of the

@@ -8,6 +8,15 @@ macro_rules! opaque {
 }
 opaque!(compeg_gpu, compeg_decoder, compeg_image, compeg_scanbuffer, compeg_op, compeg_batch);
 
+/// Host microseconds of a decode's stages (the reference's trace timers, src/lib.rs:391-396,452-475,516-522).
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct compeg_stage_times {
+    pub preprocess_us: c_double,
+    pub enqueue_writes_us: c_double,
+    pub poll_us: c_double,
+}
+
 pub const COMPEG_OK: c_int = 0;
 pub const COMPEG_E_INVALID_ARG: c_int = -1;
 pub const COMPEG_E_UNSUPPORTED: c_int = -2;
@@ -62,6 +71,7 @@ extern "C" {
     pub fn compeg_decoder_decode_blocking(dec: *mut compeg_decoder, img: *const compeg_image,
                                           op: *mut *mut compeg_op) -> c_int;
     pub fn compeg_decoder_last_warning(dec: *const compeg_decoder) -> *const c_char;
+    pub fn compeg_decoder_last_stage_times(dec: *const compeg_decoder, out: *mut compeg_stage_times) -> c_int;
     pub fn compeg_decoder_set_device_preprocess(dec: *mut compeg_decoder, on: c_int) -> c_int;
     pub fn compeg_decoder_set_scan_threads(dec: *mut compeg_decoder, threads: c_uint) -> c_int;
     pub fn compeg_op_wait(op: *mut compeg_op) -> c_int;

@@ -279,6 +279,15 @@ impl Decoder {
         if s.is_empty() { None } else { Some(s.into_owned()) }
     }
 
+    /// Host time of the stages of the last decode: what the reference traces as `t_preprocess`,
+    /// `t_enqueue_writes` and `t_poll` (src/lib.rs:391-396,452-475,516-522).
+    pub fn last_stage_times(&self) -> ffi::compeg_stage_times {
+        let mut t = ffi::compeg_stage_times::default();
+        check(unsafe { ffi::compeg_decoder_last_stage_times(self.raw.as_ptr(), &mut t) })
+            .expect("compeg_decoder_last_stage_times");
+        t
+    }
+
     pub fn texture(&self) -> Texture<'_> {
         let (mut p, mut w, mut h, mut pitch) = (ptr::null_mut(), 0, 0, 0);
         check(unsafe { ffi::compeg_decoder_output(self.raw.as_ptr(), &mut p, &mut w, &mut h, &mut pitch) })

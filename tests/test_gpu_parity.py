@@ -150,6 +150,31 @@ def test_enqueue_on_caller_stream_and_start_decode(ca, gpu):
     _assert_equal(dec.read_texture(640, 480), want)
 
 
+def test_stage_times_through_the_c_abi(ca, gpu):
+    """The reference traces three host timers per decode (t_preprocess, t_enqueue_writes, t_poll:
+    src/lib.rs:391-396,452-475,516-522); here they come back through compeg_decoder_last_stage_times."""
+    import time
+    jpeg = synth.make_jpeg(1920, 1080, seed=33, ri=4)
+    data = ca.ImageData(jpeg)
+    dec = ca.Decoder(gpu)
+    assert dec.last_stage_times() == {"preprocess_us": 0.0, "enqueue_writes_us": 0.0, "poll_us": 0.0}
+    dec.decode_blocking(data)
+    t0 = time.perf_counter()
+    dec.decode_blocking(data)
+    wall_us = (time.perf_counter() - t0) * 1e6
+    t = dec.last_stage_times()
+    assert t["preprocess_us"] > 0 and t["enqueue_writes_us"] > 0 and t["poll_us"] > 0
+    assert sum(t.values()) <= wall_us * 1.05
+    for threads_device in ((1, False), (4, True)):
+        dec.set_scan_threads(threads_device[0])
+        dec.set_device_preprocess(threads_device[1])
+        dec.decode_blocking(data)
+        t = dec.last_stage_times()
+        assert t["preprocess_us"] > 0 and t["poll_us"] > 0
+    dec.start_decode(data).wait()
+    assert dec.last_stage_times()["poll_us"] == 0.0      # nothing waited inside start_decode
+
+
 def test_count_mismatch_is_a_warning_like_the_reference(ca, gpu):
     """lib.rs:391-394 drops process() errors; we decode and surface the text as a warning."""
     jpeg = bytearray(synth.make_jpeg(128, 32, seed=40, ri=2))

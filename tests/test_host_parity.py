@@ -305,17 +305,141 @@ def test_scanbuffer_reuse_gives_fresh_buffer_output():
     assert sb.processed_scan_data() == bytes([0x11, 0, 0, 0, 0x22, 0, 0, 0])
 
 
-def test_rust_binding_covers_the_header():
-    """integration/rust/compeg-hip/src/ffi.rs (the reference-side binding) declares exactly
-    the entry points include/compeg_hip.h declares."""
+def _c_prototypes(header):
+    """name -> (return type, [parameter types]) of every function include/compeg_hip.h declares, C spelling
+    normalised (no parameter names, single spaces, '*' detached)."""
+    import re
+    text = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    text = re.sub(r"^\s*#.*$", "", text, flags=re.M)
+    text = re.sub(r'extern\s+"C"\s*\{', "", text)
+    text = re.sub(r"typedef\s+struct\s+\w+\s*\{.*?\}\s*\w+\s*;", "", text, flags=re.S)   # struct bodies are checked apart
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(compeg_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", text, flags=re.S):
+        ret, name, params = m.group(1), m.group(2), m.group(3)
+
+        def norm(t, is_param):
+            t = re.sub(r"(\w+)\s*\[\s*\d*\s*\]\s*$", r"* \1", t.strip())   # an array parameter is a pointer
+            t = re.sub(r"\s+", " ", t.replace("*", " * ")).strip()
+            if is_param:   # drop the parameter's name: the last identifier, unless it is the type itself
+                toks = t.split(" ")
+                if len(toks) > 1 and re.fullmatch(r"[A-Za-z_]\w*", toks[-1]) and toks[-1] not in ("int", "char", "void"):
+                    toks = toks[:-1]
+                t = " ".join(toks)
+            return t
+        ps = [norm(x, True) for x in params.split(",")] if params.strip() not in ("", "void") else []
+        protos[name] = (norm(ret, False), ps)
+    return protos
+
+
+_SCALARS = {"int": "c_int", "unsigned": "c_uint", "unsigned int": "c_uint", "uint32_t": "u32", "uint8_t": "u8",
+            "uint16_t": "u16", "uint64_t": "u64", "int32_t": "i32", "int16_t": "i16", "int64_t": "i64", "size_t": "usize", "double": "c_double", "char": "c_char",
+            "void": "c_void"}
+
+
+def _rust_type_of(c_type):
+    """The Rust FFI type a C type (as _c_prototypes spells it) must be bound with."""
+    toks = c_type.split(" ")
+    # split into base (with its const) and the pointer levels, each with an optional const behind the star
+    base, levels, i = [], [], 0
+    while i < len(toks) and toks[i] != "*":
+        base.append(toks[i])
+        i += 1
+    while i < len(toks):
+        assert toks[i] == "*", c_type
+        const_ptr = i + 1 < len(toks) and toks[i + 1] == "const"
+        levels.append(const_ptr)
+        i += 2 if const_ptr else 1
+    base_const = "const" in base
+    name = " ".join(t for t in base if t != "const")
+    rust = _SCALARS.get(name, name)            # opaque handle types keep their name
+    pointee_const = base_const
+    for const_ptr in levels:
+        rust = ("*const " if pointee_const else "*mut ") + rust
+        pointee_const = const_ptr
+    return rust
+
+
+def _rust_prototypes(ffi):
+    import re
+    protos = {}
+    for m in re.finditer(r"pub fn (compeg_[a-z0-9_]+)\s*\((.*?)\)\s*(?:->\s*([^;]+?))?\s*;", ffi, flags=re.S):
+        params = [re.sub(r"\s+", " ", x.split(":", 1)[1]).strip() for x in m.group(2).split(",") if ":" in x]
+        protos[m.group(1)] = ((m.group(3) or "()").strip(), params)
+    return protos
+
+
+def test_rust_binding_matches_the_header_signature_by_signature():
+    """integration/rust/compeg-hip/src/ffi.rs (the reference-side binding; no Rust toolchain
+    here to compile it) against include/compeg_hip.h: the same entry points, and for each one the same arity,
+    every parameter's C type bound with the Rust FFI type it has to be bound with (integer width and
+    signedness, pointer depth, const-ness at every level, opaque handle names), the same return type; the
+    same constants; the plain-data struct field by field."""
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     header = open(os.path.join(root, "include", "compeg_hip.h")).read()
-    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
-    in_header = set(re.findall(r"\b(compeg_[a-z0-9_]+)\s*\(", header))
     ffi = open(os.path.join(root, "integration", "rust", "compeg-hip", "src", "ffi.rs")).read()
-    in_ffi = set(re.findall(r"pub fn (compeg_[a-z0-9_]+)\s*\(", ffi))
-    assert in_header == in_ffi, (sorted(in_header - in_ffi), sorted(in_ffi - in_header))
+    c, r = _c_prototypes(header), _rust_prototypes(ffi)
+    assert len(c) >= 50 and set(c) == set(r), (sorted(set(c) - set(r)), sorted(set(r) - set(c)))
+    for name, (ret, params) in c.items():
+        rret, rparams = r[name]
+        assert len(params) == len(rparams), (name, params, rparams)
+        for i, (ct, rt) in enumerate(zip(params, rparams)):
+            assert _rust_type_of(ct) == rt, f"{name}: parameter {i} is `{ct}` in C, `{rt}` in Rust (expected `{_rust_type_of(ct)}`)"
+        want_ret = "()" if ret == "void" else _rust_type_of(ret)
+        assert want_ret == rret, f"{name}: returns `{ret}` in C, `{rret}` in Rust"
+    # constants
+    c_consts = {k: int(v, 0) for k, v in re.findall(r"#define\s+(COMPEG_[A-Z0-9_]+)\s+\(?(-?(?:0x)?[0-9a-fA-F]+)u?\)?", header)}
+    r_consts = {k: int(v, 0) for k, v in re.findall(r"pub const (COMPEG_[A-Z0-9_]+):\s*\w+\s*=\s*(-?(?:0x)?[0-9a-fA-F]+)\s*;", ffi)}
+    for k in ("COMPEG_OK", "COMPEG_E_INVALID_ARG", "COMPEG_E_UNSUPPORTED", "COMPEG_E_MALFORMED", "COMPEG_E_COUNT_MISMATCH",
+              "COMPEG_E_HIP", "COMPEG_PARSE_ANY_LUMA_SAMPLING", "COMPEG_PARSE_STANDARD_ENTROPY"):
+        assert k in c_consts and r_consts.get(k) == c_consts[k], (k, c_consts.get(k), r_consts.get(k))
+    # the one plain-data struct
+    body = re.search(r"typedef\s+struct\s+compeg_stage_times\s*\{(.*?)\}", re.sub(r"/\*.*?\*/", "", header, flags=re.S), flags=re.S).group(1)
+    c_fields = re.findall(r"(\w+)\s+(\w+)\s*;", body)
+    r_body = re.search(r"#\[repr\(C\)\][^{]*pub struct compeg_stage_times\s*\{(.*?)\}", ffi, flags=re.S).group(1)
+    r_fields = re.findall(r"pub (\w+):\s*(\w+)", r_body)
+    assert [(n, _SCALARS[t]) for t, n in c_fields] == r_fields, (c_fields, r_fields)
+
+
+def test_type_mapping_of_the_signature_check_itself():
+    assert _rust_type_of("const compeg_image * const *") == "*const *const compeg_image"
+    assert _rust_type_of("compeg_gpu * *") == "*mut *mut compeg_gpu"
+    assert _rust_type_of("const char *") == "*const c_char"
+    assert _rust_type_of("void *") == "*mut c_void"
+    assert _rust_type_of("uint32_t") == "u32" and _rust_type_of("size_t *") == "*mut usize"
+
+
+def test_a_plain_c_consumer_of_the_header(tmp_path):
+    """A C99 program (tests/c_consumer/consumer.c) compiled with gcc -Wall -Wextra -Werror against
+    include/compeg_hip.h and linked with libcompeg_hip.so -- a non-Python FFI user of the boundary, built on
+    every run: parses a reference fixture (same numbers as the Python binding), gets the reference's error
+    texts through status code + compeg_last_error, runs the ScanBuffer known-answer vector (src/scan.rs:151-159)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "consumer")
+    libdir = os.path.dirname(ca.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c_consumer", "consumer.c"), "-o", exe,
+                           "-L", libdir, "-l:libcompeg_hip.so", "-Wl,-rpath," + libdir])
+    fixture = os.path.join(root, "tests", "golden", "parser", "mjpeg.jpg")
+    r = subprocess.run([exe, fixture], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = dict(l.split(" ", 1) for l in r.stdout.splitlines())
+    img = ca.ImageData(open(fixture, "rb").read())
+    assert lines["version"] == ca.version()
+    assert lines["image"] == f"{img.width()} {img.height()} {img.parallelism()}" == "960 720 540"
+    off, length = img.scan_range()
+    assert lines["scan"] == f"{off} {length} l2 {len(img.huffman_l2())}"
+    acc = 0
+    for b in img.metadata():
+        acc = (acc * 131 + b) & 0xffffffffffffffff
+    assert int(lines["metadata"]) == acc & 0xffffffff
+    E_MALFORMED, E_INVALID_ARG, E_COUNT_MISMATCH = ca.E_MALFORMED, ca.E_INVALID_ARG, ca.E_COUNT_MISMATCH
+    assert lines["junk"] == f"{E_MALFORMED} JPEG image does not start with SOI marker"
+    assert lines["null"] == str(E_INVALID_ARG)
+    assert lines["scanbuffer"] == "ff 44 55 00 34 00 00 00 | 00 00 00 00 01 00 00 00"
+    assert lines["mismatch"] == f"{E_COUNT_MISMATCH} restart interval count mismatch: counted 2, expected 1"
+    assert lines["stage_times"] == f"24 {E_INVALID_ARG}"
 
 
 def test_sampling_extension_front_end():
