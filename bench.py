@@ -53,6 +53,8 @@ def parse_args():
     p.add_argument("--cpu-seconds", type=float, default=12.0,
                    help="budget for the CPU-oracle baseline sample (0 disables it)")
     p.add_argument("--no-verify", action="store_true")
+    p.add_argument("--no-extra-configs", action="store_true",
+                   help="skip the sub-records for BASELINE configs[0], [2] and [4] (they run on rank 0 at N = 1 only)")
     p.add_argument("--rehearse-on-one-gpu", action="store_true",
                    help="development only: run the multi-rank code path with every rank on cuda:0 and gloo "
                         "for the barrier / max (RCCL needs one device per rank); the number is meaningless")
@@ -96,6 +98,124 @@ def cpu_baseline(jpegs, budget_s, pixels_per_image):
             "kind": "port", "ms_per_frame": round(el / done * 1e3, 2),
             "sample": f"{done} frames of the same workload through oracle/libcompeg_oracle.so "
                       f"(parse + scan preprocess + huffman + IDCT + composite), 1 thread, {el:.1f} s"}
+
+
+def cpu_baseline_all_cores(jpegs, budget_s, pixels_per_image):
+    """The same oracle on every host core at once (one frame per call, the ctypes call releases the GIL):
+    SURVEY.md 8(d) baseline (ii).  The reference itself is single-threaded; this is what its algorithm does
+    with the whole host."""
+    from oracle import oracle as orc
+
+    cores = os.cpu_count() or 1
+    deadline = time.perf_counter() + budget_s
+
+    def work(t):
+        done = 0
+        while time.perf_counter() < deadline:
+            orc.ImageData(jpegs[(t + done * cores) % len(jpegs)], allow_sampling=True).decode()
+            done += 1
+        return done
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        done = sum(ex.map(work, range(cores)))
+    el = time.perf_counter() - t0
+    return {"value": round(done * pixels_per_image / el / 1e6, 3), "unit": "Mpixels/s", "cores": cores,
+            "sample": f"{done} frames on {cores} threads, {el:.1f} s"}
+
+
+def rate_of(fn, nbytes, min_s=0.4):
+    """GB/s of input bytes over at least min_s of back-to-back calls (after one untimed call)."""
+    fn()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        fn()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= min_s:
+            return round(n * nbytes / el / 1e9, 3)
+
+
+def bench_scan_dat(compeg_amd, gpu, frame_jpeg, frame_pixels):
+    """BASELINE configs[0], the `cargo bench` analogue (benches/bench.rs:10-21): ScanBuffer::process on
+    benches/scan.dat (496 464 bytes, 42 876 restart intervals), reused buffer, GB/s of input -- through the
+    oracle's restatement of the reference's byte loop and through the product's three preprocessors.  Plus the
+    same on one 4K benchmark frame's entropy-coded segment (A1 alone, what SURVEY.md 8(d) asks beside the
+    decode baseline)."""
+    from oracle import oracle as orc
+
+    path = os.path.join(ROOT, "tests", "golden", "scan", "scan.dat")
+    data = open(path, "rb").read()
+    out = {"workload": "ScanBuffer::process(benches/scan.dat, 42876), 496464 B per call", "unit": "GB/s of input"}
+    o = orc.ScanBuffer()
+    out["oracle_scalar_1_thread"] = rate_of(lambda: o.process(data, 42876), len(data))
+    sb = compeg_amd.ScanBuffer()
+    out["product_host_1_thread"] = rate_of(lambda: sb.process(data, 42876), len(data))
+    sb4 = compeg_amd.ScanBuffer()
+    sb4.set_threads(4)      # (the helpers take segments of at least 64 KiB per thread: four fit this file)
+    out["product_host_4_threads"] = rate_of(lambda: sb4.process(data, 42876), len(data))
+    sbg = compeg_amd.ScanBuffer()
+    out["product_gpu_scan_kernels_incl_pcie_both_ways"] = rate_of(lambda: sbg.process_on_gpu(gpu, data, 42876), len(data))
+    assert sb.processed_scan_data() == o.processed_scan_data() == sb4.processed_scan_data() == sbg.processed_scan_data()
+    assert sb.start_positions() == o.start_positions() == sb4.start_positions() == sbg.start_positions()
+    out["outputs_identical"] = True
+    # A1 alone on the benchmark frame
+    ref = orc.ImageData(frame_jpeg)
+    seg = ref.scan_data()
+    n_int = ref.parallelism()
+    a1 = {"segment_bytes": len(seg), "restart_intervals": n_int}
+    a1["oracle_scalar_1_thread_gbs"] = rate_of(lambda: o.process(seg, n_int), len(seg))
+    a1["oracle_scalar_1_thread_mpix_s"] = round(a1["oracle_scalar_1_thread_gbs"] * 1e9 / len(seg) * frame_pixels / 1e6, 1)
+    a1["product_host_1_thread_gbs"] = rate_of(lambda: sb.process(seg, n_int), len(seg))
+    threads = max(1, min(8, (os.cpu_count() or 2) // 2))
+    sbn = compeg_amd.ScanBuffer()
+    sbn.set_threads(threads)
+    a1[f"product_host_{threads}_threads_gbs"] = rate_of(lambda: sbn.process(seg, n_int), len(seg))
+    out["a1_on_one_benchmark_frame"] = a1
+    return out
+
+
+def bench_config(compeg_amd, gpu, width, height, ri, quality, batch, steps, warmup, threads, distinct, label):
+    """One more single-GPU configuration of BASELINE.json, measured like the headline one: resident inputs, `steps`
+    timed decodes of the whole batch, kernel time from the batch's HIP events, a spread of slots verified."""
+    import numpy as np
+    from oracle import oracle as orc
+    from tools import synth
+
+    def one(i):
+        return synth.make_jpeg(width, height, seed=0xC0FFEE + i, kind=0, quality=quality, ri=ri)
+
+    with ThreadPoolExecutor(threads) as ex:
+        jpegs = list(ex.map(one, range(distinct)))
+    images = [compeg_amd.ImageData(j, copy=False) for j in jpegs]
+    b = compeg_amd.Batch(gpu)
+    b.upload([images[i % distinct] for i in range(batch)], host_threads=threads)
+    for _ in range(warmup):
+        b.decode()
+    b.wait()
+    b.timing(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        b.decode()
+    b.wait()
+    el = time.perf_counter() - t0
+    n, ev_ms, _, _ = b.timing(reset=True)
+    kernel_ms = ev_ms / max(n, 1)
+    alg = b.algorithmic_bytes()
+    ok = True
+    slots = sorted({0, batch - 1, batch // 2})
+    for i in slots:
+        ok = ok and bool(np.array_equal(b.read_output(i), orc.ImageData(jpegs[i % distinct]).decode()))
+    if not ok:
+        raise SystemExit(f"bench: {label}: GPU output differs from the oracle")
+    achieved = alg / (kernel_ms * 1e-3) / 1e9
+    return {"workload": label, "value": round(b.pixels() * steps / el / 1e6, 1), "unit": "Mpixels/s",
+            "ms_per_step": round(el / steps * 1e3, 4), "ms_per_frame": round(el / steps / batch * 1e3, 5),
+            "steps": steps, "bits_per_pixel": round(8 * sum(len(j) for j in jpegs) / distinct / (width * height), 3),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": alg,
+                         "kernel_ms": round(kernel_ms, 4)},
+            "verified_bit_exact_vs_oracle": ok, "verified_slots": slots}
 
 
 def main():
@@ -229,10 +349,17 @@ def main():
 
         dec = compeg_amd.Decoder(gpu)           # default: host scan preprocessor (several threads) + pulls + kernel + wait
         e2e = blocking_ms(dec)
+        stages = dec.last_stage_times()          # the reference's three trace timers, through the C ABI
         dec.set_scan_threads(1)                  # the reference's data flow to the letter: one host thread
         e2e_1t = blocking_ms(dec)
+        stages_1t = dec.last_stage_times()
         dec.set_device_preprocess(True)          # raw segment pulled to HBM + scan kernels + decode kernel + wait
         e2e_dev = blocking_ms(dec)
+        stages_dev = dec.last_stage_times()
+        t_parse = time.perf_counter()
+        for _ in range(20):
+            compeg_amd.ImageData(jpegs[0], copy=False, allow_sampling=ext)
+        t_parse = (time.perf_counter() - t_parse) / 20 * 1e3
         single = {"frames": 1, "device_ms_per_frame": round(dev_wall, 4),
                   "kernel_ms": round(tot1 / n1, 4),
                   "device_mpix_s": round(one.pixels() / dev_wall / 1e3, 1),
@@ -240,11 +367,31 @@ def main():
                   "host_end_to_end_mpix_s": round(one.pixels() / e2e / 1e3, 1),
                   "host_end_to_end_one_thread_ms": round(e2e_1t, 3),
                   "end_to_end_device_scan_ms": round(e2e_dev, 3),
-                  "end_to_end_device_scan_mpix_s": round(one.pixels() / e2e_dev / 1e3, 1)}
+                  "end_to_end_device_scan_mpix_s": round(one.pixels() / e2e_dev / 1e3, 1),
+                  "image_parse_ms": round(t_parse, 4),
+                  "stage_times_us": {"what": "compeg_decoder_last_stage_times of the last blocking decode (t_preprocess, "
+                                             "t_enqueue_writes, t_poll of src/lib.rs:391-396,452-475,516-522)",
+                                     "default": {k: round(v, 1) for k, v in stages.items()},
+                                     "one_host_thread": {k: round(v, 1) for k, v in stages_1t.items()},
+                                     "device_scan": {k: round(v, 1) for k, v in stages_dev.items()}}}
 
     base = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         base = cpu_baseline(jpegs, args.cpu_seconds, args.width * args.height)
+        base["host_nproc"] = os.cpu_count()
+        base["all_cores"] = cpu_baseline_all_cores(jpegs, min(8.0, args.cpu_seconds), args.width * args.height)
+
+    extra = None
+    if rank == 0 and world == 1 and not args.no_extra_configs and not ext:
+        extra = {"configs[0] scan.dat": bench_scan_dat(compeg_amd, gpu, jpegs[0], args.width * args.height)}
+        if base is not None:
+            base["a1_scan_preprocess_only"] = extra["configs[0] scan.dat"]["a1_on_one_benchmark_frame"]
+        extra["configs[2] 256 x 1080p"] = bench_config(
+            compeg_amd, gpu, 1920, 1080, 4, args.quality, 256, args.steps, args.warmup, threads, 64,
+            "256 x 1920x1080 YUV 4:2:2 baseline JPEG, DRI=4 (BASELINE configs[2]), 64 distinct frames")
+        extra["configs[4] 8K DRI=1"] = bench_config(
+            compeg_amd, gpu, 7680, 4320, 1, args.quality, 8, args.steps, args.warmup, threads, 4,
+            "8 x 7680x4320 YUV 4:2:2 baseline JPEG, DRI=1 per step (BASELINE configs[4] frame), 4 distinct frames")
 
     if rank == 0:
         total_pixels = pixels * world * args.steps
@@ -307,6 +454,7 @@ def main():
                 "timing": "HIP events on the decode stream, averaged over the timed steps",
             },
             "cpu_baseline": base,
+            "other_configs": extra,
             "single_frame": single,
             "pcie_inclusive": inclusive,
             "verified_bit_exact_vs_oracle": verified,
