@@ -53,6 +53,8 @@ def parse_args():
     p.add_argument("--cpu-seconds", type=float, default=12.0,
                    help="budget for the CPU-oracle baseline sample (0 disables it)")
     p.add_argument("--no-verify", action="store_true")
+    p.add_argument("--e2e-reps", type=int, default=5,
+                   help="batches per arm (x2) of the host-fed pipeline measurement `end_to_end` (0 disables it)")
     p.add_argument("--no-extra-configs", action="store_true",
                    help="skip the sub-records for BASELINE configs[0], [2] and [4] (they run on rank 0 at N = 1 only)")
     p.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -218,6 +220,68 @@ def bench_config(compeg_amd, gpu, width, height, ri, quality, batch, steps, warm
             "verified_bit_exact_vs_oracle": ok, "verified_slots": slots}
 
 
+PCIE_LINK_GBS = 63.0  # MI355X_MICROARCH.md: host link PCIe Gen5 x16, 63 GB/s (spec)
+
+
+def bench_end_to_end(compeg_amd, device, jpegs, images, threads, reps, ext):
+    """The host-fed path as a pipeline: two batches on two streams, the upload of one (ImageData::new +
+    ScanBuffer::process on `threads` host threads, staging in pinned memory, H2D over PCIe) runs under the decode
+    of the other.  Steady state, `reps` batches per arm, median batch period.  Two arms: from JPEG bytes (parse
+    included) and from parsed images (parse excluded).  Never `value`: that one starts with inputs in HBM."""
+    import statistics
+
+    import numpy as np
+    from oracle import oracle as orc
+
+    gpus = [compeg_amd.Gpu.open(device) for _ in range(2)]      # a stream each
+    batches = [compeg_amd.Batch(g) for g in gpus]
+    jpeg_bytes = sum(len(j) for j in jpegs)
+
+    def arm(upload):
+        for b in batches:                                        # warm-up: allocations, pinning, first launches
+            upload(b)
+            b.decode()
+        for b in batches:
+            b.wait()
+        periods, uploads = [], []
+        t_prev = time.perf_counter()
+        for r in range(2 * reps):
+            b = batches[r & 1]
+            b.wait()                                             # its previous decode (two batches ago)
+            t_u = time.perf_counter()
+            upload(b)                                            # the other batch is decoding meanwhile
+            uploads.append(time.perf_counter() - t_u)
+            b.decode()
+            t = time.perf_counter()
+            periods.append(t - t_prev)
+            t_prev = t
+        for b in batches:
+            b.wait()
+        return statistics.median(periods), statistics.median(uploads), min(periods), max(periods)
+
+    pix = len(jpegs) * 0  # (set below from the batch itself)
+    res = {}
+    for name, upload in (("from_jpeg_bytes_parse_included", lambda b: b.upload_jpegs(jpegs, host_threads=threads, allow_sampling=ext)),
+                         ("from_parsed_images_parse_excluded", lambda b: b.upload(images, host_threads=threads))):
+        period, up, lo, hi = arm(upload)
+        pix = batches[0].pixels()
+        h2d = batches[0].algorithmic_bytes() - 4 * pix           # what crosses PCIe: preprocessed scans, start positions, tables
+        res[name] = {"ms_per_batch": round(period * 1e3, 3), "mpix_s": round(pix / period / 1e6, 1),
+                     "upload_ms": round(up * 1e3, 3), "min_max_ms": [round(lo * 1e3, 3), round(hi * 1e3, 3)],
+                     "pcie_gbs_during_upload": round(h2d / up / 1e9, 2),
+                     "pcie_fraction_of_link": round(h2d / up / 1e9 / PCIE_LINK_GBS, 3),
+                     "jpeg_gbs_consumed": round(jpeg_bytes / period / 1e9, 2)}
+    ok = all(bool(np.array_equal(batches[k].read_output(i), orc.ImageData(jpegs[i], allow_sampling=ext).decode()))
+             for k in (0, 1) for i in (0, len(jpegs) - 1))
+    if not ok:
+        raise SystemExit("bench: end_to_end output differs from the oracle")
+    res.update({"frames_per_batch": len(jpegs), "batches_timed_per_arm": 2 * reps, "host_threads": threads,
+                "verified_bit_exact_vs_oracle": ok, "pcie_link_gbs": PCIE_LINK_GBS,
+                "what": "two compeg_batch objects on two streams; upload(k+1) = ImageData::new + ScanBuffer::process on the "
+                        "host threads + H2D from pinned staging, under decode(k); median period of a batch in steady state"})
+    return res
+
+
 def main():
     args = parse_args()
     args.sampling_hv = tuple(int(v) for v in args.sampling.lower().split("x"))
@@ -249,7 +313,22 @@ def main():
         if world > 1:
             dist.barrier()
 
-    threads = max(1, min(16, (os.cpu_count() or 8) // max(1, min(world, 8))))
+    # each rank keeps to its share of the cores of its own GPU's NUMA node (compeg_amd/sharding.py)
+    from compeg_amd.sharding import bind_rank_to_its_cores
+    def bus_id(i):
+        pr = torch.cuda.get_device_properties(i)
+        b = getattr(pr, "pci_bus_id", None)
+        if isinstance(b, str):
+            return b
+        if b is None:
+            return ""
+        return "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), b, getattr(pr, "pci_device_id", 0))
+    try:
+        bus_ids = [bus_id(i) for i in range(torch.cuda.device_count())]
+    except Exception:
+        bus_ids = []
+    cores, numa = bind_rank_to_its_cores(local_rank, world if not args.rehearse_on_one_gpu else 1, bus_ids)
+    threads = max(1, min(32, len(cores)))
     t_gen = time.perf_counter()
     jpegs, distinct = make_inputs(args, rank, world, threads)
     t_gen = time.perf_counter() - t_gen
@@ -306,19 +385,22 @@ def main():
         if not verified:
             raise SystemExit("bench: GPU output differs from the oracle -- refusing to report a number")
 
-    # the same batch from host memory: upload (preprocess + PCIe) + decode, steady state (the staging arena is
-    # pinned by now) -- the PCIe/host-inclusive rate, reported beside `value`, never as it
-    inclusive = None
-    if rank == 0 and world == 1:
-        t_i = time.perf_counter()
-        batch.upload(images, host_threads=threads)
-        batch.decode()
-        batch.wait()
-        t_i = time.perf_counter() - t_i
-        batch.timing(reset=True)
-        inclusive = {"ms_per_batch": round(t_i * 1e3, 2), "mpix_s": round(batch.pixels() / t_i / 1e6, 1),
-                     "what": "compeg_batch_upload (%s preprocessing, %d host threads, PCIe) + compeg_batch_decode + wait"
-                             % (args.preprocess, threads)}
+    # the host-fed path (JPEG bytes in host memory -> RGBA in HBM) as a two-deep pipeline, every rank its own --
+    # reported beside `value`, never as it
+    end_to_end = None
+    if args.e2e_reps > 0:
+        barrier()
+        e2e = bench_end_to_end(compeg_amd, local_rank, jpegs, images, threads, args.e2e_reps, ext)
+        barrier()
+        if world > 1:
+            # whole-job rate: every rank's frames over the slowest rank's period
+            for arm_name in ("from_jpeg_bytes_parse_included", "from_parsed_images_parse_excluded"):
+                slowest = max_over_ranks(e2e[arm_name]["ms_per_batch"], device="cpu" if args.rehearse_on_one_gpu else "cuda")
+                e2e[arm_name]["whole_job_mpix_s"] = round(pixels * world / (slowest * 1e-3) / 1e6, 1)
+        if rank == 0:
+            end_to_end = e2e
+            end_to_end["host_cores_of_this_rank"] = len(cores)
+            end_to_end["numa_node_of_this_rank"] = numa
 
     # single-frame latency (BASELINE config 2: one 4K frame), device-only and end-to-end
     single = None
@@ -456,7 +538,7 @@ def main():
             "cpu_baseline": base,
             "other_configs": extra,
             "single_frame": single,
-            "pcie_inclusive": inclusive,
+            "end_to_end": end_to_end,
             "verified_bit_exact_vs_oracle": verified,
             "verified_slots": None if verified is None else verified_slots,
             "setup_s": {"synthesize": round(t_gen, 2), "host_preprocess_and_upload": round(t_up, 2)},

@@ -285,6 +285,15 @@ class Batch:
         arr = (C.c_void_p * len(self._images))(*[im._h for im in self._images])
         check(lib.compeg_batch_upload(self._h, arr, len(self._images), host_threads))
 
+    def upload_jpegs(self, jpegs, host_threads=0, allow_sampling=False, standard_entropy=False):
+        """Host-fed use: parse (on the worker threads), preprocess, upload.  jpegs: bytes-like objects."""
+        views = [_host_view(j) for j in jpegs]
+        ptrs = (C.c_void_p * len(views))(*[v.ctypes.data for v in views])
+        lens = (C.c_size_t * len(views))(*[v.nbytes for v in views])
+        flags = (1 if allow_sampling else 0) | (2 if standard_entropy else 0)
+        self._images = []
+        check(lib.compeg_batch_upload_jpegs(self._h, ptrs, lens, len(views), host_threads, flags))
+
     def set_device_preprocess(self, mode):
         """0 host (default), 1 scan kernels once at upload, 2 scan kernels in every decode."""
         check(lib.compeg_batch_set_device_preprocess(self._h, mode))

@@ -6,6 +6,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 namespace compeg {
 namespace {
@@ -100,7 +103,7 @@ bool is_sof(uint8_t m)
 // (file.rs:163-201): FF 00 and FF D0..D7 belong to the segment, FF fill bytes
 // in front of them too; any other marker ends it (the segment then stops in
 // front of the last FF).  Returns false when the file ends first.
-bool find_scan_end(const uint8_t *buf, size_t len, size_t from, size_t &end_out)
+bool find_scan_end_bytes(const uint8_t *buf, size_t len, size_t from, size_t &end_out)
 {
     size_t p = from;
     for (;;) {
@@ -121,6 +124,42 @@ bool find_scan_end(const uint8_t *buf, size_t len, size_t from, size_t &end_out)
             return true;
         }
     }
+}
+
+#if defined(__x86_64__)
+// The same walk 32 bytes at a time: a restart-interval stream has an FF every hundred bytes or so, and a
+// memchr call per FF costs more than the bytes between them (a 4K frame: 0.23 ms, as much as preprocessing
+// it).  Anything but the plain cases -- FF 00, FF RSTn -- is left to the byte loop above, from that FF on.
+__attribute__((target("avx2"))) bool find_scan_end_avx2(const uint8_t *buf, size_t len, size_t from, size_t &end_out)
+{
+    size_t p = from;
+    const __m256i ff = _mm256_set1_epi8(char(0xff)), zero = _mm256_setzero_si256();
+    const __m256i hi5 = _mm256_set1_epi8(char(0xf8)), rst = _mm256_set1_epi8(char(0xd0));
+    uint64_t carry = 0; // the byte in front of this vector is an FF
+    while (p + 32 <= len) {
+        const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(buf + p));
+        const uint64_t is_ff = uint32_t(_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, ff)));
+        // bytes that may follow an FF inside the segment: 00 and D0..D7
+        const uint32_t fine = uint32_t(_mm256_movemask_epi8(_mm256_or_si256(
+            _mm256_cmpeq_epi8(v, zero), _mm256_cmpeq_epi8(_mm256_and_si256(v, hi5), rst))));
+        const uint32_t other = uint32_t((is_ff << 1) | carry) & ~fine; // something else follows an FF (one branch per vector)
+        if (other)
+            return find_scan_end_bytes(buf, len, p + uint32_t(__builtin_ctz(other)) - 1, end_out);
+        carry = is_ff >> 31;
+        p += 32;
+    }
+    return find_scan_end_bytes(buf, len, p - size_t(carry), end_out);
+}
+#endif
+
+bool find_scan_end(const uint8_t *buf, size_t len, size_t from, size_t &end_out)
+{
+#if defined(__x86_64__)
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2)
+        return find_scan_end_avx2(buf, len, from, end_out);
+#endif
+    return find_scan_end_bytes(buf, len, from, end_out);
 }
 
 } // namespace

@@ -237,6 +237,7 @@ uint32_t staged_lut_entries(const ImageData &img)
 }
 
 } // namespace
+
 } // namespace compeg
 
 using namespace compeg;
@@ -691,13 +692,127 @@ Status compeg::ScanBuffer::process_on_gpu(compeg_gpu *gpu, const uint8_t *scan, 
 compeg_batch::~compeg_batch()
 {
     (void)hipStreamSynchronize(last_stream);
+    for (hipStream_t c : copy_streams) {
+        (void)hipStreamSynchronize(c);
+        (void)hipStreamDestroy(c);
+    }
     for (hipEvent_t e : events)
         (void)hipEventDestroy(e);
     if (gpu)
         compeg_gpu_release(gpu);
 }
 
+namespace {
+
+// What the layout of a batch needs to know about an image before its threads start: exact for parsed images,
+// upper bounds (from the file's headers and its length) for images that the threads are going to parse.
+struct UploadItem {
+    uint32_t width = 0, height = 0;
+    uint32_t intervals = 0, total_dus = 0;
+    size_t tables_cap = 0, scan_cap = 0; // bytes of the LUT blob / of the entropy-coded segment, at most
+    bool is422 = true;
+};
+
+UploadItem item_of(const ImageData &img)
+{
+    UploadItem it;
+    it.width = img.width;
+    it.height = img.height;
+    it.intervals = img.metadata.total_restart_intervals;
+    it.total_dus = img.total_dus();
+    it.tables_cap = table_blob_bytes(img);
+    it.scan_cap = img.scan_len;
+    it.is422 = is_422(img);
+    return it;
+}
+
+// The same from the headers alone (SOF0, DRI; everything up to SOS): no walk over the entropy-coded data.
+// false: anything unusual -- the caller then parses first and lays out afterwards.
+bool peek_item(const uint8_t *j, size_t len, unsigned flags, UploadItem &it)
+{
+    if (len < 4 || j[0] != 0xff || j[1] != 0xd8)
+        return false;
+    size_t p = 2;
+    uint32_t ri = 0, w = 0, h = 0, hs = 0, vs = 0, comps = 0;
+    bool sof = false;
+    while (p + 4 <= len) {
+        if (j[p] != 0xff)
+            return false;
+        const uint8_t m = j[p + 1];
+        if (m == 0xff) { // fill byte
+            p++;
+            continue;
+        }
+        if (m == 0xd8 || m == 0x01 || (m >= 0xd0 && m <= 0xd7))
+            return false;
+        const size_t seg = (size_t(j[p + 2]) << 8) | j[p + 3];
+        if (seg < 2 || p + 2 + seg > len)
+            return false;
+        const uint8_t *d = j + p + 4;
+        if (m == 0xc0) {
+            if (sof || seg < 8 + 3)
+                return false;
+            sof = true;
+            h = (uint32_t(d[1]) << 8) | d[2];
+            w = (uint32_t(d[3]) << 8) | d[4];
+            comps = d[5];
+            if (comps != 3 || seg < 8 + 3 * comps)
+                return false;
+            hs = d[7] >> 4;
+            vs = d[7] & 15;
+        } else if (m == 0xdd) {
+            if (seg < 4)
+                return false;
+            ri = (uint32_t(d[0]) << 8) | d[1];
+        } else if (m == 0xda) {
+            if (!sof || w == 0 || h == 0)
+                return false;
+            const bool ok422 = hs == 2 && vs == 1;
+            if (!ok422 && !(flags & COMPEG_PARSE_ANY_LUMA_SAMPLING))
+                return false;
+            if (hs < 1 || hs > 2 || vs < 1 || vs > 2)
+                return false;
+            const uint32_t wm = ((w + 7) / 8 + hs - 1) / hs, hm = ((h + 7) / 8 + vs - 1) / vs;
+            const uint64_t mcus = uint64_t(wm) * hm;
+            const uint64_t r = ri ? ri : mcus;
+            if (r == 0 || mcus / r > kMaxRestartIntervals)
+                return false;
+            it.width = w;
+            it.height = h;
+            it.intervals = uint32_t(mcus / r);
+            it.total_dus = uint32_t(it.intervals * r * (hs * vs + 2));
+            it.is422 = ok422;
+            // five LUT sections at their largest: L1, an L2 LUT of 32767 entries, the direct tables
+            it.tables_cap = COMPEG_HUFFMAN_L1_BYTES + 65536 + 2 * kFastEntries * 2 + 2 * kDcFastEntries * 2;
+            it.scan_cap = len - (p + 2 + seg);
+            return true;
+        }
+        p += 2 + seg;
+    }
+    return false;
+}
+
+} // namespace
+
 Status compeg_batch::upload(const ImageData *const *images, size_t n, int threads)
+{
+    std::vector<UploadItem> items(n);
+    for (size_t i = 0; i < n; i++)
+        items[i] = item_of(*images[i]);
+    if (preprocess_mode != 0) {
+        if (!use_fused_pipeline())
+            return Status::error(COMPEG_E_INVALID_ARG, "device preprocessing needs the fused pipeline");
+        for (size_t i = 0; i < n; i++)
+            if (!items[i].is422)
+                return Status::error(COMPEG_E_UNSUPPORTED, "device preprocessing of a batch supports 4:2:2 images only");
+        note_batch_properties(images, n);
+        return upload_device_scan(images, n, threads);
+    }
+    return upload_host(n, threads, items.data(), [&](size_t i, Status &) { return images[i]; });
+}
+
+// generic_layout, uniform, largest output: what decode() wants to know about the images of the batch
+void compeg_batch::note_batch_properties(const ImageData *const *images, size_t n)
 {
     generic_layout = false;
     max_out_w = max_out_h = 0;
@@ -710,21 +825,34 @@ Status compeg_batch::upload(const ImageData *const *images, size_t n, int thread
         max_out_w = std::max(max_out_w, img.width);
         max_out_h = std::max(max_out_h, img.height);
         uniform = uniform && img.metadata.total_restart_intervals == first.metadata.total_restart_intervals &&
-                  img.l2 == first.l2 && img.ac_fast == first.ac_fast && img.dc_fast == first.dc_fast && memcmp(img.l1, first.l1, sizeof img.l1) == 0;
+                  img.l2 == first.l2 && img.ac_fast == first.ac_fast && img.dc_fast == first.dc_fast &&
+                  memcmp(img.l1, first.l1, sizeof img.l1) == 0;
     }
-    if (preprocess_mode != 0) {
-        if (!use_fused_pipeline())
-            return Status::error(COMPEG_E_INVALID_ARG, "device preprocessing needs the fused pipeline");
-        if (generic_layout)
-            return Status::error(COMPEG_E_UNSUPPORTED,
-                                 "device preprocessing of a batch supports 4:2:2 images only");
-        return upload_device_scan(images, n, threads);
-    }
+}
+
+// Host path of an upload.  image_of(i, status) hands out image i -- parsing it first when the batch is fed with
+// JPEG bytes -- on whichever worker thread takes the image; items: what the layout may assume about it.
+Status compeg_batch::upload_host(size_t n, int threads, const void *items_, const ImageSource &image_of)
+{
+    const UploadItem *items = static_cast<const UploadItem *>(items_);
     CG_HIP(hipSetDevice(gpu->device));
     CG_HIP(hipStreamSynchronize(last_stream));
     count = 0;
     if (n > 65535)
         return Status::error(COMPEG_E_INVALID_ARG, "at most 65535 images per batch");
+    static const bool trace_on = getenv("COMPEG_TRACE_BATCH") != nullptr; // one stderr line per upload: host time of its steps
+    const auto t_up0 = std::chrono::steady_clock::now();
+    auto t_last = t_up0;
+    std::string trace_line;
+    auto mark = [&](const char *what) {
+        if (!trace_on)
+            return;
+        const auto now = std::chrono::steady_clock::now();
+        char buf[64];
+        snprintf(buf, sizeof buf, " %s=%.2f", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        trace_line += buf;
+        t_last = now;
+    };
 
     // One input arena, per image [L1][L2 + direct tables][start positions][words], 256-byte aligned, laid
     // out for the worst case of every scan (scan.rs:38-44) so that nothing depends on another image's size:
@@ -734,25 +862,20 @@ Status compeg_batch::upload(const ImageData *const *images, size_t n, int thread
     out_offset.assign(n, 0);
     std::vector<size_t> in_off(n);
     size_t in_total = 0, ac_total = 0, dc_total = 0, out_total = 0;
-    max_intervals = max_dus = max_l2 = 0;
-    algorithmic_bytes = pixels = 0;
-    max_span = 0;
+    bool any_generic = false;
     for (size_t i = 0; i < n; i++) {
-        const ImageData &img = *images[i];
+        const UploadItem &it = items[i];
         in_off[i] = in_total;
-        in_total += align_up(table_blob_bytes(img) + ScanBuffer::start_slots(img.metadata.total_restart_intervals) * 4 +
-                                 ScanBuffer::output_capacity(img.scan_len) + 16, 256);
+        in_total += align_up(it.tables_cap + ScanBuffer::start_slots(it.intervals) * 4 +
+                                 ScanBuffer::output_capacity(it.scan_cap) + 16, 256);
         out_offset[i] = out_total;
-        out_total += align_up(size_t(img.width) * 4 * img.height, 256);
-        ac_total += size_t(img.total_dus()) * kRetained * 2;
-        dc_total += size_t(img.total_dus()) * 4;
-        max_intervals = std::max(max_intervals, img.metadata.total_restart_intervals);
-        max_dus = std::max(max_dus, img.total_dus());
-        max_l2 = std::max<uint32_t>(max_l2, staged_lut_entries(img));
-        pixels += uint64_t(img.width) * img.height;
+        out_total += align_up(size_t(it.width) * 4 * it.height, 256);
+        ac_total += size_t(it.total_dus) * kRetained * 2;
+        dc_total += size_t(it.total_dus) * 4;
+        any_generic = any_generic || !it.is422;
     }
 
-    const bool fused = use_fused_pipeline() && !generic_layout;
+    const bool fused = use_fused_pipeline() && !any_generic;
     CG_TRY(inputs.reserve(in_total + 256));
     const bool stamps = getenv("COMPEG_STAMPS") != nullptr; // diagnostic builds park cycle stamps in dc
     if (!fused) { // the fused kernel keeps coefficients on chip
@@ -761,9 +884,24 @@ Status compeg_batch::upload(const ImageData *const *images, size_t n, int thread
     } else if (stamps) {
         CG_TRY(dc.reserve(dc_total + 256));
     }
-    CG_TRY(out.reserve(out_total + 256));
+    bool fresh_out = false;
+    CG_TRY(out.reserve(out_total + 256, &fresh_out));
     hipStream_t st = gpu->stream;
-    CG_HIP(hipMemsetAsync(out.ptr, 0, out.capacity, st)); // (the card does this while the host preprocesses)
+    // Texels no MCU covers (a truncated last restart interval) read 0 in the reference's fresh texture: the
+    // output is cleared -- when it is new, or when this upload lays it out differently from the last one.  Frame
+    // after frame of one geometry (a stream) writes the same texels every time; nothing stale can show.
+    std::vector<uint64_t> layout(n);
+    for (size_t i = 0; i < n; i++)
+        layout[i] = uint64_t(items[i].width) | uint64_t(items[i].height) << 16 |
+                    uint64_t(items[i].intervals & 0xffffu) << 32 | uint64_t(out_offset[i] >> 8) << 48;
+    if (fresh_out || layout != out_layout)
+        CG_HIP(hipMemsetAsync(out.ptr, 0, out.capacity, st)); // (the card does this while the host preprocesses)
+    out_layout.swap(layout);
+    while (copy_streams.size() < 4) {
+        hipStream_t c = nullptr;
+        CG_HIP(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
+        copy_streams.push_back(c);
+    }
     CG_TRY(dev_descs.reserve(n * sizeof(ImageDesc) + 256));
     CG_TRY(stage.reserve(in_total + 256));
     uint8_t *hs = static_cast<uint8_t *>(stage.ptr);
@@ -772,11 +910,13 @@ Status compeg_batch::upload(const ImageData *const *images, size_t n, int thread
     for (size_t i = 0, a = 0, c = 0; i < n; i++) {
         ac_at[i] = a;
         dc_at[i] = c;
-        a += size_t(images[i]->total_dus()) * kRetained * 2;
-        c += size_t(images[i]->total_dus()) * 4;
+        a += size_t(items[i].total_dus) * kRetained * 2;
+        c += size_t(items[i].total_dus) * 4;
     }
+    mark("layout+reserve");
 
     std::vector<Status> results(n);
+    std::vector<const ImageData *> got(n, nullptr);
     std::vector<uint32_t> spans(n, 0), group_spans(n, 0);
     std::vector<uint64_t> alg(n, 0);
     std::atomic<int> hip_error{int(hipSuccess)};
@@ -789,7 +929,19 @@ Status compeg_batch::upload(const ImageData *const *images, size_t n, int thread
             return;
         }
         for (size_t i = t; i < n; i += nthreads) {
-            const ImageData &img = *images[i];
+            const ImageData *imgp = image_of(i, results[i]);
+            if (!imgp)
+                continue;
+            const ImageData &img = *imgp;
+            const UploadItem &it = items[i];
+            // (an image that does not fit what the layout assumed about it: the caller lays out again, exactly)
+            if (img.width != it.width || img.height != it.height || img.metadata.total_restart_intervals != it.intervals ||
+                table_blob_bytes(img) > it.tables_cap || img.scan_len > it.scan_cap || is_422(img) != it.is422 ||
+                img.total_dus() > it.total_dus) {
+                results[i] = Status::error(COMPEG_E_INVALID_ARG, "layout bound exceeded");
+                continue;
+            }
+            got[i] = imgp;
             ImageDesc &d = descs[i];
             fill_desc(img, d);
             size_t o = in_off[i];
@@ -823,34 +975,99 @@ Status compeg_batch::upload(const ImageData *const *images, size_t n, int thread
                      COMPEG_HUFFMAN_L1_BYTES + img.l2.size() * 2 + 4ull * img.width * img.height;
             // this image's part of the arena, as far as it is used
             const size_t used = table_blob_bytes(img) + slots * 4 + nwords * 4;
-            const hipError_t e = hipMemcpyAsync(di + in_off[i], hs + in_off[i], used, hipMemcpyHostToDevice, st);
+            const hipError_t e = hipMemcpyAsync(di + in_off[i], hs + in_off[i], used, hipMemcpyHostToDevice,
+                                                copy_streams[t % copy_streams.size()]);
             if (e != hipSuccess)
                 hip_error = int(e);
         }
     };
     run_on_threads(nthreads, work);
+    mark("parse+preprocess+issue");
     CG_HIP(hipError_t(hip_error.load()));
+    for (hipStream_t c : copy_streams)
+        CG_HIP(hipStreamSynchronize(c));
+    mark("copies_done");
+    max_intervals = max_dus = max_l2 = 0;
+    algorithmic_bytes = pixels = 0;
+    max_span = 0;
     for (size_t i = 0; i < n; i++) {
         if (!results[i].ok() && results[i].code != COMPEG_E_COUNT_MISMATCH) {
             (void)hipStreamSynchronize(st);
             return results[i];
         }
+        const ImageData &img = *got[i];
+        max_intervals = std::max(max_intervals, img.metadata.total_restart_intervals);
+        max_dus = std::max(max_dus, img.total_dus());
+        max_l2 = std::max<uint32_t>(max_l2, staged_lut_entries(img));
+        pixels += uint64_t(img.width) * img.height;
         max_span = std::max(max_span, spans[i]);
         algorithmic_bytes += alg[i];
     }
-    coop_r = n ? images[0]->metadata.restart_interval : 0;
+    note_batch_properties(got.data(), n);
+    coop_r = n ? got[0]->metadata.restart_interval : 0;
     coop_span = 0;
     for (size_t i = 0; i < n; i++) {
-        if (!descs[i].coop_ok || images[i]->metadata.restart_interval != coop_r)
+        if (!descs[i].coop_ok || got[i]->metadata.restart_interval != coop_r)
             coop_r = 0;
         coop_span = std::max(coop_span, group_spans[i]);
     }
     CG_HIP(hipMemcpyAsync(dev_descs.ptr, descs.data(), n * sizeof(ImageDesc), hipMemcpyHostToDevice, st));
     CG_HIP(hipStreamSynchronize(st)); // descs (pageable) and the staging arena may be reused from here on
+    mark("descs");
+    if (trace_on)
+        fprintf(stderr, "[compeg] batch upload (%zu images, %u threads):%s total=%.2f ms\n", n, nthreads, trace_line.c_str(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_up0).count());
     last_stream = st;
     count = n;
     decodes_timed = 0;
     return Status{};
+}
+
+// Host-fed use: JPEG bytes in.  ImageData::new (src/lib.rs:597-824) for every image runs on the worker threads,
+// in the same pass as its preprocessing: the layout of the batch is made from the files' headers and lengths
+// (upper bounds), so that nothing has to wait for all images to be parsed.  A file whose headers are unusual in
+// any way takes the plain road: parse everything (in parallel), then upload().
+Status compeg_batch::upload_jpegs(const uint8_t *const *jpegs, const size_t *lens, size_t n, int threads, unsigned flags)
+{
+    std::vector<std::unique_ptr<ImageData>> fresh(n);
+    std::vector<UploadItem> items(n);
+    bool peeked = preprocess_mode == 0;
+    for (size_t i = 0; i < n && peeked; i++)
+        peeked = peek_item(jpegs[i], lens[i], flags, items[i]);
+    auto parse_one = [&](size_t i, Status &st) -> const ImageData * {
+        ImageData *img = nullptr;
+        st = ImageData::parse(jpegs[i], lens[i], false, &img, flags);
+        fresh[i].reset(img);
+        if (!st.ok())
+            st = Status::error(st.code, "image " + std::to_string(i) + ": " + st.message);
+        return st.ok() ? img : nullptr;
+    };
+    Status s;
+    bool done = false;
+    if (peeked) {
+        s = upload_host(n, threads, items.data(), parse_one);
+        done = s.ok() || s.message != "layout bound exceeded";
+    }
+    if (!done) {
+        std::vector<Status> results(n);
+        unsigned nthreads = threads > 0 ? unsigned(threads) : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        nthreads = unsigned(std::min<size_t>(nthreads, std::max<size_t>(n, 1)));
+        auto work = [&](unsigned t) {
+            for (size_t i = t; i < n; i += nthreads)
+                if (!fresh[i])
+                    parse_one(i, results[i]);
+        };
+        run_on_threads(nthreads, work);
+        std::vector<const ImageData *> ptrs(n);
+        for (size_t i = 0; i < n; i++) {
+            if (!results[i].ok())
+                return results[i];
+            ptrs[i] = fresh[i].get();
+        }
+        s = upload(ptrs.data(), n, threads);
+    }
+    parsed.swap(fresh); // (the previous upload's images go; nothing on the device refers to them)
+    return s;
 }
 
 // Device-side preprocessing: raw entropy-coded segments go to HBM as they are

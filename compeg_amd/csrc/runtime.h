@@ -9,6 +9,7 @@
 
 #include <atomic>
 #include <functional>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -148,8 +149,22 @@ struct compeg_batch {
     uint32_t max_tiles = 0;
     size_t host_fallbacks = 0; // images the scan kernels handed back to the host
 
+    // host-fed use (upload_jpegs): the images parsed from the caller's bytes, kept until the next upload
+    std::vector<std::unique_ptr<compeg::ImageData>> parsed;
+    // H2D copies of an upload are spread over a few streams: 256 copies of 1.6 MB on one stream reach 43 GB/s
+    // on the target node, on two to four streams 54-56 (one copy of the whole arena: 57)
+    std::vector<hipStream_t> copy_streams;
+    // the output is cleared when its layout changes, not on every upload (see upload)
+    std::vector<uint64_t> out_layout;
+
     ~compeg_batch();
     compeg::Status upload(const compeg::ImageData *const *images, size_t n, int threads);
+    // the same from JPEG bytes: ImageData::new for every image on the worker threads first (the bytes are
+    // borrowed for the duration of the call)
+    compeg::Status upload_jpegs(const uint8_t *const *jpegs, const size_t *lens, size_t n, int threads, unsigned flags);
+    using ImageSource = std::function<const compeg::ImageData *(size_t index, compeg::Status &status)>;
+    compeg::Status upload_host(size_t n, int threads, const void *items, const ImageSource &image_of);
+    void note_batch_properties(const compeg::ImageData *const *images, size_t n);
     compeg::Status upload_device_scan(const compeg::ImageData *const *images, size_t n, int threads);
     compeg::Status decode(hipStream_t stream);
 };

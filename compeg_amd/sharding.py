@@ -31,3 +31,72 @@ def max_over_ranks(value, device=None):
     t = torch.tensor([value], dtype=torch.float64, device=device or "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+# ---- host side of a rank: which cores its threads run on ------------------------------------
+#
+# With images sharded over the GPUs the data path has no exchange, but the ranks share the host: every
+# rank parses, preprocesses and stages its own frames ("host preprocess + PCIe decide the
+# 8-GPU curve").  Each rank therefore gets a share of the cores of its own GPU's NUMA node -- pinned
+# staging memory is then allocated, written and read by the DMA engine next to that GPU -- and sizes
+# its thread pool to that share.
+
+
+def parse_cpu_list(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the format of /sys/devices/system/node/nodeN/cpulist)."""
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def cpu_share(available, node_cpus, ranks_on_node, index_on_node):
+    """The cores of one rank: the rank's NUMA node's cores (as far as this process may use them) cut evenly
+    among the ranks whose GPUs sit on that node; without NUMA information, `available` cut evenly instead.
+    available: cores this process may run on; node_cpus: cores of the GPU's node, or None."""
+    pool = sorted(set(available) & set(node_cpus)) if node_cpus else []
+    if not pool:
+        pool = sorted(available)
+    ranks_on_node = max(1, ranks_on_node)
+    per = max(1, len(pool) // ranks_on_node)
+    lo = min(len(pool) - 1, (index_on_node % ranks_on_node) * per) if pool else 0
+    return pool[lo:lo + per] or pool
+
+
+def gpu_numa_node(pci_bus_id):
+    """NUMA node of a GPU from sysfs, or None (single-node hosts report -1)."""
+    try:
+        with open(f"/sys/bus/pci/devices/{pci_bus_id.lower()}/numa_node") as f:
+            node = int(f.read().strip())
+        return node if node >= 0 else None
+    except (OSError, ValueError):
+        return None
+
+
+def node_cpus(node):
+    try:
+        with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+            return parse_cpu_list(f.read())
+    except OSError:
+        return None
+
+
+def bind_rank_to_its_cores(local_rank, world, pci_bus_ids):
+    """Restricts this process (and the threads it starts later) to its share of the host and returns
+    (cores, numa node or None).  pci_bus_ids: bus id of every local GPU, index = local rank."""
+    import os
+
+    available = sorted(os.sched_getaffinity(0))
+    nodes = [gpu_numa_node(b) for b in pci_bus_ids]
+    mine = nodes[local_rank] if local_rank < len(nodes) else None
+    if mine is None:
+        share = cpu_share(available, None, world, local_rank)
+    else:
+        same = [r for r in range(min(world, len(nodes))) if nodes[r] == mine]
+        share = cpu_share(available, node_cpus(mine), len(same), same.index(local_rank))
+    if world > 1 and share:
+        os.sched_setaffinity(0, share)
+    return share, mine

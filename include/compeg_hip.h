@@ -222,6 +222,13 @@ int compeg_batch_upload(compeg_batch *batch, const compeg_image *const *images, 
                         int host_threads);
 /* Records the decode of every uploaded image on hip_stream (NULL = the gpu's
  * stream) and returns without waiting. */
+/* The same from JPEG bytes (host-fed use): `ImageData::new` for every image -- on the worker threads, it walks the
+ * whole entropy-coded segment -- then what compeg_batch_upload does.  flags: COMPEG_PARSE_*.  The bytes are
+ * borrowed until the call returns.  An image the front-end rejects fails the whole call with its error text,
+ * prefixed "image <index>: ".  Two batches on two compeg_gpu handles (two streams) pipeline a stream of frames:
+ * the upload of one runs under the decode of the other (bench.py, "end_to_end"). */
+int compeg_batch_upload_jpegs(compeg_batch *batch, const uint8_t *const *jpegs, const size_t *lengths, size_t count,
+                              int host_threads, unsigned flags);
 int compeg_batch_decode(compeg_batch *batch, void *hip_stream);
 /* Where the scans are preprocessed.  0 (default): on the host during
  * compeg_batch_upload, like the reference.  1: raw entropy-coded segments are

@@ -90,6 +90,8 @@ extern "C" {
     pub fn compeg_batch_free(batch: *mut compeg_batch);
     pub fn compeg_batch_upload(batch: *mut compeg_batch, images: *const *const compeg_image, count: usize,
                                host_threads: c_int) -> c_int;
+    pub fn compeg_batch_upload_jpegs(batch: *mut compeg_batch, jpegs: *const *const u8, lengths: *const usize,
+                                     count: usize, host_threads: c_int, flags: c_uint) -> c_int;
     pub fn compeg_batch_decode(batch: *mut compeg_batch, hip_stream: *mut c_void) -> c_int;
     pub fn compeg_batch_set_device_preprocess(batch: *mut compeg_batch, mode: c_int) -> c_int;
     pub fn compeg_batch_host_fallbacks(batch: *const compeg_batch) -> usize;

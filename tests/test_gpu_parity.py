@@ -222,6 +222,59 @@ def test_batch_matches_single_decodes(ca, gpu):
         _assert_equal(batch.read_output(i), orc.ImageData(j).decode())
 
 
+def test_batch_fed_with_jpeg_bytes(ca, gpu):
+    """compeg_batch_upload_jpegs: ImageData::new on the batch's worker threads, in the pass that preprocesses and
+    uploads (layout from the files' headers); same outputs as uploading parsed images; a file the front-end
+    rejects fails the call with the reference's message and the image's index; files with unusual headers (a
+    fill byte in front of a marker, trailing data) take the parse-first road and decode the same."""
+    jpegs = [synth.make_jpeg(w, h, seed=700 + i, kind=k, quality=q, ri=ri)
+             for i, (w, h, k, q, ri) in enumerate([(640, 360, 0, 85, 4), (320, 240, 1, 95, 1), (1280, 720, 0, 70, 8),
+                                                   (64, 8, 0, 100, 2), (250, 70, 2, 85, 3), (1000, 1000, 0, 80, 16)])]
+    wants = [orc.ImageData(j).decode() for j in jpegs]
+    batch = ca.Batch(gpu)
+    for threads in (1, 3, 8):
+        batch.upload_jpegs(jpegs, host_threads=threads)
+        assert batch.count() == len(jpegs)
+        batch.decode()
+        batch.wait()
+        for i, want in enumerate(wants):
+            _assert_equal(batch.read_output(i), want)
+    # a rejected file: progressive SOF (the reference: "not a baseline JPEG ..."), reported with its index
+    bad = bytearray(jpegs[1])
+    sof = bad.find(b"\xff\xc0")
+    bad[sof + 1] = 0xC2
+    with pytest.raises(ca.Error) as e:
+        batch.upload_jpegs(jpegs[:2] + [bytes(bad)] + jpegs[3:], host_threads=4)
+    assert str(e.value).startswith("image 2: ")
+    with pytest.raises(ca.Error):
+        ca.ImageData(bytes(bad))
+    # unusual but valid framing: a fill byte (FF FF) in front of the SOF marker; the headers are then not "peeked"
+    odd = bytearray(jpegs[0])
+    sof = odd.find(b"\xff\xc0")
+    odd = bytes(odd[:sof] + b"\xff" + odd[sof:])
+    if _accepts(orc, odd):
+        batch.upload_jpegs([odd, jpegs[2]], host_threads=2)
+        batch.decode()
+        batch.wait()
+        _assert_equal(batch.read_output(0), orc.ImageData(odd).decode())
+        _assert_equal(batch.read_output(1), wants[2])
+    # extension layouts through the same entry point
+    j420 = synth.make_jpeg(320, 200, seed=710, ri=2, sampling=(2, 2))
+    batch.upload_jpegs([j420, jpegs[0]], host_threads=2, allow_sampling=True)
+    batch.decode()
+    batch.wait()
+    _assert_equal(batch.read_output(0), orc.ImageData(j420, allow_sampling=True).decode())
+    _assert_equal(batch.read_output(1), wants[0])
+
+
+def _accepts(orc_mod, jpeg):
+    try:
+        orc_mod.ImageData(jpeg)
+        return True
+    except orc_mod.OracleError:
+        return False
+
+
 def test_full_size_8k_dri1_roundtrip_properties(ca, gpu):
     """Config 5 (7680x4320, DRI=1): size-independent checks -- alpha is 255 everywhere,
     decoding twice is idempotent, and a sampled set of MCU rows matches the oracle run on a

@@ -26,6 +26,24 @@ def test_shard_bounds_cover_exactly_once():
         shard_bounds(4, 2, 2)
 
 
+def test_host_core_shares_of_the_ranks():
+    """Every rank gets a disjoint share of its GPU's NUMA node (or of the host, without NUMA information)."""
+    from compeg_amd.sharding import cpu_share, parse_cpu_list
+    assert parse_cpu_list("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    host = list(range(256))
+    node0, node1 = list(range(0, 64)) + list(range(128, 192)), list(range(64, 128)) + list(range(192, 256))
+    shares = [cpu_share(host, node0 if r < 4 else node1, 4, r % 4) for r in range(8)]
+    assert all(len(s) == 32 for s in shares)
+    assert sorted(c for s in shares for c in s) == host                      # disjoint, everything used
+    assert all(set(shares[r]) <= set(node0 if r < 4 else node1) for r in range(8))
+    # no NUMA information: an even cut of what the process may use
+    flat = [cpu_share(list(range(8)), None, 2, r) for r in range(2)]
+    assert flat == [[0, 1, 2, 3], [4, 5, 6, 7]]
+    # a cpuset smaller than the node, more ranks than cores: never empty
+    assert cpu_share([3, 5], node0, 4, 3) in ([3], [5])
+    assert cpu_share([9], None, 8, 7) == [9]
+
+
 def _worker(rank, world, port, out_dir):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import torch.distributed as dist
