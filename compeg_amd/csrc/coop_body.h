@@ -224,14 +224,53 @@ CG_DEV void chase_run(ChaseState &c, const ImageDesc &d, const HuffShared &s, co
     const uint32_t acsel = t.acsel, dcsel = t.dcsel; // (vector copies: one scalar operand per instruction)
     if (__builtin_amdgcn_ballot_w64(alive != 0u) != 0u)
         for (;;) {
+            // Software-pipelined: the masks of "this lane is done" and "this lane met a long code" are computed
+            // by vector compares, but taking them to EXEC and to a branch is scalar work, and a scalar instruction
+            // right behind the compare it depends on stalls for some forty cycles.  The next symbol's lookup --
+            // which depends on neither mask -- sits between the two.  An escape entry applied like a symbol
+            // changes nothing (device_types.h), so its lane may run through "apply" before anybody looks.
             asm volatile(
                 "s_mov_b64 s[74:75], exec\n\t"
                 "v_cmp_ne_u32 vcc, 0, %[alive]\n\t"
                 "s_and_b64 exec, exec, vcc\n\t"
                 "s_cbranch_execz 4f\n\t"
                 "s_cmp_lg_u32 %[resume], 0\n\t"
-                "s_cbranch_scc1 2f\n"
-                "1:\n\t" // ---- fetch the stream bits at p, look the symbol up
+                "s_cbranch_scc1 1f\n\t"
+                // ---- first lookup
+                "v_lshrrev_b32 v40, 5, %[p]\n\t"
+                "v_lshl_add_u32 v40, v40, 2, %[win]\n\t"
+                "ds_read2_b32 v[42:43], v40 offset0:1 offset1:0\n\t"
+                "v_and_b32 v44, 31, %[p]\n\t"
+                "v_cmp_eq_u32 vcc, 0, %[st]\n\t"
+                "v_cndmask_b32 v46, %[acsel], %[dcsel], vcc\n\t"
+                "v_bfe_u32 v46, v46, %[k8], 8\n\t"
+                "v_cndmask_b32_e64 v45, 21, 23, vcc\n\t"
+                "v_lshl_add_u32 v46, v46, 10, %[tab]\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_lshlrev_b64 v[42:43], v44, v[42:43]\n\t"
+                "v_lshrrev_b32 v45, v45, v43\n\t"
+                "v_lshl_add_u32 v46, v45, 1, v46\n\t"
+                "ds_read_u16 %[ent], v46\n"
+                "1:\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                // ---- apply the symbol: advance, note the state behind it, end of data unit?
+                "v_bfe_u32 v40, %[ent], 4, 5\n\t"                     // size
+                "v_lshrrev_b32 v44, 9, %[ent]\n\t"                    // zig-zag advance
+                "v_add_u32 %[p], %[p], v40\n\t"
+                "v_add_u32 %[st], %[st], v44\n\t"
+                "v_lshl_or_b32 v40, v40, 16, %[p]\n\t"
+                "ds_write_b32 %[lp], v40\n\t"
+                "v_cmp_lt_u32 vcc, 63, %[st]\n\t"                     // the data unit is complete
+                "v_cndmask_b32_e64 v44, 0, 1, vcc\n\t"
+                "v_lshl_add_u32 %[lp], v44, 2, %[lp]\n\t"
+                "v_lshl_add_u32 %[k8], v44, 3, %[k8]\n\t"
+                "v_cndmask_b32_e64 v45, 0, %[p], vcc\n\t"             // its end position, or 0 inside a data unit
+                "v_cndmask_b32_e64 %[st], %[st], 0, vcc\n\t"
+                "v_cmp_eq_u32 s[76:77], 15, %[ent]\n\t"               // kFastEscape: lanes that met a long code
+                "v_cmp_ge_u32 s[72:73], %[lp], %[lpmax]\n\t"
+                "v_cndmask_b32_e64 v46, %[stopp], 1, s[72:73]\n\t"    // where the walk ends: nowhere further if the list is full
+                "v_cmp_ge_u32 s[72:73], v45, v46\n\t"                 // lanes whose walk ends here
+                // ---- the next symbol's lookup
                 "v_lshrrev_b32 v40, 5, %[p]\n\t"
                 "v_lshl_add_u32 v40, v40, 2, %[win]\n\t"
                 "ds_read2_b32 v[42:43], v40 offset0:1 offset1:0\n\t" // v43 = word at p, v42 = the next one
@@ -246,36 +285,22 @@ CG_DEV void chase_run(ChaseState &c, const ImageDesc &d, const HuffShared &s, co
                 "v_lshrrev_b32 v45, v45, v43\n\t"
                 "v_lshl_add_u32 v46, v45, 1, v46\n\t"
                 "ds_read_u16 %[ent], v46\n\t"
-                "s_waitcnt lgkmcnt(0)\n\t"
-                "v_cmp_le_u32 vcc, 0xfe00, %[ent]\n\t"                // kFastEscape
-                "s_cbranch_vccnz 3f\n"
-                "2:\n\t" // ---- apply: advance, note the state behind the symbol, end of data unit?
-                "v_bfe_u32 v40, %[ent], 4, 5\n\t"                     // size
-                "v_lshrrev_b32 v44, 9, %[ent]\n\t"                    // zig-zag advance
-                "v_add_u32 %[p], %[p], v40\n\t"
-                "v_add_u32 %[st], %[st], v44\n\t"
-                "v_lshl_or_b32 v40, v40, 16, %[p]\n\t"
-                "ds_write_b32 %[lp], v40\n\t"
-                "v_cmp_lt_u32 vcc, 63, %[st]\n\t"                     // the data unit is complete
-                "v_cndmask_b32_e64 v44, 0, 1, vcc\n\t"
-                "v_lshl_add_u32 %[lp], v44, 2, %[lp]\n\t"
-                "v_lshl_add_u32 %[k8], v44, 3, %[k8]\n\t"
-                "v_cndmask_b32_e64 v45, 0, %[p], vcc\n\t"             // its end position, or 0 inside a data unit
-                "v_cndmask_b32_e64 %[st], %[st], 0, vcc\n\t"
-                "v_cmp_ge_u32 s[72:73], %[lp], %[lpmax]\n\t"
-                "v_cndmask_b32_e64 v46, %[stopp], 1, s[72:73]\n\t"    // where the walk ends: nowhere further if the list is full
-                "v_cmp_ge_u32 vcc, v45, v46\n\t"                      // lanes whose walk ends here
-                "s_andn2_b64 exec, exec, vcc\n\t"
+                // ---- who goes on
+                "s_andn2_b64 exec, exec, s[72:73]\n\t"
+                "s_and_b64 s[76:77], s[76:77], exec\n\t"              // (sets SCC: some walking lane met a long code)
+                "s_cbranch_scc1 3f\n\t"
                 "s_cbranch_execnz 1b\n\t"
                 "s_mov_b32 %[code], 0\n\t"
                 "s_branch 5f\n"
-                "3:\n\t" // ---- a lane met a long code: out, with the bits it looked at
+                "3:\n\t" // ---- out, with the bits the lanes looked at: the long codes go through the two-level tables
+                "s_waitcnt lgkmcnt(0)\n\t"
                 "v_mov_b32 %[cur], v43\n\t"
                 "s_mov_b32 %[code], 1\n\t"
                 "s_branch 5f\n"
                 "4:\n\t"
                 "s_mov_b32 %[code], 0\n"
                 "5:\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
                 "s_mov_b64 s[72:73], exec\n\t"                        // lanes still walking
                 "s_mov_b64 exec, s[74:75]\n\t"
                 "v_cndmask_b32_e64 %[alive], 0, 1, s[72:73]\n\t"
@@ -283,10 +308,10 @@ CG_DEV void chase_run(ChaseState &c, const ImageDesc &d, const HuffShared &s, co
                   [alive] "+v"(alive), [code] "=s"(code)
                 : [resume] "s"(resume), [win] "s"(win), [tab] "s"(tab), [acsel] "v"(acsel), [dcsel] "v"(dcsel),
                   [stopp] "v"(c.stop_p), [lpmax] "v"(lpmax)
-                : "memory", "vcc", "scc", "v40", "v42", "v43", "v44", "v45", "v46", "s70", "s71", "s72", "s73", "s74", "s75");
+                : "memory", "vcc", "scc", "v40", "v42", "v43", "v44", "v45", "v46", "s72", "s73", "s74", "s75", "s76", "s77");
             if (code == 0u)
                 break;
-            if (alive != 0u && ent >= kFastEscape) {
+            if (alive != 0u && ent == kFastEscape) {
                 // longer than the direct table's prefix: through the reference's two-level tables
                 const uint32_t comp = comp_of_k((k8 >> 3) & 3u);
                 if (st == 0u) {
@@ -317,7 +342,7 @@ CG_DEV void chase_run(ChaseState &c, const ImageDesc &d, const HuffShared &s, co
             const uint32_t kib = ((dc ? t.dcsel : t.acsel) >> (k8 & 31u)) & 0xffu;
             const uint16_t *tab = t.ac_fast + kib * 512u;
             uint32_t ent = tab[cur >> (dc ? 32u - kDcFastBits : 32u - kFastBits)];
-            if (ent >= kFastEscape) {
+            if (ent == kFastEscape) {
                 // longer than the direct table's prefix: through the reference's two-level tables
                 CG_COUNT(escapes);
                 const uint32_t comp = comp_of_k((k8 >> 3) & 3u);
@@ -856,6 +881,13 @@ CG_DEV void coop_wave_422(const ImageDesc &d, const CoopShared &cs, const CoopTa
             }
             CG_COOP_COUNT(wave_steps, most);
             CG_COOP_COUNT(true_max, most_true);
+#if defined(CG_EMUL_STATS)
+            if (const char *path = getenv("EMUL_COOP_WAVE_STEPS")) { // (analysis only) steps of every wave and round
+                static FILE *f = fopen(path, "w");
+                if (f)
+                    fprintf(f, "%u %u %lu\n", wave_index, round, most);
+            }
+#endif
             (void)most_true;
         }
         CG_COOP_STAMP(1);

@@ -15,12 +15,14 @@ constexpr uint32_t kStripMcus = 32;    // MCUs per workgroup of the generic comp
 //   bits 0..3   magnitude bits of the symbol
 //   bits 4..8   code length + magnitude bits (<= 31)
 //   bits 9..15  zig-zag positions to advance: run + 1; 17 for ZRL (quirk Q2);
-//               64 for EOB (ends the data unit); 127 = escape: the code is
-//               longer than 11 bits
+//               64 for EOB (ends the data unit)
+// and kFastEscape (size 0, advance 0, 15 magnitude bits: nothing a symbol can look like) when the code is longer
+// than 11 bits.  An escape entry that is applied like a symbol changes nothing: no bits consumed, no position
+// advanced -- the cooperative kernel's walk relies on that and looks at escapes once per step, late.
 constexpr uint32_t kFastBits = 11;
 constexpr uint32_t kFastEntries = 1u << kFastBits;
-constexpr uint32_t kFastAdvEob = 64, kFastAdvEscape = 127;
-constexpr uint32_t kFastEscape = kFastAdvEscape << 9;
+constexpr uint32_t kFastAdvEob = 64;
+constexpr uint32_t kFastEscape = 15u;
 
 // ref: an entry of the reference's LUTs, code length << 8 | symbol;
 // zrl_advance: 17 like the reference (quirk Q2), 16 with COMPEG_PARSE_STANDARD_ENTROPY

@@ -1092,7 +1092,7 @@ CG_DEV void fast_ac(EntropyState &e, const ImageDesc &d, const HuffShared &s, ui
         *pend_at = pend_val;
 #endif
 #if CG_EXP != 7 // (7: diagnostic build without the escape test)
-        if (__builtin_expect(ent >= kFastEscape, 0))
+        if (__builtin_expect(ent == kFastEscape, 0))
 #else
         if (false)
 #endif

@@ -629,3 +629,32 @@ def test_bounded_gpu_fuzz_seed(ca, gpu):
                                       log=lambda *a, **k: lines.append(" ".join(str(x) for x in a)))
     assert bad == 0, "\n".join(lines[-20:])
     assert runs >= 60, (runs, skipped)
+
+
+def test_bench_multi_rank_path_rehearsed_on_one_gpu(tmp_path):
+    """bench.py's multi-rank code path as the driver launches it (torch.distributed.run, one process per rank):
+    two fresh ranks share this box's one card, gloo stands in for RCCL (--rehearse-on-one-gpu).  Not a
+    measurement -- it proves that sharding, per-rank core shares, barriers, the max-over-ranks reduction, the
+    per-rank host-fed pipeline and the single JSON line work with more than one rank."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--rehearse-on-one-gpu", "--batch", "6", "--width", "640", "--height", "360", "--cpu-seconds", "0",
+           "--no-extra-configs", "--e2e-reps", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # rank 0 alone prints
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["value"] > 0 and j["scaling"] == "weak"
+    assert j["verified_bit_exact_vs_oracle"] is True
+    e2e = j["end_to_end"]
+    assert e2e["verified_bit_exact_vs_oracle"] is True and e2e["from_jpeg_bytes_parse_included"]["whole_job_mpix_s"] > 0
+    assert j["config"]["images_per_gpu"] == 6

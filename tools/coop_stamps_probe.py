@@ -29,3 +29,19 @@ print("waves", waves, "cycles/wave mean %.0f max %.0f p99 %.0f" % (tot.mean(), t
 names = ("setup", "chase", "validate", "decode", "fixups", "dc+idct", "composite", "-")
 for name, col in zip(names, buf.T):
     print("  %-10s %8.0f cycles/wave (max %8.0f)  %5.1f %%" % (name, col.mean(), col.max(), 100 * col.sum() / max(tot.sum(), 1)))
+# per-wave walk steps from the emulation (tools/probes/wave_steps_<shift>.txt, if present): cycles per step
+shift = os.environ.get("COMPEG_COOP_SPEC_SHIFT", "0")
+path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes", "wave_steps_%s.txt" % shift)
+if os.path.exists(path) and (w, h, ri) == (3840, 2160, 4):
+    steps = np.zeros(waves)
+    for line in open(path):
+        wv, rnd, n = (int(v) for v in line.split())
+        steps[wv] += n
+    per = buf[:, 1] / np.maximum(steps, 1)
+    print("walk: steps/wave mean %.1f; cycles per step mean %.0f p10 %.0f p90 %.0f" % (steps.mean(), per.mean(), np.percentile(per, 10), np.percentile(per, 90)))
+    if os.environ.get("COOP_STAMPS_DUMP"):
+        print("cycles per step of the first 64 waves:", " ".join("%d" % v for v in per[:64]))
+        print("setup cycles of the first 64 waves:  ", " ".join("%d" % v for v in buf[:64, 0]))
+        # by position inside the workgroup (8 waves each)
+        for k in range(8):
+            print("wave %d of its workgroup: cycles per step mean %.0f" % (k, per[k::8].mean()))

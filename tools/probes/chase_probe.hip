@@ -35,6 +35,13 @@
     "v_cmp_ge_u32 vcc, v45, v46\n\t"                                                                   \
     "s_andn2_b64 exec, exec, vcc\n\t"
 #endif
+#if V & 32
+#undef ESC
+#define ESC "v_cmp_le_u32 vcc, 0xfe00, %[ent]\n\t"
+#define ESCBR "s_cbranch_vccnz 3f\n\t"
+#else
+#define ESCBR ""
+#endif
 #if V & 16
 #define TABLE "v_mov_b32 %[ent], 0x252\n\t"
 #else
@@ -81,9 +88,12 @@ __global__ void probe(unsigned *out, int steps)
         ESC
         "v_bfe_u32 v40, %[ent], 4, 5\n\t"
         "v_lshrrev_b32 v44, 9, %[ent]\n\t"
-        "v_add_u32 %[p], %[p], v40\n\t"
-        "v_add_u32 %[st], %[st], v44\n\t"
-        "v_lshl_or_b32 v40, v40, 16, %[p]\n\t"
+        "v_add_u32 v47, %[p], v40\n\t"
+        "v_add_u32 v48, %[st], v44\n\t"
+        "v_lshl_or_b32 v40, v40, 16, v47\n\t"
+        ESCBR
+        "v_mov_b32 %[p], v47\n\t"
+        "v_mov_b32 %[st], v48\n\t"
         STORE
         "v_cmp_lt_u32 vcc, 63, %[st]\n\t"
         "v_cndmask_b32_e64 v44, 0, 1, vcc\n\t"
@@ -97,7 +107,7 @@ __global__ void probe(unsigned *out, int steps)
         "s_mov_b64 exec, s[74:75]\n\t"
         : [p] "+v"(p), [st] "+v"(st), [k8] "+v"(k8), [lp] "+v"(lp), [ent] "+v"(ent), [n] "+s"(n)
         : [win] "s"(winaddr), [tab] "s"(tabaddr), [acsel] "v"(acsel), [dcsel] "v"(dcsel), [stopp] "v"(stopp), [lpmax] "v"(lpmax)
-        : "memory", "vcc", "scc", "v40", "v42", "v43", "v44", "v45", "v46", "s72", "s73", "s74", "s75");
+        : "memory", "vcc", "scc", "v40", "v42", "v43", "v44", "v45", "v46", "s72", "s73", "s74", "s75", "v47", "v48");
     const long long t1 = __builtin_readcyclecounter();
     if (threadIdx.x == 0)
         out[blockIdx.x * 2] = unsigned(t1 - t0);
