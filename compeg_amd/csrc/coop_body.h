@@ -7,31 +7,32 @@
 // wave takes only as many intervals as have 64 data units together (4 with DRI = 4) and spends its lanes inside
 // them:
 //
-//  1. Chase.  What is serial in an interval is only *where each data unit begins*: bit position, and the
-//     reference reader's `left` there (quirk Q1).  Lane 0 of an interval walks the symbols from the
-//     interval's start (lengths and zig-zag advances only, no values).  The other lanes start at word
-//     boundaries further into the interval ("subsequences") WITHOUT knowing the decoder state there: each
-//     assumes it is inside the AC part of data unit k of an MCU, one lane per k = 0..3, and walks on from
-//     that guess.  Huffman streams re-synchronise: after a few symbols a wrong start lands on a true symbol
-//     boundary, and from the next end-of-block on it walks the true sequence of data units (if its k was the
-//     right one).  Every lane lists the data-unit starts it passes (bit position, reference `left`, k).
+//  1. Walk.  What is serial in an interval is only *where each data unit begins*: bit position, and the size of
+//     the symbol in front of it (together they fix the reference reader's `left` at the DC code, quirk Q1).
+//     Lane 0 of an interval walks the symbols from the interval's start (sizes and zig-zag advances only, no
+//     values).  The other lanes start at word boundaries further into the interval ("subsequences") WITHOUT
+//     knowing the decoder state there: each assumes it is inside the AC part of data unit h of an MCU, one
+//     lane per h = 0..3, and walks on from that guess.  Huffman streams re-synchronise: after a few symbols a
+//     wrong start lands on a true symbol boundary, and from the next end-of-block on it walks the true sequence
+//     of data units (if its h was the right one).  Every lane lists the data-unit starts it passes.
 //  2. Validate.  A lane walks a little beyond the end of its subsequence.  If one of the data-unit starts it
-//     lists there equals -- same bit position, same `left`, same k -- an entry of a lane of the next
-//     subsequence, the two walks are identical from that point on (the state is the whole state), so the
-//     successor's list continues the predecessor's.  Following these links from lane 0, whose start state is
-//     known, yields the start state of every data unit of the interval.  A link that is missing (no
-//     synchronisation within the overlap) is not an error: the last validated lane simply walks on through
-//     the next subsequence, and validation runs again.  Nothing is ever assumed: a state is used only if the
-//     chain from the interval's start proves it.
+//     lists there equals -- same bit position, same size of the symbol in front, same index inside the MCU --
+//     an entry of a lane of the next subsequence, the two walks are identical from that point on (the state is
+//     the whole state), so the successor's list continues the predecessor's.  Following these links from lane
+//     0, whose start state is known, yields the start state of every data unit of the interval.  A link that is
+//     missing (no synchronisation within the overlap) is not an error: the last validated lane simply walks on
+//     through the next subsequence, and validation runs again.  Nothing is ever assumed: a state is used only
+//     if the chain from the interval's start proves it.
 //  3. Decode.  One lane per DATA UNIT: the proven fast-mode decoder of the fused kernel (fast_dc / fast_ac,
 //     exact path behind it) started at the data unit's state, coefficients into the lane's LDS slot, then DC
 //     prediction (a sum over the interval's earlier data units of the component), IDCT and composite with
 //     all 64 lanes busy.
 //
-// Quirk Q1 in this scheme: an underflow of the reference reader at a DC code depends on (bit position, size of
-// the previous symbol) only, so the chase sees it; behind it the reference reads zeros for the rest of the
-// interval, and those data units decode to a per-component constant that the host front-end computes with the
-// exact-path reader (ImageDesc::zero_du).  Anything else out of the ordinary (a walk that leaves the LDS
+// Quirk Q1 in this scheme: the walk follows the stream as if the reference's reader never ran dry.  The lane that
+// decodes a data unit whose DC code does underflow the reference reader finds that out (fast_dc refuses); behind
+// it the reference reads zeros for the rest of the interval, and those data units decode to a per-component
+// constant that the host front-end computes with the exact-path reader (ImageDesc::zero_du) -- whatever their
+// lanes decoded from the walk's states is dropped.  Anything else out of the ordinary (a walk that leaves the LDS
 // window on a corrupt stream, DC categories above 15 from a hostile table) sends the interval to one lane
 // running the interval-serial decoder the other kernels use.
 #pragma once
@@ -208,9 +209,10 @@ struct ChaseState {
 // the symbol does end a data unit (no branch around the store).
 //
 // On the GPU the loop is hand-written: it is where a small launch spends most of its time, and the compiler's
-// version of it carried twenty instructions of mask bookkeeping per symbol.  34 instructions per symbol; lanes
+// version of it carried twenty instructions of mask bookkeeping per symbol.  37 instructions per symbol; lanes
 // that are done leave through EXEC.  Codes longer than the direct tables' prefix are rare: when a lane meets one
-// the block hands the step to the C++ below (two-level tables) and is entered again at "apply".
+// the block is left with the symbol unapplied (an escape entry applies as a no-op), the C++ below resolves it
+// through the two-level tables, and the block is entered again at "apply".
 CG_DEV void chase_run(ChaseState &c, const ImageDesc &d, const HuffShared &s, const CoopTables &t, unsigned long &steps)
 {
     uint32_t p = c.p, st = c.s, k8 = c.k8;
