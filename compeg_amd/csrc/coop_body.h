@@ -90,23 +90,41 @@ struct CoopTables {
 struct CoopShared {
     HuffShared h;        // tables, window, the 64 data-unit slots
     uint32_t *lists;     // 64 x kCoopListCap state words: the same bytes as the slots (lists die before slots live)
-    uint32_t *du_state;  // [64] start state of every data unit of the wave
+    uint32_t *du_state;  // [64 x passes] start state of every data unit of the wave
     uint32_t *lane_n;    // [64] chasing lanes: entries listed | stop reason << 8
     uint32_t *link;      // [64] chasing lanes: 1 | successor lane << 8 | its entry << 16 | own entry << 24, or 0
-    uint32_t *seg;       // [16] this round's stretches of every interval's sequence (see coop_follow)
-    uint32_t *verdict;   // [16] per interval: kVerdict* | lane << 8 | data units settled << 16
-    uint32_t *nseg;      // [16] per interval: stretches in seg
-    uint32_t *dead_from; // [16] per interval: first data unit whose DC code underflows the reference reader
-    int32_t *diffs;      // [64] DC differences
+    uint32_t *seg;       // [64] this round's stretches of every interval's sequence (see coop_follow)
+    uint32_t *verdict;   // [64] per interval: kVerdict* | lane << 8 | data units settled << 16
+    uint32_t *nseg;      // [64] per interval: stretches in seg
+    uint32_t *dead_from; // [64] per interval: first data unit whose DC code underflows the reference reader
+    int32_t *diffs;      // [64] DC differences of the data units being decoded
     const float *quant;  // 3 rows of quantisers (workgroup-wide)
 };
-constexpr uint32_t kCoopMiscWords = 4 * 64 + 4 * 16; // du_state, lane_n, link, diffs; seg, verdict, nseg, dead_from
+
+CG_DEV void coop_bind_misc(CoopShared &cs, uint32_t *misc)
+{
+    cs.lane_n = misc;
+    cs.link = misc + 64;
+    cs.diffs = reinterpret_cast<int32_t *>(misc + 128);
+    cs.seg = misc + 192;
+    cs.verdict = misc + 256;
+    cs.nseg = misc + 320;
+    cs.dead_from = misc + 384;
+    cs.du_state = misc + 448;
+}
+constexpr uint32_t kCoopMaxPasses = 4;
+// a walk's bookkeeping words: lane_n, link, diffs, seg, verdict, nseg, dead_from (64 each), then du_state (64 per round)
+constexpr uint32_t coop_misc_words(uint32_t passes) { return 7u * 64u + passes * 64u; }
+constexpr uint32_t kCoopMiscWords = coop_misc_words(kCoopMaxPasses);
 
 constexpr uint32_t kVerdictDone = 1u, kVerdictContinue = 2u, kVerdictSerial = 3u;
 
 struct CoopGeom {
     uint32_t R, dpi, ipw;    // MCUs and data units per interval, intervals per wave (all powers of two)
     uint32_t dpi_shift;      // log2(dpi)
+    uint32_t passes;         // the walk covers this many rounds of 64 data units (1, 2 or 4)
+    uint32_t ipp;            // intervals per such round: 64 / dpi
+    uint32_t lpi, lpi_shift; // lanes that walk one interval: dpi / passes
     uint32_t count;          // subsequences per interval: 1 + the speculative ones (a power of two)
     uint32_t count_shift;
     uint32_t first_interval; // of this wave
@@ -121,14 +139,21 @@ CG_DEV uint32_t ilog2(uint32_t v)
     return r;
 }
 
-// spec_shift: experiment knob -- the number of subsequences is divided by 2^spec_shift (0: as many as lanes allow)
-CG_DEV void coop_geom(const ImageDesc &d, uint32_t wave_index, CoopGeom &g, uint32_t spec_shift = 0u)
+// passes: 1 -- a wave takes 64 data units' worth of intervals and every interval has as many lanes to walk it as it
+// has data units; 2 -- twice the intervals, half the lanes each, and the decode phases run twice (fewer waves on a
+// SIMD, each with more lanes walking).  spec_shift: the number of subsequences is divided by 2^spec_shift (0: as
+// many as the lanes allow; large: none, lane 0 walks the whole interval).
+CG_DEV void coop_geom(const ImageDesc &d, uint32_t wave_index, CoopGeom &g, uint32_t spec_shift = 0u, uint32_t passes = 1u)
 {
     g.R = d.restart_interval; // 1, 2, 4, 8 or 16 (ImageDesc::coop_ok)
     g.dpi = 4u * g.R;
     g.dpi_shift = ilog2(g.dpi);
-    g.ipw = uint32_t(kWave) >> g.dpi_shift;
-    g.count = 1u + (g.dpi - 1u) / 4u; // lane 0, then four lanes per speculative subsequence: 1, 2, 4, 8, 16
+    g.passes = passes >= 4u ? 4u : (passes >= 2u ? 2u : 1u); // (dpi >= 4: every interval keeps a lane to walk it)
+    g.ipp = uint32_t(kWave) >> g.dpi_shift;
+    g.ipw = g.ipp * g.passes;
+    g.lpi = g.dpi / g.passes;
+    g.lpi_shift = ilog2(g.lpi);
+    g.count = 1u + (g.lpi - 1u) / 4u; // lane 0, then four lanes per speculative subsequence: 1, 2, 4, 8, 16
     g.count = g.count >> spec_shift ? g.count >> spec_shift : 1u;
     g.count_shift = ilog2(g.count);
     g.first_interval = wave_index * g.ipw;
@@ -209,8 +234,7 @@ struct ChaseState {
 // the symbol does end a data unit (no branch around the store).
 //
 // On the GPU the loop is hand-written: it is where a small launch spends most of its time, and the compiler's
-// version of it carried twenty instructions of mask bookkeeping per symbol.  37 instructions per symbol; lanes
-// that are done leave through EXEC.  Codes longer than the direct tables' prefix are rare: when a lane meets one
+// version of it carried twenty instructions of mask bookkeeping per symbol.  Lanes that are done leave through EXEC.  Codes longer than the direct tables' prefix are rare: when a lane meets one
 // the block is left with the symbol unapplied (an escape entry applies as a no-op), the C++ below resolves it
 // through the two-level tables, and the block is entered again at "apply".
 CG_DEV void chase_run(ChaseState &c, const ImageDesc &d, const HuffShared &s, const CoopTables &t, unsigned long &steps)
@@ -219,84 +243,95 @@ CG_DEV void chase_run(ChaseState &c, const ImageDesc &d, const HuffShared &s, co
     uint32_t *lp = c.lp;
     (void)steps;
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(CG_COOP_NO_ASM)
-    uint32_t alive = c.active ? 1u : 0u, ent = 0u, cur = 0u, resume = 0u, code = 0u;
-    uint32_t lpa = uint32_t(reinterpret_cast<uintptr_t>(lp));
+    uint32_t alive = c.active ? 1u : 0u, code = 0u;
+    const uint32_t lpa0 = uint32_t(reinterpret_cast<uintptr_t>(lp)), k8_0 = k8;
+    uint32_t lpa = lpa0;
     const uint32_t lpmax = uint32_t(reinterpret_cast<uintptr_t>(c.lp_max));
     const uint32_t win = uint32_t(reinterpret_cast<uintptr_t>(s.win)), tab = uint32_t(reinterpret_cast<uintptr_t>(t.ac_fast));
     const uint32_t acsel = t.acsel, dcsel = t.dcsel; // (vector copies: one scalar operand per instruction)
+    const uint32_t dcsel_next = (dcsel >> 8) | (dcsel << 24); // byte k: the DC table of data unit k + 1
+    // The reader: three stream words A B C in registers (A holds the position, of which 32 - sn bits are consumed,
+    // 1..32 of them), reloaded from LDS every symbol -- but for the *next* symbol, so that no window read sits between
+    // one symbol's table entry and the next one's table address.  A symbol is at most 31 bits: the next position lies
+    // in {A B} or in {B C}, both are taken and one is kept.
+    const uint32_t wi1 = (p + 31u) >> 5; // (the word in front of an aligned position is never looked at: sn = 0)
+    uint32_t wa = win + 4u * wi1 - 4u, sn = 32u * wi1 - p;
+    const uint32_t kc = k8 - 2u * lpa0; // 2 lp + kc = 8 x the data unit's index, modulo 32
+    // the first symbol's entry, looked up here
+    auto lookup = [&](uint32_t p_, uint32_t st_, uint32_t k8_) {
+        const uint32_t *wp = s.win + (p_ >> 5);
+        const uint32_t cur = uint32_t(((uint64_t(wp[0]) << 32 | wp[1]) << (p_ & 31u)) >> 32);
+        const bool dc = st_ == 0u;
+        const uint32_t kib = ((dc ? dcsel : acsel) >> (k8_ & 31u)) & 0xffu;
+        return uint32_t((t.ac_fast + kib * 512u)[cur >> (dc ? 32u - kDcFastBits : 32u - kFastBits)]);
+    };
+    uint32_t ent = c.active ? lookup(p, st, k8) : 0u;
     if (__builtin_amdgcn_ballot_w64(alive != 0u) != 0u)
         for (;;) {
-            // Software-pipelined: the masks of "this lane is done" and "this lane met a long code" are computed
-            // by vector compares, but taking them to EXEC and to a branch is scalar work, and a scalar instruction
-            // right behind the compare it depends on stalls for some forty cycles.  The next symbol's lookup --
-            // which depends on neither mask -- sits between the two.  An escape entry applied like a symbol
-            // changes nothing (device_types.h), so its lane may run through "apply" before anybody looks.
+            // 33 vector instructions per symbol, 15 of them between a table entry's arrival and the next lookup's
+            // issue; the rest (the list, the tables of the coming data unit, the reload, who is done) runs while that
+            // lookup is in flight.  Masks go to the scalar side only at the end of the body, well behind the
+            // compares that made them.  An escape entry (a code longer than the direct tables' prefix) applies as a
+            // no-op (device_types.h): its lane runs through the body once, then everybody leaves, the C++ below
+            // resolves the code through the two-level tables, and the block is entered again.
             asm volatile(
                 "s_mov_b64 s[74:75], exec\n\t"
                 "v_cmp_ne_u32 vcc, 0, %[alive]\n\t"
                 "s_and_b64 exec, exec, vcc\n\t"
                 "s_cbranch_execz 4f\n\t"
-                "s_cmp_lg_u32 %[resume], 0\n\t"
-                "s_cbranch_scc1 1f\n\t"
-                // ---- first lookup
-                "v_lshrrev_b32 v40, 5, %[p]\n\t"
-                "v_lshl_add_u32 v40, v40, 2, %[win]\n\t"
-                "ds_read2_b32 v[42:43], v40 offset0:1 offset1:0\n\t"
-                "v_and_b32 v44, 31, %[p]\n\t"
-                "v_cmp_eq_u32 vcc, 0, %[st]\n\t"
-                "v_cndmask_b32 v46, %[acsel], %[dcsel], vcc\n\t"
-                "v_bfe_u32 v46, v46, %[k8], 8\n\t"
-                "v_cndmask_b32_e64 v45, 21, 23, vcc\n\t"
-                "v_lshl_add_u32 v46, v46, 10, %[tab]\n\t"
-                "s_waitcnt lgkmcnt(0)\n\t"
-                "v_lshlrev_b64 v[42:43], v44, v[42:43]\n\t"
-                "v_lshrrev_b32 v45, v45, v43\n\t"
-                "v_lshl_add_u32 v46, v45, 1, v46\n\t"
-                "ds_read_u16 %[ent], v46\n"
+                "ds_read2_b32 v[42:43], %[wa] offset1:1\n\t"          // A, B
+                "ds_read_b32 v47, %[wa] offset:8\n\t"                 // C
+                "v_lshl_add_u32 v44, %[lp], 1, %[kc]\n\t"
+                "v_bfe_u32 v48, %[acsel], v44, 8\n\t"
+                "v_bfe_u32 v49, %[dcseln], v44, 8\n\t"
+                "v_lshl_add_u32 v48, v48, 10, %[tab]\n\t"             // the AC table of this data unit
+                "v_lshl_add_u32 v49, v49, 10, %[tab]\n"                // the DC table of the next one
                 "1:\n\t"
                 "s_waitcnt lgkmcnt(0)\n\t"
-                // ---- apply the symbol: advance, note the state behind it, end of data unit?
+                // ---- from the entry to the next lookup
                 "v_bfe_u32 v40, %[ent], 4, 5\n\t"                     // size
                 "v_lshrrev_b32 v44, 9, %[ent]\n\t"                    // zig-zag advance
-                "v_add_u32 %[p], %[p], v40\n\t"
-                "v_add_u32 %[st], %[st], v44\n\t"
-                "v_lshl_or_b32 v40, v40, 16, %[p]\n\t"
-                "ds_write_b32 %[lp], v40\n\t"
-                "v_cmp_lt_u32 vcc, 63, %[st]\n\t"                     // the data unit is complete
-                "v_cndmask_b32_e64 v44, 0, 1, vcc\n\t"
-                "v_lshl_add_u32 %[lp], v44, 2, %[lp]\n\t"
-                "v_lshl_add_u32 %[k8], v44, 3, %[k8]\n\t"
-                "v_cndmask_b32_e64 v45, 0, %[p], vcc\n\t"             // its end position, or 0 inside a data unit
-                "v_cndmask_b32_e64 %[st], %[st], 0, vcc\n\t"
                 "v_cmp_eq_u32 s[76:77], 15, %[ent]\n\t"               // kFastEscape: lanes that met a long code
-                "v_cmp_ge_u32 s[72:73], %[lp], %[lpmax]\n\t"
-                "v_cndmask_b32_e64 v46, %[stopp], 1, s[72:73]\n\t"    // where the walk ends: nowhere further if the list is full
-                "v_cmp_ge_u32 s[72:73], v45, v46\n\t"                 // lanes whose walk ends here
-                // ---- the next symbol's lookup
-                "v_lshrrev_b32 v40, 5, %[p]\n\t"
-                "v_lshl_add_u32 v40, v40, 2, %[win]\n\t"
-                "ds_read2_b32 v[42:43], v40 offset0:1 offset1:0\n\t" // v43 = word at p, v42 = the next one
-                "v_and_b32 v44, 31, %[p]\n\t"
-                "v_cmp_eq_u32 vcc, 0, %[st]\n\t"                      // a DC code comes next
-                "v_cndmask_b32 v46, %[acsel], %[dcsel], vcc\n\t"
-                "v_bfe_u32 v46, v46, %[k8], 8\n\t"                    // the table's offset in KiB
-                "v_cndmask_b32_e64 v45, 21, 23, vcc\n\t"              // 32 - index bits
-                "v_lshl_add_u32 v46, v46, 10, %[tab]\n\t"
-                "s_waitcnt lgkmcnt(0)\n\t"
-                "v_lshlrev_b64 v[42:43], v44, v[42:43]\n\t"           // v43 = the next 32 stream bits
-                "v_lshrrev_b32 v45, v45, v43\n\t"
+                "v_sub_u32 %[sn], %[sn], v40\n\t"                     // (negative: the position has left A)
+                "v_add_u32 %[st], %[st], v44\n\t"
+                "v_alignbit_b32 v41, v42, v43, %[sn]\n\t"             // (the shift is taken modulo 32)
+                "v_alignbit_b32 v45, v43, v47, %[sn]\n\t"
+                "v_cmp_gt_i32 vcc, 0, %[sn]\n\t"
+                "v_cmp_lt_u32 s[72:73], 63, %[st]\n\t"                // the data unit is complete: a DC code comes next
+                "v_cndmask_b32 v41, v41, v45, vcc\n\t"                // the next 32 stream bits
+                "v_cndmask_b32_e64 v46, v48, v49, s[72:73]\n\t"
+                "v_cndmask_b32_e64 v45, 21, 23, s[72:73]\n\t"         // 32 - index bits
+                "v_lshrrev_b32 v45, v45, v41\n\t"
                 "v_lshl_add_u32 v46, v45, 1, v46\n\t"
                 "ds_read_u16 %[ent], v46\n\t"
-                // ---- who goes on
+                // ---- under that read: the list, the coming data unit's tables, the reload, who goes on
+                "v_add_u32 %[p], %[p], v40\n\t"
+                "v_lshl_or_b32 v40, v40, 16, %[p]\n\t"
+                "ds_write_b32 %[lp], v40\n\t"                         // (stays when the data unit ends here)
+                "v_cndmask_b32_e64 v44, 0, 4, s[72:73]\n\t"
+                "v_add_u32 %[lp], %[lp], v44\n\t"
+                "v_cndmask_b32_e64 %[st], %[st], 0, s[72:73]\n\t"
+                "v_cndmask_b32_e64 v44, 0, 4, vcc\n\t"
+                "v_add_u32 %[wa], %[wa], v44\n\t"
+                "v_and_b32 %[sn], 31, %[sn]\n\t"
+                "ds_read2_b32 v[42:43], %[wa] offset1:1\n\t"
+                "ds_read_b32 v47, %[wa] offset:8\n\t"
+                "v_lshl_add_u32 v44, %[lp], 1, %[kc]\n\t"
+                "v_bfe_u32 v48, %[acsel], v44, 8\n\t"
+                "v_bfe_u32 v49, %[dcseln], v44, 8\n\t"
+                "v_lshl_add_u32 v48, v48, 10, %[tab]\n\t"
+                "v_lshl_add_u32 v49, v49, 10, %[tab]\n\t"
+                "v_cmp_ge_u32 s[78:79], %[p], %[stopp]\n\t"
+                "v_cmp_ge_u32 s[80:81], %[lp], %[lpmax]\n\t"          // the list is full
+                "s_or_b64 s[78:79], s[78:79], s[80:81]\n\t"
+                "s_and_b64 s[72:73], s[72:73], s[78:79]\n\t"          // lanes whose walk ends here
                 "s_andn2_b64 exec, exec, s[72:73]\n\t"
                 "s_and_b64 s[76:77], s[76:77], exec\n\t"              // (sets SCC: some walking lane met a long code)
                 "s_cbranch_scc1 3f\n\t"
                 "s_cbranch_execnz 1b\n\t"
                 "s_mov_b32 %[code], 0\n\t"
                 "s_branch 5f\n"
-                "3:\n\t" // ---- out, with the bits the lanes looked at: the long codes go through the two-level tables
-                "s_waitcnt lgkmcnt(0)\n\t"
-                "v_mov_b32 %[cur], v43\n\t"
+                "3:\n\t" // ---- out: the long codes go through the two-level tables
                 "s_mov_b32 %[code], 1\n\t"
                 "s_branch 5f\n"
                 "4:\n\t"
@@ -306,16 +341,19 @@ CG_DEV void chase_run(ChaseState &c, const ImageDesc &d, const HuffShared &s, co
                 "s_mov_b64 s[72:73], exec\n\t"                        // lanes still walking
                 "s_mov_b64 exec, s[74:75]\n\t"
                 "v_cndmask_b32_e64 %[alive], 0, 1, s[72:73]\n\t"
-                : [p] "+v"(p), [st] "+v"(st), [k8] "+v"(k8), [lp] "+v"(lpa), [ent] "+v"(ent), [cur] "+v"(cur),
+                : [p] "+v"(p), [st] "+v"(st), [lp] "+v"(lpa), [ent] "+v"(ent), [sn] "+v"(sn), [wa] "+v"(wa),
                   [alive] "+v"(alive), [code] "=s"(code)
-                : [resume] "s"(resume), [win] "s"(win), [tab] "s"(tab), [acsel] "v"(acsel), [dcsel] "v"(dcsel),
+                : [tab] "s"(tab), [acsel] "v"(acsel), [dcseln] "v"(dcsel_next), [kc] "v"(kc),
                   [stopp] "v"(c.stop_p), [lpmax] "v"(lpmax)
-                : "memory", "vcc", "scc", "v40", "v42", "v43", "v44", "v45", "v46", "s72", "s73", "s74", "s75", "s76", "s77");
+                : "memory", "vcc", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49",
+                  "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81");
             if (code == 0u)
                 break;
             if (alive != 0u && ent == kFastEscape) {
                 // longer than the direct table's prefix: through the reference's two-level tables
-                const uint32_t comp = comp_of_k((k8 >> 3) & 3u);
+                const uint32_t *wp = s.win + (p >> 5);
+                const uint32_t cur = uint32_t(((uint64_t(wp[0]) << 32 | wp[1]) << (p & 31u)) >> 32);
+                const uint32_t comp = comp_of_k(((k8_0 + 2u * (lpa - lpa0)) >> 3) & 3u);
                 if (st == 0u) {
                     const uint32_t e2 = lut_lookup<true>(d, s, sel3(comp, t.dc_off[0], t.dc_off[1], t.dc_off[2]), cur);
                     const uint32_t len = e2 >> 8, cat = e2 & 0xffu;
@@ -327,8 +365,8 @@ CG_DEV void chase_run(ChaseState &c, const ImageDesc &d, const HuffShared &s, co
                     ent = fast_entry(lut_lookup<true>(d, s, sel3(comp, t.ac_off[0], t.ac_off[1], t.ac_off[2]), cur), t.zrl);
                 }
             }
-            resume = 1u;
         }
+    k8 = k8_0 + 2u * (lpa - lpa0);
     lp = c.lp + (lpa - uint32_t(reinterpret_cast<uintptr_t>(c.lp))) / 4u;
 #else
     if (c.active)
@@ -559,7 +597,7 @@ CG_DEV void coop_follow(const CoopShared &cs, const CoopGeom &g, uint32_t il, ui
                 fprintf(stderr, "fail il %u lane %u n %u du %u :", il, x, n, du);
                 for (uint32_t i = n > 4 ? n - 4 : 0; i < n; i++)
                     fprintf(stderr, " %u/%u", cs.lists[x * kCoopListCap + i] & 0xffffu, (cs.lists[x * kCoopListCap + i] >> 16) & 31u);
-                const uint32_t lane0 = (x >> g.dpi_shift) << g.dpi_shift;
+                const uint32_t lane0 = (x >> g.lpi_shift) << g.lpi_shift;
                 const uint32_t j = x == lane0 ? 0u : 1u + (x - lane0 - 1u) / 4u;
                 for (uint32_t h = 0; h < 4u && j + 1u < g.count; h++) {
                     const uint32_t o = lane0 + coop_spec_lane(j + 1u, h);
@@ -581,8 +619,9 @@ CG_DEV void coop_follow(const CoopShared &cs, const CoopGeom &g, uint32_t il, ui
     cs.verdict[il] = v;
 }
 
-// Every lane fetches the start state of its own data unit, if this round's stretches hold it.
-CG_DEV void coop_emit(const CoopShared &cs, const CoopGeom &g, uint32_t il, uint32_t tl, uint32_t lane)
+// Every lane fetches the start state of its own data unit(s), if this round's stretches hold it: data unit tl of
+// interval il of the wave, state word `slot`.
+CG_DEV void coop_emit(const CoopShared &cs, const CoopGeom &g, uint32_t il, uint32_t tl, uint32_t slot)
 {
     const uint32_t nseg = cs.nseg[il];
     const uint32_t *seg = cs.seg + il * g.count;
@@ -590,7 +629,7 @@ CG_DEV void coop_emit(const CoopShared &cs, const CoopGeom &g, uint32_t il, uint
         const uint32_t sg = seg[i];
         const uint32_t x = sg & 63u, from = (sg >> 6) & 31u, cnt = (sg >> 11) & 31u, du0 = sg >> 16;
         if (tl >= du0 && tl - du0 < cnt)
-            cs.du_state[lane] = cs.lists[x * kCoopListCap + from + (tl - du0)] & kCoopStateMask;
+            cs.du_state[slot] = cs.lists[x * kCoopListCap + from + (tl - du0)] & kCoopStateMask;
     }
 }
 
@@ -798,9 +837,9 @@ struct CoopLane {
 CG_DEV void coop_lane(const ImageDesc &d, const HuffShared &s, const CoopGeom &g, uint32_t lane, CoopLane &L)
 {
     L.lane = lane;
-    L.il = lane >> g.dpi_shift;
-    L.tl = lane & (g.dpi - 1u);
-    L.lane0 = L.il << g.dpi_shift;
+    L.il = lane >> g.lpi_shift;
+    L.tl = lane & (g.lpi - 1u);
+    L.lane0 = L.il << g.lpi_shift;
     L.exists = L.il < g.intervals;
     const uint32_t interval = g.first_interval + (L.exists ? L.il : 0u);
     const uint32_t ws = interval < d.nstarts ? CG_GLOBAL(const uint32_t, d.starts)[interval] : 0u;
@@ -810,8 +849,39 @@ CG_DEV void coop_lane(const ImageDesc &d, const HuffShared &s, const CoopGeom &g
     L.len_words = we > ws ? umin(we - ws, kCoopMaxWindow) : 0u;
 }
 
+// diagnostic builds (-DCG_COOP_STAMPS): cycles per phase of every wave, parked in the (otherwise unused) dc buffer
+struct CoopClock {
 #if defined(CG_COOP_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
-#define CG_COOP_STAMP(i) do { const uint64_t now_ = __builtin_readcyclecounter(); stamp_[i] += now_ - tprev_; tprev_ = now_; } while (0)
+    uint64_t tprev, stamp[8], wall0;
+#endif
+};
+CG_DEV void coop_clock_start(CoopClock &clk)
+{
+#if defined(CG_COOP_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+    clk.tprev = __builtin_readcyclecounter();
+    clk.wall0 = wall_clock64(); // (100 MHz: when this wave got going, and below when it was done, on the device's clock)
+    for (int i = 0; i < 8; i++)
+        clk.stamp[i] = 0;
+#else
+    (void)clk;
+#endif
+}
+CG_DEV void coop_clock_store(const CoopClock &clk, const ImageDesc &d, uint32_t wave_index, uint32_t lane)
+{
+#if defined(CG_COOP_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+    if (lane == 0u && d.dc) {
+        uint64_t *o = reinterpret_cast<uint64_t *>(d.dc) + size_t(wave_index) * 16u;
+        for (int i = 0; i < 8; i++)
+            o[i] = clk.stamp[i];
+        o[8] = clk.wall0;
+        o[9] = wall_clock64();
+    }
+#else
+    (void)clk, (void)d, (void)wave_index, (void)lane;
+#endif
+}
+#if defined(CG_COOP_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+#define CG_COOP_STAMP(i) do { const uint64_t now_ = __builtin_readcyclecounter(); clk.stamp[i] += now_ - clk.tprev; clk.tprev = now_; } while (0)
 #else
 #define CG_COOP_STAMP(i) do { } while (0)
 #endif
@@ -829,30 +899,29 @@ CG_DEV bool coop_any(const bool (&flag)[LANES])
 #endif
 }
 
-// 64 data units' worth of restart intervals (CoopGeom), from bitstream to pixels.
+#define CG_EACH_LANE for (int li = 0; li < LANES; li++)
+
+// Phases 1 and 2 for the intervals of one walk (CoopGeom): the start state of every data unit into cs.du_state,
+// how every interval stands into cs.verdict.
 template <int LANES>
-CG_DEV void coop_wave_422(const ImageDesc &d, const CoopShared &cs, const CoopTables &t, const CoopGeom &g,
-                          uint32_t my_lane, uint32_t wave_index)
+CG_DEV void coop_walk_422(const ImageDesc &d, const CoopShared &cs, const CoopTables &t, const CoopGeom &g,
+                          uint32_t my_lane, uint32_t wave_index, CoopClock &clk)
 {
     const HuffShared &s = cs.h;
     CoopLane L[LANES];
     ChaseState c[LANES];
     bool active[LANES];
-#if defined(CG_COOP_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
-    uint64_t tprev_ = __builtin_readcyclecounter(), stamp_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
     (void)wave_index;
-#define CG_EACH_LANE for (int li = 0; li < LANES; li++)
+    (void)clk;
     CG_EACH_LANE
     {
         coop_lane(d, s, g, LANES == 1 ? my_lane : uint32_t(li), L[li]);
         const uint32_t lane = L[li].lane;
-        cs.du_state[lane] = kCoopUnset;
-        if (lane < 16u) {
-            cs.verdict[lane] = 0u;
-            cs.nseg[lane] = 0u;
-            cs.dead_from[lane] = 0xffffu;
-        }
+        for (uint32_t pass = 0; pass < g.passes; pass++)
+            cs.du_state[pass * uint32_t(kWave) + lane] = kCoopUnset;
+        cs.verdict[lane] = 0u;
+        cs.nseg[lane] = 0u;
+        cs.dead_from[lane] = 0xffffu;
         chase_assign(c[li], s, g, L[li].tl, L[li].start_rel, L[li].len_words, L[li].exists, cs.lists + lane * kCoopListCap);
         active[li] = c[li].active;
     }
@@ -912,8 +981,11 @@ CG_DEV void coop_wave_422(const ImageDesc &d, const CoopShared &cs, const CoopTa
         CG_WAVE_SYNC();
         CG_EACH_LANE
         {
-            if (L[li].exists)
-                coop_emit(cs, g, L[li].il, L[li].tl, L[li].lane);
+            for (uint32_t pass = 0; pass < g.passes; pass++) {
+                const uint32_t il_d = pass * g.ipp + (L[li].lane >> g.dpi_shift);
+                if (il_d < g.intervals)
+                    coop_emit(cs, g, il_d, L[li].lane & (g.dpi - 1u), pass * uint32_t(kWave) + L[li].lane);
+            }
         }
         CG_WAVE_SYNC();
         CG_EACH_LANE
@@ -931,16 +1003,35 @@ CG_DEV void coop_wave_422(const ImageDesc &d, const CoopShared &cs, const CoopTa
         CG_COOP_STAMP(2);
     }
 
-    // ---- 3: one lane per data unit ----
+}
+
+// Phase 3 for 64 data units of a walk: round `pass` of them -- one lane per data unit, from its start state to pixels.
+// cs.h.du_slots / cs.diffs: this wave's; cs.du_state / verdict / dead_from: the walk's.
+template <int LANES>
+CG_DEV void coop_decode_pass_422(const ImageDesc &d, const CoopShared &cs, const CoopTables &t, const CoopGeom &g,
+                                 uint32_t my_lane, uint32_t wave_index, uint32_t pass, CoopClock &clk)
+{
+    const HuffShared &s = cs.h;
+    struct { uint32_t lane; } L[LANES];
+    CG_EACH_LANE L[li].lane = LANES == 1 ? my_lane : uint32_t(li);
+    (void)wave_index;
+    (void)clk;
+    if (pass * g.ipp >= g.intervals)
+        return;
+    // this round's lane -> data unit: interval D_il of the walk, data unit D_tl of it
+#define D_il(li) (pass * g.ipp + (L[li].lane >> g.dpi_shift))
+#define D_tl(li) (L[li].lane & (g.dpi - 1u))
+#define D_lane0(li) ((L[li].lane >> g.dpi_shift) << g.dpi_shift)
+#define D_exists(li) (D_il(li) < g.intervals)
     uint32_t state[LANES];
     int32_t dc[LANES];
     CG_EACH_LANE
     {
         uint32_t st = kCoopUnset;
-        if (L[li].exists) {
-            st = cs.du_state[L[li].lane];
+        if (D_exists(li)) {
+            st = cs.du_state[pass * uint32_t(kWave) + L[li].lane];
             // (an interval still waiting for a walk after the last round goes the same way as one given up on)
-            if ((cs.verdict[L[li].il] & 0xffu) != kVerdictDone || (st & kCoopUnset))
+            if ((cs.verdict[D_il(li)] & 0xffu) != kVerdictDone || (st & kCoopUnset))
                 st = kCoopSerial;
         }
         state[li] = st;
@@ -953,16 +1044,16 @@ CG_DEV void coop_wave_422(const ImageDesc &d, const CoopShared &cs, const CoopTa
     {
         const uint32_t lane = L[li].lane;
         bool hostile = false;
-        const int32_t diff = coop_decode_du(d, s, t, state[li], comp_of_k(L[li].tl & 3u),
+        const int32_t diff = coop_decode_du(d, s, t, state[li], comp_of_k(D_tl(li) & 3u),
                                             reinterpret_cast<int16_t *>(s.du_slots + lane * kDuSlotBytes), under[li], hostile);
         cs.diffs[lane] = diff;
         if (hostile)
-            cs.verdict[L[li].il] = kVerdictSerial; // (every lane that says so says the same)
+            cs.verdict[D_il(li)] = kVerdictSerial; // (every lane that says so says the same)
         if (under[li]) {
 #if defined(__HIP_DEVICE_COMPILE__)
-            atomicMin(&cs.dead_from[L[li].il], L[li].tl);
+            atomicMin(&cs.dead_from[D_il(li)], D_tl(li));
 #else
-            cs.dead_from[L[li].il] = umin(cs.dead_from[L[li].il], L[li].tl);
+            cs.dead_from[D_il(li)] = umin(cs.dead_from[D_il(li)], D_tl(li));
 #endif
         }
     }
@@ -971,7 +1062,7 @@ CG_DEV void coop_wave_422(const ImageDesc &d, const CoopShared &cs, const CoopTa
     CG_EACH_LANE
     {
         // an interval that turned out to need the serial decoder after all: what its lanes decoded is dropped
-        if (L[li].exists && !(state[li] & (kCoopSerial | kCoopUnset)) && (cs.verdict[L[li].il] & 0xffu) == kVerdictSerial) {
+        if (D_exists(li) && !(state[li] & (kCoopSerial | kCoopUnset)) && (cs.verdict[D_il(li)] & 0xffu) == kVerdictSerial) {
             state[li] = kCoopSerial;
             under[li] = false;
             zero_slot(s.du_slots + L[li].lane * kDuSlotBytes);
@@ -983,14 +1074,14 @@ CG_DEV void coop_wave_422(const ImageDesc &d, const CoopShared &cs, const CoopTa
         // from zeros -- whatever those lanes have decoded from the walk's states is replaced
         CG_EACH_LANE
         {
-            if (!L[li].exists || (state[li] & (kCoopSerial | kCoopUnset)))
+            if (!D_exists(li) || (state[li] & (kCoopSerial | kCoopUnset)))
                 continue;
-            const uint32_t first_dead = cs.dead_from[L[li].il];
-            if (LANES != 1 && L[li].tl == first_dead)
+            const uint32_t first_dead = cs.dead_from[D_il(li)];
+            if (LANES != 1 && D_tl(li) == first_dead)
                 CG_COOP_COUNT(dead, 1);
-            if (L[li].tl <= first_dead)
+            if (D_tl(li) <= first_dead)
                 continue;
-            const uint32_t comp = comp_of_k(L[li].tl & 3u);
+            const uint32_t comp = comp_of_k(D_tl(li) & 3u);
             uint8_t *slot = s.du_slots + L[li].lane * kDuSlotBytes;
             zero_slot(slot);
             copy_zero_levels(d, comp, reinterpret_cast<int16_t *>(slot));
@@ -1003,8 +1094,8 @@ CG_DEV void coop_wave_422(const ImageDesc &d, const CoopShared &cs, const CoopTa
     }
     CG_EACH_LANE
     {
-        if ((state[li] & kCoopSerial) && L[li].tl == 0u) {
-            coop_decode_serial(d, s, g.first_interval + L[li].il, g.dpi, s.du_slots + L[li].lane * kDuSlotBytes,
+        if ((state[li] & kCoopSerial) && D_tl(li) == 0u) {
+            coop_decode_serial(d, s, g.first_interval + D_il(li), g.dpi, s.du_slots + L[li].lane * kDuSlotBytes,
                                cs.diffs + L[li].lane);
             if (LANES != 1)
                 CG_COOP_COUNT(serial, 1);
@@ -1015,9 +1106,9 @@ CG_DEV void coop_wave_422(const ImageDesc &d, const CoopShared &cs, const CoopTa
 #if defined(CG_EMUL_STATS)
     if (getenv("EMUL_COOP_DEBUG")) {
         CG_EACH_LANE
-            if (L[li].exists)
+            if (D_exists(li))
                 fprintf(stderr, "dbg wave %u lane %u il %u tl %u state %08x verdict %08x dead_from %u diff %d under %d\n", wave_index,
-                        L[li].lane, L[li].il, L[li].tl, state[li], cs.verdict[L[li].il], cs.dead_from[L[li].il], cs.diffs[L[li].lane], int(under[li]));
+                        L[li].lane, D_il(li), D_tl(li), state[li], cs.verdict[D_il(li)], cs.dead_from[D_il(li)], cs.diffs[L[li].lane], int(under[li]));
     }
 #endif
     uint32_t px[LANES][16];
@@ -1026,10 +1117,10 @@ CG_DEV void coop_wave_422(const ImageDesc &d, const CoopShared &cs, const CoopTa
         const uint32_t lane = L[li].lane;
         if (state[li] & kCoopUnset)
             continue;
-        dc[li] = (state[li] & kCoopSerial) ? cs.diffs[lane] : coop_dc_term(t, cs.diffs + L[li].lane0, L[li].tl);
+        dc[li] = (state[li] & kCoopSerial) ? cs.diffs[lane] : coop_dc_term(t, cs.diffs + D_lane0(li), D_tl(li));
         uint32_t rec[kRetained / 2];
         read_slot(s.du_slots + lane * kDuSlotBytes, rec);
-        idct_data_unit(rec, dc[li], cs.quant + comp_of_k(L[li].tl & 3u) * kCoopQuantStride, px[li]);
+        idct_data_unit(rec, dc[li], cs.quant + comp_of_k(D_tl(li) & 3u) * kCoopQuantStride, px[li]);
     }
     CG_WAVE_SYNC(); // every slot has been read: the area now holds the samples, kPxSlotWords apart
     CG_COOP_STAMP(5);
@@ -1043,16 +1134,29 @@ CG_DEV void coop_wave_422(const ImageDesc &d, const CoopShared &cs, const CoopTa
             reinterpret_cast<slot_word_t *>(samples)[L[li].lane * kPxSlotWords + w] = px[li][w];
     }
     CG_WAVE_SYNC();
-    CG_EACH_LANE coop_composite(d, samples, g.first_interval * g.R, g.intervals * g.R, L[li].lane);
+    CG_EACH_LANE coop_composite(d, samples, (g.first_interval + pass * g.ipp) * g.R,
+                                umin(g.intervals - pass * g.ipp, g.ipp) * g.R, L[li].lane);
+    CG_WAVE_SYNC(); // (the samples have been read: the area serves the next round's data units)
     CG_COOP_STAMP(6);
-#if defined(CG_COOP_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
-    if (my_lane == 0u && d.dc) { // diagnostic build only: per-wave phase cycles into the (otherwise unused) dc buffer
-        uint64_t *o = reinterpret_cast<uint64_t *>(d.dc) + size_t(wave_index) * 8u;
-        for (int i = 0; i < 8; i++)
-            o[i] = stamp_[i];
-    }
-#endif
-#undef CG_EACH_LANE
+#undef D_il
+#undef D_tl
+#undef D_lane0
+#undef D_exists
 }
+
+// One wave does it all: the walk, then its rounds of 64 data units one after the other.
+template <int LANES>
+CG_DEV void coop_wave_422(const ImageDesc &d, const CoopShared &cs, const CoopTables &t, const CoopGeom &g,
+                          uint32_t my_lane, uint32_t wave_index)
+{
+    CoopClock clk;
+    coop_clock_start(clk);
+    coop_walk_422<LANES>(d, cs, t, g, my_lane, wave_index, clk);
+    for (uint32_t pass = 0; pass < g.passes; pass++)
+        coop_decode_pass_422<LANES>(d, cs, t, g, my_lane, wave_index, pass, clk);
+    coop_clock_store(clk, d, wave_index, my_lane);
+}
+
+#undef CG_EACH_LANE
 
 } // namespace compeg

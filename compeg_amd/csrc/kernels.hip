@@ -275,29 +275,28 @@ decode_pair_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, 
 // A wave takes as many consecutive intervals as have 64 data units together and splits their bitstreams
 // among its lanes; a workgroup is a handful of such waves sharing one copy of the tables.
 // LDS: [L1][L2 + direct AC + direct DC tables][quantisers 3 x 36 f32][per wave: window | 64 slots | bookkeeping]
-constexpr uint32_t kCoopWaveMisc = kCoopMiscWords * 4u;
-
-__device__ __forceinline__ uint32_t coop_wave_area(uint32_t window_words)
+__host__ __device__ __forceinline__ uint32_t coop_wave_area(uint32_t window_words, uint32_t passes)
 {
-    return align16(window_words * 4u) + kWave * kDuSlotBytes + kCoopWaveMisc;
+    return ((window_words * 4u + 15u) & ~15u) + kWave * kDuSlotBytes + coop_misc_words(passes) * 4u;
 }
 
 __global__ void __launch_bounds__(512)
-decode_coop_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words, uint32_t spec_shift)
+decode_coop_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words, uint32_t spec_shift,
+                       uint32_t passes)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const ImageDesc &d = descs[blockIdx.y];
     const uint32_t waves = blockDim.x / kWave;
     const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x / kWave))), lane = threadIdx.x % kWave;
     CoopGeom g;
-    coop_geom(d, blockIdx.x * waves + wave, g, spec_shift);
+    coop_geom(d, blockIdx.x * waves + wave, g, spec_shift, passes);
     if (blockIdx.x * waves * g.ipw >= d.total_intervals)
         return; // the whole workgroup
 
     uint16_t *l1 = reinterpret_cast<uint16_t *>(smem);
     uint16_t *l2 = l1 + kL1Entries;
     float *quant = reinterpret_cast<float *>(smem + align16((kL1Entries + l2_in_lds) * 2u));
-    uint8_t *wave_base = reinterpret_cast<uint8_t *>(quant + 3u * kCoopQuantStride) + wave * coop_wave_area(window_words);
+    uint8_t *wave_base = reinterpret_cast<uint8_t *>(quant + 3u * kCoopQuantStride) + wave * coop_wave_area(window_words, passes);
     uint32_t *win = reinterpret_cast<uint32_t *>(wave_base);
     uint8_t *slots = wave_base + align16(window_words * 4u);
     uint32_t *misc = reinterpret_cast<uint32_t *>(slots + kWave * kDuSlotBytes);
@@ -322,14 +321,7 @@ decode_coop_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, 
     cs.h.win_len = win_len;
     cs.h.du_slots = slots;
     cs.lists = reinterpret_cast<uint32_t *>(slots);
-    cs.du_state = misc;
-    cs.lane_n = misc + 64;
-    cs.link = misc + 128;
-    cs.diffs = reinterpret_cast<int32_t *>(misc + 192);
-    cs.seg = misc + 256;
-    cs.verdict = misc + 272;
-    cs.nseg = misc + 288;
-    cs.dead_from = misc + 304;
+    coop_bind_misc(cs, misc);
     cs.quant = quant;
     CoopTables t;
     coop_tables(d, cs.h, t);
@@ -563,7 +555,104 @@ hipError_t launch_pair_422(const ImageDesc *descs, uint32_t images, uint32_t max
     return hipGetLastError();
 }
 
+// The cooperative kernel's work split over the waves of a workgroup ("team" form): one wave of four walks
+// 4 x 64 data units' worth of intervals (16 with DRI = 4, a lane each -- the other three waves wait at a
+// barrier), then each of the four decodes 64 of those data units.  The walk is then not
+// replicated in four waves with four busy lanes each: a quarter of the walking instructions, walker waves that
+// have their SIMD to themselves, and no speculation (hence no tail).
+// LDS: [L1][L2 + direct tables][quantisers][per team of 4 waves: window | walk bookkeeping | 4 x (64 slots | 64 DC differences)]
+constexpr uint32_t kCoopTeamWaves = 4;
+
+__device__ __forceinline__ uint32_t coop_team_area(uint32_t window_words)
+{
+    return align16(window_words * 4u) + kCoopMiscWords * 4u + kCoopTeamWaves * (kWave * kDuSlotBytes + kWave * 4u);
+}
+
+__global__ void __launch_bounds__(512)
+decode_coop_team_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words, uint32_t spec_shift)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const ImageDesc &d = descs[blockIdx.y];
+    const uint32_t teams = blockDim.x / (kWave * kCoopTeamWaves);
+    const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x / kWave))), lane = threadIdx.x % kWave;
+    const uint32_t team = wave / kCoopTeamWaves, member = wave % kCoopTeamWaves;
+    CoopClock clk;
+    coop_clock_start(clk);
+    CoopGeom g;
+    coop_geom(d, blockIdx.x * teams + team, g, spec_shift, kCoopTeamWaves);
+    if (blockIdx.x * teams * g.ipw >= d.total_intervals)
+        return; // the whole workgroup
+
+    uint16_t *l1 = reinterpret_cast<uint16_t *>(smem);
+    uint16_t *l2 = l1 + kL1Entries;
+    float *quant = reinterpret_cast<float *>(smem + align16((kL1Entries + l2_in_lds) * 2u));
+    uint8_t *team_base = reinterpret_cast<uint8_t *>(quant + 3u * kCoopQuantStride) + team * coop_team_area(window_words);
+    uint32_t *win = reinterpret_cast<uint32_t *>(team_base);
+    uint32_t *misc = reinterpret_cast<uint32_t *>(team_base + align16(window_words * 4u));
+    uint8_t *mine = reinterpret_cast<uint8_t *>(misc + kCoopMiscWords) + member * (kWave * kDuSlotBytes + kWave * 4u);
+
+    uint32_t win_base = 0, win_len = 0;
+    if (g.intervals)
+        coop_window(d, g, window_words, win_base, win_len);
+    // the team's window is staged by its four waves together: wave `member` takes every fourth round of 512 vectors
+    stage_luts(d, l1, l2, l2_in_lds, threadIdx.x, blockDim.x, 2u * kDcFastEntries);
+    {
+        const uint32_t nvec = (win_len + 3u) / 4u;
+        for (uint32_t v0 = member * 8u * kWave + lane; v0 < nvec; v0 += kCoopTeamWaves * 8u * kWave) {
+            SlotVec w[8];
+            window_load_round(d, win_base, win_len, v0, w);
+            window_store_round(win, win_len, v0, w);
+        }
+    }
+    if (threadIdx.x < 3u * kRetained)
+        quant[(threadIdx.x / kRetained) * kCoopQuantStride + threadIdx.x % kRetained] =
+            d.quant[threadIdx.x / kRetained][threadIdx.x % kRetained];
+    __syncthreads();
+
+    CoopShared cs;
+    cs.h.l1 = l1;
+    cs.h.l2 = l2;
+    cs.h.l2_staged = umin(l2_in_lds, d.fast_off + 2u * kFastEntries + 2u * kDcFastEntries);
+    cs.h.win = win;
+    cs.h.win_base = win_base;
+    cs.h.win_len = win_len;
+    cs.h.du_slots = mine;
+    cs.lists = reinterpret_cast<uint32_t *>(mine); // (only the walker uses them: its own slot area, as in the one-wave form)
+    coop_bind_misc(cs, misc);
+    cs.diffs = reinterpret_cast<int32_t *>(mine + kWave * kDuSlotBytes);
+    cs.quant = quant;
+    CoopTables t;
+    coop_tables(d, cs.h, t);
+    const uint32_t team_index = blockIdx.x * teams + team;
+    // (team t's walker is its wave t: waves go to the SIMDs round robin, so the walkers of a workgroup do not share one)
+    if (member == (team & (kCoopTeamWaves - 1u)) && g.intervals)
+        coop_walk_422<1>(d, cs, t, g, lane, team_index, clk);
+    __syncthreads();
+    CG_COOP_STAMP(7); // (the waves that do not walk: their wait)
+    if (g.intervals)
+        coop_decode_pass_422<1>(d, cs, t, g, lane, team_index, member, clk);
+    coop_clock_store(clk, d, team_index * kCoopTeamWaves + member, lane);
+}
+
 // window_words: plan_coop's.  Every image of the launch must have ImageDesc::coop_ok and the same restart interval.
+bool coop_team()
+{
+    static const bool team = [] {
+        const char *e = getenv("COMPEG_COOP_TEAM"); // experiment knob: 0 = every wave walks its own intervals
+        return e ? atoi(e) != 0 : true;
+    }();
+    return team;
+}
+
+uint32_t coop_passes()
+{
+    static const uint32_t passes = [] {
+        const char *e = getenv("COMPEG_COOP_PASSES"); // experiment knob: 1 or 2 rounds of 64 data units per wave
+        return e ? uint32_t(atoi(e) >= 4 ? 4 : (atoi(e) >= 2 ? 2 : 1)) : 1u;
+    }();
+    return passes;
+}
+
 CoopPlan plan_coop(uint32_t max_intervals, uint32_t images, uint32_t restart_interval, uint32_t max_l2,
                    uint32_t max_group_words)
 {
@@ -571,14 +660,34 @@ CoopPlan plan_coop(uint32_t max_intervals, uint32_t images, uint32_t restart_int
     const uint32_t dpi = 4u * restart_interval;
     if (restart_interval == 0 || restart_interval > kCoopMaxRestart)
         return p;
-    p.intervals_per_wave = uint32_t(kWave) / dpi;
+    p.team = coop_team();
+    p.intervals_per_wave = uint32_t(kWave) / dpi * (p.team ? kCoopTeamWaves : coop_passes());
     p.l2_entries_in_lds = (max_l2 + 2u * kDcFastEntries + 1u) & ~1u;
     uint32_t w = max_group_words + kDuWordSlack + 4u;
     w = std::max(w, 128u);
     w = std::min(w, kCoopMaxWindow);
     p.window_words = (w + 3u) & ~3u;
     const uint32_t tables = ((((kL1Entries + p.l2_entries_in_lds) * 2u) + 15u) & ~15u) + 3u * kCoopQuantStride * 4u;
-    const uint32_t wave_area = ((p.window_words * 4u + 15u) & ~15u) + kWave * kDuSlotBytes + kCoopWaveMisc;
+    if (p.team) {
+        // two teams of four waves per workgroup, two workgroups per CU
+        const uint32_t team_area = ((p.window_words * 4u + 15u) & ~15u) + kCoopMiscWords * 4u +
+                                   kCoopTeamWaves * (kWave * kDuSlotBytes + kWave * 4u);
+        uint32_t teams = 2;
+        while (teams > 1 && tables + teams * team_area > kLdsBytesPerCu / 2u)
+            teams--;
+        if (tables + teams * team_area > kLdsBytesPerCu)
+            return p;
+        p.waves_per_block = teams * kCoopTeamWaves;
+        p.total_bytes = tables + teams * team_area;
+        const uint64_t teams_total = uint64_t((max_intervals + p.intervals_per_wave - 1) / p.intervals_per_wave) * images;
+        p.total_waves = uint32_t(std::min<uint64_t>(teams_total * kCoopTeamWaves, 0xffffffffu));
+        p.usable = true;
+        if (getenv("COMPEG_VERBOSE"))
+            fprintf(stderr, "[compeg] coop team plan: images=%u intervals=%u per team=%u teams/block=%u window=%u words lds=%u B\n",
+                    images, max_intervals, p.intervals_per_wave, teams, p.window_words, p.total_bytes);
+        return p;
+    }
+    const uint32_t wave_area = coop_wave_area(p.window_words, coop_passes());
     // as many waves per workgroup as share one copy of the tables without costing residency: two workgroups per CU
     uint32_t wpb = 8;
     if (const char *e = getenv("COMPEG_COOP_WPB"))
@@ -605,6 +714,22 @@ hipError_t launch_coop_422(const ImageDesc *descs, uint32_t images, uint32_t max
 {
     if (images == 0 || max_intervals == 0)
         return hipSuccess;
+    static const uint32_t spec_shift = [] {
+        const char *e = getenv("COMPEG_COOP_SPEC_SHIFT"); // experiment knob: fewer speculative subsequences
+        return e ? uint32_t(atoi(e)) : 0u;
+    }();
+    if (plan.team) {
+        const uint32_t teams = plan.waves_per_block / kCoopTeamWaves, per_block = plan.intervals_per_wave * teams;
+        dim3 grid((max_intervals + per_block - 1) / per_block, images, 1);
+        static const hipError_t attr = hipFuncSetAttribute(
+            reinterpret_cast<const void *>(decode_coop_team_422_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+            int(kLdsBytesPerCu));
+        if (attr != hipSuccess)
+            return attr;
+        hipLaunchKernelGGL(decode_coop_team_422_kernel, grid, dim3(plan.waves_per_block * kWave), plan.total_bytes, stream, descs,
+                           plan.l2_entries_in_lds, plan.window_words, spec_shift);
+        return hipGetLastError();
+    }
     const uint32_t per_block = plan.intervals_per_wave * plan.waves_per_block;
     dim3 grid((max_intervals + per_block - 1) / per_block, images, 1);
     static const hipError_t attr = hipFuncSetAttribute(
@@ -612,12 +737,8 @@ hipError_t launch_coop_422(const ImageDesc *descs, uint32_t images, uint32_t max
         int(kLdsBytesPerCu));
     if (attr != hipSuccess)
         return attr;
-    static const uint32_t spec_shift = [] {
-        const char *e = getenv("COMPEG_COOP_SPEC_SHIFT"); // experiment knob: fewer speculative subsequences
-        return e ? uint32_t(atoi(e)) : 0u;
-    }();
     hipLaunchKernelGGL(decode_coop_422_kernel, grid, dim3(plan.waves_per_block * kWave), plan.total_bytes, stream, descs,
-                       plan.l2_entries_in_lds, plan.window_words, spec_shift);
+                       plan.l2_entries_in_lds, plan.window_words, spec_shift, coop_passes());
     return hipGetLastError();
 }
 

@@ -600,7 +600,7 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     } else if (fused) {
         CoopPlan coop{};
         if (reinterpret_cast<const ImageDesc *>(hb)->coop_ok && use_coop_kernel(md.total_restart_intervals, 1)) {
-            const uint32_t ipw = uint32_t(kWave) / (4u * md.restart_interval);
+            const uint32_t ipw = uint32_t(kWave) / (4u * md.restart_interval) * (coop_team() ? 4u : coop_passes());
             const uint32_t group_span = on_device ? uint32_t(std::min<uint64_t>(uint64_t(dev_span) * ipw / kWave + 64, 0x7fffffffu))
                                                   : max_wave_span(scan.starts(), scan.nstarts(), scan.nwords(),
                                                                   md.total_restart_intervals, ipw);
@@ -970,7 +970,7 @@ Status compeg_batch::upload_host(size_t n, int threads, const void *items_, cons
             spans[i] = max_wave_span(starts_at, nstarts, nwords, img.metadata.total_restart_intervals);
             if (d.coop_ok)
                 group_spans[i] = max_wave_span(starts_at, nstarts, nwords, img.metadata.total_restart_intervals,
-                                               uint32_t(kWave) / (4u * img.metadata.restart_interval));
+                                               uint32_t(kWave) / (4u * img.metadata.restart_interval) * (coop_team() ? 4u : coop_passes()));
             alg[i] = 4ull * nwords + 4ull * img.metadata.total_restart_intervals + COMPEG_METADATA_BYTES +
                      COMPEG_HUFFMAN_L1_BYTES + img.l2.size() * 2 + 4ull * img.width * img.height;
             // this image's part of the arena, as far as it is used
@@ -1229,7 +1229,7 @@ Status compeg_batch::upload_device_scan(const ImageData *const *images, size_t n
         } else {
             // (the kernels report the span of 64 intervals only: four times the average for a wave's group;
             // a group that is longer than that still decodes, its intervals one lane each)
-            const uint64_t ipw = uint64_t(kWave) / (4u * coop_r), avg = expected ? (uint64_t(nwords) + expected - 1) / expected : nwords;
+            const uint64_t ipw = uint64_t(kWave) / (4u * coop_r) * (coop_team() ? 4u : coop_passes()), avg = expected ? (uint64_t(nwords) + expected - 1) / expected : nwords;
             coop_span = std::max(coop_span, uint32_t(std::min<uint64_t>(std::min<uint64_t>(span, 4 * avg * ipw + 64), 0x7fffffffu)));
         }
         algorithmic_bytes += 4ull * nwords + 4ull * expected + COMPEG_METADATA_BYTES +

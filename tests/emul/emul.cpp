@@ -86,7 +86,8 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
             return -5;
         }
         l2_in_lds = (uint32_t(l2.size()) + 1u) & ~1u;
-        const uint32_t ipw = uint32_t(kWave) / (4u * d.restart_interval);
+        const uint32_t passes = getenv("EMUL_COOP_PASSES") ? uint32_t(atoi(getenv("EMUL_COOP_PASSES"))) : 1u;
+        const uint32_t ipw = uint32_t(kWave) / (4u * d.restart_interval) * (passes >= 4 ? 4u : (passes >= 2 ? 2u : 1u));
         if (window_words == 0) { // as the runtime plans it
             window_words = max_wave_span(starts.data(), starts.size(), words.size(), d.total_intervals, ipw) + kDuWordSlack + 4u;
             window_words = std::min(std::max(window_words, 128u), kCoopMaxWindow);
@@ -110,7 +111,7 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
             for (uint32_t t = 0; t < 3u * kRetained; t++)
                 quant[(t / kRetained) * kCoopQuantStride + t % kRetained] = d.quant[t / kRetained][t % kRetained];
             CoopGeom g;
-            coop_geom(d, wave, g, getenv("EMUL_COOP_SPEC_SHIFT") ? uint32_t(atoi(getenv("EMUL_COOP_SPEC_SHIFT"))) : 0u);
+            coop_geom(d, wave, g, getenv("EMUL_COOP_SPEC_SHIFT") ? uint32_t(atoi(getenv("EMUL_COOP_SPEC_SHIFT"))) : 0u, passes);
             uint32_t wb = 0, wl = 0;
             coop_window(d, g, window_words, wb, wl);
             for (uint32_t i = 0; i < wl; i++)
@@ -118,14 +119,7 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
             CoopShared cs;
             cs.h = HuffShared{sl1, sl2, umin(l2_in_lds, d.fast_off + 2u * kFastEntries + 2u * kDcFastEntries), win, wb, wl, slots};
             cs.lists = reinterpret_cast<uint32_t *>(slots);
-            cs.du_state = misc;
-            cs.lane_n = misc + 64;
-            cs.link = misc + 128;
-            cs.diffs = reinterpret_cast<int32_t *>(misc + 192);
-            cs.seg = misc + 256;
-            cs.verdict = misc + 272;
-            cs.nseg = misc + 288;
-            cs.dead_from = misc + 304;
+            coop_bind_misc(cs, misc);
             cs.quant = quant;
             CoopTables t;
             coop_tables(d, cs.h, t);

@@ -15,24 +15,42 @@ from tools import synth
 lib.compeg_debug_read_dc.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 gpu = ca.Gpu.open(0)
 w, h, ri = (int(v) for v in (sys.argv[1:4] if len(sys.argv) > 3 else (3840, 2160, 4)))
-jpeg = synth.make_jpeg(w, h, seed=0xC0FFEE, ri=ri)
+jpeg = synth.make_jpeg(w, h, seed=0xC0FFEE, ri=ri, quality=int(os.environ.get('PROBE_QUALITY', '85')))
 img = ca.ImageData(jpeg)
 dec = ca.Decoder(gpu)
 for _ in range(3):
     dec.decode_blocking(img)
+team = os.environ.get("COMPEG_COOP_TEAM", "1") != "0"
 ipw = 64 // (4 * ri)
 waves = (img.parallelism() + ipw - 1) // ipw
-buf = np.zeros((waves, 8), dtype=np.uint64)
-assert lib.compeg_debug_read_dc(dec._h, buf.ctypes.data, buf.nbytes) == 0
+if team:
+    waves = (waves + 3) // 4 * 4
+full = np.zeros((waves, 16), dtype=np.uint64)
+assert lib.compeg_debug_read_dc(dec._h, full.ctypes.data, full.nbytes) == 0
+buf = full[:, :8]
+wall = full[:, 8:10].astype(np.int64)
+ok = wall[:, 0] > 0
+t0 = wall[ok, 0].min()
+print("device clock (10 ns ticks): first wave starts at 0; starts p50 %d max %d; ends p50 %d p99 %d max %d" % (
+    np.median(wall[ok, 0] - t0), (wall[ok, 0] - t0).max(), np.median(wall[ok, 1] - t0), np.percentile(wall[ok, 1] - t0, 99),
+    (wall[ok, 1] - t0).max()))
+if team:
+    walker = np.zeros(waves, dtype=bool)
+    idx = np.arange(waves)
+    walker[(idx % 4) == ((idx // 4) % 2)] = True  # team t of a workgroup of two teams walks with its wave t
+    for name, sel in (("walkers", walker), ("others", ~walker)):
+        sub = buf[sel & ok]
+        print(name, "cycles/wave by phase:", " ".join("%s %.0f" % (n, c) for n, c in zip(
+            ("setup", "chase", "validate", "decode", "fixups", "dc+idct", "composite", "wait"), sub.mean(axis=0))))
 tot = buf.sum(axis=1)
 print("waves", waves, "cycles/wave mean %.0f max %.0f p99 %.0f" % (tot.mean(), tot.max(), np.percentile(tot, 99)))
-names = ("setup", "chase", "validate", "decode", "fixups", "dc+idct", "composite", "-")
+names = ("setup", "chase", "validate", "decode", "fixups", "dc+idct", "composite", "wait")
 for name, col in zip(names, buf.T):
     print("  %-10s %8.0f cycles/wave (max %8.0f)  %5.1f %%" % (name, col.mean(), col.max(), 100 * col.sum() / max(tot.sum(), 1)))
 # per-wave walk steps from the emulation (tools/probes/wave_steps_<shift>.txt, if present): cycles per step
 shift = os.environ.get("COMPEG_COOP_SPEC_SHIFT", "0")
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes", "wave_steps_%s.txt" % shift)
-if os.path.exists(path) and (w, h, ri) == (3840, 2160, 4):
+if os.path.exists(path) and (w, h, ri) == (3840, 2160, 4) and not team:
     steps = np.zeros(waves)
     for line in open(path):
         wv, rnd, n = (int(v) for v in line.split())
