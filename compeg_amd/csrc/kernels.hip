@@ -563,12 +563,28 @@ hipError_t launch_pair_422(const ImageDesc *descs, uint32_t images, uint32_t max
 // LDS: [L1][L2 + direct tables][quantisers][per team of 4 waves: window | walk bookkeeping | 4 x (64 slots | 64 DC differences)]
 constexpr uint32_t kCoopTeamWaves = 4;
 
-__device__ __forceinline__ uint32_t coop_team_area(uint32_t window_words)
+constexpr uint32_t kCoopTeamFlagWords = 4; // [0]: the walk is done
+__host__ __device__ __forceinline__ uint32_t coop_team_area(uint32_t window_words)
 {
-    return align16(window_words * 4u) + kCoopMiscWords * 4u + kCoopTeamWaves * (kWave * kDuSlotBytes + kWave * 4u);
+    return ((window_words * 4u + 15u) & ~15u) + (kCoopMiscWords + kCoopTeamFlagWords) * 4u +
+           kCoopTeamWaves * (kWave * kDuSlotBytes + kWave * 4u);
 }
 
-__global__ void __launch_bounds__(512)
+// One wave tells the others of its team (through LDS; a workgroup barrier would tie the teams together).
+__device__ __forceinline__ void team_signal(uint32_t *flag, uint32_t lane)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0u)
+        __hip_atomic_store(flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void team_wait(uint32_t *flag)
+{
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u)
+        __builtin_amdgcn_s_sleep(4);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__global__ void __launch_bounds__(1024)
 decode_coop_team_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words, uint32_t spec_shift)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -589,7 +605,10 @@ decode_coop_team_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_
     uint8_t *team_base = reinterpret_cast<uint8_t *>(quant + 3u * kCoopQuantStride) + team * coop_team_area(window_words);
     uint32_t *win = reinterpret_cast<uint32_t *>(team_base);
     uint32_t *misc = reinterpret_cast<uint32_t *>(team_base + align16(window_words * 4u));
-    uint8_t *mine = reinterpret_cast<uint8_t *>(misc + kCoopMiscWords) + member * (kWave * kDuSlotBytes + kWave * 4u);
+    uint32_t *flags = misc + kCoopMiscWords;
+    uint8_t *mine = reinterpret_cast<uint8_t *>(flags + kCoopTeamFlagWords) + member * (kWave * kDuSlotBytes + kWave * 4u);
+    if (member == 0u && lane < kCoopTeamFlagWords)
+        flags[lane] = 0u;
 
     uint32_t win_base = 0, win_len = 0;
     if (g.intervals)
@@ -625,9 +644,13 @@ decode_coop_team_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_
     coop_tables(d, cs.h, t);
     const uint32_t team_index = blockIdx.x * teams + team;
     // (team t's walker is its wave t: waves go to the SIMDs round robin, so the walkers of a workgroup do not share one)
-    if (member == (team & (kCoopTeamWaves - 1u)) && g.intervals)
-        coop_walk_422<1>(d, cs, t, g, lane, team_index, clk);
-    __syncthreads();
+    if (member == (team & (kCoopTeamWaves - 1u))) {
+        if (g.intervals)
+            coop_walk_422<1>(d, cs, t, g, lane, team_index, clk);
+        team_signal(flags, lane);
+    } else {
+        team_wait(flags);
+    }
     CG_COOP_STAMP(7); // (the waves that do not walk: their wait)
     if (g.intervals)
         coop_decode_pass_422<1>(d, cs, t, g, lane, team_index, member, clk);
@@ -669,14 +692,17 @@ CoopPlan plan_coop(uint32_t max_intervals, uint32_t images, uint32_t restart_int
     p.window_words = (w + 3u) & ~3u;
     const uint32_t tables = ((((kL1Entries + p.l2_entries_in_lds) * 2u) + 15u) & ~15u) + 3u * kCoopQuantStride * 4u;
     if (p.team) {
-        // two teams of four waves per workgroup, two workgroups per CU
-        const uint32_t team_area = ((p.window_words * 4u + 15u) & ~15u) + kCoopMiscWords * 4u +
-                                   kCoopTeamWaves * (kWave * kDuSlotBytes + kWave * 4u);
-        uint32_t teams = 2;
-        while (teams > 1 && tables + teams * team_area > kLdsBytesPerCu / 2u)
+        // four teams of four waves: one workgroup per CU, one copy of the tables
+        const uint32_t team_area = coop_team_area(p.window_words);
+        uint32_t teams = 4;
+        while (teams > 1 && tables + teams * team_area > kLdsBytesPerCu)
             teams--;
         if (tables + teams * team_area > kLdsBytesPerCu)
             return p;
+        // (a small launch: more workgroups rather than fuller ones)
+        const uint64_t all_teams = uint64_t((max_intervals + p.intervals_per_wave - 1) / p.intervals_per_wave) * images;
+        while (teams > 1 && all_teams / teams < 256u)
+            teams /= 2u;
         p.waves_per_block = teams * kCoopTeamWaves;
         p.total_bytes = tables + teams * team_area;
         const uint64_t teams_total = uint64_t((max_intervals + p.intervals_per_wave - 1) / p.intervals_per_wave) * images;
