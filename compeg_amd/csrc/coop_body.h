@@ -84,7 +84,71 @@ struct CoopTables {
     uint32_t dc_quant[3];
     uint32_t zrl;            // 17 (the reference, quirk Q2) or 16
     bool standard;
+    const uint32_t *walk;    // the walk tables (coop_walk_entry), or null: kWalkTables x kWalkEntries words
+    uint32_t walk_acsel, walk_dcsel; // byte k: the index of the AC table / of the DC + AC table of data unit k of an MCU
+    uint32_t walk_ids;       // bits 2i, 2i + 1: which direct DC table, which direct AC table walk table 2 + i is made of
+    bool walk_ok;            // the components use at most two different pairs of tables
 };
+
+// ---------------------------------------------------------------------------
+// Walk tables: what a walk that only has to find where the data units begin looks up.  One 32-bit entry per
+// 11-bit prefix of the coming stream bits:
+//   bits  0..15  minus the bits consumed (two's complement: added to the reader's shift by the same packed add
+//                that adds bits 21..28 to the zig-zag state)
+//   bits 16..20  size of the last symbol consumed (what a data unit's start state records, quirk Q1)
+//   bits 21..28  zig-zag advance, 64 for an end-of-block
+//   0            the prefix does not determine a symbol (code longer than the prefix): the two-level tables decide
+// Tables 0, 1: the two AC tables, a symbol per entry.  Tables 2, 3: a DC code and, where its code lies inside the
+// prefix as well, the first AC symbol (or the end-of-block) behind it -- for the (at most two) pairs of DC and AC
+// table that the components use.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kWalkBits = 11, kWalkEntries = 1u << kWalkBits, kWalkTables = 4;
+constexpr uint32_t kWalkStShift = 21, kWalkLastShift = 16;
+
+CG_DEV uint32_t walk_pack(uint32_t tot, uint32_t last, uint32_t adv)
+{
+    return (adv << kWalkStShift) | (last << kWalkLastShift) | ((0u - tot) & 0xffffu);
+}
+
+// ac_fast / dc_fast: the direct tables (device_types.h); table 0, 1: that AC table; 2, 3: DC table dc_id and AC
+// table ac_id
+CG_DEV uint32_t coop_walk_entry(const uint16_t *ac_fast, const uint16_t *dc_fast, uint32_t table, uint32_t idx,
+                                uint32_t dc_id, uint32_t ac_id)
+{
+    uint32_t tot1, adv1;
+    if (table < 2u) {
+        ac_id = table;
+        const uint32_t e = ac_fast[ac_id * kFastEntries + idx];
+        tot1 = (e >> 4) & 31u;
+        adv1 = e >> 9;
+        if (e == kFastEscape || tot1 == 0u)
+            return 0u;
+    } else {
+        const uint32_t e = dc_fast[dc_id * kDcFastEntries + (idx >> (kWalkBits - kDcFastBits))];
+        tot1 = (e >> 4) & 31u;
+        adv1 = 1u;
+        if (e == kFastEscape || tot1 == 0u)
+            return 0u;
+    }
+    // (behind an AC symbol nothing: a data unit may end with that symbol -- its coefficient is number 63 or, with
+    // quirk Q2, beyond -- and what follows is then the next data unit's DC code; the state word shows this only
+    // after the fact)
+    if (table >= 2u && tot1 < kWalkBits) {
+        const uint32_t rest = (idx << tot1) & (kWalkEntries - 1u); // the prefix behind the DC code, zeros behind it
+        const uint32_t e = ac_fast[ac_id * kFastEntries + rest];
+        const uint32_t tot2 = (e >> 4) & 31u, adv2 = e >> 9;
+        if (e != kFastEscape && tot2 != 0u && tot2 - (e & 15u) <= kWalkBits - tot1 && tot1 + tot2 <= 31u)
+            return walk_pack(tot1 + tot2, tot2, adv1 + adv2);
+    }
+    return walk_pack(tot1, tot1, adv1);
+}
+
+// Entry number i of the kWalkTables x kWalkEntries words.
+CG_DEV uint32_t coop_walk_word(const CoopTables &t, uint32_t i)
+{
+    const uint32_t table = i >> kWalkBits, ids = t.walk_ids >> (table >= 2u ? 2u * (table - 2u) : 0u);
+    return coop_walk_entry(t.ac_fast, t.dc_fast, table, i & (kWalkEntries - 1u), ids & 1u, (ids >> 1) & 1u);
+}
 
 // The wave's share of LDS.
 struct CoopShared {
@@ -187,6 +251,25 @@ CG_DEV void coop_tables(const ImageDesc &d, const HuffShared &s, CoopTables &t)
     }
     t.standard = d.standard_entropy != 0u;
     t.zrl = t.standard ? 16u : 17u;
+    t.walk = nullptr;
+    t.walk_acsel = t.walk_dcsel = 0u;
+    // the pairs (DC table, AC table) in use: component 0's is walk table 2, the first different one walk table 3
+    const uint32_t pair0 = (d.dc_fast_table[0] & 1u) | ((d.fast_table[0] & 1u) << 1);
+    uint32_t pair1 = pair0;
+    t.walk_ok = true;
+    for (uint32_t c = 1; c < 3u; c++) {
+        const uint32_t pr = (d.dc_fast_table[c] & 1u) | ((d.fast_table[c] & 1u) << 1);
+        if (pr != pair0 && pair1 == pair0)
+            pair1 = pr;
+        t.walk_ok = t.walk_ok && (pr == pair0 || pr == pair1);
+    }
+    t.walk_ids = pair0 | (pair1 << 2);
+    for (uint32_t k = 0; k < 4u; k++) {
+        const uint32_t c = comp_of_k(k);
+        const uint32_t pr = (d.dc_fast_table[c] & 1u) | ((d.fast_table[c] & 1u) << 1);
+        t.walk_acsel |= (d.fast_table[c] & 1u) << (8u * k);
+        t.walk_dcsel |= (pr == pair0 ? 2u : 3u) << (8u * k);
+    }
 }
 
 // The window of the wave's intervals: their contiguous words plus the reader's slack.
@@ -225,6 +308,11 @@ struct ChaseState {
     uint32_t flags;    // kStopAnomaly
     bool used;         // this lane walks at all
     bool active;
+#if defined(CG_COOP_STAMPS)
+    uint64_t loop_cycles; // (diagnostic builds) inside the hand-written loop: cycles, steps, times entered
+    uint32_t loop_steps, loop_entries;
+    uint64_t init_cycles, tail_cycles; // before the loop is entered first, behind it
+#endif
 };
 
 // The walk: a per-lane loop (lanes that are done drop out of it, the wave leaves it when the last one has).
@@ -418,6 +506,232 @@ CG_DEV void chase_run(ChaseState &c, const ImageDesc &d, const HuffShared &s, co
     c.active = false;
 }
 
+// The walk of a lane that starts at the beginning of a data unit and only has to find where the following ones
+// begin (no speculation: the team form), through the walk tables: up to two symbols per step.
+//
+// While it runs, the lane's list is a row of 16-byte entries, one per data unit: {address of stream word A, state
+// word} -- written after every step, final once the data unit is complete -- and {this data unit's AC pair table,
+// the next one's DC table}, filled in beforehand.  The state word holds the reader's shift (bits 0..15, signed:
+// 32 - the bits of A that are consumed, below zero when the position has moved on into B), the size of the last
+// symbol (16..20) and the zig-zag state (21..28).  At the end the entries are rewritten as the state words
+// everybody else reads (position | size << 16).
+// Per step on the GPU: 28 instructions (a lone wave issues one every four cycles at best, whatever its kind).
+CG_DEV void chase_run_lean(ChaseState &c, const ImageDesc &d, const HuffShared &s, const CoopTables &t, uint32_t *list,
+                           unsigned long &steps)
+{
+    (void)steps;
+#if defined(CG_COOP_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+    const uint64_t t_fn = __builtin_readcyclecounter();
+#endif
+    const uint32_t j0 = uint32_t(c.lp - list), jmax = uint32_t(c.lp_max - list), k0 = (c.k8 >> 3) & 3u;
+    constexpr uint32_t kStMask = 0xffu << kWalkStShift, kKeep = kStMask | 31u;
+    constexpr uint32_t kEndAbove = (64u << kWalkStShift) - 1u;
+    uint32_t done = j0;
+    if (c.active) {
+        for (uint32_t j = j0; j <= jmax; j++) {
+            const uint32_t k = (k0 + j - j0) & 3u;
+#if defined(__HIP_DEVICE_COMPILE__)
+            list[4u * j + 2u] = uint32_t(reinterpret_cast<uintptr_t>(t.walk)) + ((t.walk_acsel >> (8u * k)) & 0xffu) * kWalkEntries * 4u;
+            list[4u * j + 3u] = uint32_t(reinterpret_cast<uintptr_t>(t.walk)) +
+                                ((t.walk_dcsel >> (8u * ((k + 1u) & 3u))) & 0xffu) * kWalkEntries * 4u;
+#else
+            list[4u * j + 2u] = ((t.walk_acsel >> (8u * k)) & 0xffu) * kWalkEntries;
+            list[4u * j + 3u] = ((t.walk_dcsel >> (8u * ((k + 1u) & 3u))) & 0xffu) * kWalkEntries;
+#endif
+        }
+    }
+    const uint32_t wi1 = (c.p + 31u) >> 5; // (the word in front of an aligned position is never looked at: shift 0)
+    uint32_t T = 32u * wi1 - c.p;          // zig-zag state 0: a DC code comes next
+    auto bits_at = [&](uint32_t p_) {
+        const uint32_t *wp = s.win + (p_ >> 5);
+        return uint32_t(((uint64_t(wp[0]) << 32 | wp[1]) << (p_ & 31u)) >> 32);
+    };
+    // a code longer than the prefix, through the reference's two-level tables: one symbol
+    auto resolve = [&](uint32_t cur, uint32_t st_, uint32_t k, bool &bad) {
+        const uint32_t comp = comp_of_k(k & 3u);
+        bad = false;
+        if (st_ == 0u) {
+            const uint32_t e2 = lut_lookup<true>(d, s, sel3(comp, t.dc_off[0], t.dc_off[1], t.dc_off[2]), cur);
+            const uint32_t len = e2 >> 8, cat = e2 & 0xffu;
+            bad = cat > 15u || len + cat > 31u; // only a hostile table has such categories
+            return walk_pack(len + cat, len + cat, 1u);
+        }
+        const uint32_t fe = fast_entry(lut_lookup<true>(d, s, sel3(comp, t.ac_off[0], t.ac_off[1], t.ac_off[2]), cur), t.zrl);
+        return walk_pack((fe >> 4) & 31u, (fe >> 4) & 31u, fe >> 9);
+    };
+    uint32_t ent = c.active ? t.walk[((t.walk_dcsel >> (8u * k0)) & 0xffu) * kWalkEntries + (bits_at(c.p) >> (32u - kWalkBits))] : 0u;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CG_COOP_NO_ASM)
+    uint32_t alive = c.active ? 1u : 0u, code = 0u, cur_out = 0u;
+    const uint32_t lb = uint32_t(reinterpret_cast<uintptr_t>(list));
+    const uint32_t win = uint32_t(reinterpret_cast<uintptr_t>(s.win));
+    uint32_t lpa = lb + 16u * j0, wa = win + 4u * wi1 - 4u;
+    const uint32_t lpmax = lb + 16u * jmax;
+#if defined(CG_COOP_STAMPS)
+    c.init_cycles += __builtin_readcyclecounter() - t_fn;
+    uint32_t nsteps = 0;
+#define CG_LEAN_STEP "s_add_u32 %[nsteps], %[nsteps], 1\n\t"
+#define CG_LEAN_STEP_OP , [nsteps] "+s"(nsteps)
+#else
+#define CG_LEAN_STEP
+#define CG_LEAN_STEP_OP
+#endif
+    if (__builtin_amdgcn_ballot_w64(alive != 0u) != 0u)
+        for (;;) {
+#if defined(CG_COOP_STAMPS)
+            const uint64_t t_in = __builtin_readcyclecounter();
+#endif
+            asm volatile(
+                "s_mov_b64 s[74:75], exec\n\t"
+                "v_cmp_ne_u32 vcc, 0, %[alive]\n\t"
+                "s_and_b64 exec, exec, vcc\n\t"
+                "s_mov_b64 s[84:85], exec\n\t"                        // lanes that walk in this block
+                "s_cbranch_execz 4f\n\t"
+                "v_mov_b32 v50, %[wa]\n\t"
+                "v_mov_b32 v51, %[T]\n\t"
+                "ds_read2_b32 v[42:43], v50 offset1:1\n\t"            // A, B
+                "ds_read_b32 v44, v50 offset:8\n\t"                   // C
+                "ds_read_b64 v[48:49], %[lp] offset:8\n"               // this data unit's AC pair table, the next one's DC table
+                "1:\n\t"
+                CG_LEAN_STEP
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_pk_add_u16 v51, v51, %[ent]\n\t"                   // bits off the shift, advance onto the zig-zag state
+                "ds_write_b64 %[lp], v[50:51]\n\t"                    // (final when the data unit ends here)
+                "v_cmp_eq_u32 s[76:77], 0, %[ent]\n\t"                // lanes that met a long code
+                "v_alignbit_b32 v41, v42, v43, v51\n\t"               // (the shift is taken modulo 32)
+                "v_alignbit_b32 v45, v43, v44, v51\n\t"
+                "v_cmp_gt_i16 vcc, 0, v51\n\t"                        // the position has left A
+                "v_cmp_lt_u32 s[72:73], %[endabove], v51\n\t"         // the data unit is complete: a DC code comes next
+                "v_cndmask_b32 v41, v41, v45, vcc\n\t"                // the next 32 stream bits
+                "v_cndmask_b32_e64 v46, v48, v49, s[72:73]\n\t"
+                "v_bfe_u32 v45, v41, 21, 11\n\t"
+                "v_lshl_add_u32 v46, v45, 2, v46\n\t"
+                "ds_read_b32 %[ent], v46\n\t"
+                // ---- under that read: move on in the stream, in the list; who goes on
+                "v_cndmask_b32_e64 v40, 0, 4, vcc\n\t"
+                "v_add_u32 v50, v50, v40\n\t"
+                "v_cndmask_b32_e64 v40, %[keep], 31, s[72:73]\n\t"
+                "v_and_b32 v51, v51, v40\n\t"
+                "v_cndmask_b32_e64 v40, 0, 16, s[72:73]\n\t"
+                "v_add_u32 %[lp], %[lp], v40\n\t"
+                "ds_read2_b32 v[42:43], v50 offset1:1\n\t"
+                "ds_read_b32 v44, v50 offset:8\n\t"
+                "ds_read_b64 v[48:49], %[lp] offset:8\n\t"
+                "v_cmp_ge_u32 s[78:79], %[lp], %[lpmax]\n\t"          // every data unit asked for is complete
+                "s_andn2_b64 exec, exec, s[78:79]\n\t"
+                "s_and_b64 s[76:77], s[76:77], exec\n\t"              // (sets SCC: some walking lane met a long code)
+                "s_cbranch_scc1 3f\n\t"
+                "s_cbranch_execnz 1b\n\t"
+                "s_mov_b32 %[code], 0\n\t"
+                "s_branch 5f\n"
+                "3:\n\t"
+                "s_mov_b32 %[code], 1\n\t"
+                "s_branch 5f\n"
+                "4:\n\t"
+                "s_mov_b32 %[code], 0\n"
+                "5:\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "s_mov_b64 s[72:73], exec\n\t"                        // lanes still walking
+                "s_mov_b64 exec, s[74:75]\n\t"
+                "v_cndmask_b32_e64 %[alive], 0, 1, s[72:73]\n\t"
+                "v_cndmask_b32_e64 %[wa], %[wa], v50, s[84:85]\n\t"   // (the others keep theirs)
+                "v_cndmask_b32_e64 %[T], %[T], v51, s[84:85]\n\t"
+                "v_mov_b32 %[cur], v41\n\t"                           // the stream bits at the position (lanes that walked)
+                : [lp] "+v"(lpa), [ent] "+v"(ent), [T] "+v"(T), [wa] "+v"(wa), [alive] "+v"(alive), [code] "=s"(code),
+                  [cur] "=v"(cur_out) CG_LEAN_STEP_OP
+                : [endabove] "s"(kEndAbove), [keep] "v"(kKeep), [lpmax] "v"(lpmax)
+                : "memory", "vcc", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v48", "v49", "v50", "v51",
+                  "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s84", "s85");
+#if defined(CG_COOP_STAMPS)
+            c.loop_cycles += __builtin_readcyclecounter() - t_in;
+            c.loop_entries++;
+            c.loop_steps = nsteps;
+#endif
+            if (code == 0u)
+                break;
+            if (alive != 0u && ent == 0u) {
+                bool bad;
+                ent = resolve(cur_out, T >> kWalkStShift, k0 + (lpa - lb) / 16u - j0, bad);
+                c.flags |= bad ? kStopAnomaly : 0u;
+                alive = bad ? 0u : alive;
+            }
+        }
+    done = (lpa - lb) / 16u;
+#if defined(CG_COOP_STAMPS)
+    const uint64_t t_tail = __builtin_readcyclecounter();
+#endif
+    // the entries, as state words: all of them are read before the first one is written (entry j moves from
+    // byte 16 j to byte 4 j)
+    {
+        uint32_t w[16], Tw[16];
+#pragma unroll
+        for (uint32_t j = 1; j < 16u; j++) {
+            const bool mine = j >= j0 && j < done;
+            w[j] = mine ? list[4u * j] : 0u;
+            Tw[j] = mine ? list[4u * j + 1u] : 0u;
+        }
+        uint32_t p_last = c.p, cut = done;
+#pragma unroll
+        for (uint32_t j = 1; j < 16u; j++) {
+            if (j >= j0 && j < cut) {
+                p_last = 8u * (w[j] - win) + 32u - uint32_t(int32_t(int16_t(Tw[j] & 0xffffu)));
+                list[j] = (p_last & 0xffffu) | (((Tw[j] >> kWalkLastShift) & 31u) << 16);
+                if (p_last >= c.stop_p)
+                    cut = j + 1u; // the walk ends here, as chase_run's does (what lies behind may be off the window)
+            }
+        }
+        done = cut;
+        c.p = p_last;
+    }
+#if defined(CG_COOP_STAMPS)
+    c.tail_cycles += __builtin_readcyclecounter() - t_tail;
+#endif
+#else
+    if (c.active) {
+        uint32_t wa = wi1 - 1u, j = j0; // (word index of A; -1 for a walk that starts at position 0)
+        uint32_t p_last = c.p;
+        while (j < jmax) {
+            steps++;
+            const uint32_t p_now = 32u * (wa + 1u) - (T & 31u);
+            if (ent == 0u) {
+                CG_COUNT(escapes);
+                bool bad;
+                ent = resolve(bits_at(p_now), T >> kWalkStShift, k0 + j - j0, bad);
+                if (bad) {
+                    c.flags |= kStopAnomaly;
+                    break;
+                }
+            }
+            // the packed add: two independent 16-bit sums
+            const uint32_t T1 = ((T + (ent & 0xffff0000u)) & 0xffff0000u) | ((T + ent) & 0xffffu);
+            const int32_t sn = int32_t(int16_t(T1 & 0xffffu));
+            const uint32_t p_next = 32u * (wa + 1u) - uint32_t(sn);
+            const bool du_end = T1 > kEndAbove;
+            list[4u * j] = wa;
+            list[4u * j + 1u] = T1;
+            const uint32_t table = du_end ? list[4u * j + 3u] : list[4u * j + 2u];
+            ent = t.walk[table + (bits_at(p_next) >> (32u - kWalkBits))];
+            wa += sn < 0 ? 1u : 0u;
+            T = T1 & (du_end ? 31u : kKeep);
+            j += du_end ? 1u : 0u;
+        }
+        done = j;
+        // the entries, as state words
+        for (uint32_t jj = j0; jj < done; jj++) {
+            const uint32_t w = list[4u * jj], Tj = list[4u * jj + 1u];
+            p_last = 32u * (w + 1u) - uint32_t(int32_t(int16_t(Tj & 0xffffu)));
+            list[jj] = (p_last & 0xffffu) | (((Tj >> kWalkLastShift) & 31u) << 16);
+            if (p_last >= c.stop_p)
+                done = jj + 1u; // the walk ends here, as chase_run's does (what lies behind may be off the window)
+        }
+        c.p = p_last;
+    }
+#endif
+    c.s = 0u;
+    c.k8 += 8u * (done - j0);
+    c.lp = list + done;
+    c.active = false;
+}
+
 // Word offset (inside the interval) at which subsequence j of `count` (a power of two) begins.
 CG_DEV uint32_t coop_sub_start(uint32_t len_words, uint32_t j, const CoopGeom &g)
 {
@@ -452,6 +766,10 @@ CG_DEV void chase_assign(ChaseState &c, const HuffShared &s, const CoopGeom &g, 
 {
     uint32_t j = 0u, h = 0u;
     bool used = exists && tl == 0u;
+#if defined(CG_COOP_STAMPS)
+    c.loop_cycles = c.init_cycles = c.tail_cycles = 0;
+    c.loop_steps = c.loop_entries = 0;
+#endif
     if (tl >= 1u && tl <= 4u * (g.count - 1u)) {
         j = 1u + (tl - 1u) / 4u;
         h = (tl - 1u) & 3u;
@@ -852,7 +1170,7 @@ CG_DEV void coop_lane(const ImageDesc &d, const HuffShared &s, const CoopGeom &g
 // diagnostic builds (-DCG_COOP_STAMPS): cycles per phase of every wave, parked in the (otherwise unused) dc buffer
 struct CoopClock {
 #if defined(CG_COOP_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
-    uint64_t tprev, stamp[8], wall0;
+    uint64_t tprev, stamp[8], wall0, extra[5];
 #endif
 };
 CG_DEV void coop_clock_start(CoopClock &clk)
@@ -862,6 +1180,8 @@ CG_DEV void coop_clock_start(CoopClock &clk)
     clk.wall0 = wall_clock64(); // (100 MHz: when this wave got going, and below when it was done, on the device's clock)
     for (int i = 0; i < 8; i++)
         clk.stamp[i] = 0;
+    for (int i = 0; i < 5; i++)
+        clk.extra[i] = 0;
 #else
     (void)clk;
 #endif
@@ -875,6 +1195,11 @@ CG_DEV void coop_clock_store(const CoopClock &clk, const ImageDesc &d, uint32_t 
             o[i] = clk.stamp[i];
         o[8] = clk.wall0;
         o[9] = wall_clock64();
+        o[10] = clk.extra[0];
+        o[11] = clk.extra[1];
+        o[12] = clk.extra[2];
+        o[13] = clk.extra[3];
+        o[14] = clk.extra[4];
     }
 #else
     (void)clk, (void)d, (void)wave_index, (void)lane;
@@ -928,6 +1253,8 @@ CG_DEV void coop_walk_422(const ImageDesc &d, const CoopShared &cs, const CoopTa
     if (LANES != 1)
         CG_COOP_COUNT(intervals, g.intervals);
     CG_COOP_STAMP(0);
+    // nobody speculates and the lists have the room: the walk tables' loop (chase_run_lean)
+    const bool lean = t.walk != nullptr && t.walk_ok && g.count == 1u && g.dpi <= 16u;
 
     // ---- 1 + 2: walk, link, follow; lanes that have to walk on do so, until every interval is settled ----
     for (uint32_t round = 0; round <= g.dpi + 1u; round++) {
@@ -940,7 +1267,10 @@ CG_DEV void coop_walk_422(const ImageDesc &d, const CoopShared &cs, const CoopTa
             CG_EACH_LANE
             {
                 unsigned long steps = 0;
-                chase_run(c[li], d, s, t, steps);
+                if (lean)
+                    chase_run_lean(c[li], d, s, t, cs.lists + L[li].lane * kCoopListCap, steps);
+                else
+                    chase_run(c[li], d, s, t, steps);
                 CG_COOP_COUNT(chase_steps, steps);
                 most = steps > most ? steps : most;
                 if (L[li].tl == 0u) {
@@ -962,6 +1292,13 @@ CG_DEV void coop_walk_422(const ImageDesc &d, const CoopShared &cs, const CoopTa
             (void)most_true;
         }
         CG_COOP_STAMP(1);
+#if defined(CG_COOP_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+        clk.extra[0] += c[0].loop_cycles;
+        clk.extra[1] += c[0].loop_steps;
+        clk.extra[2] += c[0].loop_entries;
+        clk.extra[3] += c[0].init_cycles;
+        clk.extra[4] += c[0].tail_cycles;
+#endif
         CG_EACH_LANE coop_publish(c[li], cs, L[li].lane);
         CG_WAVE_SYNC();
         CG_EACH_LANE coop_find_link(c[li], cs, g, L[li].lane, L[li].lane0);

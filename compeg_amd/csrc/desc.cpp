@@ -17,6 +17,7 @@ uint32_t max_wave_span(const uint32_t *starts, size_t nstarts, size_t nwords, ui
 
 void fill_desc(const ImageData &img, ImageDesc &d)
 {
+    d.walk = nullptr; // (set by callers that keep walk tables for this image)
     const Metadata &md = img.metadata;
     memset(&d, 0, sizeof d);
     d.l2_entries = uint32_t(img.l2.size());

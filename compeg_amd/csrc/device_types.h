@@ -69,6 +69,9 @@ struct ImageDesc {
     uint32_t dc_fast_table[3];
     uint32_t coop_ok;
     int16_t zero_du[3][kRetained];
+    // the walk tables (coop_body.h: kWalkTables x kWalkEntries words, made by launch_walk_tables from the direct
+    // tables), or null: the cooperative kernel's walks then go symbol by symbol
+    const uint32_t *walk;
     // geometry
     uint32_t total_intervals;
     uint32_t restart_interval; // MCUs per interval

@@ -44,6 +44,9 @@ CoopPlan plan_coop(uint32_t max_intervals, uint32_t images, uint32_t restart_int
                    uint32_t max_group_words);
 hipError_t launch_coop_422(const ImageDesc *descs, uint32_t images, uint32_t max_intervals, const CoopPlan &plan,
                            hipStream_t stream);
+// Fills ImageDesc::walk (kWalkTableBytes each) of every image that has one, from its direct tables.
+constexpr size_t kWalkTableBytes = 4u * 2048u * 4u;
+hipError_t launch_walk_tables(const ImageDesc *descs, uint32_t images, hipStream_t stream);
 hipError_t launch_idct_composite(const ImageDesc *descs, uint32_t images, uint32_t max_dus,
                                  hipStream_t stream);
 

@@ -29,6 +29,7 @@
 namespace compeg {
 
 constexpr uint32_t kLdsBytesPerCu = 160u * 1024u;
+constexpr uint32_t kCuCount = 256;
 
 // LDS layout (dynamic, 16-byte aligned carve-outs):
 //   [L1: 5*256 u16][L2: l2_in_lds u16][per wave: window_words u32 | 64 DU slots]
@@ -560,8 +561,30 @@ hipError_t launch_pair_422(const ImageDesc *descs, uint32_t images, uint32_t max
 // barrier), then each of the four decodes 64 of those data units.  The walk is then not
 // replicated in four waves with four busy lanes each: a quarter of the walking instructions, walker waves that
 // have their SIMD to themselves, and no speculation (hence no tail).
-// LDS: [L1][L2 + direct tables][quantisers][per team of 4 waves: window | walk bookkeeping | 4 x (64 slots | 64 DC differences)]
+// LDS: [L1][L2 + direct tables][quantisers][walk tables][per team of 4 waves: window | walk bookkeeping | flags | 4 x (64 slots | 64 DC differences)]
 constexpr uint32_t kCoopTeamWaves = 4;
+
+// The walk tables of every image of a launch, from its direct tables (global memory to global memory: once per
+// set of Huffman tables, not per frame -- the runtime keeps them).
+__global__ void __launch_bounds__(1024) walk_tables_kernel(const ImageDesc *__restrict__ descs)
+{
+    const ImageDesc &d = descs[blockIdx.y];
+    if (!d.walk || !d.coop_ok)
+        return;
+    HuffShared h{};
+    h.l2 = d.l2;
+    CoopTables t;
+    coop_tables(d, h, t);
+    uint32_t *out = const_cast<uint32_t *>(d.walk);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < kWalkTables * kWalkEntries; i += gridDim.x * blockDim.x)
+        out[i] = t.walk_ok ? coop_walk_word(t, i) : 0u;
+}
+
+hipError_t launch_walk_tables(const ImageDesc *descs, uint32_t images, hipStream_t stream)
+{
+    hipLaunchKernelGGL(walk_tables_kernel, dim3(kWalkTables * kWalkEntries / 1024u, images, 1), dim3(1024), 0, stream, descs);
+    return hipGetLastError();
+}
 
 constexpr uint32_t kCoopTeamFlagWords = 4; // [0]: the walk is done
 __host__ __device__ __forceinline__ uint32_t coop_team_area(uint32_t window_words)
@@ -602,7 +625,8 @@ decode_coop_team_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_
     uint16_t *l1 = reinterpret_cast<uint16_t *>(smem);
     uint16_t *l2 = l1 + kL1Entries;
     float *quant = reinterpret_cast<float *>(smem + align16((kL1Entries + l2_in_lds) * 2u));
-    uint8_t *team_base = reinterpret_cast<uint8_t *>(quant + 3u * kCoopQuantStride) + team * coop_team_area(window_words);
+    uint32_t *walk = reinterpret_cast<uint32_t *>(quant + 3u * kCoopQuantStride);
+    uint8_t *team_base = reinterpret_cast<uint8_t *>(walk + kWalkTables * kWalkEntries) + team * coop_team_area(window_words);
     uint32_t *win = reinterpret_cast<uint32_t *>(team_base);
     uint32_t *misc = reinterpret_cast<uint32_t *>(team_base + align16(window_words * 4u));
     uint32_t *flags = misc + kCoopMiscWords;
@@ -626,6 +650,11 @@ decode_coop_team_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_
     if (threadIdx.x < 3u * kRetained)
         quant[(threadIdx.x / kRetained) * kCoopQuantStride + threadIdx.x % kRetained] =
             d.quant[threadIdx.x / kRetained][threadIdx.x % kRetained];
+    if (d.walk) {
+        SlotVec *dst = reinterpret_cast<SlotVec *>(walk);
+        for (uint32_t i = threadIdx.x; i < kWalkTables * kWalkEntries / 4u; i += blockDim.x)
+            dst[i] = CG_GLOBAL(const SlotVec, reinterpret_cast<const SlotVec *>(d.walk))[i];
+    }
     __syncthreads();
 
     CoopShared cs;
@@ -642,6 +671,7 @@ decode_coop_team_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_
     cs.quant = quant;
     CoopTables t;
     coop_tables(d, cs.h, t);
+    t.walk = d.walk ? walk : nullptr;
     const uint32_t team_index = blockIdx.x * teams + team;
     // (team t's walker is its wave t: waves go to the SIMDs round robin, so the walkers of a workgroup do not share one)
     if (member == (team & (kCoopTeamWaves - 1u))) {
@@ -690,19 +720,26 @@ CoopPlan plan_coop(uint32_t max_intervals, uint32_t images, uint32_t restart_int
     w = std::max(w, 128u);
     w = std::min(w, kCoopMaxWindow);
     p.window_words = (w + 3u) & ~3u;
-    const uint32_t tables = ((((kL1Entries + p.l2_entries_in_lds) * 2u) + 15u) & ~15u) + 3u * kCoopQuantStride * 4u;
+    uint32_t tables = ((((kL1Entries + p.l2_entries_in_lds) * 2u) + 15u) & ~15u) + 3u * kCoopQuantStride * 4u;
     if (p.team) {
         // four teams of four waves: one workgroup per CU, one copy of the tables
         const uint32_t team_area = coop_team_area(p.window_words);
+        tables += kWalkTables * kWalkEntries * 4u;
         uint32_t teams = 4;
         while (teams > 1 && tables + teams * team_area > kLdsBytesPerCu)
             teams--;
         if (tables + teams * team_area > kLdsBytesPerCu)
             return p;
-        // (a small launch: more workgroups rather than fuller ones)
+        // the fewest teams per workgroup with which the whole launch is resident at once (a small launch spreads
+        // over the CUs; a large one shares a copy of the tables among four teams)
         const uint64_t all_teams = uint64_t((max_intervals + p.intervals_per_wave - 1) / p.intervals_per_wave) * images;
-        while (teams > 1 && all_teams / teams < 256u)
-            teams /= 2u;
+        for (uint32_t fewer = 1; fewer < teams; fewer *= 2u) {
+            const uint64_t resident = uint64_t(kCuCount) * (kLdsBytesPerCu / (tables + fewer * team_area));
+            if ((all_teams + fewer - 1) / fewer <= resident) {
+                teams = fewer;
+                break;
+            }
+        }
         p.waves_per_block = teams * kCoopTeamWaves;
         p.total_bytes = tables + teams * team_area;
         const uint64_t teams_total = uint64_t((max_intervals + p.intervals_per_wave - 1) / p.intervals_per_wave) * images;

@@ -472,10 +472,16 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     uint8_t *db = static_cast<uint8_t *>(dev_blob.ptr);
     const size_t l1_off = align_up(sizeof(ImageDesc), 256), l2_off = l1_off + COMPEG_HUFFMAN_L1_BYTES;
 
+    // the cooperative kernel may take this image: its walk tables' place
+    const bool want_walk = is_422(img) && use_fused_pipeline() && coop_team() && use_coop_kernel(md.total_restart_intervals, 1);
+    if (want_walk)
+        CG_TRY(walk_tables.reserve(kWalkTableBytes));
+
     // image descriptor + LUTs into the staging blob at hb, as they will sit at db
     auto write_blob = [&](const void *words_ptr, const void *starts_ptr, size_t n_words, size_t n_starts) {
         ImageDesc &d = *reinterpret_cast<ImageDesc *>(hb);
         fill_desc(img, d);
+        d.walk = want_walk && d.coop_ok ? static_cast<const uint32_t *>(walk_tables.ptr) : nullptr;
         d.words = static_cast<const uint32_t *>(words_ptr);
         d.starts = static_cast<const uint32_t *>(starts_ptr);
         d.nwords = uint32_t(n_words);
@@ -606,9 +612,24 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
                                                                   md.total_restart_intervals, ipw);
             coop = plan_coop(md.total_restart_intervals, 1, md.restart_interval, staged_lut_entries(img), group_span);
         }
-        if (coop.usable)
+        if (coop.usable) {
+            const ImageDesc &hd = *reinterpret_cast<const ImageDesc *>(hb);
+            if (hd.walk) {
+                // made from the direct tables and from which of them each component uses
+                const size_t tb = table_blob_bytes(img), extra = sizeof hd.fast_table + sizeof hd.dc_fast_table + sizeof hd.fast_off;
+                uint8_t ids[sizeof hd.fast_table + sizeof hd.dc_fast_table + sizeof hd.fast_off];
+                memcpy(ids, hd.fast_table, sizeof hd.fast_table);
+                memcpy(ids + sizeof hd.fast_table, hd.dc_fast_table, sizeof hd.dc_fast_table);
+                memcpy(ids + sizeof hd.fast_table + sizeof hd.dc_fast_table, &hd.fast_off, sizeof hd.fast_off);
+                if (walk_key.size() != tb + extra || memcmp(walk_key.data(), hb + l1_off, tb) != 0 ||
+                    memcmp(walk_key.data() + tb, ids, extra) != 0) {
+                    walk_key.assign(hb + l1_off, hb + l1_off + tb);
+                    walk_key.insert(walk_key.end(), ids, ids + extra);
+                    CG_HIP(launch_walk_tables(reinterpret_cast<const ImageDesc *>(db), 1, stream));
+                }
+            }
             CG_HIP(launch_coop_422(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals, coop, stream));
-        else if (use_pair_kernel(md.total_restart_intervals, 1))
+        } else if (use_pair_kernel(md.total_restart_intervals, 1))
             CG_HIP(launch_pair_422(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals,
                                    plan, stream));
         else
@@ -1011,7 +1032,8 @@ Status compeg_batch::upload_host(size_t n, int threads, const void *items_, cons
             coop_r = 0;
         coop_span = std::max(coop_span, group_spans[i]);
     }
-    CG_HIP(hipMemcpyAsync(dev_descs.ptr, descs.data(), n * sizeof(ImageDesc), hipMemcpyHostToDevice, st));
+    count = n;
+    CG_TRY(make_walk_tables(st));
     CG_HIP(hipStreamSynchronize(st)); // descs (pageable) and the staging arena may be reused from here on
     mark("descs");
     if (trace_on)
@@ -1235,9 +1257,35 @@ Status compeg_batch::upload_device_scan(const ImageData *const *images, size_t n
         algorithmic_bytes += 4ull * nwords + 4ull * expected + COMPEG_METADATA_BYTES +
                              COMPEG_HUFFMAN_L1_BYTES + img.l2.size() * 2 + 4ull * img.width * img.height;
     }
-    CG_HIP(hipMemcpy(dev_descs.ptr, descs.data(), n * sizeof(ImageDesc), hipMemcpyHostToDevice));
     count = n;
+    CG_TRY(make_walk_tables(gpu->stream));
+    CG_HIP(hipStreamSynchronize(gpu->stream));
     decodes_timed = 0;
+    return Status{};
+}
+
+// Uploads the descriptors; in front of that, gives every image its walk tables if the cooperative kernel may
+// decode this batch (uniform batches share one set), and makes them behind the upload.
+Status compeg_batch::make_walk_tables(hipStream_t stream)
+{
+    const size_t n = count;
+    const bool want = n > 0 && coop_r != 0 && !generic_layout && use_fused_pipeline() && coop_team() &&
+                      use_coop_kernel(max_intervals, uint32_t(chunk ? std::min<size_t>(chunk, n) : n));
+    // one set for all: the same tables (uniform) used by the same components
+    bool shared = uniform;
+    for (size_t i = 1; i < n && shared; i++)
+        shared = memcmp(descs[i].fast_table, descs[0].fast_table, sizeof descs[0].fast_table) == 0 &&
+                 memcmp(descs[i].dc_fast_table, descs[0].dc_fast_table, sizeof descs[0].dc_fast_table) == 0 &&
+                 descs[i].fast_off == descs[0].fast_off;
+    if (want)
+        CG_TRY(walk_tables.reserve(kWalkTableBytes * (shared ? 1 : n)));
+    for (size_t i = 0; i < n; i++)
+        descs[i].walk = want ? reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(walk_tables.ptr) +
+                                                                  (shared ? 0 : i) * kWalkTableBytes)
+                             : nullptr;
+    CG_HIP(hipMemcpyAsync(dev_descs.ptr, descs.data(), n * sizeof(ImageDesc), hipMemcpyHostToDevice, stream));
+    if (want)
+        CG_HIP(launch_walk_tables(static_cast<const ImageDesc *>(dev_descs.ptr), uint32_t(shared ? 1 : n), stream));
     return Status{};
 }
 

@@ -71,6 +71,10 @@ struct compeg_decoder {
     compeg::ScanBuffer scan;
     compeg::PinnedBuffer host_blob;   // ImageDesc + L1 + L2 for the next upload
     compeg::DeviceBuffer dev_blob, words, starts, ac, dc, out;
+    // the cooperative kernel's walk tables (kernels.h) and the Huffman tables they were made from: frames of one
+    // stream carry the same tables, the walk tables are made again only when those change
+    compeg::DeviceBuffer walk_tables;
+    std::vector<uint8_t> walk_key;
     uint32_t out_w = 0, out_h = 0;
     size_t out_pitch = 0;
     hipEvent_t upload_done = nullptr; // host staging may be rewritten after this
@@ -122,6 +126,8 @@ struct compeg_batch {
     size_t count = 0;
     std::vector<compeg::ImageDesc> descs; // host copy (device pointers inside)
     compeg::DeviceBuffer dev_descs, inputs, ac, dc, out;
+    compeg::DeviceBuffer walk_tables; // the cooperative kernel's (kernels.h), made at upload when it may run
+    compeg::Status make_walk_tables(hipStream_t stream); // (behind the descriptors' upload)
     compeg::PinnedBuffer stage; // host copy of the input arena (kept between uploads: pinning is slow)
     std::vector<size_t> out_offset;
     uint32_t max_intervals = 0, max_dus = 0, max_l2 = 0, max_span = 0;

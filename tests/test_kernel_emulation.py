@@ -26,12 +26,14 @@ def runner():
 STATS = {}   # rare-path counters of the emulated kernels, summed over every run of this module
 
 
-def _run(runner, tmp_path, jpeg, fused, waves=1, window=2048, l2=12288, standard=False):
+def _run(runner, tmp_path, jpeg, fused, waves=1, window=2048, l2=12288, standard=False, coop_passes=1):
     p = tmp_path / "in.jpg"
     p.write_bytes(jpeg)
     env = dict(os.environ)
     env.pop("EMUL_FUSED", None)
     env.pop("EMUL_STANDARD", None)
+    # 4: the team form's walk (sixteen intervals of DRI = 4 per walk, through the walk tables), 1: the one-wave form's
+    env["EMUL_COOP_PASSES"] = str(coop_passes)
     if standard:
         env["EMUL_STANDARD"] = "1"
     if fused:
@@ -59,9 +61,11 @@ def _check(runner, tmp_path, jpeg, **kw):
     # the cooperative kernel, with the window the runtime would plan and with the test's (possibly cut short: the
     # walks that leave it hand their interval to the serial decoder)
     for window in sorted({0, kw.get("window", 0)}):
-        got = _run(runner, tmp_path, jpeg, 5, window=window)
-        if got is not None:
-            assert np.array_equal(got, want), f"cooperative kernel, window {window}: {(got != want).any(axis=2).sum()} pixels differ"
+        for passes in (4, 1):
+            got = _run(runner, tmp_path, jpeg, 5, window=window, coop_passes=passes)
+            if got is not None:
+                assert np.array_equal(got, want), (f"cooperative kernel, window {window}, {passes} round(s) per walk: "
+                                                   f"{(got != want).any(axis=2).sum()} pixels differ")
 
 
 CASES = [
@@ -139,10 +143,11 @@ def test_emulated_cooperative_kernel_on_the_gpu_suite_inputs(runner, tmp_path):
             want = orc.ImageData(j).decode()
         except orc.OracleError:
             continue
-        got = _run(runner, tmp_path, j, 5, window=0)
-        if got is not None:
-            assert np.array_equal(got, want), f"{(got != want).any(axis=2).sum()} pixels differ"
-            checked += 1
+        for passes in (4, 1):
+            got = _run(runner, tmp_path, j, 5, window=0, coop_passes=passes)
+            if got is not None:
+                assert np.array_equal(got, want), f"{passes} round(s) per walk: {(got != want).any(axis=2).sum()} pixels differ"
+                checked += passes == 4
     assert checked >= 10
 
 
@@ -197,8 +202,8 @@ def test_emulated_standard_entropy_extension(runner, tmp_path):
         want = orc.ImageData(jpeg, standard_entropy=True).decode()
         if kind == 0:
             assert not np.array_equal(want, orc.ImageData(jpeg).decode())   # the switch matters on this input
-        for fused in (1, 2, 3, 0, 5):
-            got = _run(runner, tmp_path, jpeg, fused, window=window, standard=True)
+        for fused in (1, 2, 3, 0, 5, 54):
+            got = _run(runner, tmp_path, jpeg, fused % 10, window=window, standard=True, coop_passes=4 if fused == 54 else 1)
             if got is None:
                 continue   # (the cooperative kernel takes restart intervals of 1, 2, 4, 8, 16 MCUs)
             assert np.array_equal(got, want), f"fused={fused} {w}x{h}: {(got != want).any(axis=2).sum()} pixels differ"

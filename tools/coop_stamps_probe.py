@@ -35,13 +35,15 @@ print("device clock (10 ns ticks): first wave starts at 0; starts p50 %d max %d;
     np.median(wall[ok, 0] - t0), (wall[ok, 0] - t0).max(), np.median(wall[ok, 1] - t0), np.percentile(wall[ok, 1] - t0, 99),
     (wall[ok, 1] - t0).max()))
 if team:
-    walker = np.zeros(waves, dtype=bool)
-    idx = np.arange(waves)
-    walker[(idx % 4) == ((idx // 4) % 2)] = True  # team t of a workgroup of two teams walks with its wave t
+    walker = buf[:, 1] > 0  # (the waves that spent time in the walk loop)
     for name, sel in (("walkers", walker), ("others", ~walker)):
         sub = buf[sel & ok]
         print(name, "cycles/wave by phase:", " ".join("%s %.0f" % (n, c) for n, c in zip(
             ("setup", "chase", "validate", "decode", "fixups", "dc+idct", "composite", "wait"), sub.mean(axis=0))))
+    ex = full[walker & ok, 10:15].astype(np.float64)
+    if ex[:, 1].sum() > 0:
+        print("walk loop alone: cycles/wave %.0f, steps/wave %.1f, cycles/step %.0f, times entered %.1f; before it %.0f, entries to state words %.0f" % (
+            ex[:, 0].mean(), ex[:, 1].mean(), ex[:, 0].sum() / ex[:, 1].sum(), ex[:, 2].mean(), ex[:, 3].mean(), ex[:, 4].mean()))
 tot = buf.sum(axis=1)
 print("waves", waves, "cycles/wave mean %.0f max %.0f p99 %.0f" % (tot.mean(), tot.max(), np.percentile(tot, 99)))
 names = ("setup", "chase", "validate", "decode", "fixups", "dc+idct", "composite", "wait")
