@@ -43,7 +43,7 @@ namespace compeg {
 
 #if defined(CG_EMUL_STATS)
 struct CoopStats {
-    unsigned long intervals, rounds, continued, serial, dead, zero, chase_steps, wave_steps, true_steps, true_max, hist[16], link_tries, link_ok, link_full_ok, link_none;
+    unsigned long intervals, rounds, direct, continued, serial, dead, zero, chase_steps, wave_steps, true_steps, true_max, hist[16], link_tries, link_ok, link_full_ok, link_none;
 };
 inline CoopStats g_coop_stats{};
 #define CG_COOP_COUNT(field, n) (g_coop_stats.field += (n))
@@ -308,6 +308,10 @@ struct ChaseState {
     uint32_t flags;    // kStopAnomaly
     bool used;         // this lane walks at all
     bool active;
+    // chase_run_lean's results, until chase_lean_finish or coop_lean_emit has read them
+    uint32_t lean_j0, lean_done; // entries [lean_j0, lean_done) of the list are 16-byte entries
+    uint32_t lean_p;             // where the walk stands
+    bool lean_walked;
 #if defined(CG_COOP_STAMPS)
     uint64_t loop_cycles; // (diagnostic builds) inside the hand-written loop: cycles, steps, times entered
     uint32_t loop_steps, loop_entries;
@@ -656,39 +660,10 @@ CG_DEV void chase_run_lean(ChaseState &c, const ImageDesc &d, const HuffShared &
             }
         }
     done = (lpa - lb) / 16u;
-#if defined(CG_COOP_STAMPS)
-    const uint64_t t_tail = __builtin_readcyclecounter();
-#endif
-    // the entries, as state words: all of them are read before the first one is written (entry j moves from
-    // byte 16 j to byte 4 j)
-    {
-        uint32_t w[16], Tw[16];
-#pragma unroll
-        for (uint32_t j = 1; j < 16u; j++) {
-            const bool mine = j >= j0 && j < done;
-            w[j] = mine ? list[4u * j] : 0u;
-            Tw[j] = mine ? list[4u * j + 1u] : 0u;
-        }
-        uint32_t p_last = c.p, cut = done;
-#pragma unroll
-        for (uint32_t j = 1; j < 16u; j++) {
-            if (j >= j0 && j < cut) {
-                p_last = 8u * (w[j] - win) + 32u - uint32_t(int32_t(int16_t(Tw[j] & 0xffffu)));
-                list[j] = (p_last & 0xffffu) | (((Tw[j] >> kWalkLastShift) & 31u) << 16);
-                if (p_last >= c.stop_p)
-                    cut = j + 1u; // the walk ends here, as chase_run's does (what lies behind may be off the window)
-            }
-        }
-        done = cut;
-        c.p = p_last;
-    }
-#if defined(CG_COOP_STAMPS)
-    c.tail_cycles += __builtin_readcyclecounter() - t_tail;
-#endif
+    c.lean_p = 8u * (wa - win) + 32u - (T & 31u);
 #else
     if (c.active) {
         uint32_t wa = wi1 - 1u, j = j0; // (word index of A; -1 for a walk that starts at position 0)
-        uint32_t p_last = c.p;
         while (j < jmax) {
             steps++;
             const uint32_t p_now = 32u * (wa + 1u) - (T & 31u);
@@ -715,21 +690,67 @@ CG_DEV void chase_run_lean(ChaseState &c, const ImageDesc &d, const HuffShared &
             j += du_end ? 1u : 0u;
         }
         done = j;
-        // the entries, as state words
-        for (uint32_t jj = j0; jj < done; jj++) {
-            const uint32_t w = list[4u * jj], Tj = list[4u * jj + 1u];
-            p_last = 32u * (w + 1u) - uint32_t(int32_t(int16_t(Tj & 0xffffu)));
-            list[jj] = (p_last & 0xffffu) | (((Tj >> kWalkLastShift) & 31u) << 16);
-            if (p_last >= c.stop_p)
-                done = jj + 1u; // the walk ends here, as chase_run's does (what lies behind may be off the window)
-        }
-        c.p = p_last;
+        c.lean_p = 32u * (wa + 1u) - (T & 31u);
     }
 #endif
-    c.s = 0u;
-    c.k8 += 8u * (done - j0);
-    c.lp = list + done;
+    c.lean_walked = c.active;
+    c.lean_j0 = j0;
+    c.lean_done = done;
     c.active = false;
+}
+
+// Position and state word of a 16-byte entry {w, Tj} of chase_run_lean.
+CG_DEV uint32_t lean_entry_pos(const HuffShared &s, uint32_t w, uint32_t Tj)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return 8u * (w - uint32_t(reinterpret_cast<uintptr_t>(s.win))) + 32u - uint32_t(int32_t(int16_t(Tj & 0xffffu)));
+#else
+    (void)s;
+    return 32u * (w + 1u) - uint32_t(int32_t(int16_t(Tj & 0xffffu)));
+#endif
+}
+CG_DEV uint32_t lean_entry_state(uint32_t pos, uint32_t Tj) { return (pos & 0xffffu) | (((Tj >> kWalkLastShift) & 31u) << 16); }
+
+// The walk went as it nearly always does: every data unit found, inside the window, in front of the interval's
+// end.  (Otherwise chase_lean_finish makes the list everybody else reads, and validation decides.)
+CG_DEV bool chase_lean_regular(const ChaseState &c, uint32_t *list)
+{
+    if (c.flags & kStopAnomaly)
+        return false;
+    return !c.lean_walked || (c.lean_done == uint32_t(c.lp_max - list) && c.lean_p < c.stop_p);
+}
+
+// The entries as state words, the lane's state as chase_run leaves it.  All entries are read before the first one
+// is written (entry j moves from byte 16 j to byte 4 j).
+CG_DEV void chase_lean_finish(ChaseState &c, const HuffShared &s, uint32_t *list)
+{
+    const uint32_t j0 = c.lean_j0;
+    uint32_t done = c.lean_done;
+    if (c.lean_walked) {
+        uint32_t w[16], Tw[16];
+#pragma unroll
+        for (uint32_t j = 1; j < 16u; j++) {
+            const bool mine = j >= j0 && j < done;
+            w[j] = mine ? list[4u * j] : 0u;
+            Tw[j] = mine ? list[4u * j + 1u] : 0u;
+        }
+        uint32_t p_last = c.p, cut = done;
+#pragma unroll
+        for (uint32_t j = 1; j < 16u; j++) {
+            if (j >= j0 && j < cut) {
+                p_last = lean_entry_pos(s, w[j], Tw[j]);
+                list[j] = lean_entry_state(p_last, Tw[j]);
+                if (p_last >= c.stop_p)
+                    cut = j + 1u; // the walk ends here, as chase_run's does (what lies behind may be off the window)
+            }
+        }
+        done = cut;
+        c.p = p_last;
+        c.s = 0u;
+        c.k8 += 8u * (done - j0);
+        c.lp = list + done;
+    }
+    c.lean_walked = false;
 }
 
 // Word offset (inside the interval) at which subsequence j of `count` (a power of two) begins.
@@ -948,6 +969,26 @@ CG_DEV void coop_emit(const CoopShared &cs, const CoopGeom &g, uint32_t il, uint
         const uint32_t x = sg & 63u, from = (sg >> 6) & 31u, cnt = (sg >> 11) & 31u, du0 = sg >> 16;
         if (tl >= du0 && tl - du0 < cnt)
             cs.du_state[slot] = cs.lists[x * kCoopListCap + from + (tl - du0)] & kCoopStateMask;
+    }
+}
+
+// After walks through the walk tables that all went regularly (chase_lean_regular): every lane fetches the start
+// state of its data unit(s) from the walker's 16-byte entries -- no lists, no links to follow.
+CG_DEV void coop_lean_emit(const CoopShared &cs, const CoopGeom &g, uint32_t lane)
+{
+    for (uint32_t pass = 0; pass < g.passes; pass++) {
+        const uint32_t il = pass * g.ipp + (lane >> g.dpi_shift), tl = lane & (g.dpi - 1u);
+        if (il >= g.intervals)
+            continue;
+        const uint32_t *list = cs.lists + (il << g.lpi_shift) * kCoopListCap;
+        uint32_t state = list[0] & kCoopStateMask;
+        if (tl != 0u) {
+            const uint32_t w = list[4u * tl], Tj = list[4u * tl + 1u];
+            state = lean_entry_state(lean_entry_pos(cs.h, w, Tj), Tj);
+        }
+        cs.du_state[pass * uint32_t(kWave) + lane] = state;
+        if (tl == 0u)
+            cs.verdict[il] = kVerdictDone;
     }
 }
 
@@ -1230,7 +1271,7 @@ CG_DEV bool coop_any(const bool (&flag)[LANES])
 // how every interval stands into cs.verdict.
 template <int LANES>
 CG_DEV void coop_walk_422(const ImageDesc &d, const CoopShared &cs, const CoopTables &t, const CoopGeom &g,
-                          uint32_t my_lane, uint32_t wave_index, CoopClock &clk)
+                          uint32_t my_lane, uint32_t wave_index, CoopClock &clk, const CoopLane *ready = nullptr)
 {
     const HuffShared &s = cs.h;
     CoopLane L[LANES];
@@ -1240,7 +1281,10 @@ CG_DEV void coop_walk_422(const ImageDesc &d, const CoopShared &cs, const CoopTa
     (void)clk;
     CG_EACH_LANE
     {
-        coop_lane(d, s, g, LANES == 1 ? my_lane : uint32_t(li), L[li]);
+        if (LANES == 1 && ready)
+            L[li] = *ready; // (looked up while the tables were on their way)
+        else
+            coop_lane(d, s, g, LANES == 1 ? my_lane : uint32_t(li), L[li]);
         const uint32_t lane = L[li].lane;
         for (uint32_t pass = 0; pass < g.passes; pass++)
             cs.du_state[pass * uint32_t(kWave) + lane] = kCoopUnset;
@@ -1267,7 +1311,7 @@ CG_DEV void coop_walk_422(const ImageDesc &d, const CoopShared &cs, const CoopTa
             CG_EACH_LANE
             {
                 unsigned long steps = 0;
-                if (lean)
+                if (lean && round == 0u)
                     chase_run_lean(c[li], d, s, t, cs.lists + L[li].lane * kCoopListCap, steps);
                 else
                     chase_run(c[li], d, s, t, steps);
@@ -1290,6 +1334,20 @@ CG_DEV void coop_walk_422(const ImageDesc &d, const CoopShared &cs, const CoopTa
             }
 #endif
             (void)most_true;
+        }
+        if (lean && round == 0u) {
+            bool irregular[LANES];
+            CG_EACH_LANE irregular[li] = !chase_lean_regular(c[li], cs.lists + L[li].lane * kCoopListCap);
+            if (!coop_any<LANES>(irregular)) {
+                CG_WAVE_SYNC();
+                CG_EACH_LANE coop_lean_emit(cs, g, L[li].lane);
+                CG_WAVE_SYNC();
+                if (LANES != 1)
+                    CG_COOP_COUNT(direct, 1);
+                CG_COOP_STAMP(1);
+                return;
+            }
+            CG_EACH_LANE chase_lean_finish(c[li], s, cs.lists + L[li].lane * kCoopListCap);
         }
         CG_COOP_STAMP(1);
 #if defined(CG_COOP_STAMPS) && defined(__HIP_DEVICE_COMPILE__)

@@ -650,6 +650,15 @@ decode_coop_team_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_
     if (threadIdx.x < 3u * kRetained)
         quant[(threadIdx.x / kRetained) * kCoopQuantStride + threadIdx.x % kRetained] =
             d.quant[threadIdx.x / kRetained][threadIdx.x % kRetained];
+    // (the walker's lanes look up where their intervals begin while all this is on its way)
+    CoopLane my_walk{};
+    const bool walker = member == (team & (kCoopTeamWaves - 1u));
+    if (walker && g.intervals) {
+        HuffShared hw{};
+        hw.win_base = win_base;
+        hw.win_len = win_len;
+        coop_lane(d, hw, g, lane, my_walk);
+    }
     if (d.walk) {
         SlotVec *dst = reinterpret_cast<SlotVec *>(walk);
         for (uint32_t i = threadIdx.x; i < kWalkTables * kWalkEntries / 4u; i += blockDim.x)
@@ -674,9 +683,9 @@ decode_coop_team_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_
     t.walk = d.walk ? walk : nullptr;
     const uint32_t team_index = blockIdx.x * teams + team;
     // (team t's walker is its wave t: waves go to the SIMDs round robin, so the walkers of a workgroup do not share one)
-    if (member == (team & (kCoopTeamWaves - 1u))) {
+    if (walker) {
         if (g.intervals)
-            coop_walk_422<1>(d, cs, t, g, lane, team_index, clk);
+            coop_walk_422<1>(d, cs, t, g, lane, team_index, clk, &my_walk);
         team_signal(flags, lane);
     } else {
         team_wait(flags);

@@ -381,8 +381,8 @@ int main(int argc, char **argv)
     const EmulStats &st = g_emul_stats;
     const CoopStats &cst = g_coop_stats;
     if (cst.intervals)
-        fprintf(stderr, "coop intervals=%lu rounds=%lu continued=%lu serial=%lu dead=%lu zero=%lu chase_steps=%lu wave_steps=%lu\n", cst.intervals,
-                cst.rounds, cst.continued, cst.serial, cst.dead, cst.zero, cst.chase_steps, cst.wave_steps);
+        fprintf(stderr, "coop intervals=%lu rounds=%lu direct=%lu continued=%lu serial=%lu dead=%lu zero=%lu chase_steps=%lu wave_steps=%lu\n", cst.intervals,
+                cst.rounds, cst.direct, cst.continued, cst.serial, cst.dead, cst.zero, cst.chase_steps, cst.wave_steps);
     if (cst.intervals && getenv("EMUL_COOP_HIST")) {
         fprintf(stderr, "cooplinks (first lane of each interval) tries=%lu ok=%lu only_full_match=%lu none=%lu\n", cst.link_tries, cst.link_ok, cst.link_full_ok, cst.link_none);
         fprintf(stderr, "coophist true_steps=%lu true_max=%lu hist(16 steps per bin):", cst.true_steps, cst.true_max);
