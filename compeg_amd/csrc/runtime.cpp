@@ -120,7 +120,7 @@ bool use_pair_kernel(uint32_t max_intervals, uint32_t images)
 
 // ... and of those, the ones whose images qualify (ImageDesc::coop_ok, one restart interval for the whole
 // launch) take the cooperative kernel, which spends the idle lanes inside the intervals (coop_body.h).
-bool use_coop_kernel(uint32_t max_intervals, uint32_t images)
+bool use_coop_kernel(uint32_t max_intervals, uint32_t images, uint32_t restart_interval)
 {
     static const int forced = [] {
         const char *e = getenv("COMPEG_COOP"); // experiment knob: 0 / 1
@@ -128,12 +128,23 @@ bool use_coop_kernel(uint32_t max_intervals, uint32_t images)
     }();
     if (forced >= 0)
         return forced != 0;
-    // Measured (one frame, DRI = 4, kernel time paired / cooperative): 640x360 57 / 50 us, 1280x720 59 / 53,
-    // 1920x1080 56 / 54, 3840x2160 59 / 72 -- the cooperative kernel wins while its waves (four intervals
-    // each with DRI = 4) find a SIMD of their own, and loses once four of them share one: its walks are
-    // bound by the latency of their dependent chain, and the slowest wave of a launch (the one whose lanes
-    // had to walk on twice) then takes too long.
-    return uint64_t(max_intervals) * images <= 6000;
+    // Measured (one frame, DRI = 4, kernel time paired / cooperative in its team form): 1280x720 59 / 42 us,
+    // 1920x1080 56 / 46, 3840x2160 59 / 52.  The cooperative kernel's teams (256 data units each) are resident
+    // four to a CU; a launch that needs a second round of them is the paired or the fused kernel's.
+    const uint64_t data_units = uint64_t(max_intervals) * images * 4u * restart_interval;
+    return data_units <= 1024ull * 256u;
+}
+
+// Device preprocessing reports the largest word span of 64 consecutive intervals only.  What the cooperative kernel
+// plans its windows with is the span of a team's group of intervals: their share of it and half as much again.
+// (A group that is longer than that still decodes: the walks that leave the window hand their interval to the
+// serial decoder.)
+uint32_t coop_span_estimate(uint32_t span_of_64, uint32_t intervals_per_group)
+{
+    if (intervals_per_group >= kWave)
+        return span_of_64;
+    const uint64_t share = uint64_t(span_of_64) * intervals_per_group / kWave;
+    return uint32_t(std::min<uint64_t>(span_of_64, share + share / 2 + 64));
 }
 
 // Single-image device preprocessing: the raw segment is fetched from the pinned staging buffer by a
@@ -473,7 +484,7 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     const size_t l1_off = align_up(sizeof(ImageDesc), 256), l2_off = l1_off + COMPEG_HUFFMAN_L1_BYTES;
 
     // the cooperative kernel may take this image: its walk tables' place
-    const bool want_walk = is_422(img) && use_fused_pipeline() && coop_team() && use_coop_kernel(md.total_restart_intervals, 1);
+    const bool want_walk = is_422(img) && use_fused_pipeline() && coop_team() && use_coop_kernel(md.total_restart_intervals, 1, md.restart_interval);
     if (want_walk)
         CG_TRY(walk_tables.reserve(kWalkTableBytes));
 
@@ -605,9 +616,9 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
         coefficients_valid = false;
     } else if (fused) {
         CoopPlan coop{};
-        if (reinterpret_cast<const ImageDesc *>(hb)->coop_ok && use_coop_kernel(md.total_restart_intervals, 1)) {
+        if (reinterpret_cast<const ImageDesc *>(hb)->coop_ok && use_coop_kernel(md.total_restart_intervals, 1, md.restart_interval)) {
             const uint32_t ipw = uint32_t(kWave) / (4u * md.restart_interval) * (coop_team() ? 4u : coop_passes());
-            const uint32_t group_span = on_device ? uint32_t(std::min<uint64_t>(uint64_t(dev_span) * ipw / kWave + 64, 0x7fffffffu))
+            const uint32_t group_span = on_device ? coop_span_estimate(dev_span, ipw)
                                                   : max_wave_span(scan.starts(), scan.nstarts(), scan.nwords(),
                                                                   md.total_restart_intervals, ipw);
             coop = plan_coop(md.total_restart_intervals, 1, md.restart_interval, staged_lut_entries(img), group_span);
@@ -1251,8 +1262,8 @@ Status compeg_batch::upload_device_scan(const ImageData *const *images, size_t n
         } else {
             // (the kernels report the span of 64 intervals only: four times the average for a wave's group;
             // a group that is longer than that still decodes, its intervals one lane each)
-            const uint64_t ipw = uint64_t(kWave) / (4u * coop_r) * (coop_team() ? 4u : coop_passes()), avg = expected ? (uint64_t(nwords) + expected - 1) / expected : nwords;
-            coop_span = std::max(coop_span, uint32_t(std::min<uint64_t>(std::min<uint64_t>(span, 4 * avg * ipw + 64), 0x7fffffffu)));
+            const uint32_t ipw = uint32_t(kWave) / (4u * coop_r) * (coop_team() ? 4u : coop_passes());
+            coop_span = std::max(coop_span, coop_span_estimate(span, ipw));
         }
         algorithmic_bytes += 4ull * nwords + 4ull * expected + COMPEG_METADATA_BYTES +
                              COMPEG_HUFFMAN_L1_BYTES + img.l2.size() * 2 + 4ull * img.width * img.height;
@@ -1270,7 +1281,7 @@ Status compeg_batch::make_walk_tables(hipStream_t stream)
 {
     const size_t n = count;
     const bool want = n > 0 && coop_r != 0 && !generic_layout && use_fused_pipeline() && coop_team() &&
-                      use_coop_kernel(max_intervals, uint32_t(chunk ? std::min<size_t>(chunk, n) : n));
+                      use_coop_kernel(max_intervals, uint32_t(chunk ? std::min<size_t>(chunk, n) : n), coop_r);
     // one set for all: the same tables (uniform) used by the same components
     bool shared = uniform;
     for (size_t i = 1; i < n && shared; i++)
@@ -1325,7 +1336,7 @@ Status compeg_batch::decode(hipStream_t stream)
         }
         if (fused) {
             CoopPlan coop{};
-            if (coop_r && use_coop_kernel(max_intervals, m))
+            if (coop_r && use_coop_kernel(max_intervals, m, coop_r))
                 coop = plan_coop(max_intervals, m, coop_r, max_l2, coop_span);
             if (coop.usable)
                 CG_HIP(launch_coop_422(dd + at, m, max_intervals, coop, stream));

@@ -24,7 +24,8 @@ namespace compeg {
 Status hip_status(hipError_t e, const char *what);
 bool use_fused_pipeline();
 bool use_pair_kernel(uint32_t max_intervals, uint32_t images);
-bool use_coop_kernel(uint32_t max_intervals, uint32_t images);
+bool use_coop_kernel(uint32_t max_intervals, uint32_t images, uint32_t restart_interval);
+uint32_t coop_span_estimate(uint32_t span_of_64, uint32_t intervals_per_group);
 
 // Grow-only device allocation; contents are not preserved across growth
 // (every user rewrites the buffer in full before reading it).

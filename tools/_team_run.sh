@@ -1,12 +1,12 @@
 set -e
-timeout -k 10 200 python tools/coop_stress.py 4 > gpurun_out/team_stress.log 2>&1 || { tail -5 gpurun_out/team_stress.log; exit 1; }
-grep bad gpurun_out/team_stress.log
-for sz in "3840 2160" "1920 1080" "1280 720"; do set -- $sz
-COMPEG_COOP=1 COMPEG_LIB=gpurun_ab/lib_coopstamps.so timeout -k 10 120 python tools/coop_stamps_probe.py $1 $2 4 2>&1 | head -5
-COMPEG_COOP=1 timeout -k 10 120 python bench.py --width $1 --height $2 --batch 2 --steps 3 --cpu-seconds 0 --no-extra-configs --e2e-reps 0 2>&1 | python -c "
-import sys,json
-for l in sys.stdin:
-    if l.startswith('{'):
-        j=json.loads(l)['single_frame']; print('$1x$2 kernel_ms', j['kernel_ms'], 'device_ms', j['device_ms_per_frame'], 'host e2e', j['host_end_to_end_ms'])
-"
-done
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/r2_pytest_gpu.log 2>&1 || { tail -30 gpurun_out/r2_pytest_gpu.log; exit 1; }
+tail -3 gpurun_out/r2_pytest_gpu.log
+timeout -k 10 600 python bench.py > gpurun_out/r2_bench_default.json 2> gpurun_out/r2_bench_default.err || { tail -20 gpurun_out/r2_bench_default.err; exit 1; }
+python - <<'PY'
+import json
+j=json.loads([l for l in open('gpurun_out/r2_bench_default.json') if l.startswith('{')][-1])
+print({k:j[k] for k in ('value','unit','ms_per_step')}, j['roofline'])
+print('single', {k:j['single_frame'][k] for k in ('kernel_ms','device_ms_per_frame','host_end_to_end_ms')})
+print('e2e', j.get('end_to_end'))
+for c in j.get('other_configs',[]): print(c)
+PY

@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_round
 rm -rf $OUT && mkdir -p $OUT
-B="python3 bench.py --steps 5 --warmup 2 --cpu-seconds 0 --no-verify"
+B="python3 bench.py --steps 5 --warmup 2 --cpu-seconds 0 --no-verify --no-extra-configs --e2e-reps 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $B > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $B > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $B > $OUT/write.log 2>&1
