@@ -732,8 +732,19 @@ CoopPlan plan_coop(uint32_t max_intervals, uint32_t images, uint32_t restart_int
     uint32_t tables = ((((kL1Entries + p.l2_entries_in_lds) * 2u) + 15u) & ~15u) + 3u * kCoopQuantStride * 4u;
     if (p.team) {
         // four teams of four waves: one workgroup per CU, one copy of the tables
-        const uint32_t team_area = coop_team_area(p.window_words);
         tables += kWalkTables * kWalkEntries * 4u;
+        const uint64_t all_teams = uint64_t((max_intervals + p.intervals_per_wave - 1) / p.intervals_per_wave) * images;
+        // A launch that needs four teams per CU to be resident at once gets them even if the window asked for is
+        // a little too large (it is an estimate where the scan was preprocessed on the device): down to three
+        // quarters of it.  A team whose intervals do not fit its window still decodes -- the walks that leave it
+        // hand their interval to the serial decoder.
+        if (all_teams > 3ull * kCuCount && tables + 4u * coop_team_area(p.window_words) > kLdsBytesPerCu) {
+            const uint32_t room = (kLdsBytesPerCu - tables) / 4u, fixed = coop_team_area(0);
+            const uint32_t fit = room > fixed ? ((room - fixed) / 4u) & ~3u : 0u;
+            if (fit >= p.window_words - p.window_words / 4u)
+                p.window_words = fit;
+        }
+        const uint32_t team_area = coop_team_area(p.window_words);
         uint32_t teams = 4;
         while (teams > 1 && tables + teams * team_area > kLdsBytesPerCu)
             teams--;
@@ -741,7 +752,6 @@ CoopPlan plan_coop(uint32_t max_intervals, uint32_t images, uint32_t restart_int
             return p;
         // the fewest teams per workgroup with which the whole launch is resident at once (a small launch spreads
         // over the CUs; a large one shares a copy of the tables among four teams)
-        const uint64_t all_teams = uint64_t((max_intervals + p.intervals_per_wave - 1) / p.intervals_per_wave) * images;
         for (uint32_t fewer = 1; fewer < teams; fewer *= 2u) {
             const uint64_t resident = uint64_t(kCuCount) * (kLdsBytesPerCu / (tables + fewer * team_area));
             if ((all_teams + fewer - 1) / fewer <= resident) {

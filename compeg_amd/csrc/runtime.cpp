@@ -618,7 +618,8 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
         CoopPlan coop{};
         if (reinterpret_cast<const ImageDesc *>(hb)->coop_ok && use_coop_kernel(md.total_restart_intervals, 1, md.restart_interval)) {
             const uint32_t ipw = uint32_t(kWave) / (4u * md.restart_interval) * (coop_team() ? 4u : coop_passes());
-            const uint32_t group_span = on_device ? coop_span_estimate(dev_span, ipw)
+            // (on the device path `dev_span` is itself an estimate, twice the average span of 64 intervals: a group's share of it)
+            const uint32_t group_span = on_device ? uint32_t(std::min<uint64_t>(uint64_t(dev_span) * ipw / kWave + 64, 0x7fffffffu))
                                                   : max_wave_span(scan.starts(), scan.nstarts(), scan.nwords(),
                                                                   md.total_restart_intervals, ipw);
             coop = plan_coop(md.total_restart_intervals, 1, md.restart_interval, staged_lut_entries(img), group_span);
