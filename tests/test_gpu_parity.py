@@ -543,6 +543,34 @@ def test_corrupt_streams_and_hostile_tables_on_the_gpu(ca, gpu):
         _assert_equal(batch.read_output(i), variants[i % len(variants)][1])
 
 
+def test_walk_tables_follow_the_huffman_tables(ca, gpu):
+    """The cooperative kernel's walk tables are made once per set of Huffman tables and kept (by a decoder: across
+    decodes; by a batch: per image unless all images share their tables).  One decoder, images whose tables
+    alternate; then small batches -- which the cooperative kernel takes -- of images with different tables."""
+    base = synth.make_jpeg(640, 360, seed=31, quality=85, ri=4)
+    others = []
+    for j in _hostile_table_variants(10):
+        try:
+            others.append((j, orc.ImageData(j).decode()))
+        except orc.OracleError:
+            pass
+    assert len(others) >= 4
+    want_base = orc.ImageData(base).decode()
+    dec = ca.Decoder(gpu)
+    for j, want in [(base, want_base), others[0], (base, want_base), others[1], others[2], (base, want_base)]:
+        data = ca.ImageData(j)
+        dec.decode_blocking(data)
+        _assert_equal(dec.read_texture(data.width(), data.height()), want)
+    for group in ([(base, want_base), others[0], others[3]], [(base, want_base), (base, want_base)],
+                  [others[1], (base, want_base)]):
+        batch = ca.Batch(gpu)
+        batch.upload([ca.ImageData(j) for j, _ in group])
+        batch.decode()
+        batch.wait()
+        for i, (_, want) in enumerate(group):
+            _assert_equal(batch.read_output(i), want)
+
+
 def test_standard_entropy_extension(ca, gpu):
     """COMPEG_PARSE_STANDARD_ENTROPY (opt-in): bit-exact against the oracle with the same switch, through
     the paired kernel, the throughput kernel and an extension layout; and what the switch is for: the
