@@ -84,25 +84,37 @@ struct CoopTables {
     uint32_t dc_quant[3];
     uint32_t zrl;            // 17 (the reference, quirk Q2) or 16
     bool standard;
-    const uint32_t *walk;    // the walk tables (coop_walk_entry), or null: kWalkTables x kWalkEntries words
-    uint32_t walk_acsel, walk_dcsel; // byte k: the index of the AC table / of the DC + AC table of data unit k of an MCU
-    uint32_t walk_ids;       // bits 2i, 2i + 1: which direct DC table, which direct AC table walk table 2 + i is made of
+    const uint32_t *walk;    // the walk tables (coop_walk_word), or null: kWalkWords words
+    uint32_t walk_acsel, walk_dcsel; // byte k: which pairs / singles tables, which dc table data unit k of an MCU uses
+    uint32_t walk_ids;       // bits 2i, 2i + 1: which direct DC table, which direct AC table dc[i] is made of
     bool walk_ok;            // the components use at most two different pairs of tables
 };
 
 // ---------------------------------------------------------------------------
 // Walk tables: what a walk that only has to find where the data units begin looks up.  One 32-bit entry per
-// 11-bit prefix of the coming stream bits:
+// prefix of the coming stream bits, covering up to TWO symbols (the second one's code has to lie inside the prefix
+// as well; its magnitude bits need not):
 //   bits  0..15  minus the bits consumed (two's complement: added to the reader's shift by the same packed add
 //                that adds bits 21..28 to the zig-zag state)
 //   bits 16..20  size of the last symbol consumed (what a data unit's start state records, quirk Q1)
 //   bits 21..28  zig-zag advance, 64 for an end-of-block
 //   0            the prefix does not determine a symbol (code longer than the prefix): the two-level tables decide
-// Tables 0, 1: the two AC tables, a symbol per entry.  Tables 2, 3: a DC code and, where its code lies inside the
-// prefix as well, the first AC symbol (or the end-of-block) behind it -- for the (at most two) pairs of DC and AC
-// table that the components use.
+// Six tables in 8192 words (entry offsets below):
+//   pairs[a]   11-bit prefixes of AC table a: a symbol and, where it fits, the one behind it.  The second symbol is
+//              an AC symbol of the same data unit by assumption, so these tables are used only while the first one
+//              cannot complete the data unit: zig-zag state below kWalkNear (its advance is at most 17, quirk Q2's
+//              ZRL).  A data unit that ends without an end-of-block would otherwise have its successor's DC code
+//              read as an AC symbol, and nothing in the loop could tell.
+//   singles[a] 10-bit prefixes of AC table a, one symbol: for the states from kWalkNear on.
+//   dc[i]      10-bit prefixes: a DC code and the first AC symbol (or end-of-block) behind it, for the (at most two)
+//              pairs of DC and AC table that the components use.
+// A table is named by one word: its byte address (LDS; offset from the tables' start on the host) with the shift
+// that takes 32 stream bits to its index in the low five bits (tables are 32-byte aligned).
 // ---------------------------------------------------------------------------
-constexpr uint32_t kWalkBits = 11, kWalkEntries = 1u << kWalkBits, kWalkTables = 4;
+constexpr uint32_t kWalkWords = 8192;
+constexpr uint32_t kWalkPairs0 = 0, kWalkPairs1 = 2048, kWalkSingles0 = 4096, kWalkDc0 = 5120, kWalkSingles1 = 6144, kWalkDc1 = 7168;
+constexpr uint32_t kWalkSinglesBehindPairs = 4096; // words, for both AC tables
+constexpr uint32_t kWalkNear = 47;                 // 46 + the largest single advance (17) = 63: the data unit goes on
 constexpr uint32_t kWalkStShift = 21, kWalkLastShift = 16;
 
 CG_DEV uint32_t walk_pack(uint32_t tot, uint32_t last, uint32_t adv)
@@ -110,44 +122,52 @@ CG_DEV uint32_t walk_pack(uint32_t tot, uint32_t last, uint32_t adv)
     return (adv << kWalkStShift) | (last << kWalkLastShift) | ((0u - tot) & 0xffffu);
 }
 
-// ac_fast / dc_fast: the direct tables (device_types.h); table 0, 1: that AC table; 2, 3: DC table dc_id and AC
-// table ac_id
-CG_DEV uint32_t coop_walk_entry(const uint16_t *ac_fast, const uint16_t *dc_fast, uint32_t table, uint32_t idx,
-                                uint32_t dc_id, uint32_t ac_id)
+// Word i of the walk tables.  ac_fast / dc_fast: the direct tables (device_types.h); walk_ids: bits 2i, 2i + 1 name
+// the direct DC table and the direct AC table that dc[i] is made of.
+CG_DEV uint32_t coop_walk_word(const uint16_t *ac_fast, const uint16_t *dc_fast, uint32_t walk_ids, uint32_t i)
 {
-    uint32_t tot1, adv1;
-    if (table < 2u) {
-        ac_id = table;
-        const uint32_t e = ac_fast[ac_id * kFastEntries + idx];
-        tot1 = (e >> 4) & 31u;
-        adv1 = e >> 9;
-        if (e == kFastEscape || tot1 == 0u)
-            return 0u;
+    // which table, how many prefix bits
+    uint32_t bits = 10u, idx, ac_id, dc_id = 0u;
+    bool dc = false, two = true;
+    if (i < kWalkSingles0) {
+        bits = 11u;
+        ac_id = i >> 11;
+        idx = i & 2047u;
     } else {
-        const uint32_t e = dc_fast[dc_id * kDcFastEntries + (idx >> (kWalkBits - kDcFastBits))];
+        const uint32_t q = (i - kWalkSingles0) >> 10; // singles0, dc0, singles1, dc1
+        idx = i & 1023u;
+        dc = (q & 1u) != 0u;
+        two = dc;
+        ac_id = q >> 1;
+        if (dc) {
+            const uint32_t ids = walk_ids >> (2u * (q >> 1));
+            dc_id = ids & 1u;
+            ac_id = (ids >> 1) & 1u;
+        }
+    }
+    const uint32_t prefix = idx << (kFastBits - bits); // as an index of the 11-bit direct AC tables (zeros behind it)
+    uint32_t tot1, adv1;
+    if (dc) {
+        const uint32_t e = dc_fast[dc_id * kDcFastEntries + (prefix >> (kFastBits - kDcFastBits))];
         tot1 = (e >> 4) & 31u;
         adv1 = 1u;
-        if (e == kFastEscape || tot1 == 0u)
+        if (e == kFastEscape || tot1 == 0u || tot1 - (e & 15u) > bits)
+            return 0u;
+    } else {
+        const uint32_t e = ac_fast[ac_id * kFastEntries + prefix];
+        tot1 = (e >> 4) & 31u;
+        adv1 = e >> 9;
+        if (e == kFastEscape || tot1 == 0u || tot1 - (e & 15u) > bits)
             return 0u;
     }
-    // (behind an AC symbol nothing: a data unit may end with that symbol -- its coefficient is number 63 or, with
-    // quirk Q2, beyond -- and what follows is then the next data unit's DC code; the state word shows this only
-    // after the fact)
-    if (table >= 2u && tot1 < kWalkBits) {
-        const uint32_t rest = (idx << tot1) & (kWalkEntries - 1u); // the prefix behind the DC code, zeros behind it
+    if (two && adv1 != kFastAdvEob && tot1 < bits) {
+        const uint32_t rest = (prefix << tot1) & (kFastEntries - 1u); // the prefix behind the first symbol, zeros behind it
         const uint32_t e = ac_fast[ac_id * kFastEntries + rest];
         const uint32_t tot2 = (e >> 4) & 31u, adv2 = e >> 9;
-        if (e != kFastEscape && tot2 != 0u && tot2 - (e & 15u) <= kWalkBits - tot1 && tot1 + tot2 <= 31u)
+        if (e != kFastEscape && tot2 != 0u && tot2 - (e & 15u) <= bits - tot1 && tot1 + tot2 <= 31u)
             return walk_pack(tot1 + tot2, tot2, adv1 + adv2);
     }
     return walk_pack(tot1, tot1, adv1);
-}
-
-// Entry number i of the kWalkTables x kWalkEntries words.
-CG_DEV uint32_t coop_walk_word(const CoopTables &t, uint32_t i)
-{
-    const uint32_t table = i >> kWalkBits, ids = t.walk_ids >> (table >= 2u ? 2u * (table - 2u) : 0u);
-    return coop_walk_entry(t.ac_fast, t.dc_fast, table, i & (kWalkEntries - 1u), ids & 1u, (ids >> 1) & 1u);
 }
 
 // The wave's share of LDS.
@@ -268,7 +288,7 @@ CG_DEV void coop_tables(const ImageDesc &d, const HuffShared &s, CoopTables &t)
         const uint32_t c = comp_of_k(k);
         const uint32_t pr = (d.dc_fast_table[c] & 1u) | ((d.fast_table[c] & 1u) << 1);
         t.walk_acsel |= (d.fast_table[c] & 1u) << (8u * k);
-        t.walk_dcsel |= (pr == pair0 ? 2u : 3u) << (8u * k);
+        t.walk_dcsel |= (pr == pair0 ? 0u : 1u) << (8u * k);
     }
 }
 
@@ -510,6 +530,16 @@ CG_DEV void chase_run(ChaseState &c, const ImageDesc &d, const HuffShared &s, co
     c.active = false;
 }
 
+// The one-word names of the walk tables (see above), relative to the tables' start.
+CG_DEV uint32_t walk_pairs_name(uint32_t ac_id) { return (ac_id ? kWalkPairs1 : kWalkPairs0) * 4u + 21u; }
+CG_DEV uint32_t walk_dc_name(uint32_t i) { return (i ? kWalkDc1 : kWalkDc0) * 4u + 22u; }
+constexpr uint32_t kWalkSinglesName = kWalkSinglesBehindPairs * 4u + 1u; // added to a pairs table's name: its singles table's
+// The entry of table `name` for the 32 stream bits cur (host and first lookups; the loop does the same in three instructions).
+CG_DEV uint32_t walk_lookup(const uint32_t *walk, uint32_t name, uint32_t cur)
+{
+    return walk[(name >> 5 << 3) + ((cur >> (name & 31u)) & 2047u)];
+}
+
 // The walk of a lane that starts at the beginning of a data unit and only has to find where the following ones
 // begin (no speculation: the team form), through the walk tables: up to two symbols per step.
 //
@@ -519,7 +549,7 @@ CG_DEV void chase_run(ChaseState &c, const ImageDesc &d, const HuffShared &s, co
 // 32 - the bits of A that are consumed, below zero when the position has moved on into B), the size of the last
 // symbol (16..20) and the zig-zag state (21..28).  At the end the entries are rewritten as the state words
 // everybody else reads (position | size << 16).
-// Per step on the GPU: 28 instructions (a lone wave issues one every four cycles at best, whatever its kind).
+// Per step on the GPU: 32 instructions (a lone wave issues one every four cycles at best, whatever its kind).
 CG_DEV void chase_run_lean(ChaseState &c, const ImageDesc &d, const HuffShared &s, const CoopTables &t, uint32_t *list,
                            unsigned long &steps)
 {
@@ -529,19 +559,18 @@ CG_DEV void chase_run_lean(ChaseState &c, const ImageDesc &d, const HuffShared &
 #endif
     const uint32_t j0 = uint32_t(c.lp - list), jmax = uint32_t(c.lp_max - list), k0 = (c.k8 >> 3) & 3u;
     constexpr uint32_t kStMask = 0xffu << kWalkStShift, kKeep = kStMask | 31u;
-    constexpr uint32_t kEndAbove = (64u << kWalkStShift) - 1u;
+    constexpr uint32_t kEndAbove = (64u << kWalkStShift) - 1u, kNearAbove = (kWalkNear << kWalkStShift) - 1u;
     uint32_t done = j0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t walk_base = uint32_t(reinterpret_cast<uintptr_t>(t.walk)); // (32-byte aligned)
+#else
+    const uint32_t walk_base = 0u;
+#endif
     if (c.active) {
         for (uint32_t j = j0; j <= jmax; j++) {
             const uint32_t k = (k0 + j - j0) & 3u;
-#if defined(__HIP_DEVICE_COMPILE__)
-            list[4u * j + 2u] = uint32_t(reinterpret_cast<uintptr_t>(t.walk)) + ((t.walk_acsel >> (8u * k)) & 0xffu) * kWalkEntries * 4u;
-            list[4u * j + 3u] = uint32_t(reinterpret_cast<uintptr_t>(t.walk)) +
-                                ((t.walk_dcsel >> (8u * ((k + 1u) & 3u))) & 0xffu) * kWalkEntries * 4u;
-#else
-            list[4u * j + 2u] = ((t.walk_acsel >> (8u * k)) & 0xffu) * kWalkEntries;
-            list[4u * j + 3u] = ((t.walk_dcsel >> (8u * ((k + 1u) & 3u))) & 0xffu) * kWalkEntries;
-#endif
+            list[4u * j + 2u] = walk_base + walk_pairs_name((t.walk_acsel >> (8u * k)) & 0xffu);
+            list[4u * j + 3u] = walk_base + walk_dc_name((t.walk_dcsel >> (8u * ((k + 1u) & 3u))) & 0xffu);
         }
     }
     const uint32_t wi1 = (c.p + 31u) >> 5; // (the word in front of an aligned position is never looked at: shift 0)
@@ -563,7 +592,7 @@ CG_DEV void chase_run_lean(ChaseState &c, const ImageDesc &d, const HuffShared &
         const uint32_t fe = fast_entry(lut_lookup<true>(d, s, sel3(comp, t.ac_off[0], t.ac_off[1], t.ac_off[2]), cur), t.zrl);
         return walk_pack((fe >> 4) & 31u, (fe >> 4) & 31u, fe >> 9);
     };
-    uint32_t ent = c.active ? t.walk[((t.walk_dcsel >> (8u * k0)) & 0xffu) * kWalkEntries + (bits_at(c.p) >> (32u - kWalkBits))] : 0u;
+    uint32_t ent = c.active ? walk_lookup(t.walk, walk_dc_name((t.walk_dcsel >> (8u * k0)) & 0xffu), bits_at(c.p)) : 0u;
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(CG_COOP_NO_ASM)
     uint32_t alive = c.active ? 1u : 0u, code = 0u, cur_out = 0u;
     const uint32_t lb = uint32_t(reinterpret_cast<uintptr_t>(list));
@@ -605,9 +634,13 @@ CG_DEV void chase_run_lean(ChaseState &c, const ImageDesc &d, const HuffShared &
                 "v_alignbit_b32 v45, v43, v44, v51\n\t"
                 "v_cmp_gt_i16 vcc, 0, v51\n\t"                        // the position has left A
                 "v_cmp_lt_u32 s[72:73], %[endabove], v51\n\t"         // the data unit is complete: a DC code comes next
+                "v_cmp_lt_u32 s[82:83], %[nearabove], v51\n\t"        // the next symbol could complete it: one at a time
+                "v_add_u32 v47, %[singles], v48\n\t"
                 "v_cndmask_b32 v41, v41, v45, vcc\n\t"                // the next 32 stream bits
-                "v_cndmask_b32_e64 v46, v48, v49, s[72:73]\n\t"
-                "v_bfe_u32 v45, v41, 21, 11\n\t"
+                "v_cndmask_b32_e64 v46, v48, v47, s[82:83]\n\t"
+                "v_cndmask_b32_e64 v46, v46, v49, s[72:73]\n\t"       // the table's name: address, shift in the low bits
+                "v_bfe_u32 v45, v41, v46, 11\n\t"                     // (a 10-bit table's shift is 22: the field ends at bit 31)
+                "v_and_b32 v46, 0xffffffe0, v46\n\t"
                 "v_lshl_add_u32 v46, v45, 2, v46\n\t"
                 "ds_read_b32 %[ent], v46\n\t"
                 // ---- under that read: move on in the stream, in the list; who goes on
@@ -642,9 +675,10 @@ CG_DEV void chase_run_lean(ChaseState &c, const ImageDesc &d, const HuffShared &
                 "v_mov_b32 %[cur], v41\n\t"                           // the stream bits at the position (lanes that walked)
                 : [lp] "+v"(lpa), [ent] "+v"(ent), [T] "+v"(T), [wa] "+v"(wa), [alive] "+v"(alive), [code] "=s"(code),
                   [cur] "=v"(cur_out) CG_LEAN_STEP_OP
-                : [endabove] "s"(kEndAbove), [keep] "v"(kKeep), [lpmax] "v"(lpmax)
-                : "memory", "vcc", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v48", "v49", "v50", "v51",
-                  "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s84", "s85");
+                : [endabove] "s"(kEndAbove), [nearabove] "s"(kNearAbove), [singles] "v"(kWalkSinglesName), [keep] "v"(kKeep),
+                  [lpmax] "v"(lpmax)
+                : "memory", "vcc", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51",
+                  "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s82", "s83", "s84", "s85");
 #if defined(CG_COOP_STAMPS)
             c.loop_cycles += __builtin_readcyclecounter() - t_in;
             c.loop_entries++;
@@ -680,11 +714,11 @@ CG_DEV void chase_run_lean(ChaseState &c, const ImageDesc &d, const HuffShared &
             const uint32_t T1 = ((T + (ent & 0xffff0000u)) & 0xffff0000u) | ((T + ent) & 0xffffu);
             const int32_t sn = int32_t(int16_t(T1 & 0xffffu));
             const uint32_t p_next = 32u * (wa + 1u) - uint32_t(sn);
-            const bool du_end = T1 > kEndAbove;
+            const bool du_end = T1 > kEndAbove, near = T1 > kNearAbove;
             list[4u * j] = wa;
             list[4u * j + 1u] = T1;
-            const uint32_t table = du_end ? list[4u * j + 3u] : list[4u * j + 2u];
-            ent = t.walk[table + (bits_at(p_next) >> (32u - kWalkBits))];
+            const uint32_t name = du_end ? list[4u * j + 3u] : list[4u * j + 2u] + (near ? kWalkSinglesName : 0u);
+            ent = walk_lookup(t.walk, name, bits_at(p_next));
             wa += sn < 0 ? 1u : 0u;
             T = T1 & (du_end ? 31u : kKeep);
             j += du_end ? 1u : 0u;

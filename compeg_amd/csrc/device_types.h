@@ -69,7 +69,7 @@ struct ImageDesc {
     uint32_t dc_fast_table[3];
     uint32_t coop_ok;
     int16_t zero_du[3][kRetained];
-    // the walk tables (coop_body.h: kWalkTables x kWalkEntries words, made by launch_walk_tables from the direct
+    // the walk tables (coop_body.h: kWalkWords words, made by launch_walk_tables from the direct
     // tables), or null: the cooperative kernel's walks then go symbol by symbol
     const uint32_t *walk;
     // geometry

@@ -576,13 +576,13 @@ __global__ void __launch_bounds__(1024) walk_tables_kernel(const ImageDesc *__re
     CoopTables t;
     coop_tables(d, h, t);
     uint32_t *out = const_cast<uint32_t *>(d.walk);
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < kWalkTables * kWalkEntries; i += gridDim.x * blockDim.x)
-        out[i] = t.walk_ok ? coop_walk_word(t, i) : 0u;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < kWalkWords; i += gridDim.x * blockDim.x)
+        out[i] = t.walk_ok ? coop_walk_word(t.ac_fast, t.dc_fast, t.walk_ids, i) : 0u;
 }
 
 hipError_t launch_walk_tables(const ImageDesc *descs, uint32_t images, hipStream_t stream)
 {
-    hipLaunchKernelGGL(walk_tables_kernel, dim3(kWalkTables * kWalkEntries / 1024u, images, 1), dim3(1024), 0, stream, descs);
+    hipLaunchKernelGGL(walk_tables_kernel, dim3(kWalkWords / 1024u, images, 1), dim3(1024), 0, stream, descs);
     return hipGetLastError();
 }
 
@@ -625,8 +625,9 @@ decode_coop_team_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_
     uint16_t *l1 = reinterpret_cast<uint16_t *>(smem);
     uint16_t *l2 = l1 + kL1Entries;
     float *quant = reinterpret_cast<float *>(smem + align16((kL1Entries + l2_in_lds) * 2u));
-    uint32_t *walk = reinterpret_cast<uint32_t *>(quant + 3u * kCoopQuantStride);
-    uint8_t *team_base = reinterpret_cast<uint8_t *>(walk + kWalkTables * kWalkEntries) + team * coop_team_area(window_words);
+    // (32-byte aligned: a walk table's name carries a shift in its low five bits)
+    uint32_t *walk = reinterpret_cast<uint32_t *>((reinterpret_cast<uintptr_t>(quant + 3u * kCoopQuantStride) + 31u) & ~uintptr_t(31));
+    uint8_t *team_base = reinterpret_cast<uint8_t *>(walk + kWalkWords) + team * coop_team_area(window_words);
     uint32_t *win = reinterpret_cast<uint32_t *>(team_base);
     uint32_t *misc = reinterpret_cast<uint32_t *>(team_base + align16(window_words * 4u));
     uint32_t *flags = misc + kCoopMiscWords;
@@ -661,7 +662,7 @@ decode_coop_team_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_
     }
     if (d.walk) {
         SlotVec *dst = reinterpret_cast<SlotVec *>(walk);
-        for (uint32_t i = threadIdx.x; i < kWalkTables * kWalkEntries / 4u; i += blockDim.x)
+        for (uint32_t i = threadIdx.x; i < kWalkWords / 4u; i += blockDim.x)
             dst[i] = CG_GLOBAL(const SlotVec, reinterpret_cast<const SlotVec *>(d.walk))[i];
     }
     __syncthreads();
@@ -732,7 +733,7 @@ CoopPlan plan_coop(uint32_t max_intervals, uint32_t images, uint32_t restart_int
     uint32_t tables = ((((kL1Entries + p.l2_entries_in_lds) * 2u) + 15u) & ~15u) + 3u * kCoopQuantStride * 4u;
     if (p.team) {
         // four teams of four waves: one workgroup per CU, one copy of the tables
-        tables += kWalkTables * kWalkEntries * 4u;
+        tables = ((tables + 31u) & ~31u) + kWalkWords * 4u;
         const uint64_t all_teams = uint64_t((max_intervals + p.intervals_per_wave - 1) / p.intervals_per_wave) * images;
         // A launch that needs four teams per CU to be resident at once gets them even if the window asked for is
         // a little too large (it is an estimate where the scan was preprocessed on the device): down to three

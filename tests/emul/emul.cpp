@@ -126,9 +126,9 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
             // the team form (four rounds per walk) walks through the walk tables, like the GPU's
             std::vector<uint32_t> walk;
             if (passes >= 4 && !(getenv("EMUL_COOP_LEAN") && atoi(getenv("EMUL_COOP_LEAN")) == 0)) {
-                walk.resize(kWalkTables * kWalkEntries);
+                walk.resize(kWalkWords);
                 for (uint32_t i = 0; i < walk.size(); i++)
-                    walk[i] = coop_walk_word(t, i);
+                    walk[i] = coop_walk_word(t.ac_fast, t.dc_fast, t.walk_ids, i);
                 t.walk = walk.data();
             }
             coop_wave_422<kWave>(d, cs, t, g, 0, wave);
