@@ -293,16 +293,27 @@ CG_DEV void coop_tables(const ImageDesc &d, const HuffShared &s, CoopTables &t)
 }
 
 // The window of the wave's intervals: their contiguous words plus the reader's slack.
-CG_DEV void coop_window(const ImageDesc &d, const CoopGeom &g, uint32_t window_words, uint32_t &base, uint32_t &len)
+// (in two steps, so that a kernel can put other loads between the two reads and their first use)
+CG_DEV void coop_window_fetch(const ImageDesc &d, const CoopGeom &g, uint32_t &first_word, uint32_t &end_word)
 {
     const uint32_t first = g.first_interval, after = first + g.ipw;
-    base = first < d.nstarts ? CG_GLOBAL(const uint32_t, d.starts)[first] : 0u;
-    uint32_t end = (after < d.total_intervals && after < d.nstarts) ? CG_GLOBAL(const uint32_t, d.starts)[after] : d.nwords;
+    first_word = first < d.nstarts ? CG_GLOBAL(const uint32_t, d.starts)[first] : 0u;
+    end_word = (after < d.total_intervals && after < d.nstarts) ? CG_GLOBAL(const uint32_t, d.starts)[after] : d.nwords;
+}
+CG_DEV void coop_window_from(const ImageDesc &d, uint32_t first_word, uint32_t end_word, uint32_t window_words,
+                             uint32_t &base, uint32_t &len)
+{
     // (+ 2: the reader keeps up to two words in hand, so at the start of the last data units of the wave's last
     // interval its position is that far beyond the interval's end -- still inside the window with these)
-    end = umin(end, d.nwords) + kDuWordSlack + 2u;
-    base = umin(base, d.nwords);
+    const uint32_t end = umin(end_word, d.nwords) + kDuWordSlack + 2u;
+    base = umin(first_word, d.nwords);
     len = end > base ? umin(end - base, window_words) : 0u;
+}
+CG_DEV void coop_window(const ImageDesc &d, const CoopGeom &g, uint32_t window_words, uint32_t &base, uint32_t &len)
+{
+    uint32_t first_word, end_word;
+    coop_window_fetch(d, g, first_word, end_word);
+    coop_window_from(d, first_word, end_word, window_words, base, len);
 }
 
 // First bit position at which a walk may not begin another data unit (it could leave the window).
@@ -1385,9 +1396,6 @@ CG_DEV void coop_walk_422(const ImageDesc &d, const CoopShared &cs, const CoopTa
         }
         CG_COOP_STAMP(1);
 #if defined(CG_COOP_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
-        clk.extra[0] += c[0].loop_cycles;
-        clk.extra[1] += c[0].loop_steps;
-        clk.extra[2] += c[0].loop_entries;
         clk.extra[3] += c[0].init_cycles;
         clk.extra[4] += c[0].tail_cycles;
 #endif

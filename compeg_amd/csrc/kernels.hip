@@ -608,11 +608,12 @@ __device__ __forceinline__ void team_wait(uint32_t *flag)
 }
 
 __global__ void __launch_bounds__(1024)
-decode_coop_team_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words, uint32_t spec_shift)
+decode_coop_team_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words, uint32_t spec_shift,
+                            uint32_t teams)
 {
+    // (the workgroup is always 16 waves: those beyond the teams' help with the staging and leave)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const ImageDesc &d = descs[blockIdx.y];
-    const uint32_t teams = blockDim.x / (kWave * kCoopTeamWaves);
     const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x / kWave))), lane = threadIdx.x % kWave;
     const uint32_t team = wave / kCoopTeamWaves, member = wave % kCoopTeamWaves;
     CoopClock clk;
@@ -632,40 +633,95 @@ decode_coop_team_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_
     uint32_t *misc = reinterpret_cast<uint32_t *>(team_base + align16(window_words * 4u));
     uint32_t *flags = misc + kCoopMiscWords;
     uint8_t *mine = reinterpret_cast<uint8_t *>(flags + kCoopTeamFlagWords) + member * (kWave * kDuSlotBytes + kWave * 4u);
-    if (member == 0u && lane < kCoopTeamFlagWords)
+    const bool helper = team >= teams;
+    if (!helper && member == 0u && lane < kCoopTeamFlagWords)
         flags[lane] = 0u;
 
-    uint32_t win_base = 0, win_len = 0;
-    if (g.intervals)
-        coop_window(d, g, window_words, win_base, win_len);
-    // the team's window is staged by its four waves together: wave `member` takes every fourth round of 512 vectors
-    stage_luts(d, l1, l2, l2_in_lds, threadIdx.x, blockDim.x, 2u * kDcFastEntries);
-    {
-        const uint32_t nvec = (win_len + 3u) / 4u;
-        for (uint32_t v0 = member * 8u * kWave + lane; v0 < nvec; v0 += kCoopTeamWaves * 8u * kWave) {
-            SlotVec w[8];
-            window_load_round(d, win_base, win_len, v0, w);
-            window_store_round(win, win_len, v0, w);
-        }
+    // Staging.  Every load of a thread is issued before its first LDS write (copy loops that wait for each load in
+    // turn cost a trip to memory per iteration: 10 k cycles for the 52 KB of tables with four waves), in this
+    // order: where the team's window begins; the tables (which need nothing but the descriptor); then -- waiting
+    // for the first two loads only -- the window and the walker's interval starts.
+    uint32_t win_base = 0, win_len = 0, first_word = 0, end_word = 0;
+    const bool has_window = !helper && g.intervals != 0u;
+    if (has_window)
+        coop_window_fetch(d, g, first_word, end_word);
+    const uint32_t tid = threadIdx.x, nth = blockDim.x;
+    const uint32_t n2 = umin(l2_in_lds, d.fast_off + 2u * kFastEntries + 2u * kDcFastEntries), n2w = (n2 + 1u) / 2u;
+    auto *g_l1 = CG_GLOBAL(const Dwords4, reinterpret_cast<const Dwords4 *>(d.l1));
+    auto *g_l2 = CG_GLOBAL(const Dwords4, reinterpret_cast<const Dwords4 *>(d.l2));
+    auto *g_wk = CG_GLOBAL(const Dwords4, reinterpret_cast<const Dwords4 *>(d.walk));
+    SlotVec *s_l1 = reinterpret_cast<SlotVec *>(l1), *s_l2 = reinterpret_cast<SlotVec *>(l2), *s_wk = reinterpret_cast<SlotVec *>(walk);
+    const uint32_t v_l1 = 4u * 128u / 4u, v_l2 = n2w / 4u, v_wk = d.walk ? kWalkWords / 4u : 0u;
+    constexpr uint32_t kRounds = 2; // (1024 threads: the tables in one go)
+    Dwords4 a1{}, a2[kRounds], aw[kRounds];
+    const bool l1_mine = tid < v_l1;
+    if (l1_mine)
+        a1 = g_l1[tid];
+#pragma unroll
+    for (uint32_t k = 0; k < kRounds; k++) {
+        const uint32_t i = k * nth + tid;
+        if (i < v_l2)
+            a2[k] = g_l2[i];
+        if (i < v_wk)
+            aw[k] = g_wk[i];
     }
-    if (threadIdx.x < 3u * kRetained)
-        quant[(threadIdx.x / kRetained) * kCoopQuantStride + threadIdx.x % kRetained] =
-            d.quant[threadIdx.x / kRetained][threadIdx.x % kRetained];
+    if (has_window)
+        coop_window_from(d, first_word, end_word, window_words, win_base, win_len);
+#if defined(CG_COOP_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+    clk.extra[0] = __builtin_readcyclecounter() - clk.tprev;
+#endif
+    const uint32_t nvec = (win_len + 3u) / 4u, wlane = member * uint32_t(kWave) + lane; // (the team's 256 lanes)
+    SlotVec w[kRounds];
+#pragma unroll
+    for (uint32_t k = 0; k < kRounds; k++)
+        if (k * 256u + wlane < nvec)
+            w[k] = scan_words4(d, win_base + 4u * (k * 256u + wlane));
     // (the walker's lanes look up where their intervals begin while all this is on its way)
     CoopLane my_walk{};
     const bool walker = member == (team & (kCoopTeamWaves - 1u));
-    if (walker && g.intervals) {
+    if (!helper && walker && g.intervals) {
         HuffShared hw{};
         hw.win_base = win_base;
         hw.win_len = win_len;
         coop_lane(d, hw, g, lane, my_walk);
     }
-    if (d.walk) {
-        SlotVec *dst = reinterpret_cast<SlotVec *>(walk);
-        for (uint32_t i = threadIdx.x; i < kWalkWords / 4u; i += blockDim.x)
-            dst[i] = CG_GLOBAL(const SlotVec, reinterpret_cast<const SlotVec *>(d.walk))[i];
+    if (l1_mine)
+        s_l1[tid] = SlotVec{a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+    for (uint32_t k = 0; k < kRounds; k++) {
+        const uint32_t i = k * nth + tid;
+        if (i < v_l2)
+            s_l2[i] = SlotVec{a2[k].x, a2[k].y, a2[k].z, a2[k].w};
+        if (i < v_wk)
+            s_wk[i] = SlotVec{aw[k].x, aw[k].y, aw[k].z, aw[k].w};
+        if (k * 256u + wlane < nvec)
+            reinterpret_cast<SlotVec *>(win)[k * 256u + wlane] = w[k];
     }
+    // what is left over (nothing with 1024 threads and windows of up to 2048 words; table 4 of L1 is all-zero; the
+    // last words of the L2 copy do not fill a vector)
+    for (uint32_t i = kRounds * nth + tid; i < v_l2; i += nth)
+        s_l2[i] = SlotVec{g_l2[i].x, g_l2[i].y, g_l2[i].z, g_l2[i].w};
+    for (uint32_t i = kRounds * nth + tid; i < v_wk; i += nth)
+        s_wk[i] = SlotVec{g_wk[i].x, g_wk[i].y, g_wk[i].z, g_wk[i].w};
+    for (uint32_t i = kRounds * 256u + wlane; i < nvec; i += 256u)
+        reinterpret_cast<SlotVec *>(win)[i] = scan_words4(d, win_base + 4u * i);
+    for (uint32_t i = tid; i < 128u; i += nth)
+        reinterpret_cast<slot_word_t *>(l1)[4u * 128u + i] = 0u;
+    for (uint32_t k = v_l2 * 4u + tid; k < n2w; k += nth)
+        reinterpret_cast<slot_word_t *>(l2)[k] = CG_GLOBAL(const uint32_t, reinterpret_cast<const uint32_t *>(d.l2))[k];
+    if (threadIdx.x < 3u * kRetained)
+        quant[(threadIdx.x / kRetained) * kCoopQuantStride + threadIdx.x % kRetained] =
+            d.quant[threadIdx.x / kRetained][threadIdx.x % kRetained];
+#if defined(CG_COOP_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    clk.extra[1] = __builtin_readcyclecounter() - clk.tprev;
+#endif
     __syncthreads();
+    if (helper)
+        return;
+#if defined(CG_COOP_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+    clk.extra[2] = __builtin_readcyclecounter() - clk.tprev;
+#endif
 
     CoopShared cs;
     cs.h.l1 = l1;
@@ -809,8 +865,8 @@ hipError_t launch_coop_422(const ImageDesc *descs, uint32_t images, uint32_t max
             int(kLdsBytesPerCu));
         if (attr != hipSuccess)
             return attr;
-        hipLaunchKernelGGL(decode_coop_team_422_kernel, grid, dim3(plan.waves_per_block * kWave), plan.total_bytes, stream, descs,
-                           plan.l2_entries_in_lds, plan.window_words, spec_shift);
+        hipLaunchKernelGGL(decode_coop_team_422_kernel, grid, dim3(1024), plan.total_bytes, stream, descs,
+                           plan.l2_entries_in_lds, plan.window_words, spec_shift, teams);
         return hipGetLastError();
     }
     const uint32_t per_block = plan.intervals_per_wave * plan.waves_per_block;

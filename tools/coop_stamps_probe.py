@@ -41,6 +41,8 @@ if team:
         print(name, "cycles/wave by phase:", " ".join("%s %.0f" % (n, c) for n, c in zip(
             ("setup", "chase", "validate", "decode", "fixups", "dc+idct", "composite", "wait"), sub.mean(axis=0))))
     ex = full[walker & ok, 10:15].astype(np.float64)
+    print("staging (cycles from the wave's start): window known %.0f, copies done %.0f, behind the barrier %.0f" % (
+        ex[:, 0].mean(), ex[:, 1].mean(), ex[:, 2].mean()))
     if ex[:, 1].sum() > 0:
         print("walk loop alone: cycles/wave %.0f, steps/wave %.1f, cycles/step %.0f, times entered %.1f; before it %.0f, entries to state words %.0f" % (
             ex[:, 0].mean(), ex[:, 1].mean(), ex[:, 0].sum() / ex[:, 1].sum(), ex[:, 2].mean(), ex[:, 3].mean(), ex[:, 4].mean()))
