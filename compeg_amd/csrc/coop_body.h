@@ -551,6 +551,26 @@ CG_DEV uint32_t walk_lookup(const uint32_t *walk, uint32_t name, uint32_t cur)
     return walk[(name >> 5 << 3) + ((cur >> (name & 31u)) & 2047u)];
 }
 
+// The table names of the walks' list entries (see chase_run_lean), written by all 64 lanes together: entry j of
+// every walking lane names the AC pairs table of data unit j - 1 and the DC table of data unit j.  (The walks of
+// the team form all begin at data unit 0 of their interval.)
+CG_DEV void coop_lean_prepare(const CoopShared &cs, const CoopTables &t, const CoopGeom &g, uint32_t lane)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t walk_base = uint32_t(reinterpret_cast<uintptr_t>(t.walk)); // (32-byte aligned)
+#else
+    const uint32_t walk_base = 0u;
+#endif
+    const uint32_t walkers = g.ipw < uint32_t(kWave) ? g.ipw : uint32_t(kWave), per = uint32_t(kWave) / walkers;
+    const uint32_t il = lane % walkers;
+    uint32_t *list = cs.lists + (il << g.lpi_shift) * kCoopListCap;
+    for (uint32_t j = 1u + lane / walkers; j <= g.dpi; j += per) {
+        const uint32_t k = (j - 1u) & 3u;
+        list[4u * j + 2u] = walk_base + walk_pairs_name((t.walk_acsel >> (8u * k)) & 0xffu);
+        list[4u * j + 3u] = walk_base + walk_dc_name((t.walk_dcsel >> (8u * ((k + 1u) & 3u))) & 0xffu);
+    }
+}
+
 // The walk of a lane that starts at the beginning of a data unit and only has to find where the following ones
 // begin (no speculation: the team form), through the walk tables: up to two symbols per step.
 //
@@ -560,7 +580,8 @@ CG_DEV uint32_t walk_lookup(const uint32_t *walk, uint32_t name, uint32_t cur)
 // 32 - the bits of A that are consumed, below zero when the position has moved on into B), the size of the last
 // symbol (16..20) and the zig-zag state (21..28).  At the end the entries are rewritten as the state words
 // everybody else reads (position | size << 16).
-// Per step on the GPU: 32 instructions (a lone wave issues one every four cycles at best, whatever its kind).
+// Per step on the GPU: 32 instructions (a lone wave issues one every four cycles at best, whatever its kind); codes
+// longer than a table's prefix are looked up in the two-level tables by a branch of the same block.
 CG_DEV void chase_run_lean(ChaseState &c, const ImageDesc &d, const HuffShared &s, const CoopTables &t, uint32_t *list,
                            unsigned long &steps)
 {
@@ -576,14 +597,9 @@ CG_DEV void chase_run_lean(ChaseState &c, const ImageDesc &d, const HuffShared &
     const uint32_t walk_base = uint32_t(reinterpret_cast<uintptr_t>(t.walk)); // (32-byte aligned)
 #else
     const uint32_t walk_base = 0u;
+    (void)walk_base;
 #endif
-    if (c.active) {
-        for (uint32_t j = j0; j <= jmax; j++) {
-            const uint32_t k = (k0 + j - j0) & 3u;
-            list[4u * j + 2u] = walk_base + walk_pairs_name((t.walk_acsel >> (8u * k)) & 0xffu);
-            list[4u * j + 3u] = walk_base + walk_dc_name((t.walk_dcsel >> (8u * ((k + 1u) & 3u))) & 0xffu);
-        }
-    }
+    // (the table names in the entries [j0, jmax] are in place: coop_lean_prepare)
     const uint32_t wi1 = (c.p + 31u) >> 5; // (the word in front of an aligned position is never looked at: shift 0)
     uint32_t T = 32u * wi1 - c.p;          // zig-zag state 0: a DC code comes next
     auto bits_at = [&](uint32_t p_) {
@@ -605,7 +621,12 @@ CG_DEV void chase_run_lean(ChaseState &c, const ImageDesc &d, const HuffShared &
     };
     uint32_t ent = c.active ? walk_lookup(t.walk, walk_dc_name((t.walk_dcsel >> (8u * k0)) & 0xffu), bits_at(c.p)) : 0u;
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(CG_COOP_NO_ASM)
-    uint32_t alive = c.active ? 1u : 0u, code = 0u, cur_out = 0u;
+    (void)resolve; // (the hand-written block has its own)
+    uint32_t alive = c.active ? 1u : 0u, code = 0u, cur_out = 0u, bad_lane = 0u;
+    // which L1 table the codes of each eighth of the walk tables belong to (pairs 0, pairs 1, singles 0, dc 0,
+    // singles 1, dc 1; the AC table of direct table a is L1 table 2 a + 1, the DC table of direct table i is 2 i)
+    const uint32_t dc0 = 2u * (t.walk_ids & 1u), dc1 = 2u * ((t.walk_ids >> 2) & 1u);
+    const uint32_t l1sel = 0x1u | 0x1u << 4 | 0x3u << 8 | 0x3u << 12 | 0x1u << 16 | dc0 << 20 | 0x3u << 24 | dc1 << 28;
     const uint32_t lb = uint32_t(reinterpret_cast<uintptr_t>(list));
     const uint32_t win = uint32_t(reinterpret_cast<uintptr_t>(s.win));
     uint32_t lpa = lb + 16u * j0, wa = win + 4u * wi1 - 4u;
@@ -651,9 +672,9 @@ CG_DEV void chase_run_lean(ChaseState &c, const ImageDesc &d, const HuffShared &
                 "v_cndmask_b32_e64 v46, v48, v47, s[82:83]\n\t"
                 "v_cndmask_b32_e64 v46, v46, v49, s[72:73]\n\t"       // the table's name: address, shift in the low bits
                 "v_bfe_u32 v45, v41, v46, 11\n\t"                     // (a 10-bit table's shift is 22: the field ends at bit 31)
-                "v_and_b32 v46, 0xffffffe0, v46\n\t"
-                "v_lshl_add_u32 v46, v45, 2, v46\n\t"
-                "ds_read_b32 %[ent], v46\n\t"
+                "v_and_b32 v52, 0xffffffe0, v46\n\t"                  // (v46 keeps the name: the long-code branch asks which table)
+                "v_lshl_add_u32 v52, v45, 2, v52\n\t"
+                "ds_read_b32 %[ent], v52\n\t"
                 // ---- under that read: move on in the stream, in the list; who goes on
                 "v_cndmask_b32_e64 v40, 0, 4, vcc\n\t"
                 "v_add_u32 v50, v50, v40\n\t"
@@ -672,7 +693,69 @@ CG_DEV void chase_run_lean(ChaseState &c, const ImageDesc &d, const HuffShared &
                 "s_mov_b32 %[code], 0\n\t"
                 "s_branch 5f\n"
                 "3:\n\t"
-                "s_mov_b32 %[code], 1\n\t"
+                // ---- (rare) lanes s[76:77] met a code longer than their table's prefix: the reference's two-level
+                // tables decide (lut_lookup<true>), one symbol, and the entry is made here (walk_pack of fast_entry's
+                // fields; a DC category above 15 -- a hostile table -- ends that lane's walk)
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "s_mov_b64 s[86:87], exec\n\t"                        // the walking lanes
+                "s_mov_b64 exec, s[76:77]\n\t"
+                "v_subrev_u32 v40, %[walkbase], v46\n\t"
+                "v_bfe_u32 v40, v40, 12, 3\n\t"                       // which eighth of the walk tables
+                "v_lshlrev_b32 v40, 2, v40\n\t"
+                "v_lshrrev_b32_e64 v45, v40, %[l1sel]\n\t"
+                "v_lshrrev_b32_e64 v52, v40, %[dcsel]\n\t"
+                "v_and_b32 v45, 15, v45\n\t"                          // the L1 table of that walk table's codes
+                "v_and_b32 v52, 1, v52\n\t"                           // 1: they are DC codes
+                "v_lshrrev_b32 v47, 24, v41\n\t"
+                "v_lshl_add_u32 v45, v45, 8, v47\n\t"
+                "v_lshl_add_u32 v45, v45, 1, %[l1base]\n\t"
+                "ds_read_u16 v45, v45\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_cmp_lt_u32 vcc, 0x7fff, v45\n\t"                   // a delegate: the second level
+                "s_and_saveexec_b64 s[88:89], vcc\n\t"
+                "s_cbranch_execz 6f\n\t"
+                "v_and_b32 v47, 0x7fff, v45\n\t"
+                "v_bfe_u32 v40, v41, 16, 8\n\t"
+                "v_add_u32 v47, v47, v40\n\t"
+                "v_mov_b32 v45, 0\n\t"
+                "v_cmp_gt_u32 vcc, %[l2n], v47\n\t"
+                "s_and_b64 exec, exec, vcc\n\t"
+                "v_lshl_add_u32 v47, v47, 1, %[l2base]\n\t"
+                "ds_read_u16 v45, v47\n\t"
+                "s_waitcnt lgkmcnt(0)\n"
+                "6:\n\t"
+                "s_mov_b64 exec, s[76:77]\n\t"
+                "v_lshrrev_b32 v40, 8, v45\n\t"                       // code length
+                "v_and_b32 v47, 0xff, v45\n\t"                        // symbol
+                "v_and_b32 v53, 15, v47\n\t"                          // AC: magnitude bits,
+                "v_and_b32 v54, 31, v40\n\t"
+                "v_add_u32 v54, v54, v53\n\t"                         // size (fast_entry's sum: may pass 31 with a hostile table),
+                "v_lshrrev_b32 v55, 4, v47\n\t"
+                "v_add_u32 v55, 1, v55\n\t"                           // advance: run + 1,
+                "v_cmp_eq_u32 vcc, 0xf0, v47\n\t"
+                "v_cndmask_b32_e64 v55, v55, %[zrl], vcc\n\t"         // ZRL,
+                "v_cmp_eq_u32 vcc, 0, v47\n\t"
+                "v_cndmask_b32_e64 v55, v55, 64, vcc\n\t"             // end-of-block
+                "v_lshrrev_b32 v53, 5, v54\n\t"
+                "v_or_b32 v55, v55, v53\n\t"                          // (fast_entry's fields overlap when the size passes 31)
+                "v_and_b32 v54, 31, v54\n\t"
+                "v_add_u32 v53, v40, v47\n\t"                         // DC: size = length + category
+                "v_cmp_lt_u32 s[88:89], 15, v47\n\t"
+                "v_cmp_lt_u32 vcc, 31, v53\n\t"
+                "s_or_b64 s[88:89], s[88:89], vcc\n\t"                // ... which only a hostile table makes that large
+                "v_cmp_eq_u32 vcc, 1, v52\n\t"
+                "v_cndmask_b32 v54, v54, v53, vcc\n\t"
+                "v_cndmask_b32_e64 v55, v55, 1, vcc\n\t"
+                "s_and_b64 s[88:89], s[88:89], vcc\n\t"
+                "v_sub_u32 v53, 0, v54\n\t"
+                "v_and_b32 v53, 0xffff, v53\n\t"
+                "v_lshl_or_b32 v53, v54, 16, v53\n\t"
+                "v_lshl_or_b32 %[ent], v55, 21, v53\n\t"
+                "v_cndmask_b32_e64 %[bad], %[bad], 1, s[88:89]\n\t"
+                "s_andn2_b64 s[86:87], s[86:87], s[88:89]\n\t"
+                "s_mov_b64 exec, s[86:87]\n\t"                        // the walking lanes again, less those
+                "s_cbranch_execnz 1b\n\t"
+                "s_mov_b32 %[code], 0\n\t"
                 "s_branch 5f\n"
                 "4:\n\t"
                 "s_mov_b32 %[code], 0\n"
@@ -685,25 +768,24 @@ CG_DEV void chase_run_lean(ChaseState &c, const ImageDesc &d, const HuffShared &
                 "v_cndmask_b32_e64 %[T], %[T], v51, s[84:85]\n\t"
                 "v_mov_b32 %[cur], v41\n\t"                           // the stream bits at the position (lanes that walked)
                 : [lp] "+v"(lpa), [ent] "+v"(ent), [T] "+v"(T), [wa] "+v"(wa), [alive] "+v"(alive), [code] "=s"(code),
-                  [cur] "=v"(cur_out) CG_LEAN_STEP_OP
+                  [cur] "=v"(cur_out), [bad] "+v"(bad_lane) CG_LEAN_STEP_OP
                 : [endabove] "s"(kEndAbove), [nearabove] "s"(kNearAbove), [singles] "v"(kWalkSinglesName), [keep] "v"(kKeep),
-                  [lpmax] "v"(lpmax)
+                  [lpmax] "v"(lpmax), [walkbase] "s"(walk_base), [l1sel] "s"(l1sel), [dcsel] "s"(0x10100000u),
+                  [l1base] "s"(uint32_t(reinterpret_cast<uintptr_t>(s.l1))), [l2base] "s"(uint32_t(reinterpret_cast<uintptr_t>(s.l2))),
+                  [l2n] "s"(d.l2_entries), [zrl] "v"(t.zrl)
                 : "memory", "vcc", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51",
-                  "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s82", "s83", "s84", "s85");
+                  "v52", "v53", "v54", "v55", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s82", "s83", "s84", "s85",
+                  "s86", "s87", "s88", "s89");
 #if defined(CG_COOP_STAMPS)
             c.loop_cycles += __builtin_readcyclecounter() - t_in;
             c.loop_entries++;
             c.loop_steps = nsteps;
 #endif
+            (void)cur_out;
             if (code == 0u)
                 break;
-            if (alive != 0u && ent == 0u) {
-                bool bad;
-                ent = resolve(cur_out, T >> kWalkStShift, k0 + (lpa - lb) / 16u - j0, bad);
-                c.flags |= bad ? kStopAnomaly : 0u;
-                alive = bad ? 0u : alive;
-            }
         }
+    c.flags |= bad_lane ? kStopAnomaly : 0u;
     done = (lpa - lb) / 16u;
     c.lean_p = 8u * (wa - win) + 32u - (T & 31u);
 #else
@@ -1344,6 +1426,10 @@ CG_DEV void coop_walk_422(const ImageDesc &d, const CoopShared &cs, const CoopTa
     CG_COOP_STAMP(0);
     // nobody speculates and the lists have the room: the walk tables' loop (chase_run_lean)
     const bool lean = t.walk != nullptr && t.walk_ok && g.count == 1u && g.dpi <= 16u;
+    if (lean) {
+        CG_EACH_LANE coop_lean_prepare(cs, t, g, L[li].lane);
+        CG_WAVE_SYNC();
+    }
 
     // ---- 1 + 2: walk, link, follow; lanes that have to walk on do so, until every interval is settled ----
     for (uint32_t round = 0; round <= g.dpi + 1u; round++) {
