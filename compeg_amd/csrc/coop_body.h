@@ -564,7 +564,8 @@ CG_DEV void coop_lean_prepare(const CoopShared &cs, const CoopTables &t, const C
     const uint32_t walkers = g.ipw < uint32_t(kWave) ? g.ipw : uint32_t(kWave), per = uint32_t(kWave) / walkers;
     const uint32_t il = lane % walkers;
     uint32_t *list = cs.lists + (il << g.lpi_shift) * kCoopListCap;
-    for (uint32_t j = 1u + lane / walkers; j <= g.dpi; j += per) {
+    // (entry 0 holds the walk's start state; its table names are there for a long DC code right at the start)
+    for (uint32_t j = lane / walkers; j <= g.dpi; j += per) {
         const uint32_t k = (j - 1u) & 3u;
         list[4u * j + 2u] = walk_base + walk_pairs_name((t.walk_acsel >> (8u * k)) & 0xffu);
         list[4u * j + 3u] = walk_base + walk_dc_name((t.walk_dcsel >> (8u * ((k + 1u) & 3u))) & 0xffu);
@@ -699,13 +700,21 @@ CG_DEV void chase_run_lean(ChaseState &c, const ImageDesc &d, const HuffShared &
                 "s_waitcnt lgkmcnt(0)\n\t"
                 "s_mov_b64 s[86:87], exec\n\t"                        // the walking lanes
                 "s_mov_b64 exec, s[76:77]\n\t"
-                "v_subrev_u32 v40, %[walkbase], v46\n\t"
+                // which table the code belongs to: an AC code (zig-zag state above 0) to the one just looked at
+                // (v46); a DC code -- the lookup of this pass took the new data unit's AC table for it -- to the one the
+                // entry in front of the lane's current one names (coop_lean_prepare)
+                "v_add_u32 v40, -4, %[lp]\n\t"
+                "ds_read_b32 v40, v40\n\t"
+                "v_lshrrev_b32 v52, 21, v51\n\t"
+                "v_cmp_eq_u32 vcc, 0, v52\n\t"
+                "v_cndmask_b32_e64 v52, 0, 1, vcc\n\t"                // 1: a DC code
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_cndmask_b32 v40, v46, v40, vcc\n\t"
+                "v_subrev_u32 v40, %[walkbase], v40\n\t"
                 "v_bfe_u32 v40, v40, 12, 3\n\t"                       // which eighth of the walk tables
                 "v_lshlrev_b32 v40, 2, v40\n\t"
                 "v_lshrrev_b32_e64 v45, v40, %[l1sel]\n\t"
-                "v_lshrrev_b32_e64 v52, v40, %[dcsel]\n\t"
                 "v_and_b32 v45, 15, v45\n\t"                          // the L1 table of that walk table's codes
-                "v_and_b32 v52, 1, v52\n\t"                           // 1: they are DC codes
                 "v_lshrrev_b32 v47, 24, v41\n\t"
                 "v_lshl_add_u32 v45, v45, 8, v47\n\t"
                 "v_lshl_add_u32 v45, v45, 1, %[l1base]\n\t"
@@ -770,7 +779,7 @@ CG_DEV void chase_run_lean(ChaseState &c, const ImageDesc &d, const HuffShared &
                 : [lp] "+v"(lpa), [ent] "+v"(ent), [T] "+v"(T), [wa] "+v"(wa), [alive] "+v"(alive), [code] "=s"(code),
                   [cur] "=v"(cur_out), [bad] "+v"(bad_lane) CG_LEAN_STEP_OP
                 : [endabove] "s"(kEndAbove), [nearabove] "s"(kNearAbove), [singles] "v"(kWalkSinglesName), [keep] "v"(kKeep),
-                  [lpmax] "v"(lpmax), [walkbase] "s"(walk_base), [l1sel] "s"(l1sel), [dcsel] "s"(0x10100000u),
+                  [lpmax] "v"(lpmax), [walkbase] "s"(walk_base), [l1sel] "s"(l1sel),
                   [l1base] "s"(uint32_t(reinterpret_cast<uintptr_t>(s.l1))), [l2base] "s"(uint32_t(reinterpret_cast<uintptr_t>(s.l2))),
                   [l2n] "s"(d.l2_entries), [zrl] "v"(t.zrl)
                 : "memory", "vcc", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51",
