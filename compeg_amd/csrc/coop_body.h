@@ -1280,26 +1280,34 @@ CG_DEV void coop_composite(const ImageDesc &d, const uint32_t *px, uint32_t firs
     const uint32_t *cbdu = px + (m * 4u + 2u) * kPxSlotWords;
     const uint32_t *crdu = px + (m * 4u + 3u) * kPxSlotWords;
     const bool whole = x0 + 3u < d.out_w && (d.out_pitch & 15u) == 0u;
+    // (all of the lane's samples first: the rows' conversions then do not wait for LDS one after the other)
+    uint32_t ys[8], cbs[8], crs[8];
 #pragma unroll
     for (uint32_t row = 0; row < 8; row++) {
-        const uint32_t y = my * 8u + row;
-        if (y >= d.out_h)
-            break;
-        const Vec4u o = rgba_quad(ydu[row * 2u + (q & 1u)], cbdu[row * 2u + (q >> 1)] >> ((q & 1u) * 16u),
-                                  crdu[row * 2u + (q >> 1)] >> ((q & 1u) * 16u));
-        uint8_t *p = d.out + size_t(y) * d.out_pitch + size_t(x0) * 4u;
-        if (whole) {
-            store_pixels<true>(p, o);
-        } else {
-            auto *w = CG_GLOBAL(uint32_t, reinterpret_cast<uint32_t *>(p));
-            w[0] = o.x;
-            if (x0 + 1u < d.out_w)
-                w[1] = o.y;
-            if (x0 + 2u < d.out_w)
-                w[2] = o.z;
-            if (x0 + 3u < d.out_w)
-                w[3] = o.w;
+        ys[row] = ydu[row * 2u + (q & 1u)];
+        cbs[row] = cbdu[row * 2u + (q >> 1)];
+        crs[row] = crdu[row * 2u + (q >> 1)];
+    }
+    const uint32_t rows = d.out_h - umin(d.out_h, my * 8u); // (rows of this MCU inside the output, if fewer than 8)
+    uint8_t *p = d.out + size_t(my * 8u) * d.out_pitch + size_t(x0) * 4u;
+#pragma unroll
+    for (uint32_t row = 0; row < 8; row++) {
+        const Vec4u o = rgba_quad(ys[row], cbs[row] >> ((q & 1u) * 16u), crs[row] >> ((q & 1u) * 16u));
+        if (row < rows) {
+            if (whole) {
+                store_pixels<true>(p, o);
+            } else {
+                auto *w = CG_GLOBAL(uint32_t, reinterpret_cast<uint32_t *>(p));
+                w[0] = o.x;
+                if (x0 + 1u < d.out_w)
+                    w[1] = o.y;
+                if (x0 + 2u < d.out_w)
+                    w[2] = o.z;
+                if (x0 + 3u < d.out_w)
+                    w[3] = o.w;
+            }
         }
+        p += d.out_pitch;
     }
 }
 
