@@ -807,15 +807,11 @@ CoopPlan plan_coop(uint32_t max_intervals, uint32_t images, uint32_t restart_int
             teams--;
         if (tables + teams * team_area > kLdsBytesPerCu)
             return p;
-        // the fewest teams per workgroup with which the whole launch is resident at once (a small launch spreads
-        // over the CUs; a large one shares a copy of the tables among four teams)
-        for (uint32_t fewer = 1; fewer < teams; fewer *= 2u) {
-            const uint64_t resident = uint64_t(kCuCount) * (kLdsBytesPerCu / (tables + fewer * team_area));
-            if ((all_teams + fewer - 1) / fewer <= resident) {
-                teams = fewer;
-                break;
-            }
-        }
+        // one workgroup per CU while that covers the launch (a small launch spreads over the CUs; the teams of a
+        // workgroup share one copy of the tables and the sixteen waves that stage it)
+        const uint32_t fit = teams;
+        teams = all_teams <= kCuCount ? 1u : (all_teams <= 2ull * kCuCount ? 2u : 4u);
+        teams = teams < fit ? teams : fit;
         p.waves_per_block = teams * kCoopTeamWaves;
         p.total_bytes = tables + teams * team_area;
         const uint64_t teams_total = uint64_t((max_intervals + p.intervals_per_wave - 1) / p.intervals_per_wave) * images;
