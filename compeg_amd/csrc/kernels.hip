@@ -612,7 +612,7 @@ decode_coop_team_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_
                             uint32_t teams)
 {
     // (the workgroup is always 16 waves: those beyond the teams' help with the staging and leave)
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    extern __shared__ __attribute__((aligned(32))) uint8_t smem[];
     const ImageDesc &d = descs[blockIdx.y];
     const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x / kWave))), lane = threadIdx.x % kWave;
     const uint32_t team = wave / kCoopTeamWaves, member = wave % kCoopTeamWaves;
@@ -626,8 +626,11 @@ decode_coop_team_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_
     uint16_t *l1 = reinterpret_cast<uint16_t *>(smem);
     uint16_t *l2 = l1 + kL1Entries;
     float *quant = reinterpret_cast<float *>(smem + align16((kL1Entries + l2_in_lds) * 2u));
-    // (32-byte aligned: a walk table's name carries a shift in its low five bits)
-    uint32_t *walk = reinterpret_cast<uint32_t *>((reinterpret_cast<uintptr_t>(quant + 3u * kCoopQuantStride) + 31u) & ~uintptr_t(31));
+    // (32-byte aligned: a walk table's name carries a shift in its low five bits.  As an offset from smem, not by
+    // rounding the pointer: behind an integer round trip the compiler no longer knows that this -- and everything
+    // laid out behind it -- is LDS, and every access becomes a flat one)
+    const uint32_t quant_off = align16((kL1Entries + l2_in_lds) * 2u);
+    uint32_t *walk = reinterpret_cast<uint32_t *>(smem + ((quant_off + 3u * kCoopQuantStride * 4u + 31u) & ~31u));
     uint8_t *team_base = reinterpret_cast<uint8_t *>(walk + kWalkWords) + team * coop_team_area(window_words);
     uint32_t *win = reinterpret_cast<uint32_t *>(team_base);
     uint32_t *misc = reinterpret_cast<uint32_t *>(team_base + align16(window_words * 4u));
