@@ -1,0 +1,48 @@
+"""What the compiler made of the decode kernels (no GPU needed): their LDS traffic has to be ds_* instructions and
+their registers must not spill.  An integer round trip of an LDS pointer is enough for the compiler to forget the
+address space: every access behind it then becomes a flat one -- correct, several times slower, and invisible in
+the results (round 2 lost 3 us of a 45 us launch that way until a profile showed the scratch and flat counts)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "compeg_amd", "libcompeg_hip.so")
+LLVM = "/opt/rocm/lib/llvm/bin"
+KERNELS = ("decode_fused_422_kernel", "decode_pair_422_kernel", "decode_coop_422_kernel", "decode_coop_team_422_kernel",
+           "entropy_kernel", "idct_composite_kernel")
+
+
+def _code_objects(tmp_path):
+    if not (os.path.exists(LIB) and os.path.exists(os.path.join(LLVM, "llvm-objdump"))):
+        pytest.skip("library or llvm-objdump not here")
+    lib = shutil.copy(LIB, tmp_path / "lib.so")
+    subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", lib], check=True, capture_output=True, cwd=tmp_path)
+    return [str(p) for p in tmp_path.iterdir() if "gfx950" in p.name]
+
+
+def test_decode_kernels_use_lds_instructions_and_no_scratch(tmp_path):
+    seen = set()
+    for co in _code_objects(tmp_path):
+        asm = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", co], check=True, capture_output=True, text=True).stdout
+        # per symbol: the text between "<name>:" labels
+        for m in re.finditer(r"^[0-9a-f]+ <(\S+)>:\n(.*?)(?=^[0-9a-f]+ <\S+>:|\Z)", asm, re.S | re.M):
+            name, body = m.group(1), m.group(2)
+            kernel = next((k for k in KERNELS if re.search(r"\d+" + k + "E", name)), None)
+            if not kernel:
+                continue
+            seen.add(kernel)
+            flat = len(re.findall(r"\bflat_(load|store|atomic)", body))
+            scratch = len(re.findall(r"\bscratch_(load|store)", body))
+            assert flat == 0, f"{kernel}: {flat} flat memory instructions (an LDS or global pointer lost its address space)"
+            assert scratch == 0, f"{kernel}: {scratch} scratch instructions (register spills)"
+        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], check=True, capture_output=True, text=True).stdout
+        for block in notes.split("- .agpr_count")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", block)
+            size = re.search(r"\.private_segment_fixed_size:\s+(\d+)", block)
+            if name and size and any(re.search(r"\d+" + k + "E", name.group(1)) for k in KERNELS):
+                assert int(size.group(1)) == 0, f"{name.group(1)}: {size.group(1)} bytes of private memory per lane"
+    assert seen == set(KERNELS), f"kernels not found in the code objects: {set(KERNELS) - seen}"
