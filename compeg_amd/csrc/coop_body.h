@@ -339,7 +339,7 @@ struct ChaseState {
     uint32_t flags;    // kStopAnomaly
     bool used;         // this lane walks at all
     bool active;
-    // chase_run_lean's results, until chase_lean_finish or coop_lean_emit has read them
+    // chase_run_lean's results, until chase_lean_regular and coop_lean_emit have read them
     uint32_t lean_j0, lean_done; // entries [lean_j0, lean_done) of the list are 16-byte entries
     uint32_t lean_p;             // where the walk stands
     bool lean_walked;
@@ -847,46 +847,14 @@ CG_DEV uint32_t lean_entry_pos(const HuffShared &s, uint32_t w, uint32_t Tj)
 }
 CG_DEV uint32_t lean_entry_state(uint32_t pos, uint32_t Tj) { return (pos & 0xffffu) | (((Tj >> kWalkLastShift) & 31u) << 16); }
 
-// The walk went as it nearly always does: every data unit found, inside the window, in front of the interval's
-// end.  (Otherwise chase_lean_finish makes the list everybody else reads, and validation decides.)
-CG_DEV bool chase_lean_regular(const ChaseState &c, uint32_t *list)
+// The walk went as it has to for its entries to be used: every data unit found, all of them starting inside the part
+// of the window where a data unit may begin.  (Beyond the interval's own end is fine: the reference decodes as many
+// data units as the interval should have, from whatever follows -- quirk Q2's drift makes some intervals run over.)
+CG_DEV bool chase_lean_regular(const ChaseState &c, const HuffShared &s, uint32_t *list)
 {
     if (c.flags & kStopAnomaly)
         return false;
-    return !c.lean_walked || (c.lean_done == uint32_t(c.lp_max - list) && c.lean_p < c.stop_p);
-}
-
-// The entries as state words, the lane's state as chase_run leaves it.  All entries are read before the first one
-// is written (entry j moves from byte 16 j to byte 4 j).
-CG_DEV void chase_lean_finish(ChaseState &c, const HuffShared &s, uint32_t *list)
-{
-    const uint32_t j0 = c.lean_j0;
-    uint32_t done = c.lean_done;
-    if (c.lean_walked) {
-        uint32_t w[16], Tw[16];
-#pragma unroll
-        for (uint32_t j = 1; j < 16u; j++) {
-            const bool mine = j >= j0 && j < done;
-            w[j] = mine ? list[4u * j] : 0u;
-            Tw[j] = mine ? list[4u * j + 1u] : 0u;
-        }
-        uint32_t p_last = c.p, cut = done;
-#pragma unroll
-        for (uint32_t j = 1; j < 16u; j++) {
-            if (j >= j0 && j < cut) {
-                p_last = lean_entry_pos(s, w[j], Tw[j]);
-                list[j] = lean_entry_state(p_last, Tw[j]);
-                if (p_last >= c.stop_p)
-                    cut = j + 1u; // the walk ends here, as chase_run's does (what lies behind may be off the window)
-            }
-        }
-        done = cut;
-        c.p = p_last;
-        c.s = 0u;
-        c.k8 += 8u * (done - j0);
-        c.lp = list + done;
-    }
-    c.lean_walked = false;
+    return !c.lean_walked || (c.lean_done == uint32_t(c.lp_max - list) && c.lean_p < coop_hard_end(s));
 }
 
 // Word offset (inside the interval) at which subsequence j of `count` (a power of two) begins.
@@ -1122,9 +1090,7 @@ CG_DEV void coop_lean_emit(const CoopShared &cs, const CoopGeom &g, uint32_t lan
             const uint32_t w = list[4u * tl], Tj = list[4u * tl + 1u];
             state = lean_entry_state(lean_entry_pos(cs.h, w, Tj), Tj);
         }
-        cs.du_state[pass * uint32_t(kWave) + lane] = state;
-        if (tl == 0u)
-            cs.verdict[il] = kVerdictDone;
+        cs.du_state[pass * uint32_t(kWave) + lane] = state; // (of no consequence where the interval's verdict is "serial")
     }
 }
 
@@ -1441,9 +1407,16 @@ CG_DEV void coop_walk_422(const ImageDesc &d, const CoopShared &cs, const CoopTa
     if (LANES != 1)
         CG_COOP_COUNT(intervals, g.intervals);
     CG_COOP_STAMP(0);
-    // nobody speculates and the lists have the room: the walk tables' loop (chase_run_lean)
-    const bool lean = t.walk != nullptr && t.walk_ok && g.count == 1u && g.dpi <= 16u;
+    // nobody speculates: the walk tables' loop (chase_run_lean), every walking lane to the end of its interval (its
+    // list of 16-byte entries has the room: 20 bytes per data unit of lane space for 16 per entry)
+    const bool lean = t.walk != nullptr && t.walk_ok && g.count == 1u;
     if (lean) {
+        CG_EACH_LANE
+        {
+            uint32_t *list = cs.lists + L[li].lane * kCoopListCap;
+            if (c[li].active)
+                c[li].lp_max = list + g.dpi;
+        }
         CG_EACH_LANE coop_lean_prepare(cs, t, g, L[li].lane);
         CG_WAVE_SYNC();
     }
@@ -1483,19 +1456,30 @@ CG_DEV void coop_walk_422(const ImageDesc &d, const CoopShared &cs, const CoopTa
 #endif
             (void)most_true;
         }
-        if (lean && round == 0u) {
-            bool irregular[LANES];
-            CG_EACH_LANE irregular[li] = !chase_lean_regular(c[li], cs.lists + L[li].lane * kCoopListCap);
-            if (!coop_any<LANES>(irregular)) {
-                CG_WAVE_SYNC();
-                CG_EACH_LANE coop_lean_emit(cs, g, L[li].lane);
-                CG_WAVE_SYNC();
-                if (LANES != 1)
-                    CG_COOP_COUNT(direct, 1);
-                CG_COOP_STAMP(1);
-                return;
+        if (lean) {
+            // An interval whose walk went regularly -- all data units found, inside the window, in front of the
+            // interval's end: nearly all of them -- hands its entries straight to the decoding lanes; any other one
+            // (corrupt stream, hostile table, window too small) goes to the serial decoder, which follows the reference
+            // literally.
+            CG_EACH_LANE
+            {
+                if (L[li].tl == 0u && L[li].exists) {
+                    cs.verdict[L[li].il] = chase_lean_regular(c[li], s, cs.lists + L[li].lane * kCoopListCap) ? kVerdictDone : kVerdictSerial;
+#if defined(CG_EMUL_STATS)
+                    if (getenv("EMUL_COOP_DEBUG") && !chase_lean_regular(c[li], s, cs.lists + L[li].lane * kCoopListCap))
+                        fprintf(stderr, "irregular wave %u il %u flags %u walked %d done %u of %u p %u stop_p %u hard_end %u\n", wave_index, L[li].il,
+                                c[li].flags, int(c[li].lean_walked), c[li].lean_done, uint32_t(c[li].lp_max - (cs.lists + L[li].lane * kCoopListCap)),
+                                c[li].lean_p, c[li].stop_p, coop_hard_end(s));
+#endif
+                }
             }
-            CG_EACH_LANE chase_lean_finish(c[li], s, cs.lists + L[li].lane * kCoopListCap);
+            CG_WAVE_SYNC();
+            CG_EACH_LANE coop_lean_emit(cs, g, L[li].lane);
+            CG_WAVE_SYNC();
+            if (LANES != 1)
+                CG_COOP_COUNT(direct, 1);
+            CG_COOP_STAMP(1);
+            return;
         }
         CG_COOP_STAMP(1);
 #if defined(CG_COOP_STAMPS) && defined(__HIP_DEVICE_COMPILE__)

@@ -111,7 +111,8 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
             for (uint32_t t = 0; t < 3u * kRetained; t++)
                 quant[(t / kRetained) * kCoopQuantStride + t % kRetained] = d.quant[t / kRetained][t % kRetained];
             CoopGeom g;
-            coop_geom(d, wave, g, getenv("EMUL_COOP_SPEC_SHIFT") ? uint32_t(atoi(getenv("EMUL_COOP_SPEC_SHIFT"))) : 0u, passes);
+            const bool with_walk_tables = passes >= 4 && !(getenv("EMUL_COOP_LEAN") && atoi(getenv("EMUL_COOP_LEAN")) == 0);
+            coop_geom(d, wave, g, getenv("EMUL_COOP_SPEC_SHIFT") ? uint32_t(atoi(getenv("EMUL_COOP_SPEC_SHIFT"))) : (with_walk_tables && d.restart_interval <= 4u ? 31u : 0u), passes);
             uint32_t wb = 0, wl = 0;
             coop_window(d, g, window_words, wb, wl);
             for (uint32_t i = 0; i < wl; i++)
@@ -125,7 +126,7 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
             coop_tables(d, cs.h, t);
             // the team form (four rounds per walk) walks through the walk tables, like the GPU's
             std::vector<uint32_t> walk;
-            if (passes >= 4 && !(getenv("EMUL_COOP_LEAN") && atoi(getenv("EMUL_COOP_LEAN")) == 0)) {
+            if (with_walk_tables) {
                 walk.resize(kWalkWords);
                 for (uint32_t i = 0; i < walk.size(); i++)
                     walk[i] = coop_walk_word(t.ac_fast, t.dc_fast, t.walk_ids, i);
