@@ -1,5 +1,11 @@
-// Per-lane bodies of the cooperative kernel (decode_coop_422_kernel): the lanes of a wave split the bitstream
-// of each restart interval among themselves.
+// Per-lane bodies of the cooperative kernels: the lanes of a wave work inside the restart intervals.
+//
+// Two kernels use them (kernels.hip).  decode_coop_team_422_kernel, the default: a team of four waves takes 4 x 64
+// data units' worth of intervals; one wave walks them (phase 1) -- for intervals of up to 16 data units a lane per
+// interval, no speculation, through the walk tables and chase_run_lean below, and its entries go straight to the
+// decoding lanes (coop_lean_emit; phase 2 is not needed) -- then each wave decodes 64 data units (phase 3).
+// decode_coop_422_kernel, the first form (COMPEG_COOP_TEAM=0, and the walks of longer intervals in the team form):
+// one wave does all three phases for 64 data units' worth of intervals, as described here.
 //
 // The reference decodes a restart interval with one thread (src/huffman.wgsl:118-204), and so do the other
 // kernels here (one lane per interval).  A launch that has few intervals -- one 4K frame with DRI = 4 is
