@@ -1,5 +1,6 @@
 """One-off randomized check (not part of the test suite): random geometry, quality, restart interval, bit flips in
-the scan, both entropy modes, cut-short windows -- the emulated fused and two-kernel pipelines against the oracle.
+the scan, both entropy modes, cut-short windows -- the emulated fused and two-kernel pipelines and the cooperative
+kernel (both forms: one-wave with speculative walks; team geometry with walk tables) against the oracle.
     python tools/fuzz_emulation.py [seed] [iterations]   (tests/emul/emul_runner must be built)"""
 import os, subprocess, sys, numpy as np, tempfile
 sys.path.insert(0,'/root/repo')
@@ -7,11 +8,12 @@ from tools import synth
 import oracle.oracle as orc
 RUN='/root/repo/tests/emul/emul_runner'
 tmp=tempfile.mkdtemp()
-def run(jpeg, fused, window=2048, standard=False):
+def run(jpeg, fused, window=2048, standard=False, coop_passes=1):
     p=os.path.join(tmp,'in.jpg'); open(p,'wb').write(jpeg)
-    env=dict(os.environ); env['EMUL_FUSED']=str(fused)
+    env=dict(os.environ); env['EMUL_FUSED']=str(fused); env['EMUL_COOP_PASSES']=str(coop_passes)
     if standard: env['EMUL_STANDARD']='1'
     r=subprocess.run([RUN,p,tmp+'/rgba',tmp+'/ac',tmp+'/dc','1',str(window),'12288'],capture_output=True,text=True,env=env,timeout=600)
+    if fused==5 and 'does not qualify' in r.stdout: return 'skip', ''
     if r.returncode!=0: return None, r.stdout+r.stderr[-500:]
     _,w,h,_=r.stdout.split()
     return np.fromfile(tmp+'/rgba',dtype=np.uint8).reshape(int(h),int(w),4), ''
@@ -34,9 +36,10 @@ for it in range(int(sys.argv[2]) if len(sys.argv)>2 else 150):
         want=orc.ImageData(j,standard_entropy=std).decode()
     except orc.OracleError:
         continue
-    for fused in (1,3):
-        got,err=run(j,fused,window=int(rng.choice([64,200,2048])),standard=std)
+    for fused, passes in ((1,1),(3,1),(5,1),(5,4)):
+        got,err=run(j,fused,window=int(rng.choice([64,200,2048])) if fused!=5 else int(rng.choice([0,0,64,200])),standard=std,coop_passes=passes)
+        if isinstance(got,str): continue
         n+=1
         if got is None or not np.array_equal(got,want):
-            bad+=1; print('MISMATCH',it,w,h,kind,q,ri,fused,std,err[:200]); open('/tmp/bad_%d.jpg'%it,'wb').write(j)
+            bad+=1; print('MISMATCH',it,w,h,kind,q,ri,fused,passes,std,err[:200]); open('/tmp/bad_%d.jpg'%it,'wb').write(j)
 print('runs',n,'bad',bad)
