@@ -40,6 +40,14 @@ if team:
         sub = buf[sel & ok]
         print(name, "cycles/wave by phase:", " ".join("%s %.0f" % (n, c) for n, c in zip(
             ("setup", "chase", "validate", "decode", "fixups", "dc+idct", "composite", "wait"), sub.mean(axis=0))))
+    # the teams that end last: their walker's phases
+    end = wall[:, 1] - t0
+    late = np.argsort(end)[-64:]
+    late_walkers = [i for i in late if walker[i]]
+    if late_walkers:
+        sub = buf[late_walkers]
+        print("the %d walkers among the 64 waves that end last (ends %d..%d): %s" % (len(late_walkers), end[late].min(), end[late].max(),
+              " ".join("%s %.0f" % (n, c) for n, c in zip(("setup", "chase", "validate", "decode", "fixups", "dc+idct", "composite", "wait"), sub.mean(axis=0)))))
     ex = full[walker & ok, 10:15].astype(np.float64)
     print("staging (cycles from the wave's start): window known %.0f, copies done %.0f, behind the barrier %.0f" % (
         ex[:, 0].mean(), ex[:, 1].mean(), ex[:, 2].mean()))
