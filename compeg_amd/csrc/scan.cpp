@@ -289,7 +289,7 @@ void ScanBuffer::copy(void *dst, const void *src, size_t bytes)
         memcpy(dst, src, bytes);
         return;
     }
-    const size_t per = (bytes / n + 63) & ~size_t(63);
+    const size_t per = ((bytes + n - 1) / n + 63) & ~size_t(63); // (rounded up before it is aligned: n pieces cover every byte)
     team_->run([&](unsigned k) {
         const size_t at = per * k;
         if (at < bytes)

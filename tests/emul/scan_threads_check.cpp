@@ -28,5 +28,13 @@ int main(){
       if(!early_ok||sb.nwords()!=ref.nwords()||memcmp(sb.data(),ref.data(),ref.nwords()*4)||memcmp(sb.starts(),ref.starts(),ref.nstarts()*4)){bad++; printf("DIFF with progress it %d T %u calls %zu\n",it,T,calls);}
       if(it==0) printf("T %u: %zu progress calls, %zu of %zu bytes reported early\n",T,calls,reported,ref.nwords()*4); }
   }
+  // ScanBuffer::copy (the decoder stages raw segments with it): every byte, whatever the length and the thread
+  // count -- lengths around multiples of 64 x threads, where a piece size rounded down first once lost the tail
+  for(unsigned T:{2u,3u,4u,5u}){ ScanBuffer sb; sb.set_threads(T);
+    for(size_t base:{size_t(64u<<10)*T, size_t(85248)*4, size_t(300000)}) for(size_t extra=0;extra<70;extra+=(extra<6?1:13)){
+      const size_t n=base+extra; std::vector<uint8_t> src(n), dst(n+64,0xee);
+      for(size_t i=0;i<n;i++) src[i]=uint8_t(rng());
+      sb.copy(dst.data(),src.data(),n);
+      if(memcmp(dst.data(),src.data(),n)||dst[n]!=0xee){bad++; printf("COPY DIFF T %u n %zu\n",T,n);} } }
   printf("bad %d\n",bad); return bad;
 }

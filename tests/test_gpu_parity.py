@@ -543,6 +543,15 @@ def test_corrupt_streams_and_hostile_tables_on_the_gpu(ca, gpu):
         _assert_equal(batch.read_output(i), variants[i % len(variants)][1])
 
 
+def test_large_frames_clean_and_corrupt(ca, gpu):
+    """A short seed of tools/fuzz_gpu_big.py: 720p to 4K+ frames, random quality / restart interval / content, bit
+    flips in every other scan, both entropy modes, host and device preprocessing.  (Its first run found a lost
+    segment tail in the device path's threaded staging copy; iteration 18 of this seed is that input.)"""
+    from tools import fuzz_gpu_big
+    n, bad = fuzz_gpu_big.run(seed=20261004, iters=20, log=lambda *a, **k: None)
+    assert n >= 30 and bad == 0
+
+
 def test_walk_tables_follow_the_huffman_tables(ca, gpu):
     """The cooperative kernel's walk tables are made once per set of Huffman tables and kept (by a decoder: across
     decodes; by a batch: per image unless all images share their tables).  One decoder, images whose tables
