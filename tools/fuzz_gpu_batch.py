@@ -1,0 +1,78 @@
+"""Randomized check of the batch paths on the GPU: batches of 1..6 images of 360p to 4K (same or mixed sizes, restart
+intervals, qualities; bit flips in some scans), uploaded as parsed images and as JPEG bytes, scans preprocessed on the
+host or by the device kernels (once / on every decode), decoded twice -- every output against the oracle.  Small
+batches take the cooperative kernel where all images qualify, larger ones the paired / fused kernels.
+    python tools/fuzz_gpu_batch.py [seed] [batches]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import compeg_amd as ca
+import oracle.oracle as orc
+from tools import synth
+
+SIZES = [(640, 360), (1280, 720), (1920, 1080), (2560, 1440), (3840, 2160), (250, 70), (1000, 600)]
+
+
+def run(seed=77, batches=40, log=print):
+    """Returns (outputs compared, mismatches)."""
+    rng = np.random.default_rng(seed)
+    gpu = ca.Gpu.open()
+    bad = n = 0
+    t0 = time.time()
+    for it in range(batches):
+        count = int(rng.integers(1, 7))
+        same = bool(rng.integers(0, 2))
+        w0, h0 = SIZES[int(rng.integers(0, len(SIZES)))]
+        ri0 = int(rng.choice([1, 2, 4, 4, 8, 16, 3]))
+        items = []
+        for i in range(count):
+            w, h = (w0, h0) if same else SIZES[int(rng.integers(0, len(SIZES)))]
+            ri = ri0 if same or rng.integers(0, 2) else int(rng.choice([1, 2, 4, 8]))
+            j = bytearray(synth.make_jpeg(w, h, seed=int(rng.integers(1, 1 << 30)), kind=int(rng.integers(0, 3)),
+                                          quality=int(rng.choice([50, 85, 95])), ri=ri))
+            if rng.integers(0, 4) == 0:
+                scan_at = j.find(b"\xff\xda") + 14
+                for _ in range(int(rng.integers(1, 30))):
+                    pos = int(rng.integers(scan_at, len(j) - 2))
+                    if j[pos] != 0xFF and j[pos - 1] != 0xFF:
+                        j[pos] ^= 1 << int(rng.integers(0, 8))
+                        if j[pos] == 0xFF:
+                            j[pos] = 0xFE
+            j = bytes(j)
+            try:
+                items.append((j, orc.ImageData(j).decode()))
+            except orc.OracleError:
+                pass
+        if not items:
+            continue
+        mode = int(rng.integers(0, 3))
+        as_bytes = bool(rng.integers(0, 2)) and mode == 0
+        batch = ca.Batch(gpu)
+        batch.set_device_preprocess(mode)
+        if as_bytes:
+            batch.upload_jpegs([j for j, _ in items], host_threads=int(rng.choice([1, 4, 8])))
+        else:
+            batch.upload([ca.ImageData(j) for j, _ in items], host_threads=int(rng.choice([1, 4, 8])))
+        for rep in range(2):
+            batch.decode()
+            batch.wait()
+            for i, (_, want) in enumerate(items):
+                got = batch.read_output(i)
+                n += 1
+                if not np.array_equal(got, want):
+                    bad += 1
+                    log("MISMATCH batch", it, "image", i, "of", len(items), "mode", mode, "bytes" if as_bytes else "parsed", "rep", rep,
+                        want.shape, int((got != want).any(axis=2).sum()), "pixels")
+        if it % 10 == 9:
+            log("batch", it, "outputs", n, "bad", bad, "%.0f s" % (time.time() - t0))
+    return n, bad
+
+
+if __name__ == "__main__":
+    n, bad = run(int(sys.argv[1]) if len(sys.argv) > 1 else 77, int(sys.argv[2]) if len(sys.argv) > 2 else 40)
+    print("batch fuzz: outputs", n, "mismatches", bad)
+    sys.exit(1 if bad else 0)
