@@ -1,4 +1,4 @@
-// Test infrastructure: the host scan preprocessor with 2, 3 and 5 threads against the one-thread loop on
+// Test infrastructure: the host scan preprocessor with 2, 3, 4, 5 and 8 threads against the one-thread loop on
 // random segments, built with -fsanitize=thread (tests/emul/Makefile) and run by tests/test_kernel_emulation.py.
 #include "scan.h"
 #include <cstdio>
@@ -20,7 +20,7 @@ int main(){
       if((r>>8)%every==0)b=0xff; if((r>>16)%90==0)b=0;}
     uint32_t exp=1+rng()%20000;
     ScanBuffer ref; ref.process(d.data(),n,exp);
-    for(unsigned T:{2u,3u,5u}){ ScanBuffer sb; sb.set_threads(T); sb.process(d.data(),n,exp); sb.process(d.data(),n,exp);
+    for(unsigned T:{2u,3u,4u,5u,8u}){ ScanBuffer sb; sb.set_threads(T); sb.process(d.data(),n,exp); sb.process(d.data(),n,exp);
       if(sb.nwords()!=ref.nwords()||sb.nstarts()!=ref.nstarts()||memcmp(sb.data(),ref.data(),ref.nwords()*4)||memcmp(sb.starts(),ref.starts(),ref.nstarts()*4)){bad++; printf("DIFF it %d T %u\n",it,T);}
       // with a progress callback (rounds): what is reported as final must already equal the final bytes
       size_t reported=0, calls=0; bool early_ok=true;
