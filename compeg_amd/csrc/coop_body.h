@@ -189,7 +189,15 @@ struct CoopShared {
     uint32_t *dead_from; // [64] per interval: first data unit whose DC code underflows the reference reader
     int32_t *diffs;      // [64] DC differences of the data units being decoded
     const float *quant;  // 3 rows of quantisers (workgroup-wide)
+    // team form, quarters (coop_decode_quarter_422): the team's flag words; the four waves' diffs areas (wave m's at
+    // team_diffs + m * team_diffs_stride); the team's number inside its workgroup
+    uint32_t *flags;
+    int32_t *team_diffs;
+    uint32_t team_diffs_stride, team_in_wg;
 };
+// flag words of a team: [0] the walk: 1 = its lists are prepared, 2 = it is done; [1] quarters whose DC differences
+// are final (bit q); [2] quarters whose pixels are stored (count); [3] quarters that have read their start states (bit q)
+constexpr uint32_t kTeamWalk = 0, kTeamDecoded = 1, kTeamStored = 2, kTeamStatesRead = 3;
 
 CG_DEV void coop_bind_misc(CoopShared &cs, uint32_t *misc)
 {
@@ -547,6 +555,7 @@ CG_DEV void chase_run(ChaseState &c, const ImageDesc &d, const HuffShared &s, co
     c.active = false;
 }
 
+constexpr uint32_t kLeanHostWordBias = 0x10000u; // (host build: an entry's first word is a word index, -1 .. 2047, plus this)
 // The one-word names of the walk tables (see above), relative to the tables' start.
 CG_DEV uint32_t walk_pairs_name(uint32_t ac_id) { return (ac_id ? kWalkPairs1 : kWalkPairs0) * 4u + 21u; }
 CG_DEV uint32_t walk_dc_name(uint32_t i) { return (i ? kWalkDc1 : kWalkDc0) * 4u + 22u; }
@@ -575,6 +584,8 @@ CG_DEV void coop_lean_prepare(const CoopShared &cs, const CoopTables &t, const C
         const uint32_t k = (j - 1u) & 3u;
         list[4u * j + 2u] = walk_base + walk_pairs_name((t.walk_acsel >> (8u * k)) & 0xffu);
         list[4u * j + 3u] = walk_base + walk_dc_name((t.walk_dcsel >> (8u * ((k + 1u) & 3u))) & 0xffu);
+        if (j)
+            list[4u * j] = 0u; // "not written yet" (the walk's first word of an entry is an LDS address, never 0)
     }
 }
 
@@ -823,7 +834,7 @@ CG_DEV void chase_run_lean(ChaseState &c, const ImageDesc &d, const HuffShared &
             const int32_t sn = int32_t(int16_t(T1 & 0xffffu));
             const uint32_t p_next = 32u * (wa + 1u) - uint32_t(sn);
             const bool du_end = T1 > kEndAbove, near = T1 > kNearAbove;
-            list[4u * j] = wa;
+            list[4u * j] = wa + kLeanHostWordBias; // (never 0: "not written yet", see coop_lean_prepare)
             list[4u * j + 1u] = T1;
             const uint32_t name = du_end ? list[4u * j + 3u] : list[4u * j + 2u] + (near ? kWalkSinglesName : 0u);
             ent = walk_lookup(t.walk, name, bits_at(p_next));
@@ -848,7 +859,7 @@ CG_DEV uint32_t lean_entry_pos(const HuffShared &s, uint32_t w, uint32_t Tj)
     return 8u * (w - uint32_t(reinterpret_cast<uintptr_t>(s.win))) + 32u - uint32_t(int32_t(int16_t(Tj & 0xffffu)));
 #else
     (void)s;
-    return 32u * (w + 1u) - uint32_t(int32_t(int16_t(Tj & 0xffffu)));
+    return 32u * (w - kLeanHostWordBias + 1u) - uint32_t(int32_t(int16_t(Tj & 0xffffu)));
 #endif
 }
 CG_DEV uint32_t lean_entry_state(uint32_t pos, uint32_t Tj) { return (pos & 0xffffu) | (((Tj >> kWalkLastShift) & 31u) << 16); }
@@ -1238,12 +1249,13 @@ CG_DEV void read_slot(const uint8_t *slot, uint32_t (&rec)[kRetained / 2])
 // Lane j composites pixel columns 4 (j % 4) .. +3 of MCU first_mcu + j / 4, all 8 rows: a wave-wide 16-byte
 // store covers 64 contiguous bytes per MCU (1 KB of a pixel row when the 16 MCUs lie side by side).
 // px: the wave's 64 sample records, kPxSlotWords apart, record i = data unit i of the wave.
-CG_DEV void coop_composite(const ImageDesc &d, const uint32_t *px, uint32_t first_mcu, uint32_t mcus, uint32_t j)
+// stride: MCUs between the MCUs of neighbouring lane quads (1: side by side)
+CG_DEV void coop_composite(const ImageDesc &d, const uint32_t *px, uint32_t first_mcu, uint32_t mcus, uint32_t j, uint32_t stride = 1u)
 {
     const uint32_t m = j >> 2, q = j & 3u;
     if (m >= mcus)
         return;
-    const uint32_t mcu = first_mcu + m;
+    const uint32_t mcu = first_mcu + m * stride;
     const uint32_t mx = mcu % d.width_mcus, my = mcu / d.width_mcus;
     const uint32_t x0 = mx * 16u + q * 4u;
     if (x0 >= d.out_w)
@@ -1387,7 +1399,8 @@ CG_DEV bool coop_any(const bool (&flag)[LANES])
 // how every interval stands into cs.verdict.
 template <int LANES>
 CG_DEV void coop_walk_422(const ImageDesc &d, const CoopShared &cs, const CoopTables &t, const CoopGeom &g,
-                          uint32_t my_lane, uint32_t wave_index, CoopClock &clk, const CoopLane *ready = nullptr)
+                          uint32_t my_lane, uint32_t wave_index, CoopClock &clk, const CoopLane *ready = nullptr,
+                          bool quarters = false)
 {
     const HuffShared &s = cs.h;
     CoopLane L[LANES];
@@ -1425,11 +1438,21 @@ CG_DEV void coop_walk_422(const ImageDesc &d, const CoopShared &cs, const CoopTa
         }
         CG_EACH_LANE coop_lean_prepare(cs, t, g, L[li].lane);
         CG_WAVE_SYNC();
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (quarters) {
+            // the waves that decode the first three quarters of the intervals may look at the lists from now on
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if ((LANES == 1 ? my_lane : 0u) == 0u)
+                __hip_atomic_store(cs.flags + kTeamWalk, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+#endif
     }
 
     // ---- 1 + 2: walk, link, follow; lanes that have to walk on do so, until every interval is settled ----
     for (uint32_t round = 0; round <= g.dpi + 1u; round++) {
-        if (!coop_any<LANES>(active))
+        // (the walk tables' round also when no lane walks -- every start outside a window cut short: it still has to
+        // give the intervals their verdicts)
+        if (!coop_any<LANES>(active) && !(lean && round == 0u))
             break;
         if (LANES != 1)
             CG_COOP_COUNT(rounds, 1);
@@ -1470,7 +1493,13 @@ CG_DEV void coop_walk_422(const ImageDesc &d, const CoopShared &cs, const CoopTa
             CG_EACH_LANE
             {
                 if (L[li].tl == 0u && L[li].exists) {
-                    cs.verdict[L[li].il] = chase_lean_regular(c[li], s, cs.lists + L[li].lane * kCoopListCap) ? kVerdictDone : kVerdictSerial;
+                    // (a maximum: with quarters, a decoding lane may have said "serial" already -- hostile table)
+                    const uint32_t v = chase_lean_regular(c[li], s, cs.lists + L[li].lane * kCoopListCap) ? kVerdictDone : kVerdictSerial;
+#if defined(__HIP_DEVICE_COMPILE__)
+                    atomicMax(&cs.verdict[L[li].il], v);
+#else
+                    cs.verdict[L[li].il] = cs.verdict[L[li].il] > v ? cs.verdict[L[li].il] : v;
+#endif
 #if defined(CG_EMUL_STATS)
                     if (getenv("EMUL_COOP_DEBUG") && !chase_lean_regular(c[li], s, cs.lists + L[li].lane * kCoopListCap))
                         fprintf(stderr, "irregular wave %u il %u flags %u walked %d done %u of %u p %u stop_p %u hard_end %u\n", wave_index, L[li].il,
@@ -1480,8 +1509,10 @@ CG_DEV void coop_walk_422(const ImageDesc &d, const CoopShared &cs, const CoopTa
                 }
             }
             CG_WAVE_SYNC();
-            CG_EACH_LANE coop_lean_emit(cs, g, L[li].lane);
-            CG_WAVE_SYNC();
+            if (!quarters) { // (with quarters every decoding lane reads its entry itself)
+                CG_EACH_LANE coop_lean_emit(cs, g, L[li].lane);
+                CG_WAVE_SYNC();
+            }
             if (LANES != 1)
                 CG_COOP_COUNT(direct, 1);
             CG_COOP_STAMP(1);
@@ -1539,7 +1570,7 @@ CG_DEV void coop_walk_422(const ImageDesc &d, const CoopShared &cs, const CoopTa
 // cs.h.du_slots / cs.diffs: this wave's; cs.du_state / verdict / dead_from: the walk's.
 template <int LANES>
 CG_DEV void coop_decode_pass_422(const ImageDesc &d, const CoopShared &cs, const CoopTables &t, const CoopGeom &g,
-                                 uint32_t my_lane, uint32_t wave_index, uint32_t pass, CoopClock &clk)
+                                 uint32_t my_lane, uint32_t wave_index, uint32_t pass, CoopClock &clk, bool only_serial = false)
 {
     const HuffShared &s = cs.h;
     struct { uint32_t lane; } L[LANES];
@@ -1559,10 +1590,15 @@ CG_DEV void coop_decode_pass_422(const ImageDesc &d, const CoopShared &cs, const
     {
         uint32_t st = kCoopUnset;
         if (D_exists(li)) {
-            st = cs.du_state[pass * uint32_t(kWave) + L[li].lane];
-            // (an interval still waiting for a walk after the last round goes the same way as one given up on)
-            if ((cs.verdict[D_il(li)] & 0xffu) != kVerdictDone || (st & kCoopUnset))
-                st = kCoopSerial;
+            if (only_serial) {
+                // (behind the quarters: the intervals that have to go through the serial decoder, nothing else)
+                st = (cs.verdict[D_il(li)] & 0xffu) == kVerdictSerial ? kCoopSerial : kCoopUnset;
+            } else {
+                st = cs.du_state[pass * uint32_t(kWave) + L[li].lane];
+                // (an interval still waiting for a walk after the last round goes the same way as one given up on)
+                if ((cs.verdict[D_il(li)] & 0xffu) != kVerdictDone || (st & kCoopUnset))
+                    st = kCoopSerial;
+            }
         }
         state[li] = st;
     }
@@ -1664,14 +1700,225 @@ CG_DEV void coop_decode_pass_422(const ImageDesc &d, const CoopShared &cs, const
             reinterpret_cast<slot_word_t *>(samples)[L[li].lane * kPxSlotWords + w] = px[li][w];
     }
     CG_WAVE_SYNC();
-    CG_EACH_LANE coop_composite(d, samples, (g.first_interval + pass * g.ipp) * g.R,
-                                umin(g.intervals - pass * g.ipp, g.ipp) * g.R, L[li].lane);
+    CG_EACH_LANE
+    {
+        if (!(state[li] & kCoopUnset)) // (the four lanes of an MCU belong to one interval: all of them or none)
+            coop_composite(d, samples, (g.first_interval + pass * g.ipp) * g.R, umin(g.intervals - pass * g.ipp, g.ipp) * g.R,
+                           L[li].lane);
+    }
     CG_WAVE_SYNC(); // (the samples have been read: the area serves the next round's data units)
     CG_COOP_STAMP(6);
 #undef D_il
 #undef D_tl
 #undef D_lane0
 #undef D_exists
+}
+
+// Team form, intervals of 16 data units (DRI = 4): the decoding waves do not wait for the walk to end.  Wave q of
+// four takes *quarter* q of every interval -- MCU q, data units 4 q .. 4 q + 3 of each of the team's 16 intervals: lane
+// 4 il + k decodes data unit 4 q + k of interval il -- as soon as the walker has passed those data units: an entry
+// of the walker's list is final once the entry behind it has been written to.  The walker itself takes quarter 3.
+// What crosses the quarters goes through LDS, in the order of the quarters: the DC differences (a data unit's DC
+// term sums those of its component's earlier data units) and quirk Q1's "dead from" (coop_decode_pass_422); an
+// interval that turns out to need the serial decoder -- known when the walk is over, or when a lane meets a
+// hostile DC category -- is decoded again, all of it, by the walker's wave once every quarter's pixels are out.
+// The decode phases that waited for the walk's end ran four waves to a SIMD; now three quarters of that work run
+// under the walk, which leaves its SIMD's issue slots mostly idle, and the last quarter runs alone.
+template <int LANES>
+CG_DEV void coop_decode_quarter_422(const ImageDesc &d, const CoopShared &cs, const CoopTables &t, const CoopGeom &g,
+                                    uint32_t my_lane, uint32_t wave_index, uint32_t q, CoopClock &clk)
+{
+    const HuffShared &s = cs.h;
+    struct { uint32_t lane; } L[LANES];
+    CG_EACH_LANE L[li].lane = LANES == 1 ? my_lane : uint32_t(li);
+    (void)wave_index;
+    (void)clk;
+    if (g.intervals == 0u)
+        return;
+#define Q_il(li) (L[li].lane >> 2)
+#define Q_tl(li) (4u * q + (L[li].lane & 3u))
+#define Q_exists(li) (Q_il(li) < g.intervals)
+#define Q_list(li) (cs.lists + (Q_il(li) << g.lpi_shift) * kCoopListCap)
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (q < 3u) {
+        // until the walker has passed this quarter's data units in every interval -- or is done (an interval whose
+        // walk ended early never gets there: it goes to the serial decoder)
+        for (;;) {
+            const uint32_t walk = __hip_atomic_load(cs.flags + kTeamWalk, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            bool ready = true;
+            if (walk >= 1u && Q_exists(0))
+                ready = __hip_atomic_load(Q_list(0) + 4u * (4u * q + 4u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u;
+            if (walk >= 2u || (walk >= 1u && __builtin_amdgcn_ballot_w64(!ready) == 0u))
+                break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+#endif
+    uint32_t state[LANES];
+    int32_t dc[LANES];
+    CG_EACH_LANE
+    {
+        uint32_t st = kCoopUnset;
+        if (Q_exists(li)) {
+            const uint32_t *list = Q_list(li);
+            const uint32_t tl = Q_tl(li);
+            // the data unit's start is entry tl: final if the entry behind it has been written to (the walker's own
+            // quarter: if its walk was regular)
+            const bool final_ = q == 3u ? (cs.verdict[Q_il(li)] & 0xffu) == kVerdictDone : list[4u * (tl + 1u)] != 0u;
+            if (final_)
+                st = tl == 0u ? list[0] & kCoopStateMask
+                              : lean_entry_state(lean_entry_pos(s, list[4u * tl], list[4u * tl + 1u]), list[4u * tl + 1u]);
+        }
+        state[li] = st;
+    }
+    CG_WAVE_SYNC();
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the lists lie in the walker's slot area: it clears that only when the others have read what they need
+    if ((LANES == 1 ? my_lane : 0u) == 0u)
+        __hip_atomic_fetch_or(cs.flags + kTeamStatesRead, 1u << q, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (q == 3u)
+        while ((__hip_atomic_load(cs.flags + kTeamStatesRead, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & 7u) != 7u)
+            __builtin_amdgcn_s_sleep(2);
+#endif
+    CG_EACH_LANE zero_slot(s.du_slots + L[li].lane * kDuSlotBytes);
+    CG_WAVE_SYNC();
+    bool under[LANES];
+    CG_EACH_LANE
+    {
+        const uint32_t lane = L[li].lane;
+        bool hostile = false;
+        const int32_t diff = coop_decode_du(d, s, t, state[li], comp_of_k(lane & 3u),
+                                            reinterpret_cast<int16_t *>(s.du_slots + lane * kDuSlotBytes), under[li], hostile);
+        cs.diffs[lane] = diff;
+        if (hostile) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            atomicMax(&cs.verdict[Q_il(li)], kVerdictSerial);
+#else
+            cs.verdict[Q_il(li)] = kVerdictSerial;
+#endif
+        }
+        if (under[li]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            atomicMin(&cs.dead_from[Q_il(li)], Q_tl(li));
+#else
+            cs.dead_from[Q_il(li)] = umin(cs.dead_from[Q_il(li)], Q_tl(li));
+#endif
+        }
+    }
+    CG_WAVE_SYNC();
+    CG_COOP_STAMP(3);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the earlier quarters' DC differences and "dead from" are final
+    {
+        const uint32_t before = (1u << q) - 1u;
+        while ((__hip_atomic_load(cs.flags + kTeamDecoded, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & before) != before)
+            __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+#endif
+    // quirk Q1: behind the first data unit whose DC code underflows the reference reader, the interval decodes from
+    // zeros -- whatever those lanes have decoded from the walk's states is replaced (this quarter's lanes or an
+    // earlier quarter's may have found it)
+    CG_EACH_LANE
+    {
+        if (!Q_exists(li) || (state[li] & kCoopUnset))
+            continue;
+        const uint32_t first_dead = cs.dead_from[Q_il(li)];
+        if (LANES != 1 && Q_tl(li) == first_dead)
+            CG_COOP_COUNT(dead, 1);
+        if (Q_tl(li) <= first_dead)
+            continue;
+        const uint32_t comp = comp_of_k(L[li].lane & 3u);
+        uint8_t *slot = s.du_slots + L[li].lane * kDuSlotBytes;
+        zero_slot(slot);
+        copy_zero_levels(d, comp, reinterpret_cast<int16_t *>(slot));
+        cs.diffs[L[li].lane] = zero_diff(d, comp);
+        state[li] |= kCoopZero;
+        if (LANES != 1)
+            CG_COOP_COUNT(zero, 1);
+    }
+    CG_WAVE_SYNC();
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if ((LANES == 1 ? my_lane : 0u) == 0u)
+        __hip_atomic_fetch_or(cs.flags + kTeamDecoded, 1u << q, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+    CG_COOP_STAMP(4);
+    uint32_t px[LANES][16];
+    CG_EACH_LANE
+    {
+        const uint32_t lane = L[li].lane;
+        if (state[li] & kCoopUnset)
+            continue;
+        // DC prediction (src/huffman.wgsl:137,170): the sum of the differences of the component's data units up to this
+        // one, inside the interval; i32 wrap like the reference.  Quarter p's differences are its wave's.
+        const uint32_t k = lane & 3u, base = lane & ~3u;
+        uint32_t sum = 0u;
+        for (uint32_t p_ = 0; p_ <= q; p_++) {
+            const int32_t *dq = cs.team_diffs + ((p_ + cs.team_in_wg) & 3u) * cs.team_diffs_stride + base;
+            if (k < 2u)
+                sum += (p_ < q || k == 1u) ? uint32_t(dq[0]) + uint32_t(dq[1]) : uint32_t(dq[0]);
+            else
+                sum += uint32_t(dq[k]);
+        }
+        dc[li] = int32_t(sum * sel3(comp_of_k(k), t.dc_quant[0], t.dc_quant[1], t.dc_quant[2]));
+        uint32_t rec[kRetained / 2];
+        read_slot(s.du_slots + lane * kDuSlotBytes, rec);
+        idct_data_unit(rec, dc[li], cs.quant + comp_of_k(k) * kCoopQuantStride, px[li]);
+    }
+    CG_WAVE_SYNC(); // every slot has been read: the area now holds the samples, kPxSlotWords apart
+    CG_COOP_STAMP(5);
+    uint32_t *samples = reinterpret_cast<uint32_t *>(s.du_slots);
+    CG_EACH_LANE
+    {
+        if (state[li] & kCoopUnset)
+            continue;
+#pragma unroll
+        for (int w = 0; w < 16; w++)
+            reinterpret_cast<slot_word_t *>(samples)[L[li].lane * kPxSlotWords + w] = px[li][w];
+    }
+    CG_WAVE_SYNC();
+    CG_EACH_LANE
+    {
+        // lane quad il holds MCU q of interval il: g.R (= 4) MCUs apart
+        if (!(state[li] & kCoopUnset))
+            coop_composite(d, samples, g.first_interval * g.R + q, g.intervals, L[li].lane, g.R);
+    }
+    CG_WAVE_SYNC();
+    CG_COOP_STAMP(6);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (the pixels are out: an interval that has to be decoded again may be written over them)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((LANES == 1 ? my_lane : 0u) == 0u)
+        __hip_atomic_fetch_add(cs.flags + kTeamStored, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+#undef Q_il
+#undef Q_tl
+#undef Q_exists
+#undef Q_list
+}
+
+// Behind the quarters, by the walker's wave: the intervals whose verdict is "serial" once more, all of their data
+// units, through the rounds' code (old layout: a wave's 64 lanes are 4 whole intervals).
+template <int LANES>
+CG_DEV void coop_quarters_serial_422(const ImageDesc &d, const CoopShared &cs, const CoopTables &t, const CoopGeom &g,
+                                     uint32_t my_lane, uint32_t wave_index, CoopClock &clk)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    while (__hip_atomic_load(cs.flags + kTeamStored, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 4u)
+        __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
+    for (uint32_t pass = 0; pass < g.passes; pass++) {
+        bool serial[LANES];
+        for (int li = 0; li < LANES; li++) {
+            const uint32_t lane = LANES == 1 ? my_lane : uint32_t(li), il = pass * g.ipp + (lane >> g.dpi_shift);
+            serial[li] = il < g.intervals && (cs.verdict[il] & 0xffu) == kVerdictSerial;
+        }
+        if (coop_any<LANES>(serial))
+            coop_decode_pass_422<LANES>(d, cs, t, g, my_lane, wave_index, pass, clk, true);
+    }
 }
 
 // One wave does it all: the walk, then its rounds of 64 data units one after the other.

@@ -586,7 +586,7 @@ hipError_t launch_walk_tables(const ImageDesc *descs, uint32_t images, hipStream
     return hipGetLastError();
 }
 
-constexpr uint32_t kCoopTeamFlagWords = 4; // [0]: the walk is done
+constexpr uint32_t kCoopTeamFlagWords = 4; // (coop_body.h: kTeamWalk ...)
 __host__ __device__ __forceinline__ uint32_t coop_team_area(uint32_t window_words)
 {
     return ((window_words * 4u + 15u) & ~15u) + (kCoopMiscWords + kCoopTeamFlagWords) * 4u +
@@ -594,22 +594,22 @@ __host__ __device__ __forceinline__ uint32_t coop_team_area(uint32_t window_word
 }
 
 // One wave tells the others of its team (through LDS; a workgroup barrier would tie the teams together).
-__device__ __forceinline__ void team_signal(uint32_t *flag, uint32_t lane)
+__device__ __forceinline__ void team_signal(uint32_t *flag, uint32_t lane, uint32_t value)
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0u)
-        __hip_atomic_store(flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ void team_wait(uint32_t *flag)
+__device__ __forceinline__ void team_wait(uint32_t *flag, uint32_t value)
 {
-    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u)
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < value)
         __builtin_amdgcn_s_sleep(4);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
 __global__ void __launch_bounds__(1024)
 decode_coop_team_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words, uint32_t spec_shift,
-                            uint32_t teams)
+                            uint32_t teams, uint32_t quarters_on)
 {
     // (the workgroup is always 16 waves: those beyond the teams' help with the staging and leave)
     extern __shared__ __attribute__((aligned(32))) uint8_t smem[];
@@ -683,7 +683,9 @@ decode_coop_team_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_
             w[k] = scan_words4(d, win_base + 4u * (k * 256u + wlane));
     // (the walker's lanes look up where their intervals begin while all this is on its way)
     CoopLane my_walk{};
-    const bool walker = member == (team & (kCoopTeamWaves - 1u));
+    // (the walkers of a workgroup's teams are different waves of theirs: waves go to the SIMDs round robin, so they do
+    // not share one; with quarters -- coop_decode_quarter_422 -- wave m of team t takes quarter (m - t) & 3, the walker the last)
+    const bool walker = member == ((team + 3u) & (kCoopTeamWaves - 1u));
     if (!helper && walker && g.intervals) {
         HuffShared hw{};
         hw.win_base = win_base;
@@ -717,6 +719,29 @@ decode_coop_team_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_
     if (threadIdx.x < 3u * kRetained)
         quant[(threadIdx.x / kRetained) * kCoopQuantStride + threadIdx.x % kRetained] =
             d.quant[threadIdx.x / kRetained][threadIdx.x % kRetained];
+    // (what the phases need of the descriptor: asked for in front of the barrier, there behind it)
+    CoopShared cs;
+    cs.h.l1 = l1;
+    cs.h.l2 = l2;
+    cs.h.l2_staged = umin(l2_in_lds, d.fast_off + 2u * kFastEntries + 2u * kDcFastEntries);
+    cs.h.win = win;
+    cs.h.win_base = win_base;
+    cs.h.win_len = win_len;
+    cs.h.du_slots = mine;
+    uint8_t *first_mine = reinterpret_cast<uint8_t *>(flags + kCoopTeamFlagWords);
+    constexpr uint32_t kMineBytes = kWave * kDuSlotBytes + kWave * 4u;
+    // (the walker's lists: its own slot area, as in the one-wave form; the other waves read them there)
+    cs.lists = reinterpret_cast<uint32_t *>(first_mine + ((team + 3u) & (kCoopTeamWaves - 1u)) * kMineBytes);
+    cs.flags = flags;
+    cs.team_diffs = reinterpret_cast<int32_t *>(first_mine + kWave * kDuSlotBytes);
+    cs.team_diffs_stride = kMineBytes / 4u;
+    cs.team_in_wg = team;
+    coop_bind_misc(cs, misc);
+    cs.diffs = reinterpret_cast<int32_t *>(mine + kWave * kDuSlotBytes);
+    cs.quant = quant;
+    CoopTables t;
+    coop_tables(d, cs.h, t);
+    t.walk = d.walk ? walk : nullptr;
 #if defined(CG_COOP_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     clk.extra[1] = __builtin_readcyclecounter() - clk.tprev;
@@ -728,33 +753,37 @@ decode_coop_team_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_
     clk.extra[2] = __builtin_readcyclecounter() - clk.tprev;
 #endif
 
-    CoopShared cs;
-    cs.h.l1 = l1;
-    cs.h.l2 = l2;
-    cs.h.l2_staged = umin(l2_in_lds, d.fast_off + 2u * kFastEntries + 2u * kDcFastEntries);
-    cs.h.win = win;
-    cs.h.win_base = win_base;
-    cs.h.win_len = win_len;
-    cs.h.du_slots = mine;
-    cs.lists = reinterpret_cast<uint32_t *>(mine); // (only the walker uses them: its own slot area, as in the one-wave form)
-    coop_bind_misc(cs, misc);
-    cs.diffs = reinterpret_cast<int32_t *>(mine + kWave * kDuSlotBytes);
-    cs.quant = quant;
-    CoopTables t;
-    coop_tables(d, cs.h, t);
-    t.walk = d.walk ? walk : nullptr;
     const uint32_t team_index = blockIdx.x * teams + team;
-    // (team t's walker is its wave t: waves go to the SIMDs round robin, so the walkers of a workgroup do not share one)
+    // intervals of 16 data units, walked through the walk tables: the decoding starts under the walk, quarter by quarter
+    // (worth it where the teams of a workgroup compete for the CU: a team alone on its CU ends with its walker's own
+    // round either way -- 34.4 against 34.9 us for one 1080p frame)
+    const bool quarters = quarters_on != 0u && teams > 1u && t.walk != nullptr && t.walk_ok && g.dpi == 16u && g.count == 1u;
     if (walker) {
+        // (the walk is the team's critical path, and with quarters its SIMD is busy with other teams' decoding waves:
+        // its instructions go first)
+        __builtin_amdgcn_s_setprio(3);
         if (g.intervals)
-            coop_walk_422<1>(d, cs, t, g, lane, team_index, clk, &my_walk);
-        team_signal(flags, lane);
-    } else {
-        team_wait(flags);
+            coop_walk_422<1>(d, cs, t, g, lane, team_index, clk, &my_walk, quarters);
+        if (!quarters)
+            __builtin_amdgcn_s_setprio(0); // (with quarters its own quarter is the team's last: it keeps going first)
+        team_signal(flags, lane, 2u);
+    } else if (!quarters) {
+        team_wait(flags, 2u);
     }
     CG_COOP_STAMP(7); // (the waves that do not walk: their wait)
-    if (g.intervals)
+    if (quarters) {
+        // (the later a quarter, the nearer it is to the team's end: it goes first among the decoding waves of its SIMD)
+        const uint32_t quarter = (member - team) & (kCoopTeamWaves - 1u);
+        if (quarter == 1u)
+            __builtin_amdgcn_s_setprio(1);
+        else if (quarter == 2u)
+            __builtin_amdgcn_s_setprio(2);
+        coop_decode_quarter_422<1>(d, cs, t, g, lane, team_index, quarter, clk);
+        if (walker && g.intervals)
+            coop_quarters_serial_422<1>(d, cs, t, g, lane, team_index, clk);
+    } else if (g.intervals) {
         coop_decode_pass_422<1>(d, cs, t, g, lane, team_index, member, clk);
+    }
     coop_clock_store(clk, d, team_index * kCoopTeamWaves + member, lane);
 }
 
@@ -866,8 +895,12 @@ hipError_t launch_coop_422(const ImageDesc *descs, uint32_t images, uint32_t max
             int(kLdsBytesPerCu));
         if (attr != hipSuccess)
             return attr;
+        static const uint32_t quarters_on = [] {
+            const char *e = getenv("COMPEG_COOP_QUARTERS"); // experiment knob: 0 = the decoding waits for the walk's end
+            return e ? uint32_t(atoi(e) != 0) : 1u;
+        }();
         hipLaunchKernelGGL(decode_coop_team_422_kernel, grid, dim3(1024), plan.total_bytes, stream, descs,
-                           plan.l2_entries_in_lds, plan.window_words, spec_shift, teams);
+                           plan.l2_entries_in_lds, plan.window_words, spec_shift, teams, quarters_on);
         return hipGetLastError();
     }
     const uint32_t per_block = plan.intervals_per_wave * plan.waves_per_block;

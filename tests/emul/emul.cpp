@@ -132,7 +132,33 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
                     walk[i] = coop_walk_word(t.ac_fast, t.dc_fast, t.walk_ids, i);
                 t.walk = walk.data();
             }
-            coop_wave_422<kWave>(d, cs, t, g, 0, wave);
+            const bool quarters = with_walk_tables && t.walk_ok && g.dpi == 16u && g.count == 1u &&
+                                  !(getenv("EMUL_COOP_QUARTERS") && atoi(getenv("EMUL_COOP_QUARTERS")) == 0);
+            if (!quarters) {
+                coop_wave_422<kWave>(d, cs, t, g, 0, wave);
+            } else {
+                // as the team kernel does it with DRI = 4: the walk (the waves of the team that wait for its entries
+                // on the GPU run behind it here), then quarter q of every interval by "wave" q with its own slots and
+                // DC differences, the walker's lists in the last wave's slots; then the serial intervals once more
+                std::vector<uint8_t> areas(4u * (kWave * kDuSlotBytes) + 64u, 0xa5);
+                std::vector<int32_t> diffs(4u * kWave, 0x5a5a5a5a);
+                uint8_t *area0 = areas.data() + (16u - reinterpret_cast<uintptr_t>(areas.data()) % 16u) % 16u;
+                uint32_t flag_words[4] = {0, 0, 0, 0};
+                cs.flags = flag_words;
+                cs.team_diffs = diffs.data();
+                cs.team_diffs_stride = kWave;
+                cs.team_in_wg = 0;
+                cs.lists = reinterpret_cast<uint32_t *>(area0 + 3u * kWave * kDuSlotBytes);
+                cs.h.du_slots = area0 + 3u * kWave * kDuSlotBytes;
+                CoopClock clk;
+                coop_walk_422<kWave>(d, cs, t, g, 0, wave, clk, nullptr, true);
+                for (uint32_t q = 0; q < 4u; q++) {
+                    cs.h.du_slots = area0 + q * kWave * kDuSlotBytes;
+                    cs.diffs = diffs.data() + q * kWave;
+                    coop_decode_quarter_422<kWave>(d, cs, t, g, 0, wave, q, clk);
+                }
+                coop_quarters_serial_422<kWave>(d, cs, t, g, 0, wave, clk);
+            }
             free(smem);
         }
         delete img;
