@@ -128,12 +128,12 @@ bool use_coop_kernel(uint32_t max_intervals, uint32_t images, uint32_t restart_i
     }();
     if (forced >= 0)
         return forced != 0;
-    // Measured (DRI = 4, kernel time by HIP events, paired / cooperative in its team form): one frame 1280x720
-    // 59 / 32 us, 1920x1080 56 / 34, 3840x2160 59 / 42; four 1080p frames 62 / 46; two 4K frames 74 / 79.  The
-    // cooperative kernel's teams (256 data units each) are resident four to a CU; a launch that needs a second
-    // round of them is the paired or the fused kernel's.
+    // Measured (DRI = 4, kernel time by HIP events, paired or fused / cooperative in its team form): one frame
+    // 1280x720 59 / 32 us, 1920x1080 56 / 34, 3840x2160 59 / 37; four 1080p frames 62 / 38; two 4K frames 74 / 63,
+    // three 76 / 88, four 81 / 117.  The cooperative kernel's teams (256 data units each) are resident four to a
+    // CU: up to two rounds of them it is ahead.
     const uint64_t data_units = uint64_t(max_intervals) * images * 4u * restart_interval;
-    return data_units <= 1024ull * 256u;
+    return data_units <= 2ull * 1024u * 256u;
 }
 
 // Device preprocessing reports the largest word span of 64 consecutive intervals only.  What the cooperative kernel
