@@ -3,7 +3,8 @@
 // Two kernels use them (kernels.hip).  decode_coop_team_422_kernel, the default: a team of four waves takes 4 x 64
 // data units' worth of intervals; one wave walks them (phase 1) -- for intervals of up to 16 data units a lane per
 // interval, no speculation, through the walk tables and chase_run_lean below, and its entries go straight to the
-// decoding lanes (coop_lean_emit; phase 2 is not needed) -- then each wave decodes 64 data units (phase 3).
+// decoding lanes (coop_lean_emit; phase 2 is not needed) -- then each wave decodes 64 data units (phase 3); with
+// DRI = 4 the decoding does not wait for the walk's end but follows it quarter by quarter (coop_decode_quarter_422).
 // decode_coop_422_kernel, the first form (COMPEG_COOP_TEAM=0, and the walks of longer intervals in the team form):
 // one wave does all three phases for 64 data units' worth of intervals, as described here.
 //
