@@ -213,7 +213,7 @@ def test_emulated_rare_paths_were_reached():
     """Runs last in this module: the cases above must have exercised every branch of the fast
     entropy path (counters come from the emulator build, -DCG_EMUL_STATS)."""
     print("emulation path counters:", STATS)
-    if not STATS:
+    if not STATS or os.environ.get("PYTEST_XDIST_WORKER"):
         pytest.skip("the cases of this module ran in other processes (pytest -n): their counters are not here")
     assert STATS.get("fast_dus", 0) > 10000
     assert STATS.get("exact_dus", 0) > 100
