@@ -134,6 +134,57 @@ entropy_samples_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, 
     entropy_kernel_body<true>(descs, l2_in_lds, window_words);
 }
 
+// What a wave of the fused kernel does for its NEXT unit while it decodes the current one.  Vector memory
+// operations complete in order, stores included, so whatever waits for a load also waits for every store issued
+// before it: each step below sits where the wave's latest stores (the composite of an MCU) are an MCU old.
+//   data unit 0        the two interval starts that bound the next window are asked for;
+//   last MCU but one   one word of every 128-byte line of that window is touched (into the L2);
+//   last data unit     decoded: the window is free -- the next one is staged in front of the last IDCT and composite.
+struct WindowAhead {
+    // (an index, not a pointer: a pointer carried around the units' loop is no longer visibly derived from the
+    // kernel's restrict argument, and every descriptor field would be read with vector loads)
+    const ImageDesc *descs;
+    uint32_t image;      // the next unit's image
+    bool any;            // ... false: there is no next unit
+    uint32_t first;      // ... and its first interval
+    uint32_t window_words, lane;
+    uint32_t *win;
+    uint32_t raw_base, raw_end, base, len, sink;
+
+    __device__ __forceinline__ void at(uint32_t du, uint32_t du_total)
+    {
+        if (!any)
+            return;
+        const ImageDesc *dn = descs + image;
+        if (du == 0u)
+            wave_window_fetch(*dn, first, raw_base, raw_end);
+        if (du_total >= 8u && du == du_total - 8u) {
+            uint32_t b, l;
+            wave_window_from(*dn, raw_base, raw_end, window_words, b, l);
+            const uint32_t have = dn->nwords > b ? umin(l, dn->nwords - b) : 0u;
+            auto *words = CG_GLOBAL(const uint32_t, dn->words);
+            for (uint32_t v = lane * 32u; v < have; v += kWave * 32u)
+                sink ^= words[b + v];
+        }
+        if (du_total >= 8u && du == du_total - 5u)
+            asm volatile("" ::"v"(sink)); // (the touches' results: never looked at; the register is free from here)
+    }
+
+    __device__ __forceinline__ void decoded(uint32_t du, uint32_t du_total)
+    {
+        if (!any || du + 1u != du_total)
+            return;
+        const ImageDesc *dn = descs + image;
+        uint32_t b, l;
+        wave_window_from(*dn, raw_base, raw_end, window_words, b, l);
+        base = uint32_t(__builtin_amdgcn_readfirstlane(int(b)));
+        len = uint32_t(__builtin_amdgcn_readfirstlane(int(l)));
+        stage_window(*dn, win, base, len, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+};
+
 // Fused path: same prologue as huffman_kernel, then every lane runs the whole
 // decode of its interval (entropy decode -> IDCT -> composite), so neither
 // coefficients nor samples ever touch HBM.
@@ -162,10 +213,9 @@ decode_fused_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds,
     // (wave-uniform by construction; said explicitly so that the descriptor is read through scalar loads)
     image = uint32_t(__builtin_amdgcn_readfirstlane(int(image)));
     wave_first = uint32_t(__builtin_amdgcn_readfirstlane(int(wave_first)));
-    const ImageDesc &d = descs[image];
-    if (!waves_per_image && blockIdx.x * blockDim.x >= d.total_intervals)
+    if (!waves_per_image && blockIdx.x * blockDim.x >= descs[image].total_intervals)
         return; // the whole workgroup
-    has_work = has_work && wave_first < d.total_intervals;
+    has_work = has_work && wave_first < descs[image].total_intervals;
 
     uint16_t *l1 = reinterpret_cast<uint16_t *>(smem);
     uint16_t *l2 = l1 + kL1Entries;
@@ -176,22 +226,50 @@ decode_fused_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds,
 
     uint32_t win_base = 0, win_len = 0;
     if (has_work)
-        wave_window(d, wave_first, window_words, win_base, win_len);
-    stage_luts_and_window(d, l1, l2, l2_in_lds, threadIdx.x, blockDim.x, win, win_base, win_len, lane);
+        wave_window(descs[image], wave_first, window_words, win_base, win_len);
+    stage_luts_and_window(descs[image], l1, l2, l2_in_lds, threadIdx.x, blockDim.x, win, win_base, win_len, lane);
     __syncthreads();
 
     if (!has_work)
         return; // the whole wave; lanes past the last interval of a partly used wave stay (quad exchange)
 
-    HuffShared s;
-    s.l1 = l1;
-    s.l2 = l2;
-    s.l2_staged = umin(l2_in_lds, d.fast_off + 2u * kFastEntries);
-    s.win = win;
-    s.win_base = win_base;
-    s.win_len = win_len;
-    s.du_slots = slots;
-    decode_wave_fused_422(d, s, wave_first + lane, lane);
+    // A launch of more waves than the chip holds at once (flat grid only) is a grid of as many workgroups as
+    // fit, whose waves go on to further units of 64 intervals on their own: no workgroup prologue, no barrier and
+    // no CU waiting for the slowest wave of a workgroup between two units -- a wave stages its next window itself
+    // (WindowAhead).
+    const uint32_t stride = gridDim.x * (blockDim.x / kWave), units = waves_per_image * images;
+    uint32_t flat = blockIdx.x * (blockDim.x / kWave) + wave;
+    for (;;) {
+        const ImageDesc &d = descs[image];
+        HuffShared s;
+        s.l1 = l1;
+        s.l2 = l2;
+        s.l2_staged = umin(l2_in_lds, d.fast_off + 2u * kFastEntries);
+        s.win = win;
+        s.win_base = win_base;
+        s.win_len = win_len;
+        s.du_slots = slots;
+        flat += stride; // (wave-uniform)
+        WindowAhead ahead;
+        ahead.descs = descs;
+        ahead.any = waves_per_image && flat < units;
+        ahead.image = ahead.first = 0u;
+        if (ahead.any) {
+            ahead.image = uint32_t(__builtin_amdgcn_readfirstlane(int(flat / waves_per_image)));
+            ahead.first = uint32_t(__builtin_amdgcn_readfirstlane(int((flat % waves_per_image) * kWave)));
+        }
+        ahead.window_words = window_words;
+        ahead.lane = lane;
+        ahead.win = win;
+        ahead.sink = 0u;
+        decode_wave_fused_422(d, s, wave_first + lane, lane, ahead);
+        if (!ahead.any)
+            break;
+        image = ahead.image;
+        wave_first = ahead.first;
+        win_base = ahead.base;
+        win_len = ahead.len;
+    }
 }
 
 // Latency-oriented variant of the fused path for launches that cannot fill
@@ -529,8 +607,16 @@ hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t ma
     const uint32_t waves_per_image = (uniform && flat_allowed) ? (max_intervals + kWave - 1) / kWave : 0u;
     const uint64_t flat_groups = (uint64_t(waves_per_image) * images + plan.waves_per_block - 1) / plan.waves_per_block;
     dim3 grid((max_intervals + threads - 1) / threads, images, 1);
-    if (waves_per_image && flat_groups <= 0x7fffffffu)
-        grid = dim3(uint32_t(flat_groups), 1, 1);
+    if (waves_per_image && flat_groups <= 0x7fffffffu) {
+        // at most as many workgroups as are resident at once; their waves loop over the rest (see the kernel)
+        static const int resident_cap = [] {
+            const char *e = getenv("COMPEG_RESIDENT"); // experiment knob: 0 = a workgroup per 12 units as before
+            return e ? atoi(e) : 1;
+        }();
+        const uint32_t per_cu = std::max(1u, std::min(kLdsBytesPerCu / plan.total_bytes, kMaxWavesFused / plan.waves_per_block));
+        const uint64_t resident = uint64_t(kCuCount) * per_cu;
+        grid = dim3(uint32_t(resident_cap ? std::min(flat_groups, resident) : flat_groups), 1, 1);
+    }
     static const hipError_t attr = hipFuncSetAttribute(
         reinterpret_cast<const void *>(decode_fused_422_kernel),
         hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsBytesPerCu));

@@ -240,19 +240,32 @@ CG_DEV void stage_luts(const ImageDesc &d, uint16_t *l1, uint16_t *l2, uint32_t 
 // The scan window of the wave whose first interval is `wave_first`: the
 // contiguous words of its 64 intervals plus the reader's two-word look-ahead,
 // cut to the LDS budget.
-CG_DEV void wave_window(const ImageDesc &d, uint32_t wave_first, uint32_t window_words,
-                        uint32_t &base, uint32_t &len)
+// (in two steps, so that a wave can have the two loads of its next window in flight while it decodes)
+CG_DEV void wave_window_fetch(const ImageDesc &d, uint32_t wave_first, uint32_t &raw_base, uint32_t &raw_end)
 {
-    base = wave_first < d.nstarts ? CG_GLOBAL(const uint32_t, d.starts)[wave_first] : 0u;
+    raw_base = wave_first < d.nstarts ? CG_GLOBAL(const uint32_t, d.starts)[wave_first] : 0u;
     const uint32_t after = wave_first + kWave;
-    uint32_t end = (after < d.total_intervals && after < d.nstarts) ? CG_GLOBAL(const uint32_t, d.starts)[after] : d.nwords;
+    raw_end = (after < d.total_intervals && after < d.nstarts) ? CG_GLOBAL(const uint32_t, d.starts)[after] : d.nwords;
+}
+
+CG_DEV void wave_window_from(const ImageDesc &d, uint32_t raw_base, uint32_t raw_end, uint32_t window_words,
+                             uint32_t &base, uint32_t &len)
+{
     // the slack lets the last intervals of the wave pass the fast mode's in-window
     // test; positions past the end of the scan are staged as zeros
     // (+ 2: the reader keeps up to two words in hand, so at the start of the last data units of the wave's last
     // interval its position is that far beyond the interval's end -- still inside the window with these)
-    end = umin(end, d.nwords) + kDuWordSlack + 2u;
-    base = umin(base, d.nwords);
+    const uint32_t end = umin(raw_end, d.nwords) + kDuWordSlack + 2u;
+    base = umin(raw_base, d.nwords);
     len = end > base ? umin(end - base, window_words) : 0u;
+}
+
+CG_DEV void wave_window(const ImageDesc &d, uint32_t wave_first, uint32_t window_words,
+                        uint32_t &base, uint32_t &len)
+{
+    uint32_t raw_base, raw_end;
+    wave_window_fetch(d, wave_first, raw_base, raw_end);
+    wave_window_from(d, raw_base, raw_end, window_words, base, len);
 }
 
 // Words idx .. idx+3 of the scan (zero past its end), MSB-first.
@@ -484,30 +497,26 @@ template <class T> CG_DEV T aan_const(float c)
     return aan_splat(c, T{});
 }
 
+// The butterflies up to the last level: e[k] and o[k] with out[k] = e[k] + o[k], out[7 - k] = e[k] - o[k].
+// The column pass works on inputs that carry the reference's factor 1/8 already (idct_data_unit folds it into
+// the dequantisation constant: a power of two commutes with every rounding here); the row pass adds 128.5 to
+// its first input.
 template <class T, int STRIDE, bool ROW_PASS>
-CG_DEV void aan_1d(T *v)
+CG_DEV void aan_core(const T *v, T (&e)[4], T (&o)[4])
 {
-    T in0 = v[0 * STRIDE], in1 = v[1 * STRIDE], in2 = v[2 * STRIDE], in3 = v[3 * STRIDE];
-    T in4 = v[4 * STRIDE], in5 = v[5 * STRIDE], in6 = v[6 * STRIDE], in7 = v[7 * STRIDE];
-    if (ROW_PASS) {
+    T in0 = v[0 * STRIDE];
+    const T in1 = v[1 * STRIDE], in2 = v[2 * STRIDE], in3 = v[3 * STRIDE];
+    const T in4 = v[4 * STRIDE], in5 = v[5 * STRIDE], in6 = v[6 * STRIDE], in7 = v[7 * STRIDE];
+    if (ROW_PASS)
         in0 = in0 + aan_const<T>(128.5f);
-    } else {
-        const T eighth = aan_const<T>(0.125f);
-        in0 = in0 * eighth;
-        in1 = in1 * eighth;
-        in2 = in2 * eighth;
-        in3 = in3 * eighth;
-        in4 = in4 * eighth;
-        in5 = in5 * eighth;
-        in6 = in6 * eighth;
-        in7 = in7 * eighth;
-    }
     // even part
     const T tmp10 = in0 + in4, tmp11 = in0 - in4;
     const T tmp13 = in2 + in6;
     const T tmp12 = (in2 - in6) * aan_const<T>(CG_C1414) - tmp13;
-    const T e0 = tmp10 + tmp13, e3 = tmp10 - tmp13;
-    const T e1 = tmp11 + tmp12, e2 = tmp11 - tmp12;
+    e[0] = tmp10 + tmp13;
+    e[3] = tmp10 - tmp13;
+    e[1] = tmp11 + tmp12;
+    e[2] = tmp11 - tmp12;
     // odd part
     const T z13 = in5 + in3, z10 = in5 - in3;
     const T z11 = in1 + in7, z12 = in1 - in7;
@@ -519,15 +528,41 @@ CG_DEV void aan_1d(T *v)
     const T o6 = t12 - o7;
     const T o5 = t11 - o6;
     const T o4 = t10 - o5;
+    o[0] = o7;
+    o[1] = o6;
+    o[2] = o5;
+    o[3] = o4;
+}
 
-    v[0 * STRIDE] = e0 + o7;
-    v[7 * STRIDE] = e0 - o7;
-    v[1 * STRIDE] = e1 + o6;
-    v[6 * STRIDE] = e1 - o6;
-    v[2 * STRIDE] = e2 + o5;
-    v[5 * STRIDE] = e2 - o5;
-    v[3 * STRIDE] = e3 + o4;
-    v[4 * STRIDE] = e3 - o4;
+template <class T, int STRIDE, bool ROW_PASS>
+CG_DEV void aan_1d(T *v)
+{
+    T e[4], o[4];
+    aan_core<T, STRIDE, ROW_PASS>(v, e, o);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        v[k * STRIDE] = e[k] + o[k];
+        v[(7 - k) * STRIDE] = e[k] - o[k];
+    }
+}
+
+// Column pass of two columns at once whose outputs come out transposed: for column HALF of the pair, {row k, row 7 - k}
+// in one register pair.  The row pass then runs on the row pairs (0,7) (1,6) (2,5) (3,4) without a single move
+// between the passes: a packed f32 instruction may take either half of each source for either half of its result
+// (op_sel / op_sel_hi) and negate per half (neg_hi).
+template <int HALF>
+CG_DEV f32x2 aan_cross(f32x2 e, f32x2 o)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    f32x2 r;
+    if (HALF == 0)
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]" : "=v"(r) : "v"(e), "v"(o));
+    else
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1] neg_hi:[0,1]" : "=v"(r) : "v"(e), "v"(o));
+    return r;
+#else
+    return f32x2{e[HALF] + o[HALF], e[HALF] - o[HALF]};
+#endif
 }
 
 CG_DEV uint32_t sample_u8(float f)
@@ -630,7 +665,8 @@ CG_DEV void idct_data_unit(const uint32_t (&ac)[kRetained / 2], int32_t dc, cons
 #pragma unroll
         for (int c = 0; c < 8; c++) {
             const int z = zigzag_of(r * 8 + c);
-            const float mul = aan_scale(r) * aan_scale(c);
+            // (the column pass's 1/8, src/dct.wgsl, rides on the constant: exact, a power of two)
+            const float mul = (aan_scale(r) * aan_scale(c)) * 0.125f;
             float x = 0.0f;
             if (z == 0) {
                 x = static_cast<float>(dc) * mul; // already dequantised with i32 wrap by the decoder
@@ -646,7 +682,7 @@ CG_DEV void idct_data_unit(const uint32_t (&ac)[kRetained / 2], int32_t dc, cons
         }
     }
 #if CG_IDCT_PACKED
-    // column pass on column pairs, row pass on row pairs; element by element the
+    // column pass on column pairs, row pass on the row pairs (k, 7 - k); element by element the
     // same operations in the same order as the scalar form below
     f32x2 cols[8][4];
 #pragma unroll
@@ -654,24 +690,28 @@ CG_DEV void idct_data_unit(const uint32_t (&ac)[kRetained / 2], int32_t dc, cons
 #pragma unroll
         for (int cp = 0; cp < 4; cp++)
             cols[r][cp] = f32x2{v[r * 8 + 2 * cp], v[r * 8 + 2 * cp + 1]};
-#pragma unroll
-    for (int cp = 0; cp < 4; cp++)
-        aan_1d<f32x2, 4, false>(&cols[0][cp]);
     f32x2 rows[4][8];
 #pragma unroll
-    for (int rp = 0; rp < 4; rp++)
+    for (int cp = 0; cp < 4; cp++) {
+        f32x2 e[4], o[4];
+        aan_core<f32x2, 4, false>(&cols[0][cp], e, o);
 #pragma unroll
-        for (int c = 0; c < 8; c++)
-            rows[rp][c] = f32x2{cols[2 * rp][c >> 1][c & 1], cols[2 * rp + 1][c >> 1][c & 1]};
+        for (int k = 0; k < 4; k++) {
+            rows[k][2 * cp] = aan_cross<0>(e[k], o[k]);
+            rows[k][2 * cp + 1] = aan_cross<1>(e[k], o[k]);
+        }
+    }
 #pragma unroll
-    for (int rp = 0; rp < 4; rp++)
-        aan_1d<f32x2, 1, true>(&rows[rp][0]);
+    for (int k = 0; k < 4; k++)
+        aan_1d<f32x2, 1, true>(&rows[k][0]);
     float f[8][8];
 #pragma unroll
-    for (int r = 0; r < 8; r++)
+    for (int k = 0; k < 4; k++)
 #pragma unroll
-        for (int c = 0; c < 8; c++)
-            f[r][c] = rows[r >> 1][c][r & 1];
+        for (int c = 0; c < 8; c++) {
+            f[k][c] = rows[k][c][0];
+            f[7 - k][c] = rows[k][c][1];
+        }
     pack_rows3(f[0], f[1], f[2], px + 0);
     pack_rows3(f[3], f[4], f[5], px + 6);
     pack_rows2(f[6], f[7], px + 12);
@@ -1728,7 +1768,15 @@ CG_DEV void composite_mcus_422(PixelState &t, const ImageDesc &d, uint8_t *wave_
 // (SIMT reconvergence), so that table selectors, quantisers, the IDCT and the
 // quad exchange run with a full wave.  Lanes past the last interval stay for
 // the exchange.
-CG_DEV void decode_wave_fused_422(const ImageDesc &d, const HuffShared &s, uint32_t interval, uint32_t lane)
+// ahead: what the wave does on the side for the unit it will decode next (see WindowAhead in kernels.hip); called
+// with the number of the data unit that is about to start.
+struct NothingAhead {
+    CG_DEV void at(uint32_t, uint32_t) {}
+    CG_DEV void decoded(uint32_t, uint32_t) {}
+};
+
+template <class AHEAD>
+CG_DEV void decode_wave_fused_422(const ImageDesc &d, const HuffShared &s, uint32_t interval, uint32_t lane, AHEAD &ahead)
 {
     // A lane past the image's last interval decodes that last interval once
     // more (it lies in this wave's window) and simply never stores its own
@@ -1757,12 +1805,14 @@ CG_DEV void decode_wave_fused_422(const ImageDesc &d, const HuffShared &s, uint3
     for (uint32_t du = 0; du < du_total; du++) {
         const uint32_t k = du & 3u;
         const uint32_t comp = k < 2u ? 0u : k - 1u; // Y0 Y1 Cb Cr (wave-uniform)
+        ahead.at(du, du_total);
         // Wave priority by phase: a wave in the dense, stall-free phases (IDCT,
         // composite) goes in front of waves in the entropy decode, whose
         // dependent chain leaves most issue slots unused anyway; the dense phases
         // finish sooner and their stores enter the memory system earlier.
         const int32_t dc = entropy_data_unit(e, d, s, comp, slot16);
         CG_STAMP(t_ac);
+        ahead.decoded(du, du_total);
         __builtin_amdgcn_s_setprio(CG_PRIO_IDCT);
         pixel_transform(t, d, comp, k, slot, dc);
         CG_STAMP(t_idct);
@@ -1782,6 +1832,12 @@ CG_DEV void decode_wave_fused_422(const ImageDesc &d, const HuffShared &s, uint3
         o[3] = t_comp;
     }
 #endif
+}
+
+CG_DEV void decode_wave_fused_422(const ImageDesc &d, const HuffShared &s, uint32_t interval, uint32_t lane)
+{
+    NothingAhead none;
+    decode_wave_fused_422(d, s, interval, lane, none);
 }
 #endif // __HIPCC__
 
