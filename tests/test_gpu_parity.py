@@ -348,6 +348,27 @@ def test_uniform_batch_spans_images_with_its_workgroups(ca, gpu):
         _assert_equal(batch.read_output(len(images)), orc.ImageData(extra).decode())
 
 
+@pytest.mark.parametrize("ri,n", [(2, 230), (8, 830)])
+def test_resident_waves_walk_over_their_units(ca, gpu, ri, n):
+    """A uniform batch of a few more units of 64 intervals than the chip holds waves (3072): the throughput
+    kernel's waves stay and some of them take a second unit, whose window they have asked for while decoding the
+    first (DRI = 2: the touch and the interval starts fall on the same data unit; DRI = 8: 32 data units per
+    interval; the image's last wave is partly filled in both).  Every slot against the oracle."""
+    jpegs = [synth.make_jpeg(640, 360, seed=900 + 10 * ri + i, kind=i % 2, quality=80 + i, ri=ri) for i in range(6)]
+    wants = [orc.ImageData(j).decode() for j in jpegs]
+    images = [ca.ImageData(j) for j in jpegs]
+    waves = (images[0].parallelism() + 63) // 64
+    assert images[0].parallelism() % 64 != 0 and 3072 < waves * n < 2 * 3072
+    src = [(5 * i + i // 6) % 6 for i in range(n)]
+    batch = ca.Batch(gpu)
+    batch.upload([images[s] for s in src])
+    batch.decode()
+    batch.wait()
+    for i, s in enumerate(src):
+        if not np.array_equal(batch.read_output(i), wants[s]):
+            _assert_equal(batch.read_output(i), wants[s])
+
+
 def test_restart_interval_changes_pixels_only_where_the_reference_does(ca, gpu):
     """The restart interval only changes where the DC predictors are reset and how the scan is
     cut into lanes -- except for the reference's quirk Q1: its reader is not refilled in front
