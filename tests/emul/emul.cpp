@@ -25,6 +25,14 @@ uint32_t max_wave_span(const uint32_t *starts, size_t nstarts, size_t nwords, ui
 }
 using namespace compeg;
 
+// EMUL_LAST_NZ=1: histogram (luma, chroma) of the highest zig-zag position filled per wave and data unit, on stderr
+static unsigned long *last_nz_hist()
+{
+    static unsigned long hist[2 * compeg::kRetained];
+    static const bool on = getenv("EMUL_LAST_NZ") != nullptr;
+    return on ? hist : nullptr;
+}
+
 // EMUL_DUMP_SYMBOLS=path: one line per wave and data unit with the 64 lanes' AC symbol counts (analysis only)
 static FILE *symbol_dump()
 {
@@ -216,6 +224,18 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
                     }
                 g_emul_stats.wave_steps++;
                 g_emul_stats.wave_step_symbols += step_max;
+                if (last_nz_hist()) { // analysis only: the highest zig-zag position any lane of the wave has filled
+                    int wave_last = 0;
+                    for (uint32_t lane = 0; lane < uint32_t(kWave); lane++) {
+                        const int16_t *c = reinterpret_cast<const int16_t *>(set_slots + lane * kDuSlotBytes);
+                        for (int z = kRetained - 1; z > wave_last; z--)
+                            if (ps[lane].active && c[z] != 0) {
+                                wave_last = z;
+                                break;
+                            }
+                    }
+                    last_nz_hist()[(k < 2u ? 0 : 1) * kRetained + wave_last]++;
+                }
                 for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
                     if (ps[lane].active)
                         pixel_transform(ps[lane], d, comp, k, set_slots + lane * kDuSlotBytes, dcs[set * kWave + lane]);
@@ -417,6 +437,13 @@ int main(int argc, char **argv)
             fprintf(stderr, " %lu", cst.hist[i]);
         fprintf(stderr, "\n");
     }
+    if (last_nz_hist())
+        for (int c = 0; c < 2; c++) {
+            fprintf(stderr, "last_nz %s:", c ? "chroma" : "luma");
+            for (int z = 0; z < compeg::kRetained; z++)
+                fprintf(stderr, " %lu", last_nz_hist()[c * compeg::kRetained + z]);
+            fprintf(stderr, "\n");
+        }
     fprintf(stderr, "stats fast_dus=%lu exact_dus=%lu left_window=%lu left_underflow=%lu dc_cut=%lu escapes=%lu symbols=%lu wave_steps=%lu wave_step_symbols=%lu\n",
             st.fast_dus, st.exact_dus, st.left_window, st.left_underflow, st.dc_cut, st.escapes, st.symbols, st.wave_steps,
             st.wave_step_symbols);
