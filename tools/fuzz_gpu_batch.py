@@ -1,7 +1,8 @@
 """Randomized check of the batch paths on the GPU: batches of 1..6 images of 360p to 4K (same or mixed sizes, restart
 intervals, qualities; bit flips in some scans), uploaded as parsed images and as JPEG bytes, scans preprocessed on the
 host or by the device kernels (once / on every decode), decoded twice -- every output against the oracle.  Small
-batches take the cooperative kernel where all images qualify, larger ones the paired / fused kernels.
+batches take the cooperative kernel where all images qualify, larger ones the paired / fused kernels; every fourth
+batch of equal frames is repeated into a long uniform one (resident waves that walk over several units).
     python tools/fuzz_gpu_batch.py [seed] [batches]"""
 import os
 import sys
@@ -49,6 +50,15 @@ def run(seed=77, batches=40, log=print):
                 pass
         if not items:
             continue
+        if same and it % 4 == 3:
+            # a long uniform batch: the same few frames over and over until the launch has more units of 64 intervals
+            # than the chip holds waves, by a random fraction of a round -- the throughput kernel's resident waves then
+            # take a second, third ... unit each (quantisers and content differ per slot, sizes and tables do not)
+            par = ca.ImageData(items[0][0]).parallelism()
+            waves = (par + 63) // 64
+            slots = int((3072 * float(rng.uniform(1.02, 2.6))) // waves) + 1
+            if slots * w0 * h0 * 4 < (3 << 30):
+                items = [items[int(rng.integers(0, len(items)))] for _ in range(slots)]
         mode = int(rng.integers(0, 3))
         as_bytes = bool(rng.integers(0, 2)) and mode == 0
         batch = ca.Batch(gpu)
