@@ -54,6 +54,9 @@
 #ifndef CG_PRIO_IDCT
 #define CG_PRIO_IDCT 1 // wave priority (0..3) in the IDCT and, below, the composite; the entropy decode runs at 0
 #endif
+#ifndef CG_PRIO_ENTROPY
+#define CG_PRIO_ENTROPY 0
+#endif
 #ifndef CG_PRIO_COMPOSITE
 #define CG_PRIO_COMPOSITE 3
 #endif
@@ -1791,6 +1794,7 @@ CG_DEV void decode_wave_fused_422(const ImageDesc &d, const HuffShared &s, uint3
     PixelState t;
     entropy_init(e, d, s, interval);
     pixel_init(t, d, interval, active);
+    __builtin_amdgcn_s_setprio(CG_PRIO_ENTROPY);
 
 #if defined(CG_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
 #define CG_STAMP(acc) do { const uint64_t now_ = __builtin_readcyclecounter(); acc += now_ - tprev; tprev = now_; } while (0)
@@ -1821,7 +1825,7 @@ CG_DEV void decode_wave_fused_422(const ImageDesc &d, const HuffShared &s, uint3
             composite_mcus_422<true>(t, d, s.du_slots, lane);
             CG_STAMP(t_comp);
         }
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(CG_PRIO_ENTROPY);
     }
 #if defined(CG_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
     if (lane == 0 && d.dc) { // diagnostic build only: per-wave phase cycles into the (otherwise unused) dc buffer
