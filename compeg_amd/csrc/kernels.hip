@@ -614,7 +614,13 @@ hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t ma
             return e ? atoi(e) : 1;
         }();
         const uint32_t per_cu = std::max(1u, std::min(kLdsBytesPerCu / plan.total_bytes, kMaxWavesFused / plan.waves_per_block));
-        const uint64_t resident = uint64_t(kCuCount) * per_cu;
+        // (the CUs of the device the launch goes to: 256 on an MI355X, fewer in a partitioned mode; a wrong count
+        // costs time, not results -- the waves' stride is the grid's size whatever it is)
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = int(kCuCount);
+        const uint64_t resident = uint64_t(cus) * per_cu;
         grid = dim3(uint32_t(resident_cap ? std::min(flat_groups, resident) : flat_groups), 1, 1);
     }
     static const hipError_t attr = hipFuncSetAttribute(
