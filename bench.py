@@ -328,7 +328,7 @@ def main():
     except Exception:
         bus_ids = []
     cores, numa = bind_rank_to_its_cores(local_rank, world if not args.rehearse_on_one_gpu else 1, bus_ids)
-    threads = max(1, min(32, len(cores)))
+    threads = max(1, min(int(os.environ.get("COMPEG_BENCH_HOST_THREADS", "32")), len(cores)))   # (the knob: thread-count experiments)
     t_gen = time.perf_counter()
     jpegs, distinct = make_inputs(args, rank, world, threads)
     t_gen = time.perf_counter() - t_gen

@@ -8,7 +8,9 @@
 #include <string>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <thread>
 
 namespace compeg {
@@ -176,7 +178,83 @@ bool is_422(const ImageData &img)
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// work(t) for t = 0 .. nthreads-1, each on a thread of its own (the caller's for a single one)
+// The threads behind run_on_threads: started once and kept, asleep between two calls.  (Thirty-two fresh threads per
+// batch upload came to life one after the other over more than a millisecond of a ten-millisecond upload.)  One call
+// at a time uses them; a second caller meanwhile gets threads of its own.
+class WorkerPool {
+public:
+    ~WorkerPool()
+    {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+        }
+        wake_.notify_all();
+        for (std::thread &t : threads_)
+            t.join();
+    }
+
+    // work(t) for t = 1 .. nthreads-1 on pool threads; false: the pool is busy
+    bool run(unsigned nthreads, void (*call)(void *, unsigned), void *work)
+    {
+        std::unique_lock<std::mutex> one(busy_, std::try_to_lock);
+        if (!one.owns_lock())
+            return false;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            while (threads_.size() + 1 < nthreads) {
+                const unsigned index = unsigned(threads_.size());
+                threads_.emplace_back([this, index] { loop(index); });
+            }
+            call_ = call;
+            work_ = work;
+            wanted_ = nthreads - 1;
+            pending_ = nthreads - 1;
+            generation_++;
+        }
+        wake_.notify_all();
+        call(work, 0);
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [this] { return pending_ == 0; });
+        return true;
+    }
+
+private:
+    void loop(unsigned index)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            void (*call)(void *, unsigned);
+            void *work;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                wake_.wait(g, [&] { return stop_ || (generation_ != seen && index < wanted_); });
+                if (stop_)
+                    return;
+                seen = generation_;
+                call = call_;
+                work = work_;
+            }
+            call(work, index + 1);
+            {
+                std::lock_guard<std::mutex> g(m_);
+                if (--pending_ == 0)
+                    done_.notify_all();
+            }
+        }
+    }
+
+    std::mutex busy_, m_;
+    std::condition_variable wake_, done_;
+    std::vector<std::thread> threads_;
+    void (*call_)(void *, unsigned) = nullptr;
+    void *work_ = nullptr;
+    unsigned wanted_ = 0, pending_ = 0;
+    uint64_t generation_ = 0;
+    bool stop_ = false;
+};
+
+// work(t) for t = 0 .. nthreads-1, t = 0 on the caller's thread
 template <typename Work>
 void run_on_threads(unsigned nthreads, Work &work)
 {
@@ -184,10 +262,13 @@ void run_on_threads(unsigned nthreads, Work &work)
         work(0);
         return;
     }
-    std::vector<std::thread> pool;
+    static WorkerPool pool;
+    if (pool.run(nthreads, [](void *w, unsigned t) { (*static_cast<Work *>(w))(t); }, &work))
+        return;
+    std::vector<std::thread> own;
     for (unsigned t = 0; t < nthreads; t++)
-        pool.emplace_back([&work, t] { work(t); });
-    for (std::thread &th : pool)
+        own.emplace_back([&work, t] { work(t); });
+    for (std::thread &th : own)
         th.join();
 }
 
@@ -957,13 +1038,18 @@ Status compeg_batch::upload_host(size_t n, int threads, const void *items_, cons
     unsigned nthreads = threads > 0 ? unsigned(threads) : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     nthreads = unsigned(std::min<size_t>(nthreads, std::max<size_t>(n, 1)));
     const int device = gpu->device;
+    std::atomic<uint64_t> thread_us[3] = {{0}, {0}, {0}}; // COMPEG_TRACE_BATCH: thread time in parse / preprocess / copy call
+    std::atomic<size_t> next_image{0}; // (images are handed out as threads come free: they do not take equally long)
     auto work = [&](unsigned t) {
         if (hipSetDevice(device) != hipSuccess) {
             hip_error = int(hipErrorInvalidDevice);
             return;
         }
-        for (size_t i = t; i < n; i += nthreads) {
+        for (size_t i; (i = next_image.fetch_add(1)) < n;) {
+            const auto tw0 = std::chrono::steady_clock::now();
             const ImageData *imgp = image_of(i, results[i]);
+            if (trace_on)
+                thread_us[0] += uint64_t(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw0).count());
             if (!imgp)
                 continue;
             const ImageData &img = *imgp;
@@ -987,8 +1073,11 @@ Status compeg_batch::upload_host(size_t n, int threads, const void *items_, cons
             uint32_t *starts_at = reinterpret_cast<uint32_t *>(hs + o);
             uint8_t *words_at = hs + o + slots * 4;
             size_t nwords = 0, nstarts = 0;
+            const auto tw1 = std::chrono::steady_clock::now();
             results[i] = ScanBuffer::process_to(img.scan_data(), img.scan_len, img.metadata.total_restart_intervals,
                                                 words_at, starts_at, nwords, nstarts);
+            if (trace_on)
+                thread_us[1] += uint64_t(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw1).count());
             if (!results[i].ok() && results[i].code != COMPEG_E_COUNT_MISMATCH)
                 continue;
             d.starts = reinterpret_cast<const uint32_t *>(di + o);
@@ -1009,8 +1098,11 @@ Status compeg_batch::upload_host(size_t n, int threads, const void *items_, cons
                      COMPEG_HUFFMAN_L1_BYTES + img.l2.size() * 2 + 4ull * img.width * img.height;
             // this image's part of the arena, as far as it is used
             const size_t used = table_blob_bytes(img) + slots * 4 + nwords * 4;
+            const auto tw2 = std::chrono::steady_clock::now();
             const hipError_t e = hipMemcpyAsync(di + in_off[i], hs + in_off[i], used, hipMemcpyHostToDevice,
                                                 copy_streams[t % copy_streams.size()]);
+            if (trace_on)
+                thread_us[2] += uint64_t(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw2).count());
             if (e != hipSuccess)
                 hip_error = int(e);
         }
@@ -1050,8 +1142,9 @@ Status compeg_batch::upload_host(size_t n, int threads, const void *items_, cons
     CG_HIP(hipStreamSynchronize(st)); // descs (pageable) and the staging arena may be reused from here on
     mark("descs");
     if (trace_on)
-        fprintf(stderr, "[compeg] batch upload (%zu images, %u threads):%s total=%.2f ms\n", n, nthreads, trace_line.c_str(),
-                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_up0).count());
+        fprintf(stderr, "[compeg] batch upload (%zu images, %u threads):%s total=%.2f ms; thread time: parse %.2f preprocess %.2f copy call %.2f ms\n",
+                n, nthreads, trace_line.c_str(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_up0).count(),
+                thread_us[0].load() / 1e3, thread_us[1].load() / 1e3, thread_us[2].load() / 1e3);
     last_stream = st;
     count = n;
     decodes_timed = 0;
