@@ -1501,12 +1501,6 @@ CG_DEV void coop_walk_422(const ImageDesc &d, const CoopShared &cs, const CoopTa
 #else
                     cs.verdict[L[li].il] = cs.verdict[L[li].il] > v ? cs.verdict[L[li].il] : v;
 #endif
-#if defined(CG_EMUL_STATS)
-                    if (getenv("EMUL_COOP_DEBUG") && !chase_lean_regular(c[li], s, cs.lists + L[li].lane * kCoopListCap))
-                        fprintf(stderr, "irregular wave %u il %u flags %u walked %d done %u of %u p %u stop_p %u hard_end %u\n", wave_index, L[li].il,
-                                c[li].flags, int(c[li].lean_walked), c[li].lean_done, uint32_t(c[li].lp_max - (cs.lists + L[li].lane * kCoopListCap)),
-                                c[li].lean_p, c[li].stop_p, coop_hard_end(s));
-#endif
                 }
             }
             CG_WAVE_SYNC();
@@ -1670,14 +1664,6 @@ CG_DEV void coop_decode_pass_422(const ImageDesc &d, const CoopShared &cs, const
     }
     CG_WAVE_SYNC();
     CG_COOP_STAMP(4);
-#if defined(CG_EMUL_STATS)
-    if (getenv("EMUL_COOP_DEBUG")) {
-        CG_EACH_LANE
-            if (D_exists(li))
-                fprintf(stderr, "dbg wave %u lane %u il %u tl %u state %08x verdict %08x dead_from %u diff %d under %d\n", wave_index,
-                        L[li].lane, D_il(li), D_tl(li), state[li], cs.verdict[D_il(li)], cs.dead_from[D_il(li)], cs.diffs[L[li].lane], int(under[li]));
-    }
-#endif
     uint32_t px[LANES][16];
     CG_EACH_LANE
     {
