@@ -369,6 +369,35 @@ def test_resident_waves_walk_over_their_units(ca, gpu, ri, n):
             _assert_equal(batch.read_output(i), wants[s])
 
 
+def test_concurrent_batch_uploads_share_the_worker_threads(ca, gpu):
+    """Two batches uploaded at the same time from two threads of the caller (ctypes releases the GIL): one finds the
+    library's worker threads busy and brings its own; then the same two one after the other on the kept threads."""
+    import threading
+    jpegs = [synth.make_jpeg(1280, 720, seed=1200 + i, kind=i % 3, quality=85, ri=4) for i in range(6)]
+    wants = [orc.ImageData(j).decode() for j in jpegs]
+    batches = [ca.Batch(gpu), ca.Batch(gpu)]
+    errors = []
+
+    def feed(k):
+        try:
+            for _ in range(3):
+                batches[k].upload_jpegs([jpegs[(i + k) % 6] for i in range(24)], host_threads=8)
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+    threads = [threading.Thread(target=feed, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors
+    for k in range(2):
+        batches[k].upload_jpegs([jpegs[(i + k) % 6] for i in range(24)], host_threads=8)
+        batches[k].decode()
+        batches[k].wait()
+        for i in range(24):
+            _assert_equal(batches[k].read_output(i), wants[(i + k) % 6])
+
+
 def test_restart_interval_changes_pixels_only_where_the_reference_does(ca, gpu):
     """The restart interval only changes where the DC predictors are reset and how the scan is
     cut into lanes -- except for the reference's quirk Q1: its reader is not refilled in front
