@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 
@@ -616,10 +617,15 @@ hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t ma
         const uint32_t per_cu = std::max(1u, std::min(kLdsBytesPerCu / plan.total_bytes, kMaxWavesFused / plan.waves_per_block));
         // (the CUs of the device the launch goes to: 256 on an MI355X, fewer in a partitioned mode; a wrong count
         // costs time, not results -- the waves' stride is the grid's size whatever it is)
+        static std::atomic<int> known[64]; // (per device, asked once)
         int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
             cus = int(kCuCount);
+        else if ((cus = known[dev].load(std::memory_order_relaxed)) == 0) {
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+                cus = int(kCuCount);
+            known[dev].store(cus, std::memory_order_relaxed);
+        }
         const uint64_t resident = uint64_t(cus) * per_cu;
         grid = dim3(uint32_t(resident_cap ? std::min(flat_groups, resident) : flat_groups), 1, 1);
     }
