@@ -611,7 +611,7 @@ hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t ma
     if (waves_per_image && flat_groups <= 0x7fffffffu) {
         // at most as many workgroups as are resident at once; their waves loop over the rest (see the kernel)
         static const int resident_cap = [] {
-            const char *e = getenv("COMPEG_RESIDENT"); // experiment knob: 0 = a workgroup per 12 units as before
+            const char *e = getenv("COMPEG_RESIDENT"); // experiment knob: 0 = a workgroup per 12 units as before, n > 1 = at most n workgroups (part of the chip)
             return e ? atoi(e) : 1;
         }();
         const uint32_t per_cu = std::max(1u, std::min(kLdsBytesPerCu / plan.total_bytes, kMaxWavesFused / plan.waves_per_block));
@@ -627,7 +627,7 @@ hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t ma
             known[dev].store(cus, std::memory_order_relaxed);
         }
         const uint64_t resident = uint64_t(cus) * per_cu;
-        grid = dim3(uint32_t(resident_cap ? std::min(flat_groups, resident) : flat_groups), 1, 1);
+        grid = dim3(uint32_t(resident_cap ? std::min(flat_groups, resident_cap > 1 ? uint64_t(resident_cap) : resident) : flat_groups), 1, 1);
     }
     static const hipError_t attr = hipFuncSetAttribute(
         reinterpret_cast<const void *>(decode_fused_422_kernel),
