@@ -1682,7 +1682,16 @@ struct McuTarget {
 
 CG_DEV McuTarget mcu_target(const PixelState &t, const ImageDesc &d)
 {
+#if CG_EXP == 14 // diagnostic build (DRI = 4 only; wrong picture, the same bytes): the MCUs of a wave's 64 intervals
+                 // change places so that every store instruction of the composite writes 1 KB in one piece (lane
+                 // 4 q + j at its MCU m goes where MCU 64 j + 16 m + q of the wave's 256 would): what the write
+                 // path would do with ideal geometry
+    const uint32_t mcu = t.my * d.width_mcus + t.mx, unit = mcu & ~255u, lane_ = (mcu >> 2) & 63u, m_ = mcu & 3u;
+    const uint32_t moved = umin(unit + 64u * (lane_ & 3u) + 16u * m_ + (lane_ >> 2), d.total_intervals * d.restart_interval - 1u);
+    const uint32_t x0 = (moved % d.width_mcus) * 16u, y0 = (moved / d.width_mcus) * 8u;
+#else
     const uint32_t x0 = t.mx * 16u, y0 = t.my * 8u;
+#endif
     McuTarget g;
     g.base = d.out + size_t(y0) * d.out_pitch + size_t(x0) * 4u;
     g.whole = t.active && x0 + 16u <= d.out_w && y0 + 8u <= d.out_h && (d.out_pitch & 15u) == 0u;
