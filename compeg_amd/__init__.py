@@ -24,6 +24,10 @@ __all__ = ["Gpu", "Decoder", "DecodeOp", "ImageData", "ScanBuffer", "Batch", "Te
            "version", "LIB_PATH"]
 
 
+# compeg_decoder_last_kernel / compeg_batch_last_kernel (include/compeg_hip.h: COMPEG_KERNEL_*)
+KERNEL_NAMES = ("none", "fused", "pair", "coop_team", "generic", "split")
+
+
 def version():
     return lib.compeg_version().decode()
 
@@ -234,6 +238,10 @@ class Decoder:
         check(lib.compeg_decoder_last_stage_times(self._h, t))
         return {"preprocess_us": t[0], "enqueue_writes_us": t[1], "poll_us": t[2]}
 
+    def last_kernel(self):
+        """Diagnostics: the decode kernel the last enqueue went to (KERNEL_* names)."""
+        return KERNEL_NAMES[lib.compeg_decoder_last_kernel(self._h)]
+
     def set_device_preprocess(self, on=True):
         """Extension: preprocess scans with the device-side scan kernels instead of on the host."""
         check(lib.compeg_decoder_set_device_preprocess(self._h, 1 if on else 0))
@@ -329,6 +337,10 @@ class Batch:
 
     def pixels(self):
         return lib.compeg_batch_pixels(self._h)
+
+    def last_kernel(self):
+        """Diagnostics: the decode kernel the first launch of the last decode went to (KERNEL_NAMES)."""
+        return KERNEL_NAMES[lib.compeg_batch_last_kernel(self._h)]
 
     def timing(self, reset=True):
         """(decodes, total_ms, huffman_ms, idct_composite_ms) summed over the decodes since the

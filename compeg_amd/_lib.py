@@ -88,6 +88,8 @@ def _load():
         "compeg_batch_algorithmic_bytes": (C.c_uint64, [vp]),
         "compeg_batch_pixels": (C.c_uint64, [vp]),
         "compeg_batch_timing": (i, [vp, i, pu32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "compeg_batch_last_kernel": (i, [vp]),
+        "compeg_decoder_last_kernel": (i, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here = header/library mismatch: fail loudly

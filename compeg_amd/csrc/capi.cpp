@@ -413,6 +413,8 @@ const char *compeg_decoder_last_warning(const compeg_decoder *dec)
     return dec ? dec->warning.c_str() : "";
 }
 
+int compeg_decoder_last_kernel(const compeg_decoder *dec) { return dec ? dec->last_kernel : COMPEG_KERNEL_NONE; }
+
 int compeg_decoder_last_stage_times(const compeg_decoder *dec, compeg_stage_times *out)
 {
     if (!dec || !out)
@@ -672,9 +674,25 @@ int compeg_batch_set_chunk(compeg_batch *batch, uint32_t images_per_launch)
 {
     if (!batch)
         return fail(COMPEG_E_INVALID_ARG, "batch is NULL");
+    if (batch->chunk == images_per_launch)
+        return ok();
     batch->chunk = images_per_launch;
+    // (the launches change size: some of them may now be the cooperative kernel's, which wants its walk tables)
+    if (batch->count) {
+        if (batch->last_stream && hipStreamSynchronize(batch->last_stream) != hipSuccess)
+            return fail(COMPEG_E_HIP, "hipStreamSynchronize failed");
+        if (hipSetDevice(batch->gpu->device) != hipSuccess)
+            return fail(COMPEG_E_HIP, "hipSetDevice failed");
+        compeg::Status st = batch->make_walk_tables(batch->gpu->stream);
+        if (!st.ok())
+            return fail(st);
+        if (hipStreamSynchronize(batch->gpu->stream) != hipSuccess)
+            return fail(COMPEG_E_HIP, "hipStreamSynchronize failed");
+    }
     return ok();
 }
+
+int compeg_batch_last_kernel(const compeg_batch *batch) { return batch ? batch->last_kernel : COMPEG_KERNEL_NONE; }
 
 int compeg_batch_output(const compeg_batch *batch, size_t index, void **device_ptr, uint32_t *width,
                         uint32_t *height, size_t *pitch_bytes)

@@ -58,8 +58,9 @@ inline CoopStats g_coop_stats{};
 #define CG_COOP_COUNT(field, n) ((void)0)
 #endif
 
-constexpr uint32_t kCoopListCap = 20;      // state words per chasing lane (64 x 20 words = the slot area)
-constexpr uint32_t kCoopMaxEntries = 19;   // ... of which the last is scratch (the entry being built)
+constexpr uint32_t kCoopListCap = 20;      // state words per chasing lane (64 x 20 words = the slot area) ...
+constexpr uint32_t kCoopMaxEntries = 19;   // ... of which the last is scratch (the entry being built); CoopGeom::list_cap / max_entries
+                                           // are these, or more where an interval is longer than a team's 256 data units
 #ifndef CG_COOP_MARGIN
 #define CG_COOP_MARGIN 64
 #endif
@@ -67,7 +68,8 @@ constexpr uint32_t kCoopMargin = CG_COOP_MARGIN; // bits a lane walks on beyond 
 constexpr uint32_t kCoopHead = 3;          // leading entries of a successor's list that a link may point at
 constexpr uint32_t kCoopTail = 3;          // trailing entries of a lane's own list that may carry the link
 constexpr uint32_t kCoopMaxWindow = 2040;  // words: bit positions inside the wave's window fit 16 bits
-constexpr uint32_t kCoopMaxRestart = 16;   // MCUs per interval: 64 data units, one per lane
+constexpr uint32_t kCoopMaxRestart = 256;  // MCUs per interval (1024 data units: 16 rounds of 64)
+constexpr uint32_t kCoopMaxRounds = 16;    // rounds of 64 data units per walk
 constexpr uint32_t kCoopQuantStride = 36;  // floats between the components' quantiser rows in LDS
 
 // Data-unit start state: bits 0..15 bit position inside the wave's window, 16..20 size of the symbol in front
@@ -76,7 +78,6 @@ constexpr uint32_t kCoopQuantStride = 36;  // floats between the components' qua
 // (index of entry 0 + i) mod 4.  Two states are equal iff these 21 bits and that index are.
 constexpr uint32_t kCoopStateMask = 0x001fffffu;
 constexpr uint32_t kCoopZero = 1u << 25;   // (decode phase) the data unit lies behind a dead one: zero-stream levels
-constexpr uint32_t kCoopSerial = 1u << 26; // (decode phase) its interval is decoded by one lane, serially
 constexpr uint32_t kCoopUnset = 1u << 27;  // (decode phase) no state: nothing to decode
 
 constexpr uint32_t kStopAnomaly = 2u;      // the walk cannot go on (window exhausted, hostile table)
@@ -180,8 +181,8 @@ CG_DEV uint32_t coop_walk_word(const uint16_t *ac_fast, const uint16_t *dc_fast,
 // The wave's share of LDS.
 struct CoopShared {
     HuffShared h;        // tables, window, the 64 data-unit slots
-    uint32_t *lists;     // 64 x kCoopListCap state words: the same bytes as the slots (lists die before slots live)
-    uint32_t *du_state;  // [64 x passes] start state of every data unit of the wave
+    uint32_t *lists;     // 64 x list_cap state words: with 20 the same bytes as the slots (lists die before slots live)
+    uint32_t *du_state;  // [64 x rounds] start state of every data unit of the walk
     uint32_t *lane_n;    // [64] chasing lanes: entries listed | stop reason << 8
     uint32_t *link;      // [64] chasing lanes: 1 | successor lane << 8 | its entry << 16 | own entry << 24, or 0
     uint32_t *seg;       // [64] this round's stretches of every interval's sequence (see coop_follow)
@@ -189,6 +190,8 @@ struct CoopShared {
     uint32_t *nseg;      // [64] per interval: stretches in seg
     uint32_t *dead_from; // [64] per interval: first data unit whose DC code underflows the reference reader
     int32_t *diffs;      // [64] DC differences of the data units being decoded
+    uint32_t *carry;     // [4 x rounds] per round: the DC sums (Y, Cb, Cr) of the interval that runs on into the next round
+                         // (the bytes of `link`: the walk is over when the rounds begin)
     const float *quant;  // 3 rows of quantisers (workgroup-wide)
     // team form, quarters (coop_decode_quarter_422): the team's flag words; the four waves' diffs areas (wave m's at
     // team_diffs + m * team_diffs_stride); the team's number inside its workgroup
@@ -197,7 +200,8 @@ struct CoopShared {
     uint32_t team_diffs_stride, team_in_wg;
 };
 // flag words of a team: [0] the walk: 1 = its lists are prepared, 2 = it is done; [1] quarters whose DC differences
-// are final (bit q); [2] quarters whose pixels are stored (count); [3] quarters that have read their start states (bit q)
+// are final (bit q) -- rounds: how many of them are, in order (count); [2] quarters / rounds whose pixels are stored
+// (count); [3] quarters that have read their start states (bit q)
 constexpr uint32_t kTeamWalk = 0, kTeamDecoded = 1, kTeamStored = 2, kTeamStatesRead = 3;
 
 CG_DEV void coop_bind_misc(CoopShared &cs, uint32_t *misc)
@@ -210,54 +214,53 @@ CG_DEV void coop_bind_misc(CoopShared &cs, uint32_t *misc)
     cs.nseg = misc + 320;
     cs.dead_from = misc + 384;
     cs.du_state = misc + 448;
+    cs.carry = misc + 64;
+    cs.flags = nullptr;
 }
-constexpr uint32_t kCoopMaxPasses = 4;
 // a walk's bookkeeping words: lane_n, link, diffs, seg, verdict, nseg, dead_from (64 each), then du_state (64 per round)
-constexpr uint32_t coop_misc_words(uint32_t passes) { return 7u * 64u + passes * 64u; }
-constexpr uint32_t kCoopMiscWords = coop_misc_words(kCoopMaxPasses);
+constexpr uint32_t coop_misc_words(uint32_t rounds) { return 7u * 64u + rounds * 64u; }
 
 constexpr uint32_t kVerdictDone = 1u, kVerdictContinue = 2u, kVerdictSerial = 3u;
 
 struct CoopGeom {
-    uint32_t R, dpi, ipw;    // MCUs and data units per interval, intervals per wave (all powers of two)
-    uint32_t dpi_shift;      // log2(dpi)
-    uint32_t passes;         // the walk covers this many rounds of 64 data units (1, 2 or 4)
-    uint32_t ipp;            // intervals per such round: 64 / dpi
-    uint32_t lpi, lpi_shift; // lanes that walk one interval: dpi / passes
-    uint32_t count;          // subsequences per interval: 1 + the speculative ones (a power of two)
-    uint32_t count_shift;
-    uint32_t first_interval; // of this wave
+    uint32_t R, dpi, ipw;    // MCUs and data units per interval, intervals per walk (device_types.h: CoopShape)
+    uint32_t rounds;         // the walk covers this many rounds of 64 data units
+    uint32_t lpi;            // lanes that walk one interval
+    uint32_t count;          // subsequences per interval: 1 + the speculative ones
+    uint32_t list_cap, max_entries; // words per walking lane's list; entries it may hold (the last word is scratch)
+    uint32_t first_interval; // of this walk
     uint32_t intervals;      // that exist (0..ipw)
+    uint32_t dus;            // data units of the walk's existing intervals
 };
 
-CG_DEV uint32_t ilog2(uint32_t v)
-{
-    uint32_t r = 0;
-    while ((1u << r) < v)
-        r++;
-    return r;
-}
-
-// passes: 1 -- a wave takes 64 data units' worth of intervals and every interval has as many lanes to walk it as it
-// has data units; 2 -- twice the intervals, half the lanes each, and the decode phases run twice (fewer waves on a
-// SIMD, each with more lanes walking).  spec_shift: the number of subsequences is divided by 2^spec_shift (0: as
+// waves: 4 -- a team (kernels.hip): one wave walks the intervals of 4 x 64 data units, four decode them; 1 -- a lone
+// wave does it all for 64 data units' worth of intervals, and every interval has as many lanes to walk it as it has
+// data units (2: twice the intervals, half the lanes each).  An interval longer than that is alone in its walk and
+// decoded in as many rounds as it needs.  spec_shift: the number of subsequences is divided by 2^spec_shift (0: as
 // many as the lanes allow; large: none, lane 0 walks the whole interval).
-CG_DEV void coop_geom(const ImageDesc &d, uint32_t wave_index, CoopGeom &g, uint32_t spec_shift = 0u, uint32_t passes = 1u)
+CG_DEV void coop_geom(const ImageDesc &d, uint32_t walk_index, CoopGeom &g, uint32_t spec_shift = 0u, uint32_t waves = 1u)
 {
-    g.R = d.restart_interval; // 1, 2, 4, 8 or 16 (ImageDesc::coop_ok)
-    g.dpi = 4u * g.R;
-    g.dpi_shift = ilog2(g.dpi);
-    g.passes = passes >= 4u ? 4u : (passes >= 2u ? 2u : 1u); // (dpi >= 4: every interval keeps a lane to walk it)
-    g.ipp = uint32_t(kWave) >> g.dpi_shift;
-    g.ipw = g.ipp * g.passes;
-    g.lpi = g.dpi / g.passes;
-    g.lpi_shift = ilog2(g.lpi);
-    g.count = 1u + (g.lpi - 1u) / 4u; // lane 0, then four lanes per speculative subsequence: 1, 2, 4, 8, 16
-    g.count = g.count >> spec_shift ? g.count >> spec_shift : 1u;
-    g.count_shift = ilog2(g.count);
-    g.first_interval = wave_index * g.ipw;
+    const CoopShape sh = coop_shape(d.restart_interval, waves >= 4u ? 4u : (waves >= 2u ? 2u : 1u));
+    g.R = d.restart_interval; // 1 .. kCoopMaxRestart (ImageDesc::coop_ok)
+    g.dpi = sh.dpi;
+    g.ipw = sh.ipw;
+    g.rounds = sh.rounds;
+    g.lpi = sh.lpi;
+    g.count = spec_shift < 31u && (sh.count >> spec_shift) ? sh.count >> spec_shift : 1u; // lane 0, then four lanes per speculative subsequence
+    g.list_cap = sh.list_cap;
+    g.max_entries = sh.list_cap - 1u;
+    g.first_interval = walk_index * g.ipw;
     const uint32_t left = d.total_intervals > g.first_interval ? d.total_intervals - g.first_interval : 0u;
     g.intervals = left < g.ipw ? left : g.ipw;
+    g.dus = g.intervals * g.dpi;
+}
+
+// Data unit n of a walk (round n / 64, lane n % 64): which of the walk's intervals, and which of its data units.
+// (An interval may begin in one round and end in another.)
+CG_DEV void coop_du_of(const CoopGeom &g, uint32_t n, uint32_t &il, uint32_t &tl)
+{
+    il = n / g.dpi;
+    tl = n - il * g.dpi;
 }
 
 CG_DEV uint32_t sel3(uint32_t c, uint32_t a0, uint32_t a1, uint32_t a2)
@@ -579,9 +582,9 @@ CG_DEV void coop_lean_prepare(const CoopShared &cs, const CoopTables &t, const C
 #endif
     const uint32_t walkers = g.ipw < uint32_t(kWave) ? g.ipw : uint32_t(kWave), per = uint32_t(kWave) / walkers;
     const uint32_t il = lane % walkers;
-    uint32_t *list = cs.lists + (il << g.lpi_shift) * kCoopListCap;
+    uint32_t *list = cs.lists + il * g.lpi * g.list_cap;
     // (entry 0 holds the walk's start state; its table names are there for a long DC code right at the start)
-    for (uint32_t j = lane / walkers; j <= g.dpi; j += per) {
+    for (uint32_t j = lane / walkers; j <= g.dpi && lane < per * walkers; j += per) {
         const uint32_t k = (j - 1u) & 3u;
         list[4u * j + 2u] = walk_base + walk_pairs_name((t.walk_acsel >> (8u * k)) & 0xffu);
         list[4u * j + 3u] = walk_base + walk_dc_name((t.walk_dcsel >> (8u * ((k + 1u) & 3u))) & 0xffu);
@@ -875,10 +878,10 @@ CG_DEV bool chase_lean_regular(const ChaseState &c, const HuffShared &s, uint32_
     return !c.lean_walked || (c.lean_done == uint32_t(c.lp_max - list) && c.lean_p < coop_hard_end(s));
 }
 
-// Word offset (inside the interval) at which subsequence j of `count` (a power of two) begins.
+// Word offset (inside the interval) at which subsequence j of `count` begins.
 CG_DEV uint32_t coop_sub_start(uint32_t len_words, uint32_t j, const CoopGeom &g)
 {
-    return j >= g.count ? len_words : (len_words * j) >> g.count_shift;
+    return j >= g.count ? len_words : (len_words * j) / g.count; // (len_words <= kCoopMaxWindow, j < 16)
 }
 
 // The first subsequence behind j that begins further into the interval than j does (count: none).
@@ -945,12 +948,12 @@ CG_DEV void chase_assign(ChaseState &c, const HuffShared &s, const CoopGeom &g, 
         c.s = 0u;
         list[0] = c.p;
         c.lp = list + 1;
-        c.lp_max = list + umin(kCoopMaxEntries, g.dpi);
+        c.lp_max = list + umin(g.max_entries, g.dpi);
         c.active = c.lp < c.lp_max;
     } else {
         // inside the AC part of data unit h, by assumption: its first entry starts data unit h + 1
         c.k0 = (h + 1u) & 3u;
-        c.lp_max = list + kCoopMaxEntries;
+        c.lp_max = list + g.max_entries;
     }
 }
 
@@ -961,10 +964,10 @@ CG_DEV void chase_assign(ChaseState &c, const HuffShared &s, const CoopGeom &g, 
 // Lane index (inside the interval) of the walk of subsequence j under assumption h
 CG_DEV uint32_t coop_spec_lane(uint32_t j, uint32_t h) { return 1u + 4u * (j - 1u) + h; }
 
-CG_DEV void coop_publish(const ChaseState &c, const CoopShared &cs, uint32_t lane)
+CG_DEV void coop_publish(const ChaseState &c, const CoopShared &cs, const CoopGeom &g, uint32_t lane)
 {
     const uint32_t anomaly = c.flags | ((c.used && c.p >= coop_hard_end(cs.h)) ? kStopAnomaly : 0u);
-    const uint32_t n = uint32_t(c.lp - (cs.lists + lane * kCoopListCap));
+    const uint32_t n = uint32_t(c.lp - (cs.lists + lane * g.list_cap));
     cs.lane_n[lane] = n | (anomaly << 8) | (c.k0 << 16);
     cs.link[lane] = 0u;
 }
@@ -973,7 +976,7 @@ CG_DEV void coop_publish(const ChaseState &c, const CoopShared &cs, uint32_t lan
 // of the next subsequence lists too (among its first entries).  lane0: first lane of the interval.
 CG_DEV void coop_find_link(const ChaseState &c, const CoopShared &cs, const CoopGeom &g, uint32_t lane, uint32_t lane0)
 {
-    const uint32_t *mine = cs.lists + lane * kCoopListCap;
+    const uint32_t *mine = cs.lists + lane * g.list_cap;
     const uint32_t n = uint32_t(c.lp - mine);
     if (n == 0u || c.next_sub >= g.count)
         return;
@@ -982,7 +985,7 @@ CG_DEV void coop_find_link(const ChaseState &c, const CoopShared &cs, const Coop
     bool own_ok[kCoopTail];
 #pragma unroll
     for (uint32_t a = 0; a < kCoopTail; a++) {
-        own[a] = mine[first + a] & kCoopStateMask; // (first + a <= n <= kCoopMaxEntries: inside the list)
+        own[a] = mine[first + a] & kCoopStateMask; // (first + a <= n <= max_entries: inside the list)
         own_ok[a] = first + a < n && (own[a] & 0xffffu) >= c.sub_end;
     }
     uint32_t best = 0u;
@@ -991,7 +994,7 @@ CG_DEV void coop_find_link(const ChaseState &c, const CoopShared &cs, const Coop
         const uint32_t other = lane0 + coop_spec_lane(c.next_sub, h);
         const uint32_t info = cs.lane_n[other];
         const uint32_t n_other = umin(info & 0xffu, kCoopHead), k_other = (info >> 16) & 3u;
-        const uint32_t *theirs = cs.lists + other * kCoopListCap;
+        const uint32_t *theirs = cs.lists + other * g.list_cap;
 #pragma unroll
         for (uint32_t q = 0; q < kCoopHead; q++) {
             const uint32_t e = theirs[q] & kCoopStateMask;
@@ -1016,7 +1019,7 @@ CG_DEV void coop_find_link(const ChaseState &c, const CoopShared &cs, const Coop
             const uint32_t n_o = info & 0xffu, k_o = (info >> 16) & 3u;
             for (uint32_t q = 0; q < n_o && !full; q++)
                 for (uint32_t i = 0; i < n && !full; i++)
-                    full = (mine[i] & kCoopStateMask) == (cs.lists[other * kCoopListCap + q] & kCoopStateMask) &&
+                    full = (mine[i] & kCoopStateMask) == (cs.lists[other * g.list_cap + q] & kCoopStateMask) &&
                            ((c.k0 + i - k_o - q) & 3u) == 0u && (mine[i] & 0xffffu) >= c.sub_end;
         }
         if (lane == lane0) {
@@ -1032,7 +1035,7 @@ CG_DEV void coop_find_link(const ChaseState &c, const CoopShared &cs, const Coop
 // First lane of every interval that is not settled yet: follows the links from the chain's current head
 // (itself at first; later the lane that walked on) and notes, for this round, which entries of which lane
 // continue the interval's sequence of data units -- one word per stretch: lane | first entry << 6 |
-// entries << 11 | index of the first data unit << 16 -- and how the interval stands.
+// entries << 13 | index of the first data unit << 20 -- and how the interval stands.
 //   head: the lane the chain continues with; from: its first entry that has not been noted yet;
 //   du: data units whose start has been noted so far
 CG_DEV void coop_follow(const CoopShared &cs, const CoopGeom &g, uint32_t il, uint32_t head, uint32_t from, uint32_t du)
@@ -1045,7 +1048,7 @@ CG_DEV void coop_follow(const CoopShared &cs, const CoopGeom &g, uint32_t il, ui
         const uint32_t l = cs.link[x];
         const bool linked = (l & 1u) && (l >> 24) >= from;
         const uint32_t upto = linked ? l >> 24 : (n > from ? n : from);
-        seg[nseg++] = x | (from << 6) | ((upto - from) << 11) | (du << 16);
+        seg[nseg++] = x | (from << 6) | ((upto - from) << 13) | (du << 20); // (entries of a list < 128, data units < 4096)
         du += upto - from;
         if (du >= g.dpi) {
             v = kVerdictDone;
@@ -1057,14 +1060,14 @@ CG_DEV void coop_follow(const CoopShared &cs, const CoopGeom &g, uint32_t il, ui
                 // (analysis only) the failed boundary: the chain lane's last entries and the successors' first ones
                 fprintf(stderr, "fail il %u lane %u n %u du %u :", il, x, n, du);
                 for (uint32_t i = n > 4 ? n - 4 : 0; i < n; i++)
-                    fprintf(stderr, " %u/%u", cs.lists[x * kCoopListCap + i] & 0xffffu, (cs.lists[x * kCoopListCap + i] >> 16) & 31u);
-                const uint32_t lane0 = (x >> g.lpi_shift) << g.lpi_shift;
+                    fprintf(stderr, " %u/%u", cs.lists[x * g.list_cap + i] & 0xffffu, (cs.lists[x * g.list_cap + i] >> 16) & 31u);
+                const uint32_t lane0 = x / g.lpi * g.lpi;
                 const uint32_t j = x == lane0 ? 0u : 1u + (x - lane0 - 1u) / 4u;
                 for (uint32_t h = 0; h < 4u && j + 1u < g.count; h++) {
                     const uint32_t o = lane0 + coop_spec_lane(j + 1u, h);
                     fprintf(stderr, " | h%u k0=%u n=%u:", h, (cs.lane_n[o] >> 16) & 3u, cs.lane_n[o] & 0xffu);
                     for (uint32_t q = 0; q < (cs.lane_n[o] & 0xffu) && q < 6u; q++)
-                        fprintf(stderr, " %u/%u", cs.lists[o * kCoopListCap + q] & 0xffffu, (cs.lists[o * kCoopListCap + q] >> 16) & 31u);
+                        fprintf(stderr, " %u/%u", cs.lists[o * g.list_cap + q] & 0xffffu, (cs.lists[o * g.list_cap + q] >> 16) & 31u);
                 }
                 fprintf(stderr, "\n");
             }
@@ -1088,9 +1091,9 @@ CG_DEV void coop_emit(const CoopShared &cs, const CoopGeom &g, uint32_t il, uint
     const uint32_t *seg = cs.seg + il * g.count;
     for (uint32_t i = 0; i < nseg; i++) {
         const uint32_t sg = seg[i];
-        const uint32_t x = sg & 63u, from = (sg >> 6) & 31u, cnt = (sg >> 11) & 31u, du0 = sg >> 16;
+        const uint32_t x = sg & 63u, from = (sg >> 6) & 127u, cnt = (sg >> 13) & 127u, du0 = sg >> 20;
         if (tl >= du0 && tl - du0 < cnt)
-            cs.du_state[slot] = cs.lists[x * kCoopListCap + from + (tl - du0)] & kCoopStateMask;
+            cs.du_state[slot] = cs.lists[x * g.list_cap + from + (tl - du0)] & kCoopStateMask;
     }
 }
 
@@ -1098,11 +1101,12 @@ CG_DEV void coop_emit(const CoopShared &cs, const CoopGeom &g, uint32_t il, uint
 // state of its data unit(s) from the walker's 16-byte entries -- no lists, no links to follow.
 CG_DEV void coop_lean_emit(const CoopShared &cs, const CoopGeom &g, uint32_t lane)
 {
-    for (uint32_t pass = 0; pass < g.passes; pass++) {
-        const uint32_t il = pass * g.ipp + (lane >> g.dpi_shift), tl = lane & (g.dpi - 1u);
+    for (uint32_t pass = 0; pass < g.rounds; pass++) {
+        uint32_t il, tl;
+        coop_du_of(g, pass * uint32_t(kWave) + lane, il, tl);
         if (il >= g.intervals)
             continue;
-        const uint32_t *list = cs.lists + (il << g.lpi_shift) * kCoopListCap;
+        const uint32_t *list = cs.lists + il * g.lpi * g.list_cap;
         uint32_t state = list[0] & kCoopStateMask;
         if (tl != 0u) {
             const uint32_t w = list[4u * tl], Tj = list[4u * tl + 1u];
@@ -1130,7 +1134,7 @@ CG_DEV void coop_continue(ChaseState &c, const CoopShared &cs, const CoopGeom &g
     if (c.next_sub < g.count)
         c.next_sub = coop_next_sub(len_words, c.next_sub, g);
     chase_set_end(c, cs.h, g, start_rel, len_words);
-    c.lp_max = list + umin(kCoopMaxEntries, 1u + (g.dpi - settled));
+    c.lp_max = list + umin(g.max_entries, 1u + (g.dpi - settled));
     c.active = c.lp < c.lp_max && c.p < coop_hard_end(cs.h);
 }
 
@@ -1171,7 +1175,7 @@ CG_DEV int32_t coop_decode_du(const ImageDesc &d, const HuffShared &s, const Coo
                               int16_t *slot16, bool &underflow, bool &hostile)
 {
     underflow = hostile = false;
-    if (state & (kCoopSerial | kCoopUnset))
+    if (state & kCoopUnset)
         return 0;
     const uint32_t p = state & 0xffffu, rel = p >> 5, sh = p & 31u, tl = (state >> 16) & 31u;
     EntropyState e;
@@ -1208,29 +1212,6 @@ CG_DEV int32_t coop_decode_du(const ImageDesc &d, const HuffShared &s, const Coo
     diff = decode_dc_diff(e.r, d, s, dc_off);
     copy_zero_levels(d, comp, slot16);
     return diff;
-}
-
-// An interval that the chase gave up on (corrupt stream / hostile table): its first lane decodes it the way the
-// other kernels do, data unit after data unit; DC terms come out dequantised.
-CG_DEV void coop_decode_serial(const ImageDesc &d, const HuffShared &s, uint32_t interval, uint32_t dpi,
-                               uint8_t *first_slot, int32_t *dcs)
-{
-    EntropyState e;
-    entropy_init(e, d, s, interval);
-    for (uint32_t du = 0; du < dpi; du++)
-        dcs[du] = entropy_data_unit(e, d, s, comp_of_k(du & 3u), reinterpret_cast<int16_t *>(first_slot + du * kDuSlotBytes));
-}
-
-// DC prediction (src/huffman.wgsl:137,170): the sum of the differences of the component's data units up to this
-// one, inside the interval; i32 wrap like the reference.  diffs: the interval's differences, du: this lane's.
-CG_DEV int32_t coop_dc_term(const CoopTables &t, const int32_t *diffs, uint32_t du)
-{
-    const uint32_t k = du & 3u, m = du >> 2;
-    uint32_t sum = 0u;
-    for (uint32_t i = 0; i < m; i++)
-        sum += k < 2u ? uint32_t(diffs[4u * i]) + uint32_t(diffs[4u * i + 1u]) : uint32_t(diffs[4u * i + k]);
-    sum += k == 1u ? uint32_t(diffs[4u * m]) + uint32_t(diffs[4u * m + 1u]) : uint32_t(diffs[4u * m + k]);
-    return int32_t(sum * sel3(comp_of_k(k), t.dc_quant[0], t.dc_quant[1], t.dc_quant[2]));
 }
 
 // The slot's coefficients without clearing it (the slots are not used again).
@@ -1325,10 +1306,10 @@ struct CoopLane {
 CG_DEV void coop_lane(const ImageDesc &d, const HuffShared &s, const CoopGeom &g, uint32_t lane, CoopLane &L)
 {
     L.lane = lane;
-    L.il = lane >> g.lpi_shift;
-    L.tl = lane & (g.lpi - 1u);
-    L.lane0 = L.il << g.lpi_shift;
-    L.exists = L.il < g.intervals;
+    L.il = lane / g.lpi;
+    L.tl = lane - L.il * g.lpi;
+    L.lane0 = L.il * g.lpi;
+    L.exists = L.il < g.intervals; // (the lanes behind the last interval's, where 64 is no multiple of lpi: none)
     const uint32_t interval = g.first_interval + (L.exists ? L.il : 0u);
     const uint32_t ws = interval < d.nstarts ? CG_GLOBAL(const uint32_t, d.starts)[interval] : 0u;
     const uint32_t we = (interval + 1u < d.total_intervals && interval + 1u < d.nstarts)
@@ -1416,12 +1397,12 @@ CG_DEV void coop_walk_422(const ImageDesc &d, const CoopShared &cs, const CoopTa
         else
             coop_lane(d, s, g, LANES == 1 ? my_lane : uint32_t(li), L[li]);
         const uint32_t lane = L[li].lane;
-        for (uint32_t pass = 0; pass < g.passes; pass++)
+        for (uint32_t pass = 0; pass < g.rounds; pass++)
             cs.du_state[pass * uint32_t(kWave) + lane] = kCoopUnset;
         cs.verdict[lane] = 0u;
         cs.nseg[lane] = 0u;
         cs.dead_from[lane] = 0xffffu;
-        chase_assign(c[li], s, g, L[li].tl, L[li].start_rel, L[li].len_words, L[li].exists, cs.lists + lane * kCoopListCap);
+        chase_assign(c[li], s, g, L[li].tl, L[li].start_rel, L[li].len_words, L[li].exists, cs.lists + lane * g.list_cap);
         active[li] = c[li].active;
     }
     if (LANES != 1)
@@ -1433,7 +1414,7 @@ CG_DEV void coop_walk_422(const ImageDesc &d, const CoopShared &cs, const CoopTa
     if (lean) {
         CG_EACH_LANE
         {
-            uint32_t *list = cs.lists + L[li].lane * kCoopListCap;
+            uint32_t *list = cs.lists + L[li].lane * g.list_cap;
             if (c[li].active)
                 c[li].lp_max = list + g.dpi;
         }
@@ -1463,7 +1444,7 @@ CG_DEV void coop_walk_422(const ImageDesc &d, const CoopShared &cs, const CoopTa
             {
                 unsigned long steps = 0;
                 if (lean && round == 0u)
-                    chase_run_lean(c[li], d, s, t, cs.lists + L[li].lane * kCoopListCap, steps);
+                    chase_run_lean(c[li], d, s, t, cs.lists + L[li].lane * g.list_cap, steps);
                 else
                     chase_run(c[li], d, s, t, steps);
                 CG_COOP_COUNT(chase_steps, steps);
@@ -1495,7 +1476,7 @@ CG_DEV void coop_walk_422(const ImageDesc &d, const CoopShared &cs, const CoopTa
             {
                 if (L[li].tl == 0u && L[li].exists) {
                     // (a maximum: with quarters, a decoding lane may have said "serial" already -- hostile table)
-                    const uint32_t v = chase_lean_regular(c[li], s, cs.lists + L[li].lane * kCoopListCap) ? kVerdictDone : kVerdictSerial;
+                    const uint32_t v = chase_lean_regular(c[li], s, cs.lists + L[li].lane * g.list_cap) ? kVerdictDone : kVerdictSerial;
 #if defined(__HIP_DEVICE_COMPILE__)
                     atomicMax(&cs.verdict[L[li].il], v);
 #else
@@ -1518,7 +1499,7 @@ CG_DEV void coop_walk_422(const ImageDesc &d, const CoopShared &cs, const CoopTa
         clk.extra[3] += c[0].init_cycles;
         clk.extra[4] += c[0].tail_cycles;
 #endif
-        CG_EACH_LANE coop_publish(c[li], cs, L[li].lane);
+        CG_EACH_LANE coop_publish(c[li], cs, g, L[li].lane);
         CG_WAVE_SYNC();
         CG_EACH_LANE coop_find_link(c[li], cs, g, L[li].lane, L[li].lane0);
         CG_WAVE_SYNC();
@@ -1537,10 +1518,11 @@ CG_DEV void coop_walk_422(const ImageDesc &d, const CoopShared &cs, const CoopTa
         CG_WAVE_SYNC();
         CG_EACH_LANE
         {
-            for (uint32_t pass = 0; pass < g.passes; pass++) {
-                const uint32_t il_d = pass * g.ipp + (L[li].lane >> g.dpi_shift);
+            for (uint32_t pass = 0; pass < g.rounds; pass++) {
+                uint32_t il_d, tl_d;
+                coop_du_of(g, pass * uint32_t(kWave) + L[li].lane, il_d, tl_d);
                 if (il_d < g.intervals)
-                    coop_emit(cs, g, il_d, L[li].lane & (g.dpi - 1u), pass * uint32_t(kWave) + L[li].lane);
+                    coop_emit(cs, g, il_d, tl_d, pass * uint32_t(kWave) + L[li].lane);
             }
         }
         CG_WAVE_SYNC();
@@ -1548,7 +1530,7 @@ CG_DEV void coop_walk_422(const ImageDesc &d, const CoopShared &cs, const CoopTa
         {
             if (L[li].exists)
                 coop_continue(c[li], cs, g, L[li].il, L[li].lane, L[li].start_rel, L[li].len_words,
-                              cs.lists + L[li].lane * kCoopListCap);
+                              cs.lists + L[li].lane * g.list_cap);
             else
                 c[li].active = false;
             active[li] = c[li].active;
@@ -1558,41 +1540,53 @@ CG_DEV void coop_walk_422(const ImageDesc &d, const CoopShared &cs, const CoopTa
         CG_WAVE_SYNC();
         CG_COOP_STAMP(2);
     }
-
+    // (an interval still waiting for a walk after the last round goes the same way as one given up on)
+    CG_EACH_LANE
+    {
+        if (L[li].tl == 0u && L[li].exists && (cs.verdict[L[li].il] & 0xffu) != kVerdictDone)
+            cs.verdict[L[li].il] = kVerdictSerial;
+    }
+    CG_WAVE_SYNC();
 }
 
-// Phase 3 for 64 data units of a walk: round `pass` of them -- one lane per data unit, from its start state to pixels.
-// cs.h.du_slots / cs.diffs: this wave's; cs.du_state / verdict / dead_from: the walk's.
+// Phase 3 for 64 data units of a walk: round `r` of them -- one lane per data unit, from its start state to pixels.
+// Lane l takes data unit n = 64 r + l of the walk's intervals laid end to end; an interval may begin in an earlier
+// round and end in a later one (any restart interval: 10 MCUs are 40 data units).  What crosses the rounds goes
+// through LDS in the order of the rounds (cs.flags, team form: the rounds run in different waves at the same time; a
+// lone wave runs them one after the other): quirk Q1's "dead from" of an interval, and the sums of DC differences
+// that the interval's data units in later rounds continue (cs.carry).  An interval that needs the serial decoder is
+// left out here (coop_serial_intervals_422 decodes it when every round's pixels are out).
+// cs.h.du_slots / cs.diffs: this wave's; cs.du_state / verdict / dead_from / carry: the walk's.
 template <int LANES>
-CG_DEV void coop_decode_pass_422(const ImageDesc &d, const CoopShared &cs, const CoopTables &t, const CoopGeom &g,
-                                 uint32_t my_lane, uint32_t wave_index, uint32_t pass, CoopClock &clk, bool only_serial = false)
+CG_DEV void coop_decode_round_422(const ImageDesc &d, const CoopShared &cs, const CoopTables &t, const CoopGeom &g,
+                                  uint32_t my_lane, uint32_t wave_index, uint32_t r, CoopClock &clk)
 {
     const HuffShared &s = cs.h;
-    struct { uint32_t lane; } L[LANES];
-    CG_EACH_LANE L[li].lane = LANES == 1 ? my_lane : uint32_t(li);
+    struct { uint32_t lane, il, tl; bool exists; } L[LANES];
     (void)wave_index;
     (void)clk;
-    if (pass * g.ipp >= g.intervals)
+    if (r * uint32_t(kWave) >= g.dus)
         return;
-    // this round's lane -> data unit: interval D_il of the walk, data unit D_tl of it
-#define D_il(li) (pass * g.ipp + (L[li].lane >> g.dpi_shift))
-#define D_tl(li) (L[li].lane & (g.dpi - 1u))
-#define D_lane0(li) ((L[li].lane >> g.dpi_shift) << g.dpi_shift)
-#define D_exists(li) (D_il(li) < g.intervals)
     uint32_t state[LANES];
     int32_t dc[LANES];
     CG_EACH_LANE
     {
+        L[li].lane = LANES == 1 ? my_lane : uint32_t(li);
+        coop_du_of(g, r * uint32_t(kWave) + L[li].lane, L[li].il, L[li].tl);
+        L[li].exists = L[li].il < g.intervals;
         uint32_t st = kCoopUnset;
-        if (D_exists(li)) {
-            if (only_serial) {
-                // (behind the quarters: the intervals that have to go through the serial decoder, nothing else)
-                st = (cs.verdict[D_il(li)] & 0xffu) == kVerdictSerial ? kCoopSerial : kCoopUnset;
-            } else {
-                st = cs.du_state[pass * uint32_t(kWave) + L[li].lane];
-                // (an interval still waiting for a walk after the last round goes the same way as one given up on)
-                if ((cs.verdict[D_il(li)] & 0xffu) != kVerdictDone || (st & kCoopUnset))
-                    st = kCoopSerial;
+        if (L[li].exists) {
+            st = cs.du_state[r * uint32_t(kWave) + L[li].lane];
+            // (an interval still waiting for a walk after the last round goes the same way as one given up on)
+            if ((cs.verdict[L[li].il] & 0xffu) != kVerdictDone)
+                st = kCoopUnset;
+            else if (st & kCoopUnset) {
+                st = kCoopUnset;
+#if defined(__HIP_DEVICE_COMPILE__)
+                atomicMax(&cs.verdict[L[li].il], kVerdictSerial);
+#else
+                cs.verdict[L[li].il] = kVerdictSerial;
+#endif
             }
         }
         state[li] = st;
@@ -1605,64 +1599,98 @@ CG_DEV void coop_decode_pass_422(const ImageDesc &d, const CoopShared &cs, const
     {
         const uint32_t lane = L[li].lane;
         bool hostile = false;
-        const int32_t diff = coop_decode_du(d, s, t, state[li], comp_of_k(D_tl(li) & 3u),
+        const int32_t diff = coop_decode_du(d, s, t, state[li], comp_of_k(lane & 3u),
                                             reinterpret_cast<int16_t *>(s.du_slots + lane * kDuSlotBytes), under[li], hostile);
         cs.diffs[lane] = diff;
-        if (hostile)
-            cs.verdict[D_il(li)] = kVerdictSerial; // (every lane that says so says the same)
+        if (hostile) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            atomicMax(&cs.verdict[L[li].il], kVerdictSerial);
+#else
+            cs.verdict[L[li].il] = kVerdictSerial; // (every lane that says so says the same)
+#endif
+        }
         if (under[li]) {
 #if defined(__HIP_DEVICE_COMPILE__)
-            atomicMin(&cs.dead_from[D_il(li)], D_tl(li));
+            atomicMin(&cs.dead_from[L[li].il], L[li].tl);
 #else
-            cs.dead_from[D_il(li)] = umin(cs.dead_from[D_il(li)], D_tl(li));
+            cs.dead_from[L[li].il] = umin(cs.dead_from[L[li].il], L[li].tl);
 #endif
         }
     }
     CG_WAVE_SYNC();
     CG_COOP_STAMP(3);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the earlier rounds' sums and "dead from" are final
+    if (cs.flags) {
+        while (__hip_atomic_load(cs.flags + kTeamDecoded, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < r)
+            __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+#endif
     CG_EACH_LANE
     {
+        if (state[li] & kCoopUnset)
+            continue;
         // an interval that turned out to need the serial decoder after all: what its lanes decoded is dropped
-        if (D_exists(li) && !(state[li] & (kCoopSerial | kCoopUnset)) && (cs.verdict[D_il(li)] & 0xffu) == kVerdictSerial) {
-            state[li] = kCoopSerial;
-            under[li] = false;
-            zero_slot(s.du_slots + L[li].lane * kDuSlotBytes);
+        if ((cs.verdict[L[li].il] & 0xffu) == kVerdictSerial) {
+            state[li] = kCoopUnset;
+            continue;
         }
+        // quirk Q1: behind the first data unit whose DC code underflows the reference reader, the interval decodes
+        // from zeros -- whatever those lanes have decoded from the walk's states is replaced (this round's lanes
+        // or an earlier round's may have found it)
+        const uint32_t first_dead = cs.dead_from[L[li].il];
+        if (LANES != 1 && L[li].tl == first_dead)
+            CG_COOP_COUNT(dead, 1);
+        if (L[li].tl <= first_dead)
+            continue;
+        const uint32_t comp = comp_of_k(L[li].lane & 3u);
+        uint8_t *slot = s.du_slots + L[li].lane * kDuSlotBytes;
+        zero_slot(slot);
+        copy_zero_levels(d, comp, reinterpret_cast<int16_t *>(slot));
+        cs.diffs[L[li].lane] = zero_diff(d, comp);
+        state[li] |= kCoopZero;
+        if (LANES != 1)
+            CG_COOP_COUNT(zero, 1);
     }
     CG_WAVE_SYNC();
-    if (coop_any<LANES>(under)) {
-        // quirk Q1: behind the first data unit whose DC code underflows the reference reader, the interval decodes
-        // from zeros -- whatever those lanes have decoded from the walk's states is replaced
-        CG_EACH_LANE
-        {
-            if (!D_exists(li) || (state[li] & (kCoopSerial | kCoopUnset)))
-                continue;
-            const uint32_t first_dead = cs.dead_from[D_il(li)];
-            if (LANES != 1 && D_tl(li) == first_dead)
-                CG_COOP_COUNT(dead, 1);
-            if (D_tl(li) <= first_dead)
-                continue;
-            const uint32_t comp = comp_of_k(D_tl(li) & 3u);
-            uint8_t *slot = s.du_slots + L[li].lane * kDuSlotBytes;
-            zero_slot(slot);
-            copy_zero_levels(d, comp, reinterpret_cast<int16_t *>(slot));
-            cs.diffs[L[li].lane] = zero_diff(d, comp);
-            state[li] |= kCoopZero;
-            if (LANES != 1)
-                CG_COOP_COUNT(zero, 1);
+    // DC prediction (src/huffman.wgsl:137,170): the sum of the differences of the component's data units up to this
+    // one, inside the interval; i32 wrap like the reference.  The part of the interval in earlier rounds: cs.carry.
+    uint32_t sum[LANES];
+    CG_EACH_LANE
+    {
+        sum[li] = 0u;
+        if (state[li] & kCoopUnset)
+            continue;
+        const uint32_t lane = L[li].lane, k = lane & 3u, base = lane & ~3u;
+        const uint32_t before = L[li].tl - (lane & 3u); // the interval's data units in front of this lane's MCU
+        uint32_t acc = 0u, from = base - before;       // (lane of the interval's first data unit, if in this round)
+        if (before > base) {
+            // the interval began in an earlier round
+            acc = cs.carry[4u * (r - 1u) + comp_of_k(k)];
+            from = 0u;
         }
-        CG_WAVE_SYNC();
+        const int32_t *df = cs.diffs;
+        for (uint32_t l = from; l < base; l += 4u)
+            acc += k < 2u ? uint32_t(df[l]) + uint32_t(df[l + 1u]) : uint32_t(df[l + k]);
+        acc += k == 1u ? uint32_t(df[base]) + uint32_t(df[base + 1u]) : uint32_t(df[base + k]);
+        sum[li] = acc;
+        dc[li] = int32_t(acc * sel3(comp_of_k(k), t.dc_quant[0], t.dc_quant[1], t.dc_quant[2]));
     }
     CG_EACH_LANE
     {
-        if ((state[li] & kCoopSerial) && D_tl(li) == 0u) {
-            coop_decode_serial(d, s, g.first_interval + D_il(li), g.dpi, s.du_slots + L[li].lane * kDuSlotBytes,
-                               cs.diffs + L[li].lane);
-            if (LANES != 1)
-                CG_COOP_COUNT(serial, 1);
-        }
+        // (the round's last MCU: lanes 61 .. 63 hold the sums of Y, Cb, Cr up to the round's end)
+        if (!(state[li] & kCoopUnset) && L[li].lane >= uint32_t(kWave) - 3u)
+            cs.carry[4u * r + (L[li].lane - (uint32_t(kWave) - 3u))] = sum[li];
     }
     CG_WAVE_SYNC();
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (cs.flags) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if ((LANES == 1 ? my_lane : 0u) == 0u)
+            __hip_atomic_store(cs.flags + kTeamDecoded, r + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+#endif
     CG_COOP_STAMP(4);
     uint32_t px[LANES][16];
     CG_EACH_LANE
@@ -1670,10 +1698,9 @@ CG_DEV void coop_decode_pass_422(const ImageDesc &d, const CoopShared &cs, const
         const uint32_t lane = L[li].lane;
         if (state[li] & kCoopUnset)
             continue;
-        dc[li] = (state[li] & kCoopSerial) ? cs.diffs[lane] : coop_dc_term(t, cs.diffs + D_lane0(li), D_tl(li));
         uint32_t rec[kRetained / 2];
         read_slot(s.du_slots + lane * kDuSlotBytes, rec);
-        idct_data_unit(rec, dc[li], cs.quant + comp_of_k(D_tl(li) & 3u) * kCoopQuantStride, px[li]);
+        idct_data_unit(rec, dc[li], cs.quant + comp_of_k(lane & 3u) * kCoopQuantStride, px[li]);
     }
     CG_WAVE_SYNC(); // every slot has been read: the area now holds the samples, kPxSlotWords apart
     CG_COOP_STAMP(5);
@@ -1690,15 +1717,87 @@ CG_DEV void coop_decode_pass_422(const ImageDesc &d, const CoopShared &cs, const
     CG_EACH_LANE
     {
         if (!(state[li] & kCoopUnset)) // (the four lanes of an MCU belong to one interval: all of them or none)
-            coop_composite(d, samples, (g.first_interval + pass * g.ipp) * g.R, umin(g.intervals - pass * g.ipp, g.ipp) * g.R,
-                           L[li].lane);
+            coop_composite(d, samples, g.first_interval * g.R + r * 16u, umin(g.intervals * g.R - r * 16u, 16u), L[li].lane);
     }
     CG_WAVE_SYNC(); // (the samples have been read: the area serves the next round's data units)
     CG_COOP_STAMP(6);
-#undef D_il
-#undef D_tl
-#undef D_lane0
-#undef D_exists
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (cs.flags) {
+        // (the pixels are out: an interval that has to be decoded again may be written over them)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if ((LANES == 1 ? my_lane : 0u) == 0u)
+            __hip_atomic_fetch_add(cs.flags + kTeamStored, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+#endif
+}
+
+// The intervals of the walk that the chase gave up on (corrupt stream, hostile table, a window planned too small),
+// when every round's pixels are out: lane 0 decodes such an interval the way the other kernels do, data unit after
+// data unit -- the reference's reader followed literally, DC terms dequantised --, 64 data units at a time into the
+// wave's slots; the wave transforms and composites them.
+template <int LANES>
+CG_DEV void coop_serial_intervals_422(const ImageDesc &d, const CoopShared &cs, const CoopTables &t, const CoopGeom &g,
+                                      uint32_t my_lane)
+{
+    const HuffShared &s = cs.h;
+    (void)t;
+    for (uint32_t il = 0; il < g.intervals; il++) {
+        bool serial[LANES];
+        CG_EACH_LANE serial[li] = (cs.verdict[il] & 0xffu) == kVerdictSerial;
+        if (!coop_any<LANES>(serial))
+            continue;
+        if (LANES != 1)
+            CG_COOP_COUNT(serial, 1);
+        EntropyState e[LANES];
+        CG_EACH_LANE
+        {
+            if ((LANES == 1 ? my_lane : uint32_t(li)) == 0u)
+                entropy_init(e[li], d, s, g.first_interval + il);
+        }
+        for (uint32_t first = 0; first < g.dpi; first += uint32_t(kWave)) {
+            const uint32_t n = umin(g.dpi - first, uint32_t(kWave));
+            CG_EACH_LANE zero_slot(s.du_slots + (LANES == 1 ? my_lane : uint32_t(li)) * kDuSlotBytes);
+            CG_WAVE_SYNC();
+            CG_EACH_LANE
+            {
+                if ((LANES == 1 ? my_lane : uint32_t(li)) != 0u)
+                    continue;
+                for (uint32_t du = 0; du < n; du++)
+                    cs.diffs[du] = entropy_data_unit(e[li], d, s, comp_of_k(du & 3u),
+                                                     reinterpret_cast<int16_t *>(s.du_slots + du * kDuSlotBytes));
+            }
+            CG_WAVE_SYNC();
+            uint32_t px[LANES][16];
+            CG_EACH_LANE
+            {
+                const uint32_t lane = LANES == 1 ? my_lane : uint32_t(li);
+                if (lane >= n)
+                    continue;
+                uint32_t rec[kRetained / 2];
+                read_slot(s.du_slots + lane * kDuSlotBytes, rec);
+                idct_data_unit(rec, cs.diffs[lane], cs.quant + comp_of_k(lane & 3u) * kCoopQuantStride, px[li]);
+            }
+            CG_WAVE_SYNC();
+            uint32_t *samples = reinterpret_cast<uint32_t *>(s.du_slots);
+            CG_EACH_LANE
+            {
+                const uint32_t lane = LANES == 1 ? my_lane : uint32_t(li);
+                if (lane >= n)
+                    continue;
+#pragma unroll
+                for (int w = 0; w < 16; w++)
+                    reinterpret_cast<slot_word_t *>(samples)[lane * kPxSlotWords + w] = px[li][w];
+            }
+            CG_WAVE_SYNC();
+            CG_EACH_LANE
+            {
+                const uint32_t lane = LANES == 1 ? my_lane : uint32_t(li);
+                if (lane < n)
+                    coop_composite(d, samples, (g.first_interval + il) * g.R + first / 4u, n / 4u, lane);
+            }
+            CG_WAVE_SYNC();
+        }
+    }
 }
 
 // Team form, intervals of 16 data units (DRI = 4): the decoding waves do not wait for the walk to end.  Wave q of
@@ -1706,7 +1805,7 @@ CG_DEV void coop_decode_pass_422(const ImageDesc &d, const CoopShared &cs, const
 // 4 il + k decodes data unit 4 q + k of interval il -- as soon as the walker has passed those data units: an entry
 // of the walker's list is final once the entry behind it has been written to.  The walker itself takes quarter 3.
 // What crosses the quarters goes through LDS, in the order of the quarters: the DC differences (a data unit's DC
-// term sums those of its component's earlier data units) and quirk Q1's "dead from" (coop_decode_pass_422); an
+// term sums those of its component's earlier data units) and quirk Q1's "dead from" (coop_decode_round_422); an
 // interval that turns out to need the serial decoder -- known when the walk is over, or when a lane meets a
 // hostile DC category -- is decoded again, all of it, by the walker's wave once every quarter's pixels are out.
 // The decode phases that waited for the walk's end ran four waves to a SIMD; now three quarters of that work run
@@ -1725,7 +1824,7 @@ CG_DEV void coop_decode_quarter_422(const ImageDesc &d, const CoopShared &cs, co
 #define Q_il(li) (L[li].lane >> 2)
 #define Q_tl(li) (4u * q + (L[li].lane & 3u))
 #define Q_exists(li) (Q_il(li) < g.intervals)
-#define Q_list(li) (cs.lists + (Q_il(li) << g.lpi_shift) * kCoopListCap)
+#define Q_list(li) (cs.lists + Q_il(li) * g.lpi * g.list_cap)
 #if defined(__HIP_DEVICE_COMPILE__)
     if (q < 3u) {
         // until the walker has passed this quarter's data units in every interval -- or is done (an interval whose
@@ -1886,26 +1985,20 @@ CG_DEV void coop_decode_quarter_422(const ImageDesc &d, const CoopShared &cs, co
 #undef Q_list
 }
 
-// Behind the quarters, by the walker's wave: the intervals whose verdict is "serial" once more, all of their data
-// units, through the rounds' code (old layout: a wave's 64 lanes are 4 whole intervals).
+// Behind the quarters / the rounds, by the walker's wave: once the pixels of all `parts` of them are out, the intervals
+// whose verdict is "serial" once more, all of their data units.
 template <int LANES>
-CG_DEV void coop_quarters_serial_422(const ImageDesc &d, const CoopShared &cs, const CoopTables &t, const CoopGeom &g,
-                                     uint32_t my_lane, uint32_t wave_index, CoopClock &clk)
+CG_DEV void coop_team_serial_422(const ImageDesc &d, const CoopShared &cs, const CoopTables &t, const CoopGeom &g,
+                                 uint32_t my_lane, uint32_t parts)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    while (__hip_atomic_load(cs.flags + kTeamStored, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 4u)
+    while (__hip_atomic_load(cs.flags + kTeamStored, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < parts)
         __builtin_amdgcn_s_sleep(2);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#else
+    (void)parts;
 #endif
-    for (uint32_t pass = 0; pass < g.passes; pass++) {
-        bool serial[LANES];
-        for (int li = 0; li < LANES; li++) {
-            const uint32_t lane = LANES == 1 ? my_lane : uint32_t(li), il = pass * g.ipp + (lane >> g.dpi_shift);
-            serial[li] = il < g.intervals && (cs.verdict[il] & 0xffu) == kVerdictSerial;
-        }
-        if (coop_any<LANES>(serial))
-            coop_decode_pass_422<LANES>(d, cs, t, g, my_lane, wave_index, pass, clk, true);
-    }
+    coop_serial_intervals_422<LANES>(d, cs, t, g, my_lane);
 }
 
 // One wave does it all: the walk, then its rounds of 64 data units one after the other.
@@ -1916,8 +2009,9 @@ CG_DEV void coop_wave_422(const ImageDesc &d, const CoopShared &cs, const CoopTa
     CoopClock clk;
     coop_clock_start(clk);
     coop_walk_422<LANES>(d, cs, t, g, my_lane, wave_index, clk);
-    for (uint32_t pass = 0; pass < g.passes; pass++)
-        coop_decode_pass_422<LANES>(d, cs, t, g, my_lane, wave_index, pass, clk);
+    for (uint32_t r = 0; r < g.rounds; r++)
+        coop_decode_round_422<LANES>(d, cs, t, g, my_lane, wave_index, r, clk);
+    coop_serial_intervals_422<LANES>(d, cs, t, g, my_lane);
     coop_clock_store(clk, d, wave_index, my_lane);
 }
 

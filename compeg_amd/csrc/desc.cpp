@@ -8,6 +8,7 @@
 #include "device_types.h"
 #include "front.h"
 #include "kernels_body.h" // (host compile of the lane bodies: the exact-path reader, for the zero-stream data units)
+#include "coop_body.h"    // (kCoopMaxRestart)
 
 namespace compeg {
 
@@ -64,8 +65,8 @@ void fill_coop(const ImageData &img, ImageDesc &d)
     const bool is422 = md.dus_per_mcu == 4 && md.components[0].hsample == 2 && md.components[0].vsample == 1 &&
                        md.components[1].hsample == 1 && md.components[1].vsample == 1 &&
                        md.components[2].hsample == 1 && md.components[2].vsample == 1;
-    // (1, 2, 4, 8 or 16 MCUs per interval: the wave's lane arithmetic is shifts)
-    if (!is422 || md.restart_interval == 0 || md.restart_interval > 16 || (md.restart_interval & (md.restart_interval - 1)))
+    // (any restart interval of up to kCoopMaxRestart MCUs: coop_shape, device_types.h)
+    if (!is422 || md.restart_interval == 0 || md.restart_interval > kCoopMaxRestart)
         return;
     for (uint32_t c = 0; c < 3; c++)
         if (d.fast_table[c] >= 2 || d.dc_fast_table[c] >= 2)

@@ -38,6 +38,38 @@ constexpr uint32_t fast_entry(uint32_t ref, uint32_t zrl_advance)
 constexpr uint32_t kDcFastBits = 9;
 constexpr uint32_t kDcFastEntries = 1u << kDcFastBits;
 
+// The cooperative kernel's geometry (coop_body.h), a function of the restart interval alone -- host planning and
+// the kernels compute it the same way.  A walk (a team of `waves` waves; or a lone wave) takes as many whole
+// restart intervals as have 64 x waves data units together -- one interval if it alone is longer -- and decodes
+// them in rounds of 64 data units; an interval may straddle rounds.
+//   dpi       data units per interval (4:2:2: four per MCU)
+//   ipw       intervals per walk
+//   rounds    rounds of 64 data units that hold them
+//   lpi       lanes of the walking wave that belong to one interval (lane 0 of them walks from its start, the
+//             others speculate in fours: coop_body.h)
+//   count     subsequences an interval is cut into: 1 + the speculative ones
+//   list_cap  words of a walking lane's list of data-unit starts: 20 (64 lists = the bytes of a wave's 64 slots)
+//             while a subsequence has at most 16 data units -- every interval of up to 64 MCUs --, more beyond
+struct CoopShape {
+    uint32_t dpi, ipw, rounds, lpi, count, list_cap;
+};
+constexpr uint32_t kCoopSlotListCap = 20;
+constexpr CoopShape coop_shape(uint32_t restart_interval, uint32_t waves)
+{
+    CoopShape sh{};
+    sh.dpi = 4u * restart_interval;
+    const uint32_t room = uint32_t(kWave) * (waves ? waves : 1u);
+    sh.ipw = (sh.dpi != 0u && sh.dpi <= room) ? room / sh.dpi : 1u;
+    sh.rounds = (sh.ipw * sh.dpi + uint32_t(kWave) - 1u) / uint32_t(kWave);
+    const uint32_t share = (sh.dpi + (waves ? waves : 1u) - 1u) / (waves ? waves : 1u); // (a lane per 64 / lanes-th of the walk's data units)
+    const uint32_t fit = uint32_t(kWave) / sh.ipw;
+    sh.lpi = share < fit ? (share ? share : 1u) : fit;
+    sh.count = 1u + (sh.lpi - 1u) / 4u;
+    const uint32_t per_sub = (sh.dpi + sh.count - 1u) / sh.count;
+    sh.list_cap = per_sub > 16u ? ((per_sub + 12u) & ~3u) : kCoopSlotListCap;
+    return sh;
+}
+
 // LDS slot of one lane's data unit while it is being decoded: 32 int16 in
 // zig-zag order + one dummy position (coefficients >= 32 are dropped there).
 // 80 bytes per lane: 16-byte aligned, so that the slot is read back, cleared

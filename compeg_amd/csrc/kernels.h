@@ -33,13 +33,11 @@ hipError_t launch_pair_422(const ImageDesc *descs, uint32_t images, uint32_t max
 // Cooperative kernel (coop_body.h) for launches too small to fill the chip with a lane per restart interval.
 struct CoopPlan {
     bool usable;
-    bool team; // team form: one wave of four walks, four decode (intervals_per_wave is then per team)
-    uint32_t intervals_per_wave, waves_per_block, window_words, l2_entries_in_lds, total_bytes, total_waves;
+    uint32_t intervals_per_wave, waves_per_block, window_words, l2_entries_in_lds, total_bytes, total_waves; // (intervals_per_wave: per team)
 };
-// max_group_words: largest word span of any group of intervals_per_wave consecutive intervals
-// (max_wave_span with that group size), or an upper estimate of it
-bool coop_team();
-uint32_t coop_passes(); // rounds of 64 data units per wave (1 or 2): the wave's group of intervals is 64 * passes data units
+// The kernel's teams of four waves each take coop_shape(restart_interval, 4).ipw whole restart intervals.
+// max_group_words: largest word span of any such group of consecutive intervals (max_wave_span with that group
+// size), or an upper estimate of it
 CoopPlan plan_coop(uint32_t max_intervals, uint32_t images, uint32_t restart_interval, uint32_t max_l2,
                    uint32_t max_group_words);
 hipError_t launch_coop_422(const ImageDesc *descs, uint32_t images, uint32_t max_intervals, const CoopPlan &plan,

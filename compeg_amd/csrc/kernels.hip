@@ -351,63 +351,6 @@ decode_pair_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, 
     }
 }
 
-// Cooperative kernel (coop_body.h): launches that cannot fill the chip with one lane per restart interval.
-// A wave takes as many consecutive intervals as have 64 data units together and splits their bitstreams
-// among its lanes; a workgroup is a handful of such waves sharing one copy of the tables.
-// LDS: [L1][L2 + direct AC + direct DC tables][quantisers 3 x 36 f32][per wave: window | 64 slots | bookkeeping]
-__host__ __device__ __forceinline__ uint32_t coop_wave_area(uint32_t window_words, uint32_t passes)
-{
-    return ((window_words * 4u + 15u) & ~15u) + kWave * kDuSlotBytes + coop_misc_words(passes) * 4u;
-}
-
-__global__ void __launch_bounds__(512)
-decode_coop_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words, uint32_t spec_shift,
-                       uint32_t passes)
-{
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const ImageDesc &d = descs[blockIdx.y];
-    const uint32_t waves = blockDim.x / kWave;
-    const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x / kWave))), lane = threadIdx.x % kWave;
-    CoopGeom g;
-    coop_geom(d, blockIdx.x * waves + wave, g, spec_shift, passes);
-    if (blockIdx.x * waves * g.ipw >= d.total_intervals)
-        return; // the whole workgroup
-
-    uint16_t *l1 = reinterpret_cast<uint16_t *>(smem);
-    uint16_t *l2 = l1 + kL1Entries;
-    float *quant = reinterpret_cast<float *>(smem + align16((kL1Entries + l2_in_lds) * 2u));
-    uint8_t *wave_base = reinterpret_cast<uint8_t *>(quant + 3u * kCoopQuantStride) + wave * coop_wave_area(window_words, passes);
-    uint32_t *win = reinterpret_cast<uint32_t *>(wave_base);
-    uint8_t *slots = wave_base + align16(window_words * 4u);
-    uint32_t *misc = reinterpret_cast<uint32_t *>(slots + kWave * kDuSlotBytes);
-
-    uint32_t win_base = 0, win_len = 0;
-    if (g.intervals)
-        coop_window(d, g, window_words, win_base, win_len);
-    stage_luts_and_window(d, l1, l2, l2_in_lds, threadIdx.x, blockDim.x, win, win_base, win_len, lane, 2u * kDcFastEntries);
-    if (threadIdx.x < 3u * kRetained)
-        quant[(threadIdx.x / kRetained) * kCoopQuantStride + threadIdx.x % kRetained] =
-            d.quant[threadIdx.x / kRetained][threadIdx.x % kRetained];
-    __syncthreads();
-    if (!g.intervals)
-        return; // the whole wave
-
-    CoopShared cs;
-    cs.h.l1 = l1;
-    cs.h.l2 = l2;
-    cs.h.l2_staged = umin(l2_in_lds, d.fast_off + 2u * kFastEntries + 2u * kDcFastEntries);
-    cs.h.win = win;
-    cs.h.win_base = win_base;
-    cs.h.win_len = win_len;
-    cs.h.du_slots = slots;
-    cs.lists = reinterpret_cast<uint32_t *>(slots);
-    coop_bind_misc(cs, misc);
-    cs.quant = quant;
-    CoopTables t;
-    coop_tables(d, cs.h, t);
-    coop_wave_422<1>(d, cs, t, g, lane, blockIdx.x * waves + wave);
-}
-
 // One lane per data unit for the IDCT, then the same lanes regroup (through
 // LDS) so that every wave-wide store writes 16 MCUs x 64 contiguous bytes.
 __global__ void __launch_bounds__(256)
@@ -685,10 +628,13 @@ hipError_t launch_walk_tables(const ImageDesc *descs, uint32_t images, hipStream
 }
 
 constexpr uint32_t kCoopTeamFlagWords = 4; // (coop_body.h: kTeamWalk ...)
-__host__ __device__ __forceinline__ uint32_t coop_team_area(uint32_t window_words)
+// A team's share of LDS: [window][walk bookkeeping: coop_misc_words(rounds)][flags][4 x (64 slots | 64 DC differences)]
+// [the walker's lists, where they are longer than the bytes of its slots: intervals of more than 64 MCUs]
+__host__ __device__ __forceinline__ uint32_t coop_team_area(uint32_t window_words, const CoopShape &sh)
 {
-    return ((window_words * 4u + 15u) & ~15u) + (kCoopMiscWords + kCoopTeamFlagWords) * 4u +
-           kCoopTeamWaves * (kWave * kDuSlotBytes + kWave * 4u);
+    return ((window_words * 4u + 15u) & ~15u) + (coop_misc_words(sh.rounds) + kCoopTeamFlagWords) * 4u +
+           kCoopTeamWaves * (kWave * kDuSlotBytes + kWave * 4u) +
+           (sh.list_cap > kCoopSlotListCap ? uint32_t(kWave) * sh.list_cap * 4u : 0u);
 }
 
 // One wave tells the others of its team (through LDS; a workgroup barrier would tie the teams together).
@@ -722,6 +668,7 @@ decode_coop_team_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_
     coop_geom(d, blockIdx.x * teams + team, g, d.walk && d.restart_interval <= 4u ? 31u : spec_shift, kCoopTeamWaves);
     if (blockIdx.x * teams * g.ipw >= d.total_intervals)
         return; // the whole workgroup
+    const CoopShape shape = coop_shape(d.restart_interval, kCoopTeamWaves);
 
     uint16_t *l1 = reinterpret_cast<uint16_t *>(smem);
     uint16_t *l2 = l1 + kL1Entries;
@@ -731,10 +678,10 @@ decode_coop_team_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_
     // laid out behind it -- is LDS, and every access becomes a flat one)
     const uint32_t quant_off = align16((kL1Entries + l2_in_lds) * 2u);
     uint32_t *walk = reinterpret_cast<uint32_t *>(smem + ((quant_off + 3u * kCoopQuantStride * 4u + 31u) & ~31u));
-    uint8_t *team_base = reinterpret_cast<uint8_t *>(walk + kWalkWords) + team * coop_team_area(window_words);
+    uint8_t *team_base = reinterpret_cast<uint8_t *>(walk + kWalkWords) + team * coop_team_area(window_words, shape);
     uint32_t *win = reinterpret_cast<uint32_t *>(team_base);
     uint32_t *misc = reinterpret_cast<uint32_t *>(team_base + align16(window_words * 4u));
-    uint32_t *flags = misc + kCoopMiscWords;
+    uint32_t *flags = misc + coop_misc_words(shape.rounds);
     uint8_t *mine = reinterpret_cast<uint8_t *>(flags + kCoopTeamFlagWords) + member * (kWave * kDuSlotBytes + kWave * 4u);
     const bool helper = team >= teams;
     if (!helper && member == 0u && lane < kCoopTeamFlagWords)
@@ -830,11 +777,13 @@ decode_coop_team_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_
     constexpr uint32_t kMineBytes = kWave * kDuSlotBytes + kWave * 4u;
     // (the walker's lists: its own slot area, as in the one-wave form; the other waves read them there)
     cs.lists = reinterpret_cast<uint32_t *>(first_mine + ((team + 3u) & (kCoopTeamWaves - 1u)) * kMineBytes);
-    cs.flags = flags;
+    if (shape.list_cap > kCoopSlotListCap)
+        cs.lists = reinterpret_cast<uint32_t *>(first_mine + kCoopTeamWaves * kMineBytes); // (longer than that: their own area)
     cs.team_diffs = reinterpret_cast<int32_t *>(first_mine + kWave * kDuSlotBytes);
     cs.team_diffs_stride = kMineBytes / 4u;
     cs.team_in_wg = team;
     coop_bind_misc(cs, misc);
+    cs.flags = flags;
     cs.diffs = reinterpret_cast<int32_t *>(mine + kWave * kDuSlotBytes);
     cs.quant = quant;
     CoopTables t;
@@ -878,101 +827,68 @@ decode_coop_team_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_
             __builtin_amdgcn_s_setprio(2);
         coop_decode_quarter_422<1>(d, cs, t, g, lane, team_index, quarter, clk);
         if (walker && g.intervals)
-            coop_quarters_serial_422<1>(d, cs, t, g, lane, team_index, clk);
+            coop_team_serial_422<1>(d, cs, t, g, lane, kCoopTeamWaves);
     } else if (g.intervals) {
-        coop_decode_pass_422<1>(d, cs, t, g, lane, team_index, member, clk);
+        // the walk's rounds of 64 data units, dealt out to the team's waves (more than one each where a single
+        // interval is longer than 256 data units)
+        for (uint32_t r = member; r < g.rounds; r += kCoopTeamWaves)
+            coop_decode_round_422<1>(d, cs, t, g, lane, team_index, r, clk);
+        if (walker)
+            coop_team_serial_422<1>(d, cs, t, g, lane, (g.dus + uint32_t(kWave) - 1u) / uint32_t(kWave));
     }
     coop_clock_store(clk, d, team_index * kCoopTeamWaves + member, lane);
 }
 
-// window_words: plan_coop's.  Every image of the launch must have ImageDesc::coop_ok and the same restart interval.
-bool coop_team()
-{
-    static const bool team = [] {
-        const char *e = getenv("COMPEG_COOP_TEAM"); // experiment knob: 0 = every wave walks its own intervals
-        return e ? atoi(e) != 0 : true;
-    }();
-    return team;
-}
-
-uint32_t coop_passes()
-{
-    static const uint32_t passes = [] {
-        const char *e = getenv("COMPEG_COOP_PASSES"); // experiment knob: 1 or 2 rounds of 64 data units per wave
-        return e ? uint32_t(atoi(e) >= 4 ? 4 : (atoi(e) >= 2 ? 2 : 1)) : 1u;
-    }();
-    return passes;
-}
-
+// Every image of the launch must have ImageDesc::coop_ok and the same restart interval.
 CoopPlan plan_coop(uint32_t max_intervals, uint32_t images, uint32_t restart_interval, uint32_t max_l2,
                    uint32_t max_group_words)
 {
     CoopPlan p{};
-    const uint32_t dpi = 4u * restart_interval;
     if (restart_interval == 0 || restart_interval > kCoopMaxRestart)
         return p;
-    p.team = coop_team();
-    p.intervals_per_wave = uint32_t(kWave) / dpi * (p.team ? kCoopTeamWaves : coop_passes());
+    const CoopShape sh = coop_shape(restart_interval, kCoopTeamWaves);
+    // a group of intervals longer than the largest window (bit positions inside it are 16-bit) would go through the
+    // serial decoder, one lane for the whole team: the other kernels do better
+    if (max_group_words + kDuWordSlack + 4u > kCoopMaxWindow)
+        return p;
+    p.intervals_per_wave = sh.ipw;
     p.l2_entries_in_lds = (max_l2 + 2u * kDcFastEntries + 1u) & ~1u;
     uint32_t w = max_group_words + kDuWordSlack + 4u;
     w = std::max(w, 128u);
     w = std::min(w, kCoopMaxWindow);
     p.window_words = (w + 3u) & ~3u;
     uint32_t tables = ((((kL1Entries + p.l2_entries_in_lds) * 2u) + 15u) & ~15u) + 3u * kCoopQuantStride * 4u;
-    if (p.team) {
-        // four teams of four waves: one workgroup per CU, one copy of the tables
-        tables = ((tables + 31u) & ~31u) + kWalkWords * 4u;
-        const uint64_t all_teams = uint64_t((max_intervals + p.intervals_per_wave - 1) / p.intervals_per_wave) * images;
-        // A launch that needs four teams per CU to be resident at once gets them even if the window asked for is
-        // a little too large (it is an estimate where the scan was preprocessed on the device): down to three
-        // quarters of it.  A team whose intervals do not fit its window still decodes -- the walks that leave it
-        // hand their interval to the serial decoder.
-        if (all_teams > 3ull * kCuCount && tables + 4u * coop_team_area(p.window_words) > kLdsBytesPerCu) {
-            const uint32_t room = (kLdsBytesPerCu - tables) / 4u, fixed = coop_team_area(0);
-            const uint32_t fit = room > fixed ? ((room - fixed) / 4u) & ~3u : 0u;
-            if (fit >= p.window_words - p.window_words / 4u)
-                p.window_words = fit;
-        }
-        const uint32_t team_area = coop_team_area(p.window_words);
-        uint32_t teams = 4;
-        while (teams > 1 && tables + teams * team_area > kLdsBytesPerCu)
-            teams--;
-        if (tables + teams * team_area > kLdsBytesPerCu)
-            return p;
-        // one workgroup per CU while that covers the launch (a small launch spreads over the CUs; the teams of a
-        // workgroup share one copy of the tables and the sixteen waves that stage it)
-        const uint32_t fit = teams;
-        teams = all_teams <= kCuCount ? 1u : (all_teams <= 2ull * kCuCount ? 2u : 4u);
-        teams = teams < fit ? teams : fit;
-        p.waves_per_block = teams * kCoopTeamWaves;
-        p.total_bytes = tables + teams * team_area;
-        const uint64_t teams_total = uint64_t((max_intervals + p.intervals_per_wave - 1) / p.intervals_per_wave) * images;
-        p.total_waves = uint32_t(std::min<uint64_t>(teams_total * kCoopTeamWaves, 0xffffffffu));
-        p.usable = true;
-        if (getenv("COMPEG_VERBOSE"))
-            fprintf(stderr, "[compeg] coop team plan: images=%u intervals=%u per team=%u teams/block=%u window=%u words lds=%u B\n",
-                    images, max_intervals, p.intervals_per_wave, teams, p.window_words, p.total_bytes);
-        return p;
+    // four teams of four waves: one workgroup per CU, one copy of the tables
+    tables = ((tables + 31u) & ~31u) + kWalkWords * 4u;
+    const uint64_t all_teams = uint64_t((max_intervals + p.intervals_per_wave - 1) / p.intervals_per_wave) * images;
+    // A launch that needs four teams per CU to be resident at once gets them even if the window asked for is
+    // a little too large (it is an estimate where the scan was preprocessed on the device): down to three
+    // quarters of it.  A team whose intervals do not fit its window still decodes -- the walks that leave it
+    // hand their interval to the serial decoder.
+    if (all_teams > 3ull * kCuCount && tables + 4u * coop_team_area(p.window_words, sh) > kLdsBytesPerCu) {
+        const uint32_t room = (kLdsBytesPerCu - tables) / 4u, fixed = coop_team_area(0, sh);
+        const uint32_t fit = room > fixed ? ((room - fixed) / 4u) & ~3u : 0u;
+        if (fit >= p.window_words - p.window_words / 4u)
+            p.window_words = fit;
     }
-    const uint32_t wave_area = coop_wave_area(p.window_words, coop_passes());
-    // as many waves per workgroup as share one copy of the tables without costing residency: two workgroups per CU
-    uint32_t wpb = 8;
-    if (const char *e = getenv("COMPEG_COOP_WPB"))
-        wpb = uint32_t(std::max(1, std::min(8, atoi(e))));
-    while (wpb > 1 && tables + wpb * wave_area > kLdsBytesPerCu / 2u)
-        wpb--;
-    if (tables + wpb * wave_area > kLdsBytesPerCu)
-        return p; // (tables too large for LDS: the other kernels read the rest from global memory)
-    p.waves_per_block = wpb;
-    p.total_bytes = tables + wpb * wave_area;
-    if (const char *e = getenv("COMPEG_LDS_PAD")) // experiment knob: lowers occupancy
-        p.total_bytes = std::min(kLdsBytesPerCu, p.total_bytes + uint32_t(atoi(e)));
-    const uint64_t waves = uint64_t((max_intervals + p.intervals_per_wave - 1) / p.intervals_per_wave) * images;
-    p.total_waves = waves > 0xffffffffu ? 0xffffffffu : uint32_t(waves);
+    const uint32_t team_area = coop_team_area(p.window_words, sh);
+    uint32_t teams = 4;
+    while (teams > 1 && tables + teams * team_area > kLdsBytesPerCu)
+        teams--;
+    if (tables + teams * team_area > kLdsBytesPerCu)
+        return p;
+    // one workgroup per CU while that covers the launch (a small launch spreads over the CUs; the teams of a
+    // workgroup share one copy of the tables and the sixteen waves that stage it)
+    const uint32_t fit = teams;
+    teams = all_teams <= kCuCount ? 1u : (all_teams <= 2ull * kCuCount ? 2u : 4u);
+    teams = teams < fit ? teams : fit;
+    p.waves_per_block = teams * kCoopTeamWaves;
+    p.total_bytes = tables + teams * team_area;
+    p.total_waves = uint32_t(std::min<uint64_t>(all_teams * kCoopTeamWaves, 0xffffffffu));
     p.usable = true;
     if (getenv("COMPEG_VERBOSE"))
-        fprintf(stderr, "[compeg] coop plan: images=%u intervals=%u per wave=%u waves/block=%u window=%u words lds=%u B waves=%u\n",
-                images, max_intervals, p.intervals_per_wave, p.waves_per_block, p.window_words, p.total_bytes, p.total_waves);
+        fprintf(stderr, "[compeg] coop team plan: images=%u intervals=%u restart interval=%u per team=%u rounds=%u teams/block=%u window=%u words lds=%u B\n",
+                images, max_intervals, restart_interval, p.intervals_per_wave, sh.rounds, teams, p.window_words, p.total_bytes);
     return p;
 }
 
@@ -985,31 +901,19 @@ hipError_t launch_coop_422(const ImageDesc *descs, uint32_t images, uint32_t max
         const char *e = getenv("COMPEG_COOP_SPEC_SHIFT"); // experiment knob: fewer speculative subsequences
         return e ? uint32_t(atoi(e)) : 0u;
     }();
-    if (plan.team) {
-        const uint32_t teams = plan.waves_per_block / kCoopTeamWaves, per_block = plan.intervals_per_wave * teams;
-        dim3 grid((max_intervals + per_block - 1) / per_block, images, 1);
-        static const hipError_t attr = hipFuncSetAttribute(
-            reinterpret_cast<const void *>(decode_coop_team_422_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-            int(kLdsBytesPerCu));
-        if (attr != hipSuccess)
-            return attr;
-        static const uint32_t quarters_on = [] {
-            const char *e = getenv("COMPEG_COOP_QUARTERS"); // experiment knob: 0 = the decoding waits for the walk's end
-            return e ? uint32_t(atoi(e) != 0) : 1u;
-        }();
-        hipLaunchKernelGGL(decode_coop_team_422_kernel, grid, dim3(1024), plan.total_bytes, stream, descs,
-                           plan.l2_entries_in_lds, plan.window_words, spec_shift, teams, quarters_on);
-        return hipGetLastError();
-    }
-    const uint32_t per_block = plan.intervals_per_wave * plan.waves_per_block;
+    const uint32_t teams = plan.waves_per_block / kCoopTeamWaves, per_block = plan.intervals_per_wave * teams;
     dim3 grid((max_intervals + per_block - 1) / per_block, images, 1);
     static const hipError_t attr = hipFuncSetAttribute(
-        reinterpret_cast<const void *>(decode_coop_422_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        reinterpret_cast<const void *>(decode_coop_team_422_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
         int(kLdsBytesPerCu));
     if (attr != hipSuccess)
         return attr;
-    hipLaunchKernelGGL(decode_coop_422_kernel, grid, dim3(plan.waves_per_block * kWave), plan.total_bytes, stream, descs,
-                       plan.l2_entries_in_lds, plan.window_words, spec_shift, coop_passes());
+    static const uint32_t quarters_on = [] {
+        const char *e = getenv("COMPEG_COOP_QUARTERS"); // experiment knob: 0 = the decoding waits for the walk's end
+        return e ? uint32_t(atoi(e) != 0) : 1u;
+    }();
+    hipLaunchKernelGGL(decode_coop_team_422_kernel, grid, dim3(1024), plan.total_bytes, stream, descs,
+                       plan.l2_entries_in_lds, plan.window_words, spec_shift, teams, quarters_on);
     return hipGetLastError();
 }
 

@@ -566,7 +566,7 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     const size_t l1_off = align_up(sizeof(ImageDesc), 256), l2_off = l1_off + COMPEG_HUFFMAN_L1_BYTES;
 
     // the cooperative kernel may take this image: its walk tables' place
-    const bool want_walk = is_422(img) && use_fused_pipeline() && coop_team() && use_coop_kernel(md.total_restart_intervals, 1, md.restart_interval);
+    const bool want_walk = is_422(img) && use_fused_pipeline() && use_coop_kernel(md.total_restart_intervals, 1, md.restart_interval);
     if (want_walk)
         CG_TRY(walk_tables.reserve(kWalkTableBytes));
 
@@ -673,6 +673,7 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     have_last = true;
     trace.mark("copies");
 
+    last_kernel = COMPEG_KERNEL_NONE;
     if (total_dus == 0) {
         if (deferred_check)
             CG_HIP(hipMemcpyAsync(scan_result.ptr, scan_result_dev, 16, hipMemcpyDeviceToHost, stream));
@@ -696,10 +697,11 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
                                       plan, stream));
         CG_HIP(launch_generic_composite(reinterpret_cast<const ImageDesc *>(db), 1, out_w, out_h, stream));
         coefficients_valid = false;
+        last_kernel = COMPEG_KERNEL_GENERIC;
     } else if (fused) {
         CoopPlan coop{};
         if (reinterpret_cast<const ImageDesc *>(hb)->coop_ok && use_coop_kernel(md.total_restart_intervals, 1, md.restart_interval)) {
-            const uint32_t ipw = uint32_t(kWave) / (4u * md.restart_interval) * (coop_team() ? 4u : coop_passes());
+            const uint32_t ipw = coop_shape(md.restart_interval, 4).ipw; // (intervals per team)
             // (on the device path `dev_span` is itself an estimate, twice the average span of 64 intervals: a group's share of it)
             const uint32_t group_span = on_device ? uint32_t(std::min<uint64_t>(uint64_t(dev_span) * ipw / kWave + 64, 0x7fffffffu))
                                                   : max_wave_span(scan.starts(), scan.nstarts(), scan.nwords(),
@@ -723,14 +725,19 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
                 }
             }
             CG_HIP(launch_coop_422(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals, coop, stream));
-        } else if (use_pair_kernel(md.total_restart_intervals, 1))
+            last_kernel = COMPEG_KERNEL_COOP_TEAM;
+        } else if (use_pair_kernel(md.total_restart_intervals, 1)) {
             CG_HIP(launch_pair_422(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals,
                                    plan, stream));
-        else
+            last_kernel = COMPEG_KERNEL_PAIR;
+        } else {
             CG_HIP(launch_fused_422(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals,
                                     plan, stream));
+            last_kernel = COMPEG_KERNEL_FUSED;
+        }
         coefficients_valid = false;
     } else {
+        last_kernel = COMPEG_KERNEL_SPLIT;
         CG_HIP(launch_entropy(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals,
                               plan, stream));
         CG_HIP(launch_idct_composite(reinterpret_cast<const ImageDesc *>(db), 1, total_dus, stream));
@@ -1093,7 +1100,7 @@ Status compeg_batch::upload_host(size_t n, int threads, const void *items_, cons
             spans[i] = max_wave_span(starts_at, nstarts, nwords, img.metadata.total_restart_intervals);
             if (d.coop_ok)
                 group_spans[i] = max_wave_span(starts_at, nstarts, nwords, img.metadata.total_restart_intervals,
-                                               uint32_t(kWave) / (4u * img.metadata.restart_interval) * (coop_team() ? 4u : coop_passes()));
+                                               coop_shape(img.metadata.restart_interval, 4).ipw);
             alg[i] = 4ull * nwords + 4ull * img.metadata.total_restart_intervals + COMPEG_METADATA_BYTES +
                      COMPEG_HUFFMAN_L1_BYTES + img.l2.size() * 2 + 4ull * img.width * img.height;
             // this image's part of the arena, as far as it is used
@@ -1357,7 +1364,7 @@ Status compeg_batch::upload_device_scan(const ImageData *const *images, size_t n
         } else {
             // (the kernels report the span of 64 intervals only: four times the average for a wave's group;
             // a group that is longer than that still decodes, its intervals one lane each)
-            const uint32_t ipw = uint32_t(kWave) / (4u * coop_r) * (coop_team() ? 4u : coop_passes());
+            const uint32_t ipw = coop_shape(coop_r, 4).ipw;
             coop_span = std::max(coop_span, coop_span_estimate(span, ipw));
         }
         algorithmic_bytes += 4ull * nwords + 4ull * expected + COMPEG_METADATA_BYTES +
@@ -1375,8 +1382,12 @@ Status compeg_batch::upload_device_scan(const ImageData *const *images, size_t n
 Status compeg_batch::make_walk_tables(hipStream_t stream)
 {
     const size_t n = count;
-    const bool want = n > 0 && coop_r != 0 && !generic_layout && use_fused_pipeline() && coop_team() &&
-                      use_coop_kernel(max_intervals, uint32_t(chunk ? std::min<size_t>(chunk, n) : n), coop_r);
+    // (whenever some launch of decode() may take the cooperative kernel: launches are `chunk` images, the last one
+    // n % chunk -- the smallest of them decides, the kernel takes the small launches)
+    const size_t step = chunk ? std::min<size_t>(chunk, n) : n;
+    const size_t smallest = step && n % step ? n % step : step;
+    const bool want = n > 0 && coop_r != 0 && !generic_layout && use_fused_pipeline() &&
+                      use_coop_kernel(max_intervals, uint32_t(smallest), coop_r);
     // one set for all: the same tables (uniform) used by the same components
     bool shared = uniform;
     for (size_t i = 1; i < n && shared; i++)
@@ -1423,6 +1434,7 @@ Status compeg_batch::decode(hipStream_t stream)
         const bool fused = use_fused_pipeline() && !generic_layout;
         const HuffLdsPlan plan = plan_huffman(max_intervals, m, max_l2, max_span, fused || generic_layout);
         if (generic_layout) {
+            last_kernel = at ? last_kernel : COMPEG_KERNEL_GENERIC;
             CG_HIP(launch_entropy_samples(dd + at, m, max_intervals, plan, stream));
             if (timing && at == 0)
                 CG_HIP(hipEventRecord(ev[1], stream));
@@ -1439,10 +1451,13 @@ Status compeg_batch::decode(hipStream_t stream)
                 CG_HIP(launch_pair_422(dd + at, m, max_intervals, plan, stream));
             else
                 CG_HIP(launch_fused_422(dd + at, m, max_intervals, plan, stream, uniform));
+            if (at == 0)
+                last_kernel = coop.usable ? COMPEG_KERNEL_COOP_TEAM : (use_pair_kernel(max_intervals, m) ? COMPEG_KERNEL_PAIR : COMPEG_KERNEL_FUSED);
             if (timing && at == 0)
                 CG_HIP(hipEventRecord(ev[1], stream));
             continue;
         }
+        last_kernel = at ? last_kernel : COMPEG_KERNEL_SPLIT;
         CG_HIP(launch_entropy(dd + at, m, max_intervals, plan, stream));
         if (timing && at == 0)
             CG_HIP(hipEventRecord(ev[1], stream)); // stage split is exact for unchunked decodes

@@ -84,6 +84,7 @@ struct compeg_decoder {
     bool decode_pending = false;
     hipStream_t last_stream = nullptr;
     std::string warning;
+    int last_kernel = 0; // COMPEG_KERNEL_*: where the last enqueue went
     compeg_stage_times stage_times{0.0, 0.0, 0.0}; // host time of the last decode's stages (lib.rs:391-396,452-475,516-522)
     // what read_coefficients needs to rebuild the reference's buffer
     compeg::Metadata last_md{};
@@ -146,6 +147,7 @@ struct compeg_batch {
     std::vector<hipEvent_t> events;
     size_t decodes_timed = 0;
     hipStream_t last_stream = nullptr;
+    int last_kernel = 0; // COMPEG_KERNEL_*: where the first launch of the last decode went
 
     // 0: scans are preprocessed on the host at upload (the reference's data flow);
     // 1: raw scans are uploaded and preprocessed once by the scan kernels;

@@ -166,6 +166,16 @@ typedef struct compeg_stage_times {
     double poll_us;
 } compeg_stage_times;
 int compeg_decoder_last_stage_times(const compeg_decoder *dec, compeg_stage_times *out);
+/* Diagnostics: which decode kernel the decoder's last enqueue (compeg_batch_last_kernel: the first launch of the
+ * batch's last decode) went to -- the dispatch is by launch size and restart interval, and tests pin a case to the
+ * path it is meant to cover.  The reference has one pipeline (lib.rs:436-448) and no counterpart. */
+#define COMPEG_KERNEL_NONE 0       /* nothing launched yet (or an image without a complete restart interval) */
+#define COMPEG_KERNEL_FUSED 1      /* decode_fused_422_kernel: a lane per restart interval, launches that fill the chip */
+#define COMPEG_KERNEL_PAIR 2       /* decode_pair_422_kernel: decoder wave + transformer wave per 64 intervals */
+#define COMPEG_KERNEL_COOP_TEAM 3  /* decode_coop_team_422_kernel: the lanes of a team work inside the intervals */
+#define COMPEG_KERNEL_GENERIC 4    /* entropy_samples_kernel + composite_generic_kernel (layouts other than 4:2:2) */
+#define COMPEG_KERNEL_SPLIT 5      /* entropy_kernel + idct_composite_kernel (development pipeline) */
+int compeg_decoder_last_kernel(const compeg_decoder *dec);
 /* Extension: on != 0 moves the scan preprocessing of every following decode
  * from the host (the reference's data flow, default) to the device-side scan
  * kernels; the raw entropy-coded segment is uploaded instead of the
@@ -259,6 +269,7 @@ uint64_t compeg_batch_pixels(const compeg_batch *batch);
  * then starts a new measurement. */
 int compeg_batch_timing(compeg_batch *batch, int reset, uint32_t *decodes, double *total_ms,
                         double stage_ms[2]);
+int compeg_batch_last_kernel(const compeg_batch *batch); /* COMPEG_KERNEL_* */
 
 #if defined(__GNUC__)
 #pragma GCC visibility pop

@@ -25,6 +25,12 @@ pub const COMPEG_E_COUNT_MISMATCH: c_int = -4;
 pub const COMPEG_E_HIP: c_int = -5;
 pub const COMPEG_PARSE_ANY_LUMA_SAMPLING: c_uint = 1;
 pub const COMPEG_PARSE_STANDARD_ENTROPY: c_uint = 2;
+pub const COMPEG_KERNEL_NONE: c_int = 0;
+pub const COMPEG_KERNEL_FUSED: c_int = 1;
+pub const COMPEG_KERNEL_PAIR: c_int = 2;
+pub const COMPEG_KERNEL_COOP_TEAM: c_int = 3;
+pub const COMPEG_KERNEL_GENERIC: c_int = 4;
+pub const COMPEG_KERNEL_SPLIT: c_int = 5;
 
 extern "C" {
     pub fn compeg_last_error() -> *const c_char;
@@ -72,6 +78,7 @@ extern "C" {
                                           op: *mut *mut compeg_op) -> c_int;
     pub fn compeg_decoder_last_warning(dec: *const compeg_decoder) -> *const c_char;
     pub fn compeg_decoder_last_stage_times(dec: *const compeg_decoder, out: *mut compeg_stage_times) -> c_int;
+    pub fn compeg_decoder_last_kernel(dec: *const compeg_decoder) -> c_int;
     pub fn compeg_decoder_set_device_preprocess(dec: *mut compeg_decoder, on: c_int) -> c_int;
     pub fn compeg_decoder_set_scan_threads(dec: *mut compeg_decoder, threads: c_uint) -> c_int;
     pub fn compeg_op_wait(op: *mut compeg_op) -> c_int;
@@ -105,4 +112,5 @@ extern "C" {
     pub fn compeg_batch_pixels(batch: *const compeg_batch) -> u64;
     pub fn compeg_batch_timing(batch: *mut compeg_batch, reset: c_int, decodes: *mut u32, total_ms: *mut c_double,
                                stage_ms: *mut c_double) -> c_int;
+    pub fn compeg_batch_last_kernel(batch: *const compeg_batch) -> c_int;
 }

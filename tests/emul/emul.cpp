@@ -94,16 +94,19 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
             return -5;
         }
         l2_in_lds = (uint32_t(l2.size()) + 1u) & ~1u;
-        const uint32_t passes = getenv("EMUL_COOP_PASSES") ? uint32_t(atoi(getenv("EMUL_COOP_PASSES"))) : 1u;
-        const uint32_t ipw = uint32_t(kWave) / (4u * d.restart_interval) * (passes >= 4 ? 4u : (passes >= 2 ? 2u : 1u));
+        // EMUL_COOP_PASSES: 4 = the team form's geometry (a walk covers 4 x 64 data units), 1 = a lone wave's
+        const uint32_t waves = getenv("EMUL_COOP_PASSES") ? uint32_t(atoi(getenv("EMUL_COOP_PASSES"))) : 1u;
+        const CoopShape shape = coop_shape(d.restart_interval, waves >= 4 ? 4u : (waves >= 2 ? 2u : 1u));
+        const uint32_t ipw = shape.ipw;
         if (window_words == 0) { // as the runtime plans it
             window_words = max_wave_span(starts.data(), starts.size(), words.size(), d.total_intervals, ipw) + kDuWordSlack + 4u;
             window_words = std::min(std::max(window_words, 128u), kCoopMaxWindow);
         }
         window_words = (window_words + 3u) & ~3u;
-        const uint32_t misc_words = kCoopMiscWords;
+        const uint32_t misc_words = coop_misc_words(shape.rounds);
+        const uint32_t list_bytes = shape.list_cap > kCoopSlotListCap ? uint32_t(kWave) * shape.list_cap * 4u : 0u;
         const uint32_t lds_bytes = align16((kL1Entries + l2_in_lds) * 2u) + 3u * kCoopQuantStride * 4u +
-                                   align16(window_words * 4u) + kWave * kDuSlotBytes + misc_words * 4u;
+                                   align16(window_words * 4u) + kWave * kDuSlotBytes + misc_words * 4u + list_bytes;
         const uint32_t nwaves = (d.total_intervals + ipw - 1) / ipw;
         for (uint32_t wave = 0; wave < nwaves; wave++) {
             uint8_t *smem = static_cast<uint8_t *>(aligned_alloc(16, align16(lds_bytes)));
@@ -119,15 +122,16 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
             for (uint32_t t = 0; t < 3u * kRetained; t++)
                 quant[(t / kRetained) * kCoopQuantStride + t % kRetained] = d.quant[t / kRetained][t % kRetained];
             CoopGeom g;
-            const bool with_walk_tables = passes >= 4 && !(getenv("EMUL_COOP_LEAN") && atoi(getenv("EMUL_COOP_LEAN")) == 0);
-            coop_geom(d, wave, g, getenv("EMUL_COOP_SPEC_SHIFT") ? uint32_t(atoi(getenv("EMUL_COOP_SPEC_SHIFT"))) : (with_walk_tables && d.restart_interval <= 4u ? 31u : 0u), passes);
+            const bool with_walk_tables = waves >= 4 && !(getenv("EMUL_COOP_LEAN") && atoi(getenv("EMUL_COOP_LEAN")) == 0);
+            coop_geom(d, wave, g, getenv("EMUL_COOP_SPEC_SHIFT") ? uint32_t(atoi(getenv("EMUL_COOP_SPEC_SHIFT"))) : (with_walk_tables && d.restart_interval <= 4u ? 31u : 0u), waves);
             uint32_t wb = 0, wl = 0;
             coop_window(d, g, window_words, wb, wl);
             for (uint32_t i = 0; i < wl; i++)
                 win[i] = wb + i < d.nwords ? bswap32(d.words[wb + i]) : 0u;
             CoopShared cs;
             cs.h = HuffShared{sl1, sl2, umin(l2_in_lds, d.fast_off + 2u * kFastEntries + 2u * kDcFastEntries), win, wb, wl, slots};
-            cs.lists = reinterpret_cast<uint32_t *>(slots);
+            // (lists longer than the bytes of the slots -- intervals of more than 64 MCUs -- have their own area)
+            cs.lists = list_bytes ? misc + misc_words : reinterpret_cast<uint32_t *>(slots);
             coop_bind_misc(cs, misc);
             cs.quant = quant;
             CoopTables t;
@@ -165,7 +169,7 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
                     cs.diffs = diffs.data() + q * kWave;
                     coop_decode_quarter_422<kWave>(d, cs, t, g, 0, wave, q, clk);
                 }
-                coop_quarters_serial_422<kWave>(d, cs, t, g, 0, wave, clk);
+                coop_serial_intervals_422<kWave>(d, cs, t, g, 0);
             }
             free(smem);
         }
