@@ -92,6 +92,8 @@ def _load():
         "compeg_decoder_last_kernel": (i, [vp]),
     }
     for name, (res, args) in sig.items():
+        if os.environ.get("COMPEG_LIB") and not hasattr(L, name):
+            continue           # (A/B runs against an older build: it may lack the newest entry points)
         fn = getattr(L, name)  # AttributeError here = header/library mismatch: fail loudly
         fn.restype, fn.argtypes = res, args
     L._signatures = sig

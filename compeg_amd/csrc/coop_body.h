@@ -67,16 +67,18 @@ constexpr uint32_t kCoopMaxEntries = 19;   // ... of which the last is scratch (
 constexpr uint32_t kCoopMargin = CG_COOP_MARGIN; // bits a lane walks on beyond the end of its subsequence
 constexpr uint32_t kCoopHead = 3;          // leading entries of a successor's list that a link may point at
 constexpr uint32_t kCoopTail = 3;          // trailing entries of a lane's own list that may carry the link
-constexpr uint32_t kCoopMaxWindow = 2040;  // words: bit positions inside the wave's window fit 16 bits
+constexpr uint32_t kCoopPosBits = 18;      // bit positions inside a walk's window
+constexpr uint32_t kCoopPosMask = (1u << kCoopPosBits) - 1u;
+constexpr uint32_t kCoopMaxWindow = (1u << (kCoopPosBits - 5u)) - 8u; // words (32 KB: what a team alone on its CU can have)
 constexpr uint32_t kCoopMaxRestart = 256;  // MCUs per interval (1024 data units: 16 rounds of 64)
 constexpr uint32_t kCoopMaxRounds = 16;    // rounds of 64 data units per walk
 constexpr uint32_t kCoopQuantStride = 36;  // floats between the components' quantiser rows in LDS
 
-// Data-unit start state: bits 0..15 bit position inside the wave's window, 16..20 size of the symbol in front
-// of it (with the position it fixes the reference reader's `left` at the DC code, quirk Q1).  The third part of
+// Data-unit start state: bits 0..17 bit position inside the walk's window (kCoopPosBits), 18..22 size of the symbol in
+// front of it (with the position it fixes the reference reader's `left` at the DC code, quirk Q1).  The third part of
 // the state, the data unit's index inside its MCU, is not stored: entry i of a list belongs to index
-// (index of entry 0 + i) mod 4.  Two states are equal iff these 21 bits and that index are.
-constexpr uint32_t kCoopStateMask = 0x001fffffu;
+// (index of entry 0 + i) mod 4.  Two states are equal iff these 23 bits and that index are.
+constexpr uint32_t kCoopStateMask = (32u << kCoopPosBits) - 1u;
 constexpr uint32_t kCoopZero = 1u << 25;   // (decode phase) the data unit lies behind a dead one: zero-stream levels
 constexpr uint32_t kCoopUnset = 1u << 27;  // (decode phase) no state: nothing to decode
 
@@ -447,7 +449,7 @@ CG_DEV void chase_run(ChaseState &c, const ImageDesc &d, const HuffShared &s, co
                 "ds_read_u16 %[ent], v46\n\t"
                 // ---- under that read: the list, the coming data unit's tables, the reload, who goes on
                 "v_add_u32 %[p], %[p], v40\n\t"
-                "v_lshl_or_b32 v40, v40, 16, %[p]\n\t"
+                "v_lshl_or_b32 v40, v40, %[posbits], %[p]\n\t"
                 "ds_write_b32 %[lp], v40\n\t"                         // (stays when the data unit ends here)
                 "v_cndmask_b32_e64 v44, 0, 4, s[72:73]\n\t"
                 "v_add_u32 %[lp], %[lp], v44\n\t"
@@ -485,7 +487,7 @@ CG_DEV void chase_run(ChaseState &c, const ImageDesc &d, const HuffShared &s, co
                 : [p] "+v"(p), [st] "+v"(st), [lp] "+v"(lpa), [ent] "+v"(ent), [sn] "+v"(sn), [wa] "+v"(wa),
                   [alive] "+v"(alive), [code] "=s"(code)
                 : [tab] "s"(tab), [acsel] "v"(acsel), [dcseln] "v"(dcsel_next), [kc] "v"(kc),
-                  [stopp] "v"(c.stop_p), [lpmax] "v"(lpmax)
+                  [stopp] "v"(c.stop_p), [lpmax] "v"(lpmax), [posbits] "n"(kCoopPosBits)
                 : "memory", "vcc", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49",
                   "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81");
             if (code == 0u)
@@ -543,7 +545,7 @@ CG_DEV void chase_run(ChaseState &c, const ImageDesc &d, const HuffShared &s, co
             p += tot;
             const uint32_t s_new = st + (ent >> 9);
             const bool du_end = s_new >= 64u;
-            *lp = p | (tot << 16);
+            *lp = p | (tot << kCoopPosBits);
             const uint32_t one = du_end ? 1u : 0u;
             lp += one;
             k8 += one << 3;
@@ -601,7 +603,7 @@ CG_DEV void coop_lean_prepare(const CoopShared &cs, const CoopTables &t, const C
 // the next one's DC table}, filled in beforehand.  The state word holds the reader's shift (bits 0..15, signed:
 // 32 - the bits of A that are consumed, below zero when the position has moved on into B), the size of the last
 // symbol (16..20) and the zig-zag state (21..28).  At the end the entries are rewritten as the state words
-// everybody else reads (position | size << 16).
+// everybody else reads (position | size << kCoopPosBits).
 // Per step on the GPU: 32 instructions (a lone wave issues one every four cycles at best, whatever its kind); codes
 // longer than a table's prefix are looked up in the two-level tables by a branch of the same block.
 CG_DEV void chase_run_lean(ChaseState &c, const ImageDesc &d, const HuffShared &s, const CoopTables &t, uint32_t *list,
@@ -866,7 +868,7 @@ CG_DEV uint32_t lean_entry_pos(const HuffShared &s, uint32_t w, uint32_t Tj)
     return 32u * (w - kLeanHostWordBias + 1u) - uint32_t(int32_t(int16_t(Tj & 0xffffu)));
 #endif
 }
-CG_DEV uint32_t lean_entry_state(uint32_t pos, uint32_t Tj) { return (pos & 0xffffu) | (((Tj >> kWalkLastShift) & 31u) << 16); }
+CG_DEV uint32_t lean_entry_state(uint32_t pos, uint32_t Tj) { return (pos & kCoopPosMask) | (((Tj >> kWalkLastShift) & 31u) << kCoopPosBits); }
 
 // The walk went as it has to for its entries to be used: every data unit found, all of them starting inside the part
 // of the window where a data unit may begin.  (Beyond the interval's own end is fine: the reference decodes as many
@@ -986,7 +988,7 @@ CG_DEV void coop_find_link(const ChaseState &c, const CoopShared &cs, const Coop
 #pragma unroll
     for (uint32_t a = 0; a < kCoopTail; a++) {
         own[a] = mine[first + a] & kCoopStateMask; // (first + a <= n <= max_entries: inside the list)
-        own_ok[a] = first + a < n && (own[a] & 0xffffu) >= c.sub_end;
+        own_ok[a] = first + a < n && (own[a] & kCoopPosMask) >= c.sub_end;
     }
     uint32_t best = 0u;
 #pragma unroll
@@ -1020,7 +1022,7 @@ CG_DEV void coop_find_link(const ChaseState &c, const CoopShared &cs, const Coop
             for (uint32_t q = 0; q < n_o && !full; q++)
                 for (uint32_t i = 0; i < n && !full; i++)
                     full = (mine[i] & kCoopStateMask) == (cs.lists[other * g.list_cap + q] & kCoopStateMask) &&
-                           ((c.k0 + i - k_o - q) & 3u) == 0u && (mine[i] & 0xffffu) >= c.sub_end;
+                           ((c.k0 + i - k_o - q) & 3u) == 0u && (mine[i] & kCoopPosMask) >= c.sub_end;
         }
         if (lane == lane0) {
             CG_COOP_COUNT(link_tries, 1);
@@ -1060,14 +1062,14 @@ CG_DEV void coop_follow(const CoopShared &cs, const CoopGeom &g, uint32_t il, ui
                 // (analysis only) the failed boundary: the chain lane's last entries and the successors' first ones
                 fprintf(stderr, "fail il %u lane %u n %u du %u :", il, x, n, du);
                 for (uint32_t i = n > 4 ? n - 4 : 0; i < n; i++)
-                    fprintf(stderr, " %u/%u", cs.lists[x * g.list_cap + i] & 0xffffu, (cs.lists[x * g.list_cap + i] >> 16) & 31u);
+                    fprintf(stderr, " %u/%u", cs.lists[x * g.list_cap + i] & kCoopPosMask, (cs.lists[x * g.list_cap + i] >> kCoopPosBits) & 31u);
                 const uint32_t lane0 = x / g.lpi * g.lpi;
                 const uint32_t j = x == lane0 ? 0u : 1u + (x - lane0 - 1u) / 4u;
                 for (uint32_t h = 0; h < 4u && j + 1u < g.count; h++) {
                     const uint32_t o = lane0 + coop_spec_lane(j + 1u, h);
                     fprintf(stderr, " | h%u k0=%u n=%u:", h, (cs.lane_n[o] >> 16) & 3u, cs.lane_n[o] & 0xffu);
                     for (uint32_t q = 0; q < (cs.lane_n[o] & 0xffu) && q < 6u; q++)
-                        fprintf(stderr, " %u/%u", cs.lists[o * g.list_cap + q] & 0xffffu, (cs.lists[o * g.list_cap + q] >> 16) & 31u);
+                        fprintf(stderr, " %u/%u", cs.lists[o * g.list_cap + q] & kCoopPosMask, (cs.lists[o * g.list_cap + q] >> kCoopPosBits) & 31u);
                 }
                 fprintf(stderr, "\n");
             }
@@ -1177,7 +1179,7 @@ CG_DEV int32_t coop_decode_du(const ImageDesc &d, const HuffShared &s, const Coo
     underflow = hostile = false;
     if (state & kCoopUnset)
         return 0;
-    const uint32_t p = state & 0xffffu, rel = p >> 5, sh = p & 31u, tl = (state >> 16) & 31u;
+    const uint32_t p = state & kCoopPosMask, rel = p >> 5, sh = p & 31u, tl = (state >> kCoopPosBits) & 31u;
     EntropyState e;
     e.r.buf = uint64_t(s.win[rel] << sh) << 32;
     e.r.left = 32u - sh;

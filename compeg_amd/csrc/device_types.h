@@ -49,7 +49,12 @@ constexpr uint32_t kDcFastEntries = 1u << kDcFastBits;
 //             others speculate in fours: coop_body.h)
 //   count     subsequences an interval is cut into: 1 + the speculative ones
 //   list_cap  words of a walking lane's list of data-unit starts: 20 (64 lists = the bytes of a wave's 64 slots)
-//             while a subsequence has at most 16 data units -- every interval of up to 64 MCUs --, more beyond
+//             while a subsequence has at most 10 data units, more beyond (the lists then have an area of their own)
+// Up to this many MCUs per interval one lane walks the whole interval through the walk tables (two symbols a step,
+// no speculation, nothing to validate); longer intervals are cut into subsequences walked side by side.  Measured on
+// one 960x720 frame (kernel time by HIP events, lane-per-interval / speculative): 5 MCUs 38 / 62 us, 10: 49 / 87,
+// 16: 64 / 106, 30: 92 / 101, 60: 164 / 154, 120: 314 / 217.
+constexpr uint32_t kCoopLeanMaxRestart = 40;
 struct CoopShape {
     uint32_t dpi, ipw, rounds, lpi, count, list_cap;
 };
@@ -66,7 +71,9 @@ constexpr CoopShape coop_shape(uint32_t restart_interval, uint32_t waves)
     sh.lpi = share < fit ? (share ? share : 1u) : fit;
     sh.count = 1u + (sh.lpi - 1u) / 4u;
     const uint32_t per_sub = (sh.dpi + sh.count - 1u) / sh.count;
-    sh.list_cap = per_sub > 16u ? ((per_sub + 12u) & ~3u) : kCoopSlotListCap;
+    // (a speculative lane's list that fills up ends its walk early; the lane-per-interval walks keep their entries in
+    // the lanes' 20 words each: 4 (dpi + 1) <= 20 lpi)
+    sh.list_cap = (restart_interval > kCoopLeanMaxRestart && per_sub > 10u) ? ((per_sub + 15u) & ~3u) : kCoopSlotListCap;
     return sh;
 }
 

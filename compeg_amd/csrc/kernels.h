@@ -33,13 +33,18 @@ hipError_t launch_pair_422(const ImageDesc *descs, uint32_t images, uint32_t max
 // Cooperative kernel (coop_body.h) for launches too small to fill the chip with a lane per restart interval.
 struct CoopPlan {
     bool usable;
+    uint32_t group_waves; // 4, 2 or 1: a team takes coop_shape(restart_interval, group_waves).ipw whole intervals
     uint32_t intervals_per_wave, waves_per_block, window_words, l2_entries_in_lds, total_bytes, total_waves; // (intervals_per_wave: per team)
 };
-// The kernel's teams of four waves each take coop_shape(restart_interval, 4).ipw whole restart intervals.
-// max_group_words: largest word span of any such group of consecutive intervals (max_wave_span with that group
-// size), or an upper estimate of it
+// The kernel's teams of four waves take the whole restart intervals of 4 x 64 data units -- of 2 x 64 or 64 where
+// those do not fit the largest window (dense streams: bit positions inside a window are 16-bit).
+// words[k]: largest word span of any group of coop_shape(restart_interval, 4 >> k).ipw consecutive intervals
+// (max_wave_span with that group size), or an upper estimate of it
+struct CoopSpans {
+    uint32_t words[3];
+};
 CoopPlan plan_coop(uint32_t max_intervals, uint32_t images, uint32_t restart_interval, uint32_t max_l2,
-                   uint32_t max_group_words);
+                   const CoopSpans &spans);
 hipError_t launch_coop_422(const ImageDesc *descs, uint32_t images, uint32_t max_intervals, const CoopPlan &plan,
                            hipStream_t stream);
 // Fills ImageDesc::walk (kWalkTableBytes each) of every image that has one, from its direct tables.

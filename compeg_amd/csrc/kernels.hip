@@ -653,7 +653,7 @@ __device__ __forceinline__ void team_wait(uint32_t *flag, uint32_t value)
 
 __global__ void __launch_bounds__(1024)
 decode_coop_team_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words, uint32_t spec_shift,
-                            uint32_t teams, uint32_t quarters_on)
+                            uint32_t teams, uint32_t quarters_on, uint32_t group_waves)
 {
     // (the workgroup is always 16 waves: those beyond the teams' help with the staging and leave)
     extern __shared__ __attribute__((aligned(32))) uint8_t smem[];
@@ -665,10 +665,10 @@ decode_coop_team_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_
     CoopGeom g;
     // (with walk tables nobody speculates, a lane walks its whole interval -- up to 16 data units: beyond that a lane's
     // chain is longer than the speculative walks of its interval's lanes, measured with DRI = 16: 164 against 108 us)
-    coop_geom(d, blockIdx.x * teams + team, g, d.walk && d.restart_interval <= 4u ? 31u : spec_shift, kCoopTeamWaves);
+    coop_geom(d, blockIdx.x * teams + team, g, d.walk && d.restart_interval <= kCoopLeanMaxRestart ? 31u : spec_shift, group_waves);
     if (blockIdx.x * teams * g.ipw >= d.total_intervals)
         return; // the whole workgroup
-    const CoopShape shape = coop_shape(d.restart_interval, kCoopTeamWaves);
+    const CoopShape shape = coop_shape(d.restart_interval, group_waves);
 
     uint16_t *l1 = reinterpret_cast<uint16_t *>(smem);
     uint16_t *l2 = l1 + kL1Entries;
@@ -749,7 +749,7 @@ decode_coop_team_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_
         if (k * 256u + wlane < nvec)
             reinterpret_cast<SlotVec *>(win)[k * 256u + wlane] = w[k];
     }
-    // what is left over (nothing with 1024 threads and windows of up to 2048 words; table 4 of L1 is all-zero; the
+    // what is left over (with 1024 threads only of windows of more than 2048 words; table 4 of L1 is all-zero; the
     // last words of the L2 copy do not fill a vector)
     for (uint32_t i = kRounds * nth + tid; i < v_l2; i += nth)
         s_l2[i] = SlotVec{g_l2[i].x, g_l2[i].y, g_l2[i].z, g_l2[i].w};
@@ -804,7 +804,7 @@ decode_coop_team_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_
     // intervals of 16 data units, walked through the walk tables: the decoding starts under the walk, quarter by quarter
     // (worth it where the teams of a workgroup compete for the CU: a team alone on its CU ends with its walker's own
     // round either way -- 34.4 against 34.9 us for one 1080p frame)
-    const bool quarters = quarters_on != 0u && teams > 1u && t.walk != nullptr && t.walk_ok && g.dpi == 16u && g.count == 1u;
+    const bool quarters = quarters_on != 0u && teams > 1u && t.walk != nullptr && t.walk_ok && g.dpi == 16u && g.ipw == 16u && g.count == 1u;
     if (walker) {
         // (the walk is the team's critical path, and with quarters its SIMD is busy with other teams' decoding waves:
         // its instructions go first)
@@ -841,16 +841,29 @@ decode_coop_team_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_
 
 // Every image of the launch must have ImageDesc::coop_ok and the same restart interval.
 CoopPlan plan_coop(uint32_t max_intervals, uint32_t images, uint32_t restart_interval, uint32_t max_l2,
-                   uint32_t max_group_words)
+                   const CoopSpans &spans)
 {
     CoopPlan p{};
     if (restart_interval == 0 || restart_interval > kCoopMaxRestart)
         return p;
-    const CoopShape sh = coop_shape(restart_interval, kCoopTeamWaves);
-    // a group of intervals longer than the largest window (bit positions inside it are 16-bit) would go through the
-    // serial decoder, one lane for the whole team: the other kernels do better
-    if (max_group_words + kDuWordSlack + 4u > kCoopMaxWindow)
-        return p;
+    // A team's intervals have to fit its window.  With windows of up to kCoopCosyWindow words four teams share a CU:
+    // 4 x 64 data units' worth of intervals fit one up to 4 bit per pixel, denser streams get teams of half and of a
+    // quarter as many intervals (fewer rounds: two or one of the team's waves decode).  What does not fit even then
+    // -- long intervals: one per MCU row of a 4K frame is 240 MCUs -- gets the largest window there is, a team
+    // alone on its CU.  A group longer than that would go through the serial decoder, one lane for the whole
+    // team: the other kernels do better.
+    constexpr uint32_t kCoopCosyWindow = 2040;
+    uint32_t k = 0;
+    while (k < 3u && spans.words[k] + kDuWordSlack + 4u > kCoopCosyWindow)
+        k++;
+    if (k == 3u) {
+        k = 2u;
+        if (spans.words[k] + kDuWordSlack + 4u > kCoopMaxWindow)
+            return p;
+    }
+    p.group_waves = kCoopTeamWaves >> k;
+    const uint32_t max_group_words = spans.words[k];
+    const CoopShape sh = coop_shape(restart_interval, p.group_waves);
     p.intervals_per_wave = sh.ipw;
     p.l2_entries_in_lds = (max_l2 + 2u * kDcFastEntries + 1u) & ~1u;
     uint32_t w = max_group_words + kDuWordSlack + 4u;
@@ -913,7 +926,7 @@ hipError_t launch_coop_422(const ImageDesc *descs, uint32_t images, uint32_t max
         return e ? uint32_t(atoi(e) != 0) : 1u;
     }();
     hipLaunchKernelGGL(decode_coop_team_422_kernel, grid, dim3(1024), plan.total_bytes, stream, descs,
-                       plan.l2_entries_in_lds, plan.window_words, spec_shift, teams, quarters_on);
+                       plan.l2_entries_in_lds, plan.window_words, spec_shift, teams, quarters_on, plan.group_waves);
     return hipGetLastError();
 }
 

@@ -138,16 +138,37 @@ bool use_coop_kernel(uint32_t max_intervals, uint32_t images, uint32_t restart_i
     return data_units <= 2ull * 1024u * 256u;
 }
 
-// Device preprocessing reports the largest word span of 64 consecutive intervals only.  What the cooperative kernel
-// plans its windows with is the span of a team's group of intervals: their share of it and half as much again.
-// (A group that is longer than that still decodes: the walks that leave the window hand their interval to the
-// serial decoder.)
-uint32_t coop_span_estimate(uint32_t span_of_64, uint32_t intervals_per_group)
+// What the cooperative kernel plans its windows with: the largest word span of a team's group of intervals, for
+// each of the three group sizes it knows (kernels.h: CoopSpans).
+CoopSpans coop_spans_exact(const uint32_t *starts, size_t nstarts, size_t nwords, uint32_t intervals, uint32_t restart_interval)
 {
-    if (intervals_per_group >= kWave)
-        return span_of_64;
-    const uint64_t share = uint64_t(span_of_64) * intervals_per_group / kWave;
-    return uint32_t(std::min<uint64_t>(span_of_64, share + share / 2 + 64));
+    CoopSpans sp{};
+    for (uint32_t k = 0; k < 3u; k++) {
+        const uint32_t ipw = coop_shape(restart_interval, 4u >> k).ipw;
+        sp.words[k] = (k && ipw == coop_shape(restart_interval, 4u >> (k - 1u)).ipw)
+                          ? sp.words[k - 1u] : max_wave_span(starts, nstarts, nwords, intervals, ipw);
+    }
+    return sp;
+}
+
+// Device preprocessing reports the largest word span of 64 consecutive intervals only: a group's share of it and
+// half as much again.  (A group that is longer than that still decodes: the walks that leave the window hand their
+// interval to the serial decoder.)
+CoopSpans coop_spans_estimate(uint32_t span_of_64, uint32_t restart_interval)
+{
+    CoopSpans sp{};
+    for (uint32_t k = 0; k < 3u; k++) {
+        const uint32_t ipw = coop_shape(restart_interval, 4u >> k).ipw;
+        const uint64_t share = uint64_t(span_of_64) * ipw / kWave;
+        sp.words[k] = ipw >= uint32_t(kWave) ? span_of_64 : uint32_t(std::min<uint64_t>(span_of_64, share + share / 2 + 64));
+    }
+    return sp;
+}
+
+void coop_spans_max(CoopSpans &into, const CoopSpans &other)
+{
+    for (uint32_t k = 0; k < 3u; k++)
+        into.words[k] = std::max(into.words[k], other.words[k]);
 }
 
 // Single-image device preprocessing: the raw segment is fetched from the pinned staging buffer by a
@@ -701,12 +722,11 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     } else if (fused) {
         CoopPlan coop{};
         if (reinterpret_cast<const ImageDesc *>(hb)->coop_ok && use_coop_kernel(md.total_restart_intervals, 1, md.restart_interval)) {
-            const uint32_t ipw = coop_shape(md.restart_interval, 4).ipw; // (intervals per team)
-            // (on the device path `dev_span` is itself an estimate, twice the average span of 64 intervals: a group's share of it)
-            const uint32_t group_span = on_device ? uint32_t(std::min<uint64_t>(uint64_t(dev_span) * ipw / kWave + 64, 0x7fffffffu))
-                                                  : max_wave_span(scan.starts(), scan.nstarts(), scan.nwords(),
-                                                                  md.total_restart_intervals, ipw);
-            coop = plan_coop(md.total_restart_intervals, 1, md.restart_interval, staged_lut_entries(img), group_span);
+            // (on the device path `dev_span` is itself an estimate, twice the average span of 64 intervals)
+            const CoopSpans spans = on_device ? coop_spans_estimate(dev_span, md.restart_interval)
+                                              : coop_spans_exact(scan.starts(), scan.nstarts(), scan.nwords(),
+                                                                 md.total_restart_intervals, md.restart_interval);
+            coop = plan_coop(md.total_restart_intervals, 1, md.restart_interval, staged_lut_entries(img), spans);
         }
         if (coop.usable) {
             const ImageDesc &hd = *reinterpret_cast<const ImageDesc *>(hb);
@@ -1039,7 +1059,8 @@ Status compeg_batch::upload_host(size_t n, int threads, const void *items_, cons
 
     std::vector<Status> results(n);
     std::vector<const ImageData *> got(n, nullptr);
-    std::vector<uint32_t> spans(n, 0), group_spans(n, 0);
+    std::vector<uint32_t> spans(n, 0);
+    std::vector<CoopSpans> group_spans(n);
     std::vector<uint64_t> alg(n, 0);
     std::atomic<int> hip_error{int(hipSuccess)};
     unsigned nthreads = threads > 0 ? unsigned(threads) : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
@@ -1099,8 +1120,8 @@ Status compeg_batch::upload_host(size_t n, int threads, const void *items_, cons
             d.out_pitch = img.width * 4;
             spans[i] = max_wave_span(starts_at, nstarts, nwords, img.metadata.total_restart_intervals);
             if (d.coop_ok)
-                group_spans[i] = max_wave_span(starts_at, nstarts, nwords, img.metadata.total_restart_intervals,
-                                               coop_shape(img.metadata.restart_interval, 4).ipw);
+                group_spans[i] = coop_spans_exact(starts_at, nstarts, nwords, img.metadata.total_restart_intervals,
+                                                  img.metadata.restart_interval);
             alg[i] = 4ull * nwords + 4ull * img.metadata.total_restart_intervals + COMPEG_METADATA_BYTES +
                      COMPEG_HUFFMAN_L1_BYTES + img.l2.size() * 2 + 4ull * img.width * img.height;
             // this image's part of the arena, as far as it is used
@@ -1138,11 +1159,11 @@ Status compeg_batch::upload_host(size_t n, int threads, const void *items_, cons
     }
     note_batch_properties(got.data(), n);
     coop_r = n ? got[0]->metadata.restart_interval : 0;
-    coop_span = 0;
+    coop_spans = CoopSpans{};
     for (size_t i = 0; i < n; i++) {
         if (!descs[i].coop_ok || got[i]->metadata.restart_interval != coop_r)
             coop_r = 0;
-        coop_span = std::max(coop_span, group_spans[i]);
+        coop_spans_max(coop_spans, group_spans[i]);
     }
     count = n;
     CG_TRY(make_walk_tables(st));
@@ -1357,15 +1378,14 @@ Status compeg_batch::upload_device_scan(const ImageData *const *images, size_t n
         max_span = std::max(max_span, span);
         if (i == 0) {
             coop_r = img.metadata.restart_interval;
-            coop_span = 0;
+            coop_spans = CoopSpans{};
         }
         if (!d.coop_ok || img.metadata.restart_interval != coop_r) {
             coop_r = 0;
         } else {
             // (the kernels report the span of 64 intervals only: four times the average for a wave's group;
             // a group that is longer than that still decodes, its intervals one lane each)
-            const uint32_t ipw = coop_shape(coop_r, 4).ipw;
-            coop_span = std::max(coop_span, coop_span_estimate(span, ipw));
+            coop_spans_max(coop_spans, coop_spans_estimate(span, coop_r));
         }
         algorithmic_bytes += 4ull * nwords + 4ull * expected + COMPEG_METADATA_BYTES +
                              COMPEG_HUFFMAN_L1_BYTES + img.l2.size() * 2 + 4ull * img.width * img.height;
@@ -1444,7 +1464,7 @@ Status compeg_batch::decode(hipStream_t stream)
         if (fused) {
             CoopPlan coop{};
             if (coop_r && use_coop_kernel(max_intervals, m, coop_r))
-                coop = plan_coop(max_intervals, m, coop_r, max_l2, coop_span);
+                coop = plan_coop(max_intervals, m, coop_r, max_l2, coop_spans);
             if (coop.usable)
                 CG_HIP(launch_coop_422(dd + at, m, max_intervals, coop, stream));
             else if (use_pair_kernel(max_intervals, m))

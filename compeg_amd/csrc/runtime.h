@@ -25,7 +25,9 @@ Status hip_status(hipError_t e, const char *what);
 bool use_fused_pipeline();
 bool use_pair_kernel(uint32_t max_intervals, uint32_t images);
 bool use_coop_kernel(uint32_t max_intervals, uint32_t images, uint32_t restart_interval);
-uint32_t coop_span_estimate(uint32_t span_of_64, uint32_t intervals_per_group);
+CoopSpans coop_spans_exact(const uint32_t *starts, size_t nstarts, size_t nwords, uint32_t intervals, uint32_t restart_interval);
+CoopSpans coop_spans_estimate(uint32_t span_of_64, uint32_t restart_interval);
+void coop_spans_max(CoopSpans &into, const CoopSpans &other);
 
 // Grow-only device allocation; contents are not preserved across growth
 // (every user rewrites the buffer in full before reading it).
@@ -138,7 +140,8 @@ struct compeg_batch {
     bool uniform = false; // same interval count and LUT bytes in every image (set by upload)
     // cooperative kernel: the restart interval all images share if every one of them qualifies (else 0), and the
     // largest word span of a wave's group of intervals
-    uint32_t coop_r = 0, coop_span = 0;
+    uint32_t coop_r = 0;
+    compeg::CoopSpans coop_spans{};
     uint32_t max_out_w = 0, max_out_h = 0;
     uint64_t algorithmic_bytes = 0, pixels = 0;
     uint32_t chunk = 0; // images per launch pair, 0 = all

@@ -123,7 +123,7 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
                 quant[(t / kRetained) * kCoopQuantStride + t % kRetained] = d.quant[t / kRetained][t % kRetained];
             CoopGeom g;
             const bool with_walk_tables = waves >= 4 && !(getenv("EMUL_COOP_LEAN") && atoi(getenv("EMUL_COOP_LEAN")) == 0);
-            coop_geom(d, wave, g, getenv("EMUL_COOP_SPEC_SHIFT") ? uint32_t(atoi(getenv("EMUL_COOP_SPEC_SHIFT"))) : (with_walk_tables && d.restart_interval <= 4u ? 31u : 0u), waves);
+            coop_geom(d, wave, g, getenv("EMUL_COOP_SPEC_SHIFT") ? uint32_t(atoi(getenv("EMUL_COOP_SPEC_SHIFT"))) : (with_walk_tables && d.restart_interval <= kCoopLeanMaxRestart ? 31u : 0u), waves);
             uint32_t wb = 0, wl = 0;
             coop_window(d, g, window_words, wb, wl);
             for (uint32_t i = 0; i < wl; i++)

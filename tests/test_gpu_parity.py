@@ -74,6 +74,7 @@ def test_reference_mjpeg_fixture(ca, gpu):
     jpeg = read_golden("parser", "mjpeg.jpg")
     dec, data, got = _decode(ca, gpu, jpeg)
     assert data.parallelism() == 540
+    assert dec.last_kernel() == "coop_team"   # (10 MCUs per interval: six whole intervals per team)
     _assert_equal(got, orc.ImageData(jpeg).decode())
     assert hashlib.sha256(got.tobytes()).hexdigest() == \
         "502b1b9c9a0401b20a04c3220710ae6c6c8a1068719a58018739b258602f9905"
@@ -593,6 +594,101 @@ def test_corrupt_streams_and_hostile_tables_on_the_gpu(ca, gpu):
         _assert_equal(batch.read_output(i), variants[i % len(variants)][1])
 
 
+# Restart intervals the cooperative kernel's teams handle differently (device_types.h: coop_shape): a lane per
+# interval through the walk tables (1..4; 4 with the decoding under the walk), speculative walks with whole
+# intervals laid end to end in the team's four rounds (5..64: intervals straddle rounds unless 4 * DRI divides 64),
+# one interval per team in more than four rounds and longer lists (65..256); 60 / 120 / 240: one interval per MCU
+# row of 960 / 1920 / 3840 pixels.
+COOP_DRIS = [1, 2, 3, 4, 5, 6, 7, 8, 10, 16, 17, 30, 60, 64, 65, 120, 240, 256]
+
+
+@pytest.mark.parametrize("ri", COOP_DRIS)
+def test_cooperative_kernel_takes_any_restart_interval(ca, gpu, ri):
+    """Single frames of every kind of restart interval go to decode_coop_team_422_kernel (asserted through
+    compeg_decoder_last_kernel) and come out bit-exact: smooth content, and busy content with long zero runs
+    (ZRL, quirk Q2: some intervals run over their end) -- host preprocessing, device preprocessing (window sized from
+    an estimate) and as a one-image batch.  ref: src/huffman.wgsl:118-204 loops over any restart_interval."""
+    for (w, h, kind, q, seed) in ((960, 720, 0, 85, 300 + ri), (640, 360, 1, 60, 400 + ri)):
+        jpeg = synth.make_jpeg(w, h, seed=seed, kind=kind, quality=q, ri=ri)
+        want = orc.ImageData(jpeg).decode()
+        for device in (False, True):
+            dec = ca.Decoder(gpu)
+            dec.set_device_preprocess(device)
+            data = ca.ImageData(jpeg)
+            dec.decode_blocking(data)
+            # (the busy frame's window from the device path's estimate may exceed what a team can have: other kernels then)
+            assert dec.last_kernel() == "coop_team" or (kind == 1 and device), (ri, w, h, device, dec.last_kernel())
+            _assert_equal(dec.read_texture(w, h), want)
+        batch = ca.Batch(gpu)
+        batch.upload([ca.ImageData(jpeg)])
+        batch.decode()
+        batch.wait()
+        assert batch.last_kernel() == "coop_team"
+        _assert_equal(batch.read_output(0), want)
+
+
+@pytest.mark.parametrize("ri", [4, 10])
+def test_cooperative_kernel_launch_size_boundary(ca, gpu, ri):
+    """The dispatch boundary: launches of up to 2 x 1024 x 256 data units are the cooperative kernel's -- two 4K
+    frames (518 400 data units) are, three are not -- and either side of it is bit-exact; so are launches in which a
+    workgroup holds one, two and four teams (small, medium, full launches) and the last team of an image is short."""
+    jpegs = [synth.make_jpeg(3840, 2160, seed=500 + i, quality=85, ri=ri) for i in range(3)]
+    wants = [orc.ImageData(j).decode() for j in jpegs]
+    for n, kernel in ((1, "coop_team"), (2, "coop_team"), (3, "pair")):
+        batch = ca.Batch(gpu)
+        batch.upload([ca.ImageData(j) for j in jpegs[:n]])
+        batch.decode()
+        batch.wait()
+        assert batch.last_kernel() == kernel, (n, batch.last_kernel())
+        for i in range(n):
+            _assert_equal(batch.read_output(i), wants[i])
+    # chunked: launches of two frames and a last one of one, all cooperative (walk tables made for the chunk size)
+    batch = ca.Batch(gpu)
+    batch.upload([ca.ImageData(j) for j in jpegs])
+    batch.set_chunk(2)
+    batch.decode()
+    batch.wait()
+    assert batch.last_kernel() == "coop_team"
+    for i in range(3):
+        _assert_equal(batch.read_output(i), wants[i])
+    small = synth.make_jpeg(250, 70, seed=77, quality=85, ri=ri)   # ragged, 32 / 4 or 10 intervals: one short team
+    want_small = orc.ImageData(small).decode()
+    for n in (1, 7, 40):
+        batch = ca.Batch(gpu)
+        batch.upload([ca.ImageData(small)] * n)
+        batch.decode()
+        batch.wait()
+        assert batch.last_kernel() == "coop_team"
+        for i in (0, n - 1):
+            _assert_equal(batch.read_output(i), want_small)
+
+
+def _with_noise_patch(w, h, seed, x0, y0, pw, ph):
+    rgb = synth.fill(w, h, seed=seed, kind=0).copy()
+    rng = np.random.default_rng(seed)
+    rgb[y0:y0 + ph, x0:x0 + pw] = rng.integers(0, 256, (ph, pw, 3), dtype=np.uint8)
+    return rgb
+
+
+@pytest.mark.parametrize("ri", [4, 10, 30])
+def test_cooperative_kernel_window_estimate_too_small(ca, gpu, ri):
+    """Device preprocessing knows the largest span of 64 consecutive intervals only; a team's window is sized from
+    its share of that.  A frame whose entropy sits in one small patch makes that estimate too small for the teams
+    of the patch: their walks leave the window and the intervals go to the serial decoder inside the same kernel
+    -- bit-exact all the same.  (With host preprocessing the spans are known exactly.)"""
+    w, h = 1920, 360
+    jpeg = synth.encode(_with_noise_patch(w, h, 900 + ri, 256, 64, 16 * ri, 24), quality=90, ri=ri)
+    want = orc.ImageData(jpeg).decode()
+    for device in (True, False):
+        dec = ca.Decoder(gpu)
+        dec.set_device_preprocess(device)
+        data = ca.ImageData(jpeg)
+        dec.decode_blocking(data)
+        if device:
+            assert dec.last_kernel() == "coop_team"
+        _assert_equal(dec.read_texture(w, h), want)
+
+
 def test_large_frames_clean_and_corrupt(ca, gpu):
     """A short seed of tools/fuzz_gpu_big.py: 720p to 4K+ frames, random quality / restart interval / content, bit
     flips in every other scan, both entropy modes, host and device preprocessing.  (Its first run found a lost
@@ -600,6 +696,9 @@ def test_large_frames_clean_and_corrupt(ca, gpu):
     from tools import fuzz_gpu_big
     n, bad = fuzz_gpu_big.run(seed=20261004, iters=20, log=lambda *a, **k: None)
     assert n >= 30 and bad == 0
+    # ... and with the restart intervals of webcams and row-per-interval encoders
+    n, bad = fuzz_gpu_big.run(seed=20261005, iters=12, log=lambda *a, **k: None, dris=(10, 30, 60, 120, 240, 7))
+    assert n >= 18 and bad == 0
 
 
 def test_walk_tables_follow_the_huffman_tables(ca, gpu):

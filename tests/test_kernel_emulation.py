@@ -32,7 +32,8 @@ def _run(runner, tmp_path, jpeg, fused, waves=1, window=2048, l2=12288, standard
     env = dict(os.environ)
     env.pop("EMUL_FUSED", None)
     env.pop("EMUL_STANDARD", None)
-    # 4: the team form's walk (sixteen intervals of DRI = 4 per walk, through the walk tables), 1: the one-wave form's
+    # a walk covers the whole restart intervals of 4 x 64 data units (a team; small intervals through the walk tables),
+    # of 2 x 64 (dense streams) or of 64 (also: a lone wave's geometry, every interval walked speculatively)
     env["EMUL_COOP_PASSES"] = str(coop_passes)
     if standard:
         env["EMUL_STANDARD"] = "1"
@@ -42,7 +43,7 @@ def _run(runner, tmp_path, jpeg, fused, waves=1, window=2048, l2=12288, standard
     r = subprocess.run([runner, str(p), str(tmp_path / "rgba"), str(tmp_path / "ac"), str(tmp_path / "dc"),
                         str(waves), str(window), str(l2)], capture_output=True, text=True, env=env, timeout=600)
     if fused == 5 and "does not qualify for the cooperative kernel" in r.stdout:
-        return None   # (no restart interval of 1..16 MCUs, or tables the direct tables cannot hold)
+        return None   # (no restart interval of 1..256 MCUs, or tables the direct tables cannot hold)
     assert r.returncode == 0, r.stdout + r.stderr[-2000:]
     _, w, h, _ = r.stdout.split()
     for line in r.stderr.splitlines():
@@ -61,7 +62,7 @@ def _check(runner, tmp_path, jpeg, **kw):
     # the cooperative kernel, with the window the runtime would plan and with the test's (possibly cut short: the
     # walks that leave it hand their interval to the serial decoder)
     for window in sorted({0, kw.get("window", 0)}):
-        for passes in (4, 1):
+        for passes in (4, 2, 1):
             got = _run(runner, tmp_path, jpeg, 5, window=window, coop_passes=passes)
             if got is not None:
                 assert np.array_equal(got, want), (f"cooperative kernel, window {window}, {passes} round(s) per walk: "
@@ -77,6 +78,37 @@ CASES = [
 @pytest.mark.parametrize("w,h,kind,q,ri,seed", CASES)
 def test_emulated_kernels_match_oracle(runner, tmp_path, w, h, kind, q, ri, seed):
     _check(runner, tmp_path, synth.make_jpeg(w, h, seed=seed, kind=kind, quality=q, ri=ri))
+
+
+# (device_types.h: coop_shape) a lane per interval through the walk tables up to 40 MCUs; whole intervals laid end to
+# end in the rounds, straddling them unless 4 * DRI divides 64; speculative walks beyond 40; one interval per team in
+# more than four rounds, lists in their own area, beyond 64
+@pytest.mark.parametrize("ri", [3, 5, 6, 7, 10, 13, 16, 17, 30, 40, 41, 60, 64, 65, 100, 120, 240, 256])
+def test_emulated_cooperative_kernel_any_restart_interval(runner, tmp_path, ri):
+    for (w, h, kind, q, seed) in [(320, 64, 0, 85, 1), (256, 48, 1, 95, 2)] + ([(960, 96, 0, 85, 3)] if ri > 60 else []):
+        jpeg = synth.make_jpeg(w, h, seed=seed + ri, kind=kind, quality=q, ri=ri)
+        want = orc.ImageData(jpeg).decode()
+        for passes in (4, 2, 1):
+            for window in (0, 200):   # as planned; cut short (walks leave it: the serial decoder inside the kernel)
+                got = _run(runner, tmp_path, jpeg, 5, window=window, coop_passes=passes)
+                assert got is not None
+                assert np.array_equal(got, want), (ri, w, h, passes, window, int((got != want).any(axis=2).sum()))
+    # corrupt streams at this restart interval
+    rng = np.random.default_rng(ri)
+    base = synth.make_jpeg(320, 64, seed=9, kind=0, quality=80, ri=ri)
+    scan_at = base.find(b"\xff\xda") + 14
+    for it in range(3):
+        j = bytearray(base)
+        for _ in range(int(rng.integers(1, 12))):
+            pos = int(rng.integers(scan_at, len(j) - 2))
+            if j[pos] != 0xFF and j[pos - 1] != 0xFF:
+                j[pos] ^= 1 << int(rng.integers(0, 8))
+                if j[pos] == 0xFF:
+                    j[pos] = 0xFE
+        want = orc.ImageData(bytes(j)).decode()
+        for passes in (4, 1):
+            got = _run(runner, tmp_path, bytes(j), 5, window=0, coop_passes=passes)
+            assert got is not None and np.array_equal(got, want), (ri, it, passes)
 
 
 @pytest.mark.parametrize("waves,window,l2", [(4, 64, 512), (2, 80, 0), (1, 4, 0), (3, 300, 1024), (2, 2048, 3000),
@@ -205,7 +237,7 @@ def test_emulated_standard_entropy_extension(runner, tmp_path):
         for fused in (1, 2, 3, 0, 5, 54):
             got = _run(runner, tmp_path, jpeg, fused % 10, window=window, standard=True, coop_passes=4 if fused == 54 else 1)
             if got is None:
-                continue   # (the cooperative kernel takes restart intervals of 1, 2, 4, 8, 16 MCUs)
+                continue   # (tables the direct tables cannot hold)
             assert np.array_equal(got, want), f"fused={fused} {w}x{h}: {(got != want).any(axis=2).sum()} pixels differ"
 
 

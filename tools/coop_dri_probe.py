@@ -32,5 +32,9 @@ for ri in dris:
         n, total, _, _ = b.timing(reset=True)
         ts.append(total * 1000.0)
     okb = np.array_equal(b.read_output(0), want)
-    print(f"{wh} dri {ri:4d} intervals {data.parallelism():6d} kernel {dec.last_kernel():9s}/{b.last_kernel():9s} "
+    try:
+        kernels = f"{dec.last_kernel():9s}/{b.last_kernel():9s}"
+    except AttributeError:   # (an older build of the library, COMPEG_LIB=...)
+        kernels = "?"
+    print(f"{wh} dri {ri:4d} intervals {data.parallelism():6d} kernel {kernels} "
           f"{'OK ' if ok and okb else 'BAD'} median {np.median(ts):7.1f} us  min {min(ts):7.1f} us", flush=True)

@@ -38,6 +38,8 @@ def run(seed=4321, iters=200, budget_s=None, log=print):
         kind = int(rng.integers(0, 3))
         q = int(rng.choice([30, 60, 85, 95, 100]))
         ri = int(rng.integers(0, 9))
+        if it % 3 == 2:                         # every restart interval is somebody's: longer ones, odd ones
+            ri = int(rng.choice([10, 12, 16, 17, 30, 40, 41, 60, 64, 65, 120, 240]))
         ext = it % 4 == 3
         sampling = [(2, 1), (1, 1), (1, 2), (2, 2)][int(rng.integers(0, 4))] if ext else (2, 1)
         std = bool(it % 2)

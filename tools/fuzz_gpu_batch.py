@@ -28,7 +28,7 @@ def run(seed=77, batches=40, log=print):
         count = int(rng.integers(1, 7))
         same = bool(rng.integers(0, 2))
         w0, h0 = SIZES[int(rng.integers(0, len(SIZES)))]
-        ri0 = int(rng.choice([1, 2, 4, 4, 8, 16, 3]))
+        ri0 = int(rng.choice([1, 2, 4, 4, 8, 16, 3, 10, 30, 7, 120]))
         items = []
         for i in range(count):
             w, h = (w0, h0) if same else SIZES[int(rng.integers(0, len(SIZES)))]
