@@ -177,7 +177,58 @@ def bench_scan_dat(compeg_amd, gpu, frame_jpeg, frame_pixels):
     return out
 
 
-def bench_config(compeg_amd, gpu, width, height, ri, quality, batch, steps, warmup, threads, distinct, label):
+def single_frame_kernel_us(compeg_amd, gpu, jpeg, reps=30):
+    """Kernel time of one frame alone on the card (one-image batch, HIP events on the decode stream: median), which
+    kernel took it, and whether the output equals the oracle's."""
+    import statistics
+
+    import numpy as np
+    from oracle import oracle as orc
+
+    b = compeg_amd.Batch(gpu)
+    b.upload([compeg_amd.ImageData(jpeg, copy=False)], host_threads=1)
+    for _ in range(5):
+        b.decode()
+    b.wait()
+    b.timing(reset=True)
+    ts = []
+    for _ in range(reps):
+        b.decode()
+        b.wait()
+        ts.append(b.timing(reset=True)[1] * 1e3)
+    ok = bool(np.array_equal(b.read_output(0), orc.ImageData(jpeg).decode()))
+    if not ok:
+        raise SystemExit("bench: single frame differs from the oracle")
+    alg = b.algorithmic_bytes()
+    us = statistics.median(ts)
+    return {"kernel": b.last_kernel(), "kernel_us": round(us, 2), "min_us": round(min(ts), 2),
+            "roofline": {"bound": "hbm", "achieved": round(alg / (us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": alg},
+            "verified_bit_exact_vs_oracle": ok}
+
+
+def bench_mjpeg_stream(compeg_amd, gpu, quality, steps, warmup, threads):
+    """The reference's real-world input (src/file/test-images/mjpeg.jpg, the webcam MJPEG frames its viewer consumes:
+    960x720, DRI = 10, Annex-K tables without DHT) as a bench row: the fixture itself and a synthetic frame of the
+    same format as single frames, a DRI = 4 frame of the same size beside them, and a 256-frame batch."""
+    from tools import synth
+
+    out = {"workload": "960x720 YUV 4:2:2 baseline JPEG, DRI=10, no DHT (webcam MJPEG stream)"}
+    fixture = os.path.join(ROOT, "tests", "golden", "parser", "mjpeg.jpg")
+    if os.path.exists(fixture):
+        out["reference_fixture_mjpeg_jpg"] = single_frame_kernel_us(compeg_amd, gpu, open(fixture, "rb").read())
+    out["single_frame_dri10"] = single_frame_kernel_us(
+        compeg_amd, gpu, synth.make_jpeg(960, 720, seed=0xC0FFEE, quality=quality, ri=10, flags=synth.NO_DHT))
+    out["single_frame_dri4_same_size"] = single_frame_kernel_us(
+        compeg_amd, gpu, synth.make_jpeg(960, 720, seed=0xC0FFEE, quality=quality, ri=4, flags=synth.NO_DHT))
+    out["dri10_over_dri4"] = round(out["single_frame_dri10"]["kernel_us"] / out["single_frame_dri4_same_size"]["kernel_us"], 3)
+    out["batch_256"] = bench_config(compeg_amd, gpu, 960, 720, 10, quality, 256, steps, warmup, threads, 64,
+                                    "256 x 960x720 YUV 4:2:2 baseline JPEG, DRI=10, no DHT, 64 distinct frames",
+                                    flags=synth.NO_DHT)
+    return out
+
+
+def bench_config(compeg_amd, gpu, width, height, ri, quality, batch, steps, warmup, threads, distinct, label, flags=0):
     """One more single-GPU configuration of BASELINE.json, measured like the headline one: resident inputs, `steps`
     timed decodes of the whole batch, kernel time from the batch's HIP events, a spread of slots verified."""
     import numpy as np
@@ -185,7 +236,7 @@ def bench_config(compeg_amd, gpu, width, height, ri, quality, batch, steps, warm
     from tools import synth
 
     def one(i):
-        return synth.make_jpeg(width, height, seed=0xC0FFEE + i, kind=0, quality=quality, ri=ri)
+        return synth.make_jpeg(width, height, seed=0xC0FFEE + i, kind=0, quality=quality, ri=ri, flags=flags)
 
     with ThreadPoolExecutor(threads) as ex:
         jpegs = list(ex.map(one, range(distinct)))
@@ -217,7 +268,7 @@ def bench_config(compeg_amd, gpu, width, height, ri, quality, batch, steps, warm
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": alg,
                          "kernel_ms": round(kernel_ms, 4)},
-            "verified_bit_exact_vs_oracle": ok, "verified_slots": slots}
+            "kernel": b.last_kernel(), "verified_bit_exact_vs_oracle": ok, "verified_slots": slots}
 
 
 PCIE_LINK_GBS = 63.0  # MI355X_MICROARCH.md: host link PCIe Gen5 x16, 63 GB/s (spec)
@@ -442,7 +493,7 @@ def main():
         for _ in range(20):
             compeg_amd.ImageData(jpegs[0], copy=False, allow_sampling=ext)
         t_parse = (time.perf_counter() - t_parse) / 20 * 1e3
-        single = {"frames": 1, "device_ms_per_frame": round(dev_wall, 4),
+        single = {"frames": 1, "kernel": one.last_kernel(), "device_ms_per_frame": round(dev_wall, 4),
                   "kernel_ms": round(tot1 / n1, 4),
                   "device_mpix_s": round(one.pixels() / dev_wall / 1e3, 1),
                   "host_end_to_end_ms": round(e2e, 3),
@@ -474,19 +525,24 @@ def main():
         extra["configs[4] 8K DRI=1"] = bench_config(
             compeg_amd, gpu, 7680, 4320, 1, args.quality, 8, args.steps, args.warmup, threads, 4,
             "8 x 7680x4320 YUV 4:2:2 baseline JPEG, DRI=1 per step (BASELINE configs[4] frame), 4 distinct frames")
+        extra["mjpeg stream 960x720 DRI=10"] = bench_mjpeg_stream(compeg_amd, gpu, args.quality, args.steps, args.warmup, threads)
 
     if rank == 0:
         total_pixels = pixels * world * args.steps
         ms_per_step = elapsed / args.steps * 1e3
         huff_ms, idct_ms = ev_huff_ms / max(n_timed, 1), ev_idct_ms / max(n_timed, 1)
-        fused = os.environ.get("COMPEG_PIPELINE", "fused") != "split"
+        which = batch.last_kernel()   # (compeg_batch_last_kernel: where the dispatch sent the timed launches)
+        fused = which not in ("split", "generic")
         if fused:
             # one kernel does the whole path; the event pair brackets exactly its launches
-            kernels_ms = {"decode_fused_422_kernel": round(ev_total_ms / max(n_timed, 1), 4)}
-            dominant = ("decode_fused_422_kernel", ev_total_ms / max(n_timed, 1))
+            name = {"fused": "decode_fused_422_kernel", "pair": "decode_pair_422_kernel",
+                    "coop_team": "decode_coop_team_422_kernel"}[which]
+            kernels_ms = {name: round(ev_total_ms / max(n_timed, 1), 4)}
+            dominant = (name, ev_total_ms / max(n_timed, 1))
         else:
-            kernels_ms = {"huffman_kernel": round(huff_ms, 4), "idct_composite_kernel": round(idct_ms, 4)}
-            dominant = ("huffman_kernel", huff_ms) if huff_ms >= idct_ms else ("idct_composite_kernel", idct_ms)
+            first, second = ("entropy_kernel", "idct_composite_kernel") if which == "split" else ("entropy_samples_kernel", "composite_generic_kernel")
+            kernels_ms = {first: round(huff_ms, 4), second: round(idct_ms, 4)}
+            dominant = (first, huff_ms) if huff_ms >= idct_ms else (second, idct_ms)
         achieved = alg_bytes / (dominant[1] * 1e-3) / 1e9 if dominant[1] > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")

@@ -683,7 +683,7 @@ int compeg_batch_set_chunk(compeg_batch *batch, uint32_t images_per_launch)
             return fail(COMPEG_E_HIP, "hipStreamSynchronize failed");
         if (hipSetDevice(batch->gpu->device) != hipSuccess)
             return fail(COMPEG_E_HIP, "hipSetDevice failed");
-        compeg::Status st = batch->make_walk_tables(batch->gpu->stream);
+        compeg::Status st = batch->make_walk_tables(batch->gpu->stream, batch->count);
         if (!st.ok())
             return fail(st);
         if (hipStreamSynchronize(batch->gpu->stream) != hipSuccess)

@@ -26,11 +26,38 @@
 #include "kernels_body.h"
 #include "coop_body.h"
 #include "kernels.h"
+#include "lab.h"
 
 namespace compeg {
 
-constexpr uint32_t kLdsBytesPerCu = 160u * 1024u;
-constexpr uint32_t kCuCount = 256;
+// What the planners size workgroups and grids for: the compute units and the LDS per compute unit of the device the
+// calling thread has current (256 and 160 KB on an MI355X in its default mode; fewer CUs in a partitioned mode), asked
+// once per device.  (A failed query -- nothing else would work either -- leaves the figures of the one architecture
+// the library opens a device of: compeg_gpu_open refuses anything but gfx950.)
+struct DeviceLimits {
+    uint32_t cus, lds_bytes;
+};
+static DeviceLimits device_limits()
+{
+    static std::atomic<uint64_t> known[64]; // cus << 32 | lds_bytes
+    int dev = 0;
+    const bool indexed = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
+    if (indexed) {
+        const uint64_t k = known[dev].load(std::memory_order_relaxed);
+        if (k)
+            return DeviceLimits{uint32_t(k >> 32), uint32_t(k)};
+    }
+    int cus = 0, lds = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        cus = 256;
+    if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) != hipSuccess || lds < 64 * 1024)
+        lds = 160 * 1024;
+    if (indexed)
+        known[dev].store(uint64_t(cus) << 32 | uint32_t(lds), std::memory_order_relaxed);
+    if (getenv("COMPEG_VERBOSE"))
+        fprintf(stderr, "[compeg] device %d: %d compute units, %d bytes of LDS each\n", dev, cus, lds);
+    return DeviceLimits{uint32_t(cus), uint32_t(lds)};
+}
 
 // LDS layout (dynamic, 16-byte aligned carve-outs):
 //   [L1: 5*256 u16][L2: l2_in_lds u16][per wave: window_words u32 | 64 DU slots]
@@ -462,7 +489,7 @@ HuffLdsPlan plan_huffman(uint32_t max_intervals, uint32_t images, uint32_t max_l
         w = 256u;
     if (w > 6144u)
         w = 6144u;
-    if (const char *e = getenv("COMPEG_WINDOW_CAP")) // experiment knob (words)
+    if (const char *e = lab_env("COMPEG_WINDOW_CAP")) // experiment knob (words)
         w = w < uint32_t(atoi(e)) ? w : uint32_t(atoi(e));
     p.window_words = (w + 3u) & ~3u;
     const uint32_t wave_area = ((p.window_words * 4u + 15u) & ~15u) + slots;
@@ -471,15 +498,17 @@ HuffLdsPlan plan_huffman(uint32_t max_intervals, uint32_t images, uint32_t max_l
     // launch that fits the chip runs in one round with one workgroup per CU (one 4K frame with DRI=4 is 254
     // waves: one wave per workgroup, a CU each); at most what the LDS holds and 12 (3 per SIMD) -- a launch
     // that oversubscribes the chip fills every CU with one such workgroup at a time.
+    const DeviceLimits lim = device_limits();
+    const uint32_t lds_per_cu = lim.lds_bytes, cu_count = lim.cus;
     const uint64_t total_waves = uint64_t((max_intervals + kWave - 1) / kWave) * images;
-    const uint32_t fit = (kLdsBytesPerCu - tables) / wave_area;
+    const uint32_t fit = (lds_per_cu - tables) / wave_area;
     const uint32_t most = std::max(1u, std::min(fit, fused ? kMaxWavesFused : kMaxWavesSplit));
-    const uint64_t per_cu = (total_waves + 255u) / 256u;
+    const uint64_t per_cu = (total_waves + cu_count - 1u) / cu_count;
     uint32_t wpb = uint32_t(std::min<uint64_t>(std::max<uint64_t>(per_cu, 1u), most));
     // (every image rounds up to whole workgroups: a few more waves per workgroup can save a second round)
     auto groups = [&](uint32_t w) { return uint64_t((max_intervals + w * kWave - 1) / (w * kWave)) * images; };
     auto groups_per_cu = [&](uint32_t w) {
-        return std::max(1u, std::min(kLdsBytesPerCu / (tables + w * wave_area), most / w));
+        return std::max(1u, std::min(lds_per_cu / (tables + w * wave_area), most / w));
     };
     uint64_t rounds = 1;
     if (per_cu > most) {
@@ -489,13 +518,13 @@ HuffLdsPlan plan_huffman(uint32_t max_intervals, uint32_t images, uint32_t max_l
         if (rounds <= 3)
             wpb = uint32_t(std::min<uint64_t>((per_cu + rounds - 1) / rounds, most));
     }
-    while (wpb < most && groups(wpb) > 256u * rounds * groups_per_cu(wpb))
+    while (wpb < most && groups(wpb) > uint64_t(cu_count) * rounds * groups_per_cu(wpb))
         wpb++;
-    if (const char *e = getenv("COMPEG_WPB")) // experiment knob
+    if (const char *e = lab_env("COMPEG_WPB")) // experiment knob
         wpb = uint32_t(atoi(e));
     p.waves_per_block = wpb;
     p.total_bytes = tables + p.waves_per_block * wave_area;
-    if (const char *e = getenv("COMPEG_LDS_PAD")) // experiment knob: lowers occupancy
+    if (const char *e = lab_env("COMPEG_LDS_PAD")) // experiment knob: lowers occupancy
         p.total_bytes += uint32_t(atoi(e));
     if (getenv("COMPEG_VERBOSE"))
         fprintf(stderr, "[compeg] plan: images=%u intervals=%u waves/block=%u window=%u words l2=%u lds=%u B\n",
@@ -512,7 +541,7 @@ hipError_t launch_huffman(const ImageDesc *descs, uint32_t images, uint32_t max_
     dim3 grid((max_intervals + threads - 1) / threads, images, 1);
     static const hipError_t attr = hipFuncSetAttribute(
         reinterpret_cast<const void *>(huffman_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-        int(kLdsBytesPerCu));
+        int(device_limits().lds_bytes));
     if (attr != hipSuccess)
         return attr;
     hipLaunchKernelGGL(huffman_kernel, grid, dim3(threads), plan.total_bytes, stream, descs,
@@ -529,7 +558,7 @@ hipError_t launch_entropy(const ImageDesc *descs, uint32_t images, uint32_t max_
     dim3 grid((max_intervals + threads - 1) / threads, images, 1);
     static const hipError_t attr = hipFuncSetAttribute(
         reinterpret_cast<const void *>(entropy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-        int(kLdsBytesPerCu));
+        int(device_limits().lds_bytes));
     if (attr != hipSuccess)
         return attr;
     hipLaunchKernelGGL(entropy_kernel, grid, dim3(threads), plan.total_bytes, stream, descs,
@@ -545,7 +574,7 @@ hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t ma
     const uint32_t threads = plan.waves_per_block * kWave;
     // uniform: every image has max_intervals intervals and the same LUT bytes -> workgroups may span images
     static const bool flat_allowed = [] {
-        const char *e = getenv("COMPEG_FLAT"); // experiment knob: 0 = always one grid row per image
+        const char *e = lab_env("COMPEG_FLAT"); // experiment knob: 0 = always one grid row per image
         return e ? atoi(e) != 0 : true;
     }();
     const uint32_t waves_per_image = (uniform && flat_allowed) ? (max_intervals + kWave - 1) / kWave : 0u;
@@ -554,27 +583,20 @@ hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t ma
     if (waves_per_image && flat_groups <= 0x7fffffffu) {
         // at most as many workgroups as are resident at once; their waves loop over the rest (see the kernel)
         static const int resident_cap = [] {
-            const char *e = getenv("COMPEG_RESIDENT"); // experiment knob: 0 = a workgroup per 12 units as before, n > 1 = at most n workgroups (part of the chip)
+            const char *e = lab_env("COMPEG_RESIDENT"); // experiment knob: 0 = a workgroup per 12 units as before, n > 1 = at most n workgroups (part of the chip)
             return e ? atoi(e) : 1;
         }();
-        const uint32_t per_cu = std::max(1u, std::min(kLdsBytesPerCu / plan.total_bytes, kMaxWavesFused / plan.waves_per_block));
-        // (the CUs of the device the launch goes to: 256 on an MI355X, fewer in a partitioned mode; a wrong count
-        // costs time, not results -- the waves' stride is the grid's size whatever it is)
-        static std::atomic<int> known[64]; // (per device, asked once)
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
-            cus = int(kCuCount);
-        else if ((cus = known[dev].load(std::memory_order_relaxed)) == 0) {
-            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-                cus = int(kCuCount);
-            known[dev].store(cus, std::memory_order_relaxed);
-        }
+        // (the CUs of the device the launch goes to: a wrong count would cost time, not results -- the waves' stride
+        // is the grid's size whatever it is)
+        const DeviceLimits lim = device_limits();
+        const uint32_t per_cu = std::max(1u, std::min(lim.lds_bytes / plan.total_bytes, kMaxWavesFused / plan.waves_per_block));
+        const uint32_t cus = lim.cus;
         const uint64_t resident = uint64_t(cus) * per_cu;
         grid = dim3(uint32_t(resident_cap ? std::min(flat_groups, resident_cap > 1 ? uint64_t(resident_cap) : resident) : flat_groups), 1, 1);
     }
     static const hipError_t attr = hipFuncSetAttribute(
         reinterpret_cast<const void *>(decode_fused_422_kernel),
-        hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsBytesPerCu));
+        hipFuncAttributeMaxDynamicSharedMemorySize, int(device_limits().lds_bytes));
     if (attr != hipSuccess)
         return attr;
     hipLaunchKernelGGL(decode_fused_422_kernel, grid, dim3(threads), plan.total_bytes, stream, descs,
@@ -864,6 +886,8 @@ CoopPlan plan_coop(uint32_t max_intervals, uint32_t images, uint32_t restart_int
     p.group_waves = kCoopTeamWaves >> k;
     const uint32_t max_group_words = spans.words[k];
     const CoopShape sh = coop_shape(restart_interval, p.group_waves);
+    const DeviceLimits lim = device_limits();
+    const uint32_t lds_per_cu = lim.lds_bytes, cu_count = lim.cus;
     p.intervals_per_wave = sh.ipw;
     p.l2_entries_in_lds = (max_l2 + 2u * kDcFastEntries + 1u) & ~1u;
     uint32_t w = max_group_words + kDuWordSlack + 4u;
@@ -878,22 +902,22 @@ CoopPlan plan_coop(uint32_t max_intervals, uint32_t images, uint32_t restart_int
     // a little too large (it is an estimate where the scan was preprocessed on the device): down to three
     // quarters of it.  A team whose intervals do not fit its window still decodes -- the walks that leave it
     // hand their interval to the serial decoder.
-    if (all_teams > 3ull * kCuCount && tables + 4u * coop_team_area(p.window_words, sh) > kLdsBytesPerCu) {
-        const uint32_t room = (kLdsBytesPerCu - tables) / 4u, fixed = coop_team_area(0, sh);
+    if (all_teams > 3ull * cu_count && tables + 4u * coop_team_area(p.window_words, sh) > lds_per_cu) {
+        const uint32_t room = (lds_per_cu - tables) / 4u, fixed = coop_team_area(0, sh);
         const uint32_t fit = room > fixed ? ((room - fixed) / 4u) & ~3u : 0u;
         if (fit >= p.window_words - p.window_words / 4u)
             p.window_words = fit;
     }
     const uint32_t team_area = coop_team_area(p.window_words, sh);
     uint32_t teams = 4;
-    while (teams > 1 && tables + teams * team_area > kLdsBytesPerCu)
+    while (teams > 1 && tables + teams * team_area > lds_per_cu)
         teams--;
-    if (tables + teams * team_area > kLdsBytesPerCu)
+    if (tables + teams * team_area > lds_per_cu)
         return p;
     // one workgroup per CU while that covers the launch (a small launch spreads over the CUs; the teams of a
     // workgroup share one copy of the tables and the sixteen waves that stage it)
     const uint32_t fit = teams;
-    teams = all_teams <= kCuCount ? 1u : (all_teams <= 2ull * kCuCount ? 2u : 4u);
+    teams = all_teams <= cu_count ? 1u : (all_teams <= 2ull * cu_count ? 2u : 4u);
     teams = teams < fit ? teams : fit;
     p.waves_per_block = teams * kCoopTeamWaves;
     p.total_bytes = tables + teams * team_area;
@@ -911,18 +935,18 @@ hipError_t launch_coop_422(const ImageDesc *descs, uint32_t images, uint32_t max
     if (images == 0 || max_intervals == 0)
         return hipSuccess;
     static const uint32_t spec_shift = [] {
-        const char *e = getenv("COMPEG_COOP_SPEC_SHIFT"); // experiment knob: fewer speculative subsequences
+        const char *e = lab_env("COMPEG_COOP_SPEC_SHIFT"); // experiment knob: fewer speculative subsequences
         return e ? uint32_t(atoi(e)) : 0u;
     }();
     const uint32_t teams = plan.waves_per_block / kCoopTeamWaves, per_block = plan.intervals_per_wave * teams;
     dim3 grid((max_intervals + per_block - 1) / per_block, images, 1);
     static const hipError_t attr = hipFuncSetAttribute(
         reinterpret_cast<const void *>(decode_coop_team_422_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-        int(kLdsBytesPerCu));
+        int(device_limits().lds_bytes));
     if (attr != hipSuccess)
         return attr;
     static const uint32_t quarters_on = [] {
-        const char *e = getenv("COMPEG_COOP_QUARTERS"); // experiment knob: 0 = the decoding waits for the walk's end
+        const char *e = lab_env("COMPEG_COOP_QUARTERS"); // experiment knob: 0 = the decoding waits for the walk's end
         return e ? uint32_t(atoi(e) != 0) : 1u;
     }();
     hipLaunchKernelGGL(decode_coop_team_422_kernel, grid, dim3(1024), plan.total_bytes, stream, descs,
@@ -949,7 +973,7 @@ hipError_t launch_entropy_samples(const ImageDesc *descs, uint32_t images, uint3
     dim3 grid((max_intervals + threads - 1) / threads, images, 1);
     static const hipError_t attr = hipFuncSetAttribute(
         reinterpret_cast<const void *>(entropy_samples_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-        int(kLdsBytesPerCu));
+        int(device_limits().lds_bytes));
     if (attr != hipSuccess)
         return attr;
     hipLaunchKernelGGL(entropy_samples_kernel, grid, dim3(threads), plan.total_bytes, stream, descs,

@@ -63,9 +63,14 @@
 #ifndef CG_NT_STORES
 #define CG_NT_STORES 1 // the output is written once and not read back by the kernel: non-temporal stores
 #endif
+// Knock-out arms of the kernel bodies (3 = AC loop twice, 4 = no IDCT, 5 = no colour arithmetic, 9 = no global stores,
+// ...: what each phase costs inside the real mix) exist in lab builds only (lab.h: -DCOMPEG_LAB -DCG_EXP=n,
+// tools/build_variant.sh, tools/ab_bench.sh); the shipped library is compiled with every arm off.
+#if !defined(COMPEG_LAB)
+#undef CG_EXP
+#endif
 #ifndef CG_EXP
-#define CG_EXP 0 // diagnostic builds only (tools/build_variant.sh, tools/ab_bench.sh): 3 = AC loop twice,
-                 // 4 = no IDCT, 5 = no colour arithmetic -- what each phase costs inside the real mix
+#define CG_EXP 0
 #endif
 
 namespace compeg {

@@ -1,5 +1,6 @@
 // See runtime.h.
 #include "runtime.h"
+#include "lab.h"
 
 #include <hip/hip_runtime.h>
 
@@ -99,7 +100,7 @@ Status PinnedBuffer::reserve(size_t bytes)
 bool use_fused_pipeline()
 {
     static const bool fused = [] {
-        const char *e = getenv("COMPEG_PIPELINE");
+        const char *e = lab_env("COMPEG_PIPELINE");
         return !(e && strcmp(e, "split") == 0);
     }();
     return fused;
@@ -111,7 +112,7 @@ bool use_fused_pipeline()
 bool use_pair_kernel(uint32_t max_intervals, uint32_t images)
 {
     static const int forced = [] {
-        const char *e = getenv("COMPEG_PAIR"); // experiment knob: 0 / 1
+        const char *e = lab_env("COMPEG_PAIR"); // experiment knob: 0 / 1
         return e ? atoi(e) : -1;
     }();
     if (forced >= 0)
@@ -125,7 +126,7 @@ bool use_pair_kernel(uint32_t max_intervals, uint32_t images)
 bool use_coop_kernel(uint32_t max_intervals, uint32_t images, uint32_t restart_interval)
 {
     static const int forced = [] {
-        const char *e = getenv("COMPEG_COOP"); // experiment knob: 0 / 1
+        const char *e = lab_env("COMPEG_COOP"); // experiment knob: 0 / 1
         return e ? atoi(e) : -1;
     }();
     if (forced >= 0)
@@ -176,7 +177,7 @@ void coop_spans_max(CoopSpans &into, const CoopSpans &other)
 bool pull_copies()
 {
     static const bool pull = [] {
-        const char *e = getenv("COMPEG_PULL");
+        const char *e = lab_env("COMPEG_PULL");
         return e ? atoi(e) != 0 : true;
     }();
     return pull;
@@ -275,6 +276,13 @@ private:
     bool stop_ = false;
 };
 
+// (one pool for every kind of work: a local static of the template below would be a pool per instantiation)
+WorkerPool &worker_pool()
+{
+    static WorkerPool pool;
+    return pool;
+}
+
 // work(t) for t = 0 .. nthreads-1, t = 0 on the caller's thread
 template <typename Work>
 void run_on_threads(unsigned nthreads, Work &work)
@@ -283,7 +291,7 @@ void run_on_threads(unsigned nthreads, Work &work)
         work(0);
         return;
     }
-    static WorkerPool pool;
+    WorkerPool &pool = worker_pool();
     if (pool.run(nthreads, [](void *w, unsigned t) { (*static_cast<Work *>(w))(t); }, &work))
         return;
     std::vector<std::thread> own;
@@ -853,6 +861,7 @@ struct UploadItem {
     uint32_t intervals = 0, total_dus = 0;
     size_t tables_cap = 0, scan_cap = 0; // bytes of the LUT blob / of the entropy-coded segment, at most
     bool is422 = true;
+    bool covered = true; // every MCU of the image belongs to a restart interval (no truncated last interval, lib.rs:784-785)
 };
 
 UploadItem item_of(const ImageData &img)
@@ -865,6 +874,12 @@ UploadItem item_of(const ImageData &img)
     it.tables_cap = table_blob_bytes(img);
     it.scan_cap = img.scan_len;
     it.is422 = is_422(img);
+    {
+        const Metadata &md = img.metadata;
+        const uint32_t mw = md.max_hsample * 8u, mh = md.max_vsample * 8u;
+        const uint64_t mcus = (mw && mh) ? uint64_t((img.width + mw - 1) / mw) * ((img.height + mh - 1) / mh) : 0;
+        it.covered = uint64_t(md.total_restart_intervals) * md.restart_interval >= mcus;
+    }
     return it;
 }
 
@@ -924,6 +939,7 @@ bool peek_item(const uint8_t *j, size_t len, unsigned flags, UploadItem &it)
             it.intervals = uint32_t(mcus / r);
             it.total_dus = uint32_t(it.intervals * r * (hs * vs + 2));
             it.is422 = ok422;
+            it.covered = uint64_t(it.intervals) * r >= mcus;
             // five LUT sections at their largest: L1, an L2 LUT of 32767 entries, the direct tables
             it.tables_cap = COMPEG_HUFFMAN_L1_BYTES + 65536 + 2 * kFastEntries * 2 + 2 * kDcFastEntries * 2;
             it.scan_cap = len - (p + 2 + seg);
@@ -1019,7 +1035,7 @@ Status compeg_batch::upload_host(size_t n, int threads, const void *items_, cons
 
     const bool fused = use_fused_pipeline() && !any_generic;
     CG_TRY(inputs.reserve(in_total + 256));
-    const bool stamps = getenv("COMPEG_STAMPS") != nullptr; // diagnostic builds park cycle stamps in dc
+    const bool stamps = lab_env("COMPEG_STAMPS") != nullptr; // diagnostic builds park cycle stamps in dc
     if (!fused) { // the fused kernel keeps coefficients on chip
         CG_TRY(ac.reserve(ac_total + 256));
         CG_TRY(dc.reserve(dc_total + 256));
@@ -1029,16 +1045,15 @@ Status compeg_batch::upload_host(size_t n, int threads, const void *items_, cons
     bool fresh_out = false;
     CG_TRY(out.reserve(out_total + 256, &fresh_out));
     hipStream_t st = gpu->stream;
-    // Texels no MCU covers (a truncated last restart interval) read 0 in the reference's fresh texture: the
-    // output is cleared -- when it is new, or when this upload lays it out differently from the last one.  Frame
-    // after frame of one geometry (a stream) writes the same texels every time; nothing stale can show.
-    std::vector<uint64_t> layout(n);
+    // Texels no MCU covers (a truncated last restart interval) read 0 in the reference's fresh texture: the output is
+    // cleared when it is new, and whenever some image of the upload has such texels.  Where every MCU of every image
+    // is decoded -- frame after frame of a stream -- each upload writes all of its texels and nothing stale can show,
+    // whatever the uploads before it looked like.
+    bool all_covered = true;
     for (size_t i = 0; i < n; i++)
-        layout[i] = uint64_t(items[i].width) | uint64_t(items[i].height) << 16 |
-                    uint64_t(items[i].intervals & 0xffffu) << 32 | uint64_t(out_offset[i] >> 8) << 48;
-    if (fresh_out || layout != out_layout)
+        all_covered = all_covered && items[i].covered;
+    if (fresh_out || !all_covered)
         CG_HIP(hipMemsetAsync(out.ptr, 0, out.capacity, st)); // (the card does this while the host preprocesses)
-    out_layout.swap(layout);
     while (copy_streams.size() < 4) {
         hipStream_t c = nullptr;
         CG_HIP(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
@@ -1137,9 +1152,14 @@ Status compeg_batch::upload_host(size_t n, int threads, const void *items_, cons
     };
     run_on_threads(nthreads, work);
     mark("parse+preprocess+issue");
+    // (before any way out: copies in flight still read the pinned arena, which the next upload rewrites)
+    hipError_t copies = hipSuccess;
+    for (hipStream_t c : copy_streams) {
+        const hipError_t e = hipStreamSynchronize(c);
+        copies = copies == hipSuccess ? e : copies;
+    }
     CG_HIP(hipError_t(hip_error.load()));
-    for (hipStream_t c : copy_streams)
-        CG_HIP(hipStreamSynchronize(c));
+    CG_HIP(copies);
     mark("copies_done");
     max_intervals = max_dus = max_l2 = 0;
     algorithmic_bytes = pixels = 0;
@@ -1165,8 +1185,7 @@ Status compeg_batch::upload_host(size_t n, int threads, const void *items_, cons
             coop_r = 0;
         coop_spans_max(coop_spans, group_spans[i]);
     }
-    count = n;
-    CG_TRY(make_walk_tables(st));
+    CG_TRY(make_walk_tables(st, n)); // (the batch holds images only once all of this has succeeded: count stays 0 on a failure)
     CG_HIP(hipStreamSynchronize(st)); // descs (pageable) and the staging arena may be reused from here on
     mark("descs");
     if (trace_on)
@@ -1390,18 +1409,17 @@ Status compeg_batch::upload_device_scan(const ImageData *const *images, size_t n
         algorithmic_bytes += 4ull * nwords + 4ull * expected + COMPEG_METADATA_BYTES +
                              COMPEG_HUFFMAN_L1_BYTES + img.l2.size() * 2 + 4ull * img.width * img.height;
     }
-    count = n;
-    CG_TRY(make_walk_tables(gpu->stream));
+    CG_TRY(make_walk_tables(gpu->stream, n));
     CG_HIP(hipStreamSynchronize(gpu->stream));
+    count = n;
     decodes_timed = 0;
     return Status{};
 }
 
 // Uploads the descriptors; in front of that, gives every image its walk tables if the cooperative kernel may
 // decode this batch (uniform batches share one set), and makes them behind the upload.
-Status compeg_batch::make_walk_tables(hipStream_t stream)
+Status compeg_batch::make_walk_tables(hipStream_t stream, size_t n)
 {
-    const size_t n = count;
     // (whenever some launch of decode() may take the cooperative kernel: launches are `chunk` images, the last one
     // n % chunk -- the smallest of them decides, the kernel takes the small launches)
     const size_t step = chunk ? std::min<size_t>(chunk, n) : n;

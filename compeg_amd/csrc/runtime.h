@@ -131,7 +131,7 @@ struct compeg_batch {
     std::vector<compeg::ImageDesc> descs; // host copy (device pointers inside)
     compeg::DeviceBuffer dev_descs, inputs, ac, dc, out;
     compeg::DeviceBuffer walk_tables; // the cooperative kernel's (kernels.h), made at upload when it may run
-    compeg::Status make_walk_tables(hipStream_t stream); // (behind the descriptors' upload)
+    compeg::Status make_walk_tables(hipStream_t stream, size_t n); // (behind the descriptors' upload; n images)
     compeg::PinnedBuffer stage; // host copy of the input arena (kept between uploads: pinning is slow)
     std::vector<size_t> out_offset;
     uint32_t max_intervals = 0, max_dus = 0, max_l2 = 0, max_span = 0;
@@ -166,8 +166,6 @@ struct compeg_batch {
     // H2D copies of an upload are spread over a few streams: 256 copies of 1.6 MB on one stream reach 43 GB/s
     // on the target node, on two to four streams 54-56 (one copy of the whole arena: 57)
     std::vector<hipStream_t> copy_streams;
-    // the output is cleared when its layout changes, not on every upload (see upload)
-    std::vector<uint64_t> out_layout;
 
     ~compeg_batch();
     compeg::Status upload(const compeg::ImageData *const *images, size_t n, int threads);

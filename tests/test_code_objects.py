@@ -46,3 +46,23 @@ def test_decode_kernels_use_lds_instructions_and_no_scratch(tmp_path):
             if name and size and any(re.search(r"\d+" + k + "E", name.group(1)) for k in KERNELS):
                 assert int(size.group(1)) == 0, f"{name.group(1)}: {size.group(1)} bytes of private memory per lane"
     assert seen == set(KERNELS), f"kernels not found in the code objects: {set(KERNELS) - seen}"
+
+
+def test_shipped_library_has_no_laboratory_switches():
+    """The experiment knobs (compeg_amd/csrc/lab.h) exist in the laboratory build only: the shipped library's
+    strings name no environment variable but the four it documents, and the knock-out arms of the kernel bodies
+    (CG_EXP) are compiled out of it -- its code objects equal those of a build that never heard of CG_EXP."""
+    if not os.path.exists(LIB):
+        pytest.skip("library not built")
+    names = set(re.findall(rb"COMPEG_[A-Z_0-9]+", open(LIB, "rb").read()))
+    allowed = {b"COMPEG_TRACE", b"COMPEG_TRACE_BATCH", b"COMPEG_VERBOSE", b"COMPEG_SCAN_THREADS"}
+    # (error-code and macro names of the header may appear in messages: they are not environment variables)
+    env_like = {n for n in names if not n.startswith((b"COMPEG_E_", b"COMPEG_OK", b"COMPEG_PARSE_", b"COMPEG_KERNEL_", b"COMPEG_HIP_H",
+                                                      b"COMPEG_METADATA", b"COMPEG_HUFFMAN"))}
+    assert env_like <= allowed, f"experiment switches in the shipped library: {sorted(env_like - allowed)}"
+    lab = os.path.join(os.path.dirname(LIB), "libcompeg_hip_lab.so")
+    if os.path.exists(lab):
+        lab_names = set(re.findall(rb"COMPEG_[A-Z_0-9]+", open(lab, "rb").read()))
+        assert {b"COMPEG_PIPELINE", b"COMPEG_COOP", b"COMPEG_RESIDENT"} <= lab_names   # (the check above can see such names)
+    src = open(os.path.join(ROOT, "compeg_amd", "csrc", "kernels_body.h")).read()
+    assert "#if !defined(COMPEG_LAB)\n#undef CG_EXP" in src   # release builds: every knock-out arm off, whatever the flags

@@ -423,7 +423,9 @@ def test_restart_interval_changes_pixels_only_where_the_reference_does(ca, gpu):
 
 
 def test_two_kernel_pipeline_in_a_subprocess(ca, gpu):
-    """COMPEG_PIPELINE=split (entropy_kernel + idct_composite_kernel) is chosen once per process."""
+    """The development pipeline (entropy_kernel + idct_composite_kernel) and the forced kernel choices: experiment
+    switches of the laboratory build (compeg_amd/csrc/lab.h, libcompeg_hip_lab.so), chosen once per process.  The
+    shipped library ignores them (its own run below stays on its dispatch)."""
     import subprocess
     import sys
     code = r'''
@@ -439,11 +441,18 @@ for (w, h, k, q, ri, s) in [(640, 360, 0, 85, 4, 2), (250, 70, 1, 50, 3, 4), (19
     dec = ca.Decoder(gpu)
     dec.decode_blocking(data)
     assert np.array_equal(dec.read_texture(w, h), orc.ImageData(j).decode()), (w, h)
+    print("kernel", dec.last_kernel())
 print("split ok")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, COMPEG_PIPELINE="split")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "split ok" in r.stdout, r.stdout + r.stderr[-2000:]
+    lab = os.path.join(os.path.dirname(ca.LIB_PATH), "libcompeg_hip_lab.so")
+    assert os.path.exists(lab), "make -C compeg_amd/csrc lab (__graft_entry__.build() does)"
+    for env_extra, kernels in (({"COMPEG_LIB": lab, "COMPEG_PIPELINE": "split"}, {"split"}),
+                               ({"COMPEG_LIB": lab, "COMPEG_COOP": "0", "COMPEG_PAIR": "0"}, {"fused"}),
+                               ({"COMPEG_LIB": lab, "COMPEG_COOP": "0", "COMPEG_PAIR": "1"}, {"pair"}),
+                               ({"COMPEG_PIPELINE": "split", "COMPEG_COOP": "0"}, {"coop_team"})):   # the shipped library
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "split ok" in r.stdout, r.stdout + r.stderr[-2000:]
+        assert {l.split()[1] for l in r.stdout.splitlines() if l.startswith("kernel ")} == kernels, (env_extra, r.stdout)
 
 
 @pytest.mark.parametrize("sampling", [(1, 1), (1, 2), (2, 2)])
