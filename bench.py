@@ -57,6 +57,11 @@ def parse_args():
                    help="batches per arm (x2) of the host-fed pipeline measurement `end_to_end` (0 disables it)")
     p.add_argument("--no-extra-configs", action="store_true",
                    help="skip the sub-records for BASELINE configs[0], [2] and [4] (they run on rank 0 at N = 1 only)")
+    p.add_argument("--host-feed-ranks", default="1,2,4,8",
+                   help="rank counts of the `host_feed_scaling` record: that many processes, bound like the ranks of a "
+                        "multi-GPU run, do the host's share of feeding their GPU at the same time, no device involved "
+                        "(empty: skip)")
+    p.add_argument("--host-feed-child", default="", help=argparse.SUPPRESS)
     p.add_argument("--rehearse-on-one-gpu", action="store_true",
                    help="development only: run the multi-rank code path with every rank on cuda:0 and gloo "
                         "for the barrier / max (RCCL needs one device per rank); the number is meaningless")
@@ -271,6 +276,73 @@ def bench_config(compeg_amd, gpu, width, height, ri, quality, batch, steps, warm
             "kernel": b.last_kernel(), "verified_bit_exact_vs_oracle": ok, "verified_slots": slots}
 
 
+def host_feed_child(spec, args):
+    """One rank of `host_feed_scaling` (no device, no torch): rank/world/start-time/seconds in `spec`."""
+    rank, world, t_start, seconds = spec.split(",")
+    rank, world, t_start, seconds = int(rank), int(world), float(t_start), float(seconds)
+    import compeg_amd
+    from compeg_amd.sharding import bind_rank_to_its_cores
+    from tools import synth
+    cores, numa = bind_rank_to_its_cores(rank, world, [])
+    threads = max(1, min(32, len(cores)))
+    distinct = 16
+    with ThreadPoolExecutor(threads) as ex:
+        jpegs = list(ex.map(lambda i: synth.make_jpeg(args.width, args.height, seed=0xC0FFEE + rank * distinct + i,
+                                                      quality=args.quality, ri=args.ri), range(distinct)))
+    frames = [jpegs[i % distinct] for i in range(64)]
+    jl = compeg_amd.JpegList(frames)
+    nbytes = sum(len(j) for j in frames)
+    out = {"rank": rank, "threads": threads, "numa": numa}
+    for road, name in ((0, "host_preprocess_road"), (1, "copy_free_road")):
+        compeg_amd.host_feed_work(jl, threads, road, 1)                       # warm-up
+        while time.time() < t_start + road * (seconds + 2.0):                  # every rank starts a road at the same time
+            time.sleep(0.001)
+        reps, el = 0, 0.0
+        t0 = time.time()
+        while time.time() - t0 < seconds:
+            k = 4 if road == 0 else 64
+            el += compeg_amd.host_feed_work(jl, threads, road, k)
+            reps += k
+        out[name] = {"frames_per_s": reps * len(frames) / el, "jpeg_gbs": reps * nbytes / el / 1e9}
+    print(json.dumps(out))
+
+
+def bench_host_feed_scaling(args, rank_counts, link_gbs_measured, seconds=2.5):
+    """What one host can prepare for N GPUs at once: N processes, each bound to the cores a rank of an N-GPU run would
+    get (compeg_amd/sharding.py), do the host's share of feeding a GPU -- both roads, see compeg_host_feed_work -- at
+    the same time, with no device involved (the GPU box has one card).  The copy-free road leaves the host the headers;
+    what it then needs per GPU is DMA reads of the JPEG bytes at the link's rate, which this cannot measure."""
+    import subprocess
+
+    pix = args.width * args.height
+    rec = {"what": "N processes at once, each on its rank's share of the host's cores, each doing the host's share of "
+                   "feeding one GPU (no device): frames/s per rank and the whole host's rate",
+           "frame": f"{args.width}x{args.height} DRI={args.ri} q{args.quality}", "ranks": {}}
+    for n in rank_counts:
+        t_start = time.time() + 12.0 + 1.5 * n   # (imports + synthesis of the ranks' frames)
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--host-feed-child", f"{r},{n},{t_start},{seconds}",
+                                   "--width", str(args.width), "--height", str(args.height), "--ri", str(args.ri),
+                                   "--quality", str(args.quality)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+                 for r in range(n)]
+        outs = []
+        for p_ in procs:
+            o, _ = p_.communicate(timeout=300)
+            outs.append(json.loads(o.strip().splitlines()[-1]))
+        row = {"threads_per_rank": outs[0]["threads"]}
+        for road in ("host_preprocess_road", "copy_free_road"):
+            per = [o[road]["frames_per_s"] for o in outs]
+            row[road] = {"gpix_s_per_rank_min": round(min(per) * pix / 1e9, 1), "gpix_s_whole_host": round(sum(per) * pix / 1e9, 1),
+                         "jpeg_gbs_whole_host": round(sum(o[road]["jpeg_gbs"] for o in outs), 1)}
+        rec["ranks"][str(n)] = row
+    # how many GPUs this host keeps at the rate one GPU's link sustains (measured above by end_to_end)
+    need = link_gbs_measured
+    rec["per_gpu_link_gbs_measured"] = round(need, 1)
+    for road in ("host_preprocess_road", "copy_free_road"):
+        ok = [int(n) for n, row in rec["ranks"].items() if row[road]["jpeg_gbs_whole_host"] / int(n) >= need]
+        rec[road + "_gpus_kept_at_link_rate"] = max(ok) if ok else 0
+    return rec
+
+
 PCIE_LINK_GBS = 63.0  # MI355X_MICROARCH.md: host link PCIe Gen5 x16, 63 GB/s (spec)
 
 
@@ -288,7 +360,7 @@ def bench_end_to_end(compeg_amd, device, jpegs, images, threads, reps, ext):
     batches = [compeg_amd.Batch(g) for g in gpus]
     jpeg_bytes = sum(len(j) for j in jpegs)
 
-    def arm(upload):
+    def arm(upload, batches=batches):
         for b in batches:                                        # warm-up: allocations, pinning, first launches
             upload(b)
             b.decode()
@@ -324,6 +396,65 @@ def bench_end_to_end(compeg_amd, device, jpegs, images, threads, reps, ext):
                      "jpeg_gbs_consumed": round(jpeg_bytes / period / 1e9, 2)}
     ok = all(bool(np.array_equal(batches[k].read_output(i), orc.ImageData(jpegs[i], allow_sampling=ext).decode()))
              for k in (0, 1) for i in (0, len(jpegs) - 1))
+    if not ext:
+        # the copy-free road: JPEG bytes in page-locked memory (a capture ring), headers parsed on the host, segments
+        # fetched by the DMA engines where they lie, scan preprocessing by the scan kernels on the card
+        pinned = compeg_amd.HostBuffer(sum(len(j) + 64 for j in jpegs))
+        views = compeg_amd.JpegList(pinned.place(jpegs))
+        dev_batches = [compeg_amd.Batch(g) for g in gpus]
+        for b in dev_batches:
+            b.set_device_preprocess(1)
+        period, up, lo, hi = arm(lambda b: b.upload_jpegs(views, host_threads=threads), dev_batches)
+        res["from_pinned_jpeg_bytes_device_scan"] = {
+            "ms_per_batch": round(period * 1e3, 3), "mpix_s": round(pix / period / 1e6, 1),
+            "upload_ms": round(up * 1e3, 3), "min_max_ms": [round(lo * 1e3, 3), round(hi * 1e3, 3)],
+            "pcie_gbs_during_upload": round(jpeg_bytes / up / 1e9, 2),
+            "pcie_fraction_of_link": round(jpeg_bytes / up / 1e9 / PCIE_LINK_GBS, 3),
+            "jpeg_gbs_consumed": round(jpeg_bytes / period / 1e9, 2),
+            "host_fallbacks": dev_batches[0].host_fallbacks(),
+            "what": "compeg_batch_upload_jpegs with device preprocessing from compeg_host_alloc'ed bytes: the host reads "
+                    "headers only (what crosses PCIe: the raw entropy-coded segments + tables)"}
+        # ... and with two feeder threads, a batch each: the link never waits for one upload's last scan kernels,
+        # results and descriptors before the next upload's first segment leaves
+        import threading
+
+        more = [compeg_amd.Batch(g) for g in gpus]
+        for b in more:
+            b.set_device_preprocess(1)
+            b.upload_jpegs(views, host_threads=threads)          # (warm-up: allocations)
+            b.decode()
+            b.wait()
+
+        def feeder(pair, n):                                     # two batches of its own: the upload of one under the decode of the other
+            for r in range(n):
+                b = pair[r & 1]
+                b.wait()
+                b.upload_jpegs(views, host_threads=max(1, threads // 2))
+                b.decode()
+
+        for b in dev_batches:
+            b.wait()
+        per_thread = 2 * reps + 2
+        ts = [threading.Thread(target=feeder, args=((dev_batches[k], more[k]), per_thread)) for k in (0, 1)]
+        t_f = time.perf_counter()
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        for b in dev_batches + more:
+            b.wait()
+        t_f = (time.perf_counter() - t_f) / (2 * per_thread)
+        res["from_pinned_jpeg_bytes_device_scan_two_feeder_threads"] = {
+            "ms_per_batch": round(t_f * 1e3, 3), "mpix_s": round(pix / t_f / 1e6, 1),
+            "pcie_gbs": round(jpeg_bytes / t_f / 1e9, 2), "pcie_fraction_of_link": round(jpeg_bytes / t_f / 1e9 / PCIE_LINK_GBS, 3),
+            "batches_timed": 2 * per_thread,
+            "what": "the same road with two feeder threads, each alternating between two batches of its own (mean period over the whole run)"}
+        ok = ok and all(bool(np.array_equal(dev_batches[k].read_output(i), orc.ImageData(jpegs[i]).decode()))
+                        for k in (0, 1) for i in (0, len(jpegs) // 2, len(jpegs) - 1))
+        for b in dev_batches + more:
+            b.wait()
+        del dev_batches, more
+        pinned.close()
     if not ok:
         raise SystemExit("bench: end_to_end output differs from the oracle")
     res.update({"frames_per_batch": len(jpegs), "batches_timed_per_arm": 2 * reps, "host_threads": threads,
@@ -335,6 +466,8 @@ def bench_end_to_end(compeg_amd, device, jpegs, images, threads, reps, ext):
 
 def main():
     args = parse_args()
+    if args.host_feed_child:
+        return host_feed_child(args.host_feed_child, args)
     args.sampling_hv = tuple(int(v) for v in args.sampling.lower().split("x"))
     ext = args.sampling_hv != (2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -526,6 +659,12 @@ def main():
             compeg_amd, gpu, 7680, 4320, 1, args.quality, 8, args.steps, args.warmup, threads, 4,
             "8 x 7680x4320 YUV 4:2:2 baseline JPEG, DRI=1 per step (BASELINE configs[4] frame), 4 distinct frames")
         extra["mjpeg stream 960x720 DRI=10"] = bench_mjpeg_stream(compeg_amd, gpu, args.quality, args.steps, args.warmup, threads)
+
+    feed_scaling = None
+    if rank == 0 and world == 1 and args.host_feed_ranks and end_to_end is not None and not ext:
+        best = max(v.get("jpeg_gbs_consumed", v.get("pcie_gbs", 0.0)) for v in end_to_end.values() if isinstance(v, dict))
+        feed_scaling = bench_host_feed_scaling(args, [int(v) for v in args.host_feed_ranks.split(",") if v], best)
+        end_to_end["host_feed_scaling"] = feed_scaling
 
     if rank == 0:
         total_pixels = pixels * world * args.steps

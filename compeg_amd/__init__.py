@@ -20,8 +20,8 @@ import numpy as np
 from ._lib import (E_COUNT_MISMATCH, E_HIP, E_INVALID_ARG, E_MALFORMED, E_UNSUPPORTED, L1_BYTES,
                    LIB_PATH, METADATA_BYTES, Error, check, lib)
 
-__all__ = ["Gpu", "Decoder", "DecodeOp", "ImageData", "ScanBuffer", "Batch", "Texture", "Error",
-           "version", "LIB_PATH"]
+__all__ = ["Gpu", "Decoder", "DecodeOp", "ImageData", "ScanBuffer", "Batch", "Texture", "Error", "HostBuffer", "JpegList",
+           "host_register", "host_unregister", "version", "LIB_PATH"]
 
 
 # compeg_decoder_last_kernel / compeg_batch_last_kernel (include/compeg_hip.h: COMPEG_KERNEL_*)
@@ -35,6 +35,70 @@ def version():
 def _host_view(data):
     a = data if isinstance(data, np.ndarray) else np.frombuffer(data, dtype=np.uint8)
     return np.ascontiguousarray(a)
+
+
+class HostBuffer:
+    """Page-locked host memory (compeg_host_alloc).  JPEG bytes that lie here -- `place()` packs a list of them -- go
+    to the card without being touched on the host when a Batch with device preprocessing uploads them: the
+    `Cow::Borrowed` road of ImageData::new + the uploads straight from the borrowed bytes (src/lib.rs:577-595,397-407)."""
+
+    def __init__(self, nbytes):
+        p = C.c_void_p()
+        check(lib.compeg_host_alloc(nbytes, C.byref(p)))
+        self._p, self.nbytes = p, nbytes
+        self.array = np.ctypeslib.as_array((C.c_uint8 * max(nbytes, 1)).from_address(p.value))[:nbytes]
+
+    def place(self, jpegs, align=64):
+        """Copies the byte strings in, one behind the other; returns views of them (to hand to Batch.upload_jpegs)."""
+        views, at = [], 0
+        for j in jpegs:
+            a = _host_view(j)
+            if at + a.nbytes > self.nbytes:
+                raise ValueError("HostBuffer too small")
+            self.array[at:at + a.nbytes] = a
+            views.append(self.array[at:at + a.nbytes])
+            at = (at + a.nbytes + align - 1) // align * align
+        return views
+
+    def close(self):
+        if self._p:
+            self.array = None
+            lib.compeg_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def host_feed_work(jpegs, host_threads, road, reps=1):
+    """Seconds the host's share of feeding this batch takes, `reps` times over (compeg_host_feed_work: no device)."""
+    jl = jpegs if isinstance(jpegs, JpegList) else JpegList(jpegs)
+    sec = C.c_double()
+    check(lib.compeg_host_feed_work(jl.ptrs, jl.lens, jl.count, host_threads, 0, road, reps, C.byref(sec)))
+    return sec.value
+
+
+def host_register(array):
+    """Page-locks a caller-owned buffer (numpy array) in place: compeg_host_register."""
+    check(lib.compeg_host_register(C.c_void_p(array.ctypes.data), array.nbytes))
+
+
+def host_unregister(array):
+    check(lib.compeg_host_unregister(C.c_void_p(array.ctypes.data)))
+
+
+class JpegList:
+    """The (pointer, length) arrays compeg_batch_upload_jpegs takes, gathered once from bytes-like objects (which this
+    object keeps alive)."""
+
+    def __init__(self, jpegs):
+        self.views = [_host_view(j) for j in jpegs]
+        self.count = len(self.views)
+        self.ptrs = (C.c_void_p * self.count)(*[v.__array_interface__["data"][0] for v in self.views])
+        self.lens = (C.c_size_t * self.count)(*[v.nbytes for v in self.views])
 
 
 class Gpu:
@@ -294,13 +358,12 @@ class Batch:
         check(lib.compeg_batch_upload(self._h, arr, len(self._images), host_threads))
 
     def upload_jpegs(self, jpegs, host_threads=0, allow_sampling=False, standard_entropy=False):
-        """Host-fed use: parse (on the worker threads), preprocess, upload.  jpegs: bytes-like objects."""
-        views = [_host_view(j) for j in jpegs]
-        ptrs = (C.c_void_p * len(views))(*[v.ctypes.data for v in views])
-        lens = (C.c_size_t * len(views))(*[v.nbytes for v in views])
+        """Host-fed use: parse (on the worker threads), preprocess, upload.  jpegs: bytes-like objects, or a
+        JpegList made from them once (saves this wrapper's per-call pointer gathering, nothing else)."""
+        jl = jpegs if isinstance(jpegs, JpegList) else JpegList(jpegs)
         flags = (1 if allow_sampling else 0) | (2 if standard_entropy else 0)
         self._images = []
-        check(lib.compeg_batch_upload_jpegs(self._h, ptrs, lens, len(views), host_threads, flags))
+        check(lib.compeg_batch_upload_jpegs(self._h, jl.ptrs, jl.lens, jl.count, host_threads, flags))
 
     def set_device_preprocess(self, mode):
         """0 host (default), 1 scan kernels once at upload, 2 scan kernels in every decode."""

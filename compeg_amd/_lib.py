@@ -89,6 +89,11 @@ def _load():
         "compeg_batch_pixels": (C.c_uint64, [vp]),
         "compeg_batch_timing": (i, [vp, i, pu32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "compeg_batch_last_kernel": (i, [vp]),
+        "compeg_host_feed_work": (i, [vp, vp, C.c_size_t, i, C.c_uint, i, i, C.POINTER(C.c_double)]),
+        "compeg_host_alloc": (i, [C.c_size_t, C.POINTER(C.c_void_p)]),
+        "compeg_host_free": (None, [vp]),
+        "compeg_host_register": (i, [vp, C.c_size_t]),
+        "compeg_host_unregister": (i, [vp]),
         "compeg_decoder_last_kernel": (i, [vp]),
     }
     for name, (res, args) in sig.items():

@@ -1,7 +1,12 @@
 // extern "C" surface of libcompeg_hip (include/compeg_hip.h).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <memory>
+#include <thread>
+#include <vector>
 #include <cstring>
 #include <new>
 #include <string>
@@ -689,6 +694,96 @@ int compeg_batch_set_chunk(compeg_batch *batch, uint32_t images_per_launch)
         if (hipStreamSynchronize(batch->gpu->stream) != hipSuccess)
             return fail(COMPEG_E_HIP, "hipStreamSynchronize failed");
     }
+    return ok();
+}
+
+int compeg_host_feed_work(const uint8_t *const *jpegs, const size_t *lengths, size_t count, int host_threads, unsigned flags,
+                          int road, int reps, double *seconds)
+{
+    if (!jpegs || !lengths || !seconds || count == 0 || reps <= 0 || (road != 0 && road != 1))
+        return fail(COMPEG_E_INVALID_ARG, "bad arguments");
+    const unsigned nthreads = unsigned(std::max(1, host_threads));
+    // road 0: every thread preprocesses into a buffer of its own, as large as its largest image needs
+    size_t largest = 0;
+    for (size_t i = 0; i < count; i++)
+        largest = std::max(largest, lengths[i]);
+    std::vector<std::vector<uint8_t>> outs(nthreads);
+    std::vector<std::vector<uint32_t>> starts(nthreads);
+    std::vector<compeg::Status> status(nthreads);
+    std::atomic<size_t> next{0};
+    const size_t total = count * size_t(reps);
+    auto work = [&](unsigned t) {
+        if (road == 0)
+            outs[t].resize(compeg::ScanBuffer::output_capacity(largest));
+        for (;;) {
+            const size_t k = next.fetch_add(1, std::memory_order_relaxed);
+            if (k >= total || !status[t].ok())
+                return;
+            const size_t i = k % count;
+            compeg::ImageData *img = nullptr;
+            compeg::Status st = compeg::ImageData::parse(jpegs[i], lengths[i], false, &img,
+                                                         road == 1 ? flags | compeg::kParseDeferScanEnd : flags);
+            std::unique_ptr<compeg::ImageData> owned(img);
+            if (st.ok() && road == 0) {
+                const uint32_t expected = img->metadata.total_restart_intervals;
+                starts[t].resize(compeg::ScanBuffer::start_slots(expected));
+                size_t nwords = 0, nstarts = 0;
+                st = compeg::ScanBuffer::process_to(img->scan_data(), img->scan_len, expected, outs[t].data(), starts[t].data(),
+                                                    nwords, nstarts);
+                if (st.code == COMPEG_E_COUNT_MISMATCH)
+                    st = compeg::Status{};
+            }
+            if (!st.ok())
+                status[t] = st;
+        }
+    };
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> threads;
+    for (unsigned t = 1; t < nthreads; t++)
+        threads.emplace_back(work, t);
+    work(0);
+    for (std::thread &th : threads)
+        th.join();
+    *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (const compeg::Status &st : status)
+        if (!st.ok())
+            return fail(st);
+    return ok();
+}
+
+int compeg_host_alloc(size_t bytes, void **out)
+{
+    if (!out)
+        return fail(COMPEG_E_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess || !p)
+        return fail(COMPEG_E_HIP, "hipHostMalloc failed");
+    *out = p;
+    return ok();
+}
+
+void compeg_host_free(void *ptr)
+{
+    if (ptr)
+        (void)hipHostFree(ptr);
+}
+
+int compeg_host_register(void *ptr, size_t bytes)
+{
+    if (!ptr || !bytes)
+        return fail(COMPEG_E_INVALID_ARG, "nothing to register");
+    if (hipHostRegister(ptr, bytes, hipHostRegisterPortable) != hipSuccess)
+        return fail(COMPEG_E_HIP, "hipHostRegister failed");
+    return ok();
+}
+
+int compeg_host_unregister(void *ptr)
+{
+    if (!ptr)
+        return fail(COMPEG_E_INVALID_ARG, "ptr is NULL");
+    if (hipHostUnregister(ptr) != hipSuccess)
+        return fail(COMPEG_E_HIP, "hipHostUnregister failed");
     return ok();
 }
 

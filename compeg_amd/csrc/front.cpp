@@ -409,7 +409,10 @@ Status ImageData::parse(const uint8_t *jpeg, size_t len, bool copy, ImageData **
                 return malformed(kEof);
             const size_t data_start = seg.at;
             size_t data_end;
-            if (!find_scan_end(jpeg, len, data_start, data_end))
+            if ((flags & kParseDeferScanEnd) && len >= data_start + 2 && jpeg[len - 2] == 0xff && jpeg[len - 1] == 0xd9) {
+                data_end = len - 2; // (where the search ends if no other marker lies in between: front.h)
+                img->scan_end_deferred = true;
+            } else if (!find_scan_end(jpeg, len, data_start, data_end))
                 return malformed(kEof);
             if (ss != 0 || se != 63 || ahal != 0)
                 return unsupported("non-baseline scan header");
@@ -514,7 +517,7 @@ Status ImageData::parse(const uint8_t *jpeg, size_t len, bool copy, ImageData **
     // two-level lookup's result when that does not depend on the bits behind
     // the prefix, i.e. for codes of at most 11 bits (and for prefixes no code
     // starts with); longer codes escape to the two-level tables.
-    img->flags = flags;
+    img->flags = flags & ~kParseDeferScanEnd;
     const uint32_t zrl_advance = (flags & COMPEG_PARSE_STANDARD_ENTROPY) ? 16u : 17u; // quirk Q2
     img->ac_fast.assign(2 * kFastEntries, uint16_t(kFastEscape));
     for (int t = 0; t < 2; t++) {

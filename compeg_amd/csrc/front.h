@@ -33,6 +33,11 @@ struct Metadata {
 };
 static_assert(sizeof(Metadata) == COMPEG_METADATA_BYTES, "Metadata layout");
 
+// Internal parse flag (beside the public COMPEG_PARSE_*): do not search for the end of the entropy-coded segment
+// (src/file.rs:163-201 walks every byte of it) when the file ends with an EOI marker -- take everything up to it.  For
+// callers that have the segment checked where it is preprocessed anyway (batch uploads with device preprocessing).
+constexpr unsigned kParseDeferScanEnd = 0x80000000u;
+
 constexpr uint32_t kRetainedCoefficients = 32;       // metadata.rs:43
 constexpr uint32_t kMaxRestartIntervals = 64u * 65535u; // lib.rs:298
 
@@ -69,6 +74,9 @@ struct ImageData {
     const uint8_t *jpeg = nullptr;
     size_t jpeg_len = 0;
     size_t scan_offset = 0, scan_len = 0;
+    // parsed with kParseDeferScanEnd and the file ends with EOI: the segment was taken to run up to that EOI without
+    // walking it (whoever preprocesses it has to see that no other marker lies inside: scan_kernels.hip, flag bit 1)
+    bool scan_end_deferred = false;
 
     const uint8_t *scan_data() const { return jpeg + scan_offset; }
     uint32_t total_mcus() const

@@ -856,6 +856,10 @@ namespace {
 
 // What the layout of a batch needs to know about an image before its threads start: exact for parsed images,
 // upper bounds (from the file's headers and its length) for images that the threads are going to parse.
+// (an upload that laid its arenas out from the files' headers and lengths and found a file that does not fit:
+// the caller parses first and lays out afterwards)
+constexpr const char *kLayoutBoundExceeded = "layout bound exceeded";
+
 struct UploadItem {
     uint32_t width = 0, height = 0;
     uint32_t intervals = 0, total_dus = 0;
@@ -963,8 +967,10 @@ Status compeg_batch::upload(const ImageData *const *images, size_t n, int thread
         for (size_t i = 0; i < n; i++)
             if (!items[i].is422)
                 return Status::error(COMPEG_E_UNSUPPORTED, "device preprocessing of a batch supports 4:2:2 images only");
-        note_batch_properties(images, n);
-        return upload_device_scan(images, n, threads);
+        std::vector<FeedSource> src(n);
+        for (size_t i = 0; i < n; i++)
+            src[i] = FeedSource{images[i]->scan_data(), images[i]->scan_len, images[i]->metadata.total_restart_intervals};
+        return upload_device_scan(n, threads, src.data(), images, nullptr, nullptr);
     }
     return upload_host(n, threads, items.data(), [&](size_t i, Status &) { return images[i]; });
 }
@@ -1101,7 +1107,7 @@ Status compeg_batch::upload_host(size_t n, int threads, const void *items_, cons
             if (img.width != it.width || img.height != it.height || img.metadata.total_restart_intervals != it.intervals ||
                 table_blob_bytes(img) > it.tables_cap || img.scan_len > it.scan_cap || is_422(img) != it.is422 ||
                 img.total_dus() > it.total_dus) {
-                results[i] = Status::error(COMPEG_E_INVALID_ARG, "layout bound exceeded");
+                results[i] = Status::error(COMPEG_E_INVALID_ARG, kLayoutBoundExceeded);
                 continue;
             }
             got[i] = imgp;
@@ -1219,9 +1225,56 @@ Status compeg_batch::upload_jpegs(const uint8_t *const *jpegs, const size_t *len
     };
     Status s;
     bool done = false;
+    if (preprocess_mode != 0 && use_fused_pipeline()) {
+        // Device preprocessing: the files go up as they are, from where they are if that is page-locked memory; the
+        // host reads headers only -- the end of each entropy-coded segment is taken from the file's final EOI and
+        // checked by the scan kernels, so that no thread walks the bytes -- and does so while the transfers run (their
+        // layout needs no more than a peek at SOF0 / DRI).  An image the kernels hand back is parsed again in full.
+        bool laid_out = true;
+        std::vector<FeedSource> src(n);
+        for (size_t i = 0; i < n && laid_out; i++) {
+            laid_out = peek_item(jpegs[i], lens[i], flags, items[i]) && items[i].is422;
+            src[i] = FeedSource{jpegs[i], lens[i], items[i].intervals};
+        }
+        auto parse_headers = [&](size_t i, Status &st) -> const ImageData * {
+            ImageData *img = nullptr;
+            st = ImageData::parse(jpegs[i], lens[i], false, &img, flags | kParseDeferScanEnd);
+            fresh[i].reset(img);
+            if (!st.ok())
+                st = Status::error(st.code, "image " + std::to_string(i) + ": " + st.message);
+            return st.ok() ? img : nullptr;
+        };
+        if (laid_out) {
+            s = upload_device_scan(n, threads, src.data(), nullptr, parse_headers, parse_one);
+            done = s.ok() || s.message != kLayoutBoundExceeded;
+        }
+        if (!done) {
+            // (unusual headers: parse first, lay out afterwards)
+            std::vector<Status> results(n);
+            unsigned nthreads = threads > 0 ? unsigned(threads) : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+            nthreads = unsigned(std::min<size_t>(nthreads, std::max<size_t>(n, 1)));
+            auto work = [&](unsigned t) {
+                for (size_t i = t; i < n; i += nthreads)
+                    parse_headers(i, results[i]);
+            };
+            run_on_threads(nthreads, work);
+            std::vector<const ImageData *> ptrs(n);
+            for (size_t i = 0; i < n; i++) {
+                if (!results[i].ok())
+                    return results[i];
+                ptrs[i] = fresh[i].get();
+                if (!is_422(*ptrs[i]))
+                    return Status::error(COMPEG_E_UNSUPPORTED, "device preprocessing of a batch supports 4:2:2 images only");
+                src[i] = FeedSource{ptrs[i]->scan_data(), ptrs[i]->scan_len, ptrs[i]->metadata.total_restart_intervals};
+            }
+            s = upload_device_scan(n, threads, src.data(), ptrs.data(), nullptr, parse_one);
+        }
+        parsed.swap(fresh);
+        return s;
+    }
     if (peeked) {
         s = upload_host(n, threads, items.data(), parse_one);
-        done = s.ok() || s.message != "layout bound exceeded";
+        done = s.ok() || s.message != kLayoutBoundExceeded;
     }
     if (!done) {
         std::vector<Status> results(n);
@@ -1248,109 +1301,294 @@ Status compeg_batch::upload_jpegs(const uint8_t *const *jpegs, const size_t *len
 // Device-side preprocessing: raw entropy-coded segments go to HBM as they are
 // and the scan kernels (scan_kernels.hip) produce words / start positions in
 // the reference layout.
-Status compeg_batch::upload_device_scan(const ImageData *const *images, size_t n, int threads)
+//
+// Nothing of a segment is touched on the host when the caller's bytes lie in pinned (page-locked) memory --
+// compeg_host_alloc / compeg_host_register, or any hipHostMalloc'ed / registered range: the DMA engines read it where
+// it is, like the reference uploads straight from the bytes it borrowed (src/lib.rs:577-595, 397-407).  Pageable
+// bytes are copied into the batch's pinned arena by the worker threads first.  The images' tables (25 KB each) are
+// staged side by side and go up in one transfer.
+//   src      what is sent for image i: its entropy-coded segment (images parsed by the caller: `given`), or the whole
+//            file (compeg_batch_upload_jpegs: the transfers start at once -- their layout needs the files' lengths
+//            only -- and `parse` reads the headers on the worker threads meanwhile)
+//   reparse  images whose segment end was left to the device (ImageData::scan_end_deferred) and turned out to end
+//            earlier (another marker inside: the scan kernels' flag bit 1) are parsed again in full through it
+Status compeg_batch::upload_device_scan(size_t n, int threads, const FeedSource *src, const ImageData *const *given,
+                                        const ImageSource &parse, const ImageSource &reparse)
 {
     CG_HIP(hipSetDevice(gpu->device));
     CG_HIP(hipStreamSynchronize(last_stream));
     count = 0;
     if (n > 65535)
         return Status::error(COMPEG_E_INVALID_ARG, "at most 65535 images per batch");
+    static const bool trace_on = getenv("COMPEG_TRACE_BATCH") != nullptr;
+    const auto t_up0 = std::chrono::steady_clock::now();
+    auto ms_since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_up0).count(); };
+    std::vector<const ImageData *> images(n, nullptr);
+    if (given)
+        images.assign(given, given + n);
 
-    // Device arena per image: [64 readable bytes][raw segment][LUTs] -- what the host sends, one transfer --
-    // then the scan kernels' scratch and output.  The pinned staging arena holds the first part only.
+    // which bytes the DMA engines can read where they are
+    std::vector<uint8_t> pinned(n, 0);
+    bool any_pageable = false;
+    for (size_t i = 0; i < n; i++) {
+        if (src[i].len > 0xfffffff0u)
+            return Status::error(COMPEG_E_INVALID_ARG, "scan segment too large");
+        hipPointerAttribute_t attr{};
+        const bool is_pinned = src[i].len != 0 && hipPointerGetAttributes(&attr, src[i].bytes) == hipSuccess && attr.type == hipMemoryTypeHost;
+        (void)hipGetLastError(); // (a pageable pointer is "invalid value" to the query: not an error here)
+        pinned[i] = is_pinned ? 1 : 0;
+        any_pageable = any_pageable || !is_pinned;
+    }
+    // Page-locked sources that follow each other in memory -- the frames of a capture ring, a receive arena -- go up
+    // as ONE transfer per run (one copy of 32 MB moves at the link's rate, sixteen copies of 1.6 MB at three quarters
+    // of it); the device copy keeps the host's spacing.  Runs end at the quarters of the batch (the scan kernels of a
+    // quarter start when it has arrived).
+    constexpr size_t kGroups = 4, kCopyStreams = 4, kMaxRunBytes = size_t(48) << 20, kMaxGap = size_t(64) << 10;
+    const auto group_of = [&](size_t i) { return i * kGroups / std::max<size_t>(n, 1); };
+    struct Run {
+        size_t first, last;      // images
+        const uint8_t *host;     // first byte sent
+        size_t bytes, dev;       // bytes sent; where they go in the arena
+    };
+    std::vector<Run> runs;
+    std::vector<size_t> run_of(n, 0);
+    for (size_t i = 0; i < n; i++) {
+        bool joins = false;
+        if (!runs.empty() && pinned[i] && pinned[i - 1]) {
+            const Run &r = runs.back();
+            const uint8_t *end = r.host + r.bytes;
+            joins = group_of(i) == group_of(r.first) && src[i].bytes >= end && size_t(src[i].bytes - end) <= kMaxGap &&
+                    size_t(src[i].bytes - r.host) + src[i].len <= kMaxRunBytes;
+        }
+        if (joins) {
+            runs.back().last = i;
+            runs.back().bytes = size_t(src[i].bytes - runs.back().host) + src[i].len;
+        } else {
+            runs.push_back(Run{i, i, src[i].bytes, src[i].len, 0});
+        }
+        run_of[i] = runs.size() - 1;
+    }
+
+    // Device arena: [results][all images' LUTs][the runs, 64 readable bytes around each] and per image the scan kernels'
+    // scratch and output, sized from the length of what is sent (an upper bound of the segment's).  The pinned
+    // staging arena: [all images' LUTs][the pageable sources].
     struct Layout {
-        size_t sent, raw, tables, sent_bytes, tile_state, starts, words; // `sent`: start of the transferred part
-        size_t staged;                                                     // the same part in the staging arena
-        uint32_t ntiles, slots;
+        size_t sent, tables, tile_state, starts, words; // `sent`: where the image's source bytes lie in the arena
+        size_t staged;
+        size_t tile_cap, slot_cap;
     };
     std::vector<Layout> lay(n);
-    size_t total = 0, staged_total = 0, out_total = 0;
-    max_tiles = 0;
-    max_intervals = max_dus = max_l2 = max_span = 0;
-    algorithmic_bytes = pixels = 0;
+    size_t total = 0;
     auto take = [&](size_t bytes) {
         const size_t at = total;
         total += align_up(bytes, 256);
         return at;
     };
     const size_t o_results = take(n * kScanResultBytes);
+    // (tables of a file whose headers are not read yet: room for 32 KB -- Annex-K tables take 19 -- or the upload goes
+    // the parse-first way)
+    constexpr size_t kUnparsedTablesCap = size_t(32) << 10;
+    size_t tables_bytes = 0;
     for (size_t i = 0; i < n; i++) {
-        const ImageData &img = *images[i];
-        if (img.scan_len > 0xfffffff0u)
-            return Status::error(COMPEG_E_INVALID_ARG, "scan segment too large");
+        lay[i].tables = tables_bytes;
+        tables_bytes += align_up(given ? table_blob_bytes(*given[i]) : kUnparsedTablesCap, 256);
+    }
+    const size_t o_tables = take(tables_bytes);
+    size_t staged_total = align_up(tables_bytes, 256);
+    for (Run &r : runs)
+        r.dev = take(64 + align_up(r.bytes + 64, 16)) + 64;
+    for (size_t i = 0; i < n; i++) {
         Layout &L = lay[i];
-        const uint32_t len = uint32_t(img.scan_len), expected = img.metadata.total_restart_intervals;
-        L.ntiles = scan_tiles(len);
-        L.slots = uint32_t(ScanBuffer::start_slots(expected));
-        const size_t raw_bytes = align_up(size_t(len) + 64, 16);
-        L.sent_bytes = 64 + raw_bytes + table_blob_bytes(img);
-        L.sent = take(L.sent_bytes);
-        L.raw = L.sent + 64;
-        L.tables = L.raw + raw_bytes;
-        L.tile_state = take(size_t(L.ntiles) * kScanTileStateBytes + 32);
-        L.starts = take(size_t(L.slots) * 4);
-        L.words = take(size_t(len) + len / 3 + 64);
-        L.staged = staged_total;
-        staged_total += align_up(L.sent_bytes, 256);
-        out_total += align_up(size_t(img.width) * 4 * img.height, 256);
-        max_tiles = std::max(max_tiles, L.ntiles);
-        max_intervals = std::max(max_intervals, expected);
-        max_dus = std::max(max_dus, img.total_dus());
-        max_l2 = std::max<uint32_t>(max_l2, staged_lut_entries(img));
-        pixels += uint64_t(img.width) * img.height;
+        const size_t len = src[i].len;
+        L.tables += o_tables;
+        L.sent = runs[run_of[i]].dev + size_t(src[i].bytes - runs[run_of[i]].host);
+        L.tile_cap = scan_tiles(uint32_t(len));
+        L.tile_state = take(L.tile_cap * kScanTileStateBytes + 32);
+        L.slot_cap = ScanBuffer::start_slots(src[i].intervals);
+        L.starts = take(L.slot_cap * 4);
+        L.words = take(len + len / 3 + 64);
+        L.staged = staged_total; // (used by pageable sources)
+        staged_total += align_up(len + 64, 256);
     }
     CG_TRY(scan_arena.reserve(total + 256));
     CG_TRY(scan_descs.reserve(n * sizeof(ScanDesc) + 256));
-    CG_TRY(out.reserve(out_total + 256));
     hipStream_t st = gpu->stream;
-    CG_HIP(hipMemsetAsync(out.ptr, 0, out.capacity, st));
     CG_TRY(dev_descs.reserve(n * sizeof(ImageDesc) + 256));
-    CG_TRY(stage.reserve(staged_total + 256));
-    uint8_t *hs = static_cast<uint8_t *>(stage.ptr), *da = static_cast<uint8_t *>(scan_arena.ptr);
+    while (copy_streams.size() < kCopyStreams) {
+        hipStream_t c = nullptr;
+        CG_HIP(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
+        copy_streams.push_back(c);
+    }
+    uint8_t *da = static_cast<uint8_t *>(scan_arena.ptr);
     CG_HIP(hipMemsetAsync(da + o_results, 0, n * kScanResultBytes, st));
+    CG_TRY(stage.reserve((any_pageable ? staged_total : align_up(tables_bytes, 256)) + 256));
+    uint8_t *hs = static_cast<uint8_t *>(stage.ptr);
+    const double t_layout = ms_since();
 
-    // the threads stage segment and LUTs of an image and send them off at once
-    std::vector<ScanDesc> sd(n);
-    std::atomic<int> hip_error{int(hipSuccess)};
+    // The worker threads read the headers (files), stage the tables and the pageable sources; this thread sends the
+    // runs off in order, round robin over the copy streams, and starts the scan kernels of a quarter of the images
+    // as soon as that quarter has arrived and its headers are read: they run under the transfers of the next one.
+    std::vector<std::atomic<uint8_t>> staged_ready(n), parsed_ready(n);
+    for (size_t i = 0; i < n; i++) {
+        staged_ready[i].store(pinned[i], std::memory_order_relaxed);
+        parsed_ready[i].store(given ? 1 : 0, std::memory_order_relaxed);
+    }
     unsigned nthreads = threads > 0 ? unsigned(threads) : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     nthreads = unsigned(std::min<size_t>(nthreads, std::max<size_t>(n, 1)));
+    std::atomic<size_t> next_image{0};
+    std::atomic<int> hip_error{int(hipSuccess)};
+    std::atomic<bool> failed{false};
+    std::vector<Status> results(n);
     const int device = gpu->device;
-    auto work = [&](unsigned t) {
-        if (hipSetDevice(device) != hipSuccess) {
-            hip_error = int(hipErrorInvalidDevice);
-            return;
-        }
-        for (size_t i = t; i < n; i += nthreads) {
-            const ImageData &img = *images[i];
-            const Layout &L = lay[i];
-            uint8_t *h = hs + L.staged;
-            memset(h, 0, 64);
-            memcpy(h + 64, img.scan_data(), img.scan_len);
-            memset(h + 64 + img.scan_len, 0, L.tables - L.raw - img.scan_len);
-            write_tables(h + (L.tables - L.sent), img);
-            const hipError_t e = hipMemcpyAsync(da + L.sent, h, L.sent_bytes, hipMemcpyHostToDevice, st);
-            if (e != hipSuccess)
-                hip_error = int(e);
-            ScanDesc &s = sd[i];
-            s.raw = da + L.raw;
-            s.len = uint32_t(img.scan_len);
-            s.ntiles = L.ntiles;
-            s.slots = L.slots;
-            s.expected = img.metadata.total_restart_intervals;
-            s.tile_state = reinterpret_cast<uint32_t *>(da + L.tile_state);
-            s.starts_out = reinterpret_cast<uint32_t *>(da + L.starts);
-            s.words_out = da + L.words;
-            s.result = reinterpret_cast<uint32_t *>(da + o_results + i * kScanResultBytes);
+    auto prepare_images = [&] {
+        for (;;) {
+            const size_t i = next_image.fetch_add(1, std::memory_order_relaxed);
+            if (i >= n)
+                return;
+            if (!given) {
+                images[i] = parse(i, results[i]);
+                if (!images[i] || table_blob_bytes(*images[i]) > kUnparsedTablesCap || !is_422(*images[i])) {
+                    if (images[i] && results[i].ok())
+                        results[i] = is_422(*images[i]) ? Status::error(COMPEG_E_INVALID_ARG, kLayoutBoundExceeded)
+                                                        : Status::error(COMPEG_E_UNSUPPORTED, "device preprocessing of a batch supports 4:2:2 images only");
+                    images[i] = nullptr;
+                    failed.store(true, std::memory_order_relaxed);
+                }
+                parsed_ready[i].store(1, std::memory_order_release);
+            }
+            if (!pinned[i]) {
+                memcpy(hs + lay[i].staged, src[i].bytes, src[i].len);
+                staged_ready[i].store(1, std::memory_order_release);
+            }
+            if (images[i])
+                write_tables(hs + (lay[i].tables - o_tables), *images[i]);
         }
     };
-    run_on_threads(nthreads, work);
-    CG_HIP(hipError_t(hip_error.load()));
-    CG_HIP(hipMemcpyAsync(scan_descs.ptr, sd.data(), n * sizeof(ScanDesc), hipMemcpyHostToDevice, st));
-    CG_HIP(launch_scan(static_cast<const ScanDesc *>(scan_descs.ptr), uint32_t(n), max_tiles, st, true));
+    std::vector<ScanDesc> sd(n);
+    std::vector<hipEvent_t> arrived;
+    auto send_runs = [&]() -> hipError_t {
+        hipError_t err = hipSuccess;
+        size_t sent = 0, next_run = 0;
+        for (size_t g = 0; g < kGroups && err == hipSuccess; g++) {
+            size_t upto = sent;
+            while (upto < n && group_of(upto) == g)
+                upto++;
+            for (; next_run < runs.size() && runs[next_run].first < upto && err == hipSuccess; next_run++) {
+                const Run &r = runs[next_run];
+                for (size_t i = r.first; i <= r.last; i++)
+                    while (!staged_ready[i].load(std::memory_order_acquire))
+                        std::this_thread::yield();
+                if (r.bytes)
+                    err = hipMemcpyAsync(da + r.dev, pinned[r.first] ? r.host : hs + lay[r.first].staged, r.bytes,
+                                         hipMemcpyHostToDevice, copy_streams[next_run % kCopyStreams]);
+            }
+            for (size_t k = 0; k < kCopyStreams && err == hipSuccess; k++) {
+                hipEvent_t e = nullptr;
+                err = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+                if (err != hipSuccess)
+                    break;
+                arrived.push_back(e);
+                err = hipEventRecord(e, copy_streams[k]);
+                if (err == hipSuccess)
+                    err = hipStreamWaitEvent(st, e, 0);
+            }
+            // the quarter's headers: where each segment lies inside what was sent
+            uint32_t group_tiles = 0;
+            for (size_t i = sent; i < upto; i++) {
+                while (!parsed_ready[i].load(std::memory_order_acquire))
+                    std::this_thread::yield();
+                if (!images[i])
+                    return err; // (a rejected image: the caller sees `failed`)
+                const ImageData &img = *images[i];
+                const Layout &L = lay[i];
+                ScanDesc &d = sd[i];
+                d.raw = da + L.sent + (given ? 0 : img.scan_offset);
+                d.len = uint32_t(img.scan_len);
+                d.ntiles = scan_tiles(d.len);
+                d.slots = uint32_t(ScanBuffer::start_slots(img.metadata.total_restart_intervals));
+                d.expected = img.metadata.total_restart_intervals;
+                d.tile_state = reinterpret_cast<uint32_t *>(da + L.tile_state);
+                d.starts_out = reinterpret_cast<uint32_t *>(da + L.starts);
+                d.words_out = da + L.words;
+                d.result = reinterpret_cast<uint32_t *>(da + o_results + i * kScanResultBytes);
+                if (d.slots > L.slot_cap || d.ntiles > L.tile_cap || d.len > src[i].len) {
+                    // (headers that say something else than the peek at them did: the parse-first way)
+                    results[i] = Status::error(COMPEG_E_INVALID_ARG, kLayoutBoundExceeded);
+                    failed.store(true, std::memory_order_relaxed);
+                    return err;
+                }
+                group_tiles = std::max(group_tiles, d.ntiles);
+            }
+            if (err == hipSuccess && upto > sent) {
+                err = hipMemcpyAsync(static_cast<ScanDesc *>(scan_descs.ptr) + sent, sd.data() + sent, (upto - sent) * sizeof(ScanDesc),
+                                     hipMemcpyHostToDevice, st);
+                if (err == hipSuccess)
+                    err = launch_scan(static_cast<const ScanDesc *>(scan_descs.ptr) + sent, uint32_t(upto - sent), group_tiles, st, true);
+            }
+            sent = upto;
+        }
+        return err;
+    };
+    hipError_t sent_status = hipSuccess;
+    {
+        auto work = [&](unsigned t) {
+            if (hipSetDevice(device) != hipSuccess) {
+                hip_error = int(hipErrorInvalidDevice);
+                return;
+            }
+            if (t == 0 && nthreads > 1)
+                sent_status = send_runs();
+            else
+                prepare_images();
+        };
+        run_on_threads(nthreads, work);
+        if (nthreads <= 1)
+            sent_status = send_runs();
+        for (hipEvent_t e : arrived)
+            (void)hipEventDestroy(e); // (destroyed once it has been reached: HIP defers that)
+    }
+    // (before any way out: transfers in flight still read the pinned arena / the caller's bytes)
+    if (sent_status != hipSuccess || hip_error.load() != int(hipSuccess) || failed.load()) {
+        for (hipStream_t c : copy_streams)
+            (void)hipStreamSynchronize(c);
+        (void)hipStreamSynchronize(st);
+        for (size_t i = 0; i < n; i++)
+            if (!results[i].ok())
+                return results[i];
+        CG_HIP(hipError_t(hip_error.load()));
+        CG_HIP(sent_status);
+        return Status::error(COMPEG_E_INVALID_ARG, "batch upload failed");
+    }
+    const double t_issued = ms_since();
+    CG_HIP(hipMemcpyAsync(da + o_tables, hs, tables_bytes, hipMemcpyHostToDevice, st));
     // all results in one read-back: sizes and window spans for the decode descriptors
     std::vector<uint32_t> res(n * (kScanResultBytes / 4));
     CG_HIP(hipMemcpyAsync(res.data(), da + o_results, n * kScanResultBytes, hipMemcpyDeviceToHost, st));
+
+    // (while the last quarter arrives: everything about the batch that needs the headers only)
+    max_tiles = 0;
+    max_intervals = max_dus = max_l2 = max_span = 0;
+    algorithmic_bytes = pixels = 0;
+    size_t out_total = 0;
+    bool all_covered = true;
+    for (size_t i = 0; i < n; i++) {
+        const ImageData &img = *images[i];
+        out_total += align_up(size_t(img.width) * 4 * img.height, 256);
+        max_tiles = std::max(max_tiles, sd[i].ntiles);
+        max_intervals = std::max(max_intervals, img.metadata.total_restart_intervals);
+        max_dus = std::max(max_dus, img.total_dus());
+        max_l2 = std::max<uint32_t>(max_l2, staged_lut_entries(img));
+        pixels += uint64_t(img.width) * img.height;
+        all_covered = all_covered && item_of(img).covered;
+    }
+    note_batch_properties(images.data(), n);
+    bool fresh_out = false;
+    CG_TRY(out.reserve(out_total + 256, &fresh_out));
+    // (texels no MCU covers read 0: see upload_host)
+    if (fresh_out || !all_covered)
+        CG_HIP(hipMemsetAsync(out.ptr, 0, out.capacity, st));
     CG_HIP(hipStreamSynchronize(st));
+    const double t_arrived = ms_since();
     last_stream = st;
 
     descs.assign(n, ImageDesc{});
@@ -1358,13 +1596,23 @@ Status compeg_batch::upload_device_scan(const ImageData *const *images, size_t n
     host_fallbacks = 0;
     size_t out_at = 0;
     for (size_t i = 0; i < n; i++) {
-        const ImageData &img = *images[i];
         const Layout &L = lay[i];
         const uint32_t *r = &res[i * (kScanResultBytes / 4)];
-        uint32_t nwords = r[2], nstarts = std::min(r[0], L.slots), span = r[4];
+        uint32_t nwords = r[2], nstarts = std::min(r[0], sd[i].slots), span = r[4];
+        const bool ends_earlier = (r[3] & 2u) != 0u && images[i]->scan_end_deferred;
+        if (ends_earlier) {
+            // another marker inside what was taken for the segment: the reference's parser ends it there
+            // (src/file.rs:163-201) -- this image once more through the whole front-end
+            Status ps;
+            const ImageData *again = reparse ? reparse(i, ps) : nullptr;
+            if (!again)
+                return ps.ok() ? Status::error(COMPEG_E_MALFORMED, "entropy-coded segment ends early") : ps;
+            images[i] = again;
+        }
+        const ImageData &img = *images[i];
         const uint32_t expected = img.metadata.total_restart_intervals;
-        if (r[3] & 1u) {
-            // pathological FF run: the host preprocessor (same output format) takes this image
+        if ((r[3] & 1u) || ends_earlier) {
+            // pathological FF run (or see above): the host preprocessor (same output format) takes this image
             ScanBuffer sb;
             Status s = sb.process(img.scan_data(), img.scan_len, expected);
             if (!s.ok() && s.code != COMPEG_E_COUNT_MISMATCH)
@@ -1413,6 +1661,13 @@ Status compeg_batch::upload_device_scan(const ImageData *const *images, size_t n
     CG_HIP(hipStreamSynchronize(gpu->stream));
     count = n;
     decodes_timed = 0;
+    if (trace_on) {
+        size_t direct = 0;
+        for (size_t i = 0; i < n; i++)
+            direct += pinned[i];
+        fprintf(stderr, "[compeg] batch upload, device scan (%zu images, %zu read where they are in %zu transfers, %u threads): layout=%.2f issued=%.2f arrived+scanned=%.2f total=%.2f ms\n",
+                n, direct, runs.size(), nthreads, t_layout, t_issued, t_arrived, ms_since());
+    }
     return Status{};
 }
 

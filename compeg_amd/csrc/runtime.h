@@ -175,6 +175,12 @@ struct compeg_batch {
     using ImageSource = std::function<const compeg::ImageData *(size_t index, compeg::Status &status)>;
     compeg::Status upload_host(size_t n, int threads, const void *items, const ImageSource &image_of);
     void note_batch_properties(const compeg::ImageData *const *images, size_t n);
-    compeg::Status upload_device_scan(const compeg::ImageData *const *images, size_t n, int threads);
+    struct FeedSource {
+        const uint8_t *bytes; // what goes up for one image: its entropy-coded segment, or the whole file
+        size_t len;
+        uint32_t intervals;   // restart intervals its header announces
+    };
+    compeg::Status upload_device_scan(size_t n, int threads, const FeedSource *src, const compeg::ImageData *const *given,
+                                      const ImageSource &parse, const ImageSource &reparse);
     compeg::Status decode(hipStream_t stream);
 };

@@ -19,7 +19,8 @@ struct ScanDesc {
     uint32_t *starts_out;    // [slots] the reference's start_positions
     uint8_t *words_out;      // preprocessed scan, (len + len/3 + 4) bytes
     uint32_t expected = 0;   // restart intervals the frame header announces (span_kernel only)
-    uint32_t *result;        // [8]: intervals counted, kept bytes, output words, flags (bit 0: FF run too long),
+    uint32_t *result;        // [8]: intervals counted, kept bytes, output words, flags (bit 0: FF run too long; bit 1:
+                             // a marker other than RSTn inside the segment -- it ends earlier than the caller said),
                              // widest 64-interval span in words (span_kernel), 3 unused
     // optional: where to drop the output word count and the number of start positions kept
     // (the nwords / nstarts fields of the image descriptor a following decode kernel reads)

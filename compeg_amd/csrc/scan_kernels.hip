@@ -240,6 +240,20 @@ __global__ void __launch_bounds__(kThreads) count_kernel(const ScanDesc *descs)
     const uint32_t g = tile * kTileBytes + threadIdx.x * kBytesPerThread;
     Chunk c;
     load_classify(d, g, c);
+    // A byte behind an FF that is neither 00 (stuffing), D0..D7 (RSTn) nor another FF (fill) is a marker that ends the
+    // entropy-coded segment in the reference's parser (src/file.rs:163-201).  A segment whose end was taken from the
+    // file's final EOI without walking it on the host (borrowed, copy-free uploads: runtime.cpp) must not hold one:
+    // flag bit 1 sends the image back to the host front-end.
+    if (c.n) {
+        uint32_t prev_ff = g > 0u && d.raw[g - 1u] == 0xffu ? 1u : 0u, foreign = 0u;
+        for (uint32_t i = 0; i < c.n; i++) {
+            const uint32_t b = byte_of(c.w, i);
+            foreign |= prev_ff & uint32_t(b != 0xffu && b != 0u && (b & 0xf8u) != 0xd0u);
+            prev_ff = b == 0xffu ? 1u : 0u;
+        }
+        if (foreign)
+            atomicOr(&d.result[3], 2u);
+    }
     Stretch total;
     block_exclusive_scan(stretch_of(c), lds, total);
     if (threadIdx.x == 0)

@@ -239,6 +239,25 @@ int compeg_batch_upload(compeg_batch *batch, const compeg_image *const *images, 
  * the upload of one runs under the decode of the other (bench.py, "end_to_end"). */
 int compeg_batch_upload_jpegs(compeg_batch *batch, const uint8_t *const *jpegs, const size_t *lengths, size_t count,
                               int host_threads, unsigned flags);
+/* The copy-free road of compeg_batch_upload_jpegs.  `ImageData::new` borrows the caller's bytes (`Cow::Borrowed`,
+ * lib.rs:577-595) and the reference uploads straight from them (lib.rs:397-407).  With device preprocessing
+ * (compeg_batch_set_device_preprocess 1 or 2) and JPEG bytes in page-locked memory -- from compeg_host_alloc, or
+ * any range made known with compeg_host_register (a capture driver's buffers, a receive ring) -- the host reads
+ * the headers only: the entropy-coded segments are fetched by the card's DMA engines from where they lie and
+ * preprocessed by the scan kernels, which also check what the skipped walk over the segment would have found (an
+ * image with a marker other than RSTn inside its segment is parsed again in full on the host).  Pageable bytes
+ * work too; the worker threads then copy them into the batch's own pinned arena first.  The bytes must stay
+ * valid and unchanged until the call returns. */
+/* Measurement aid (bench.py --host-feed-ranks; no device is touched): the host's share of feeding one batch,
+ * `reps` times over on `host_threads` threads -- road 0: ImageData::new + ScanBuffer::process of every image into a
+ * buffer of the call's own (what compeg_batch_upload_jpegs does on the host with host preprocessing: every byte read
+ * once and written once); road 1: the headers only (the copy-free road above).  *seconds: wall time of all reps. */
+int compeg_host_feed_work(const uint8_t *const *jpegs, const size_t *lengths, size_t count, int host_threads, unsigned flags,
+                          int road, int reps, double *seconds);
+int compeg_host_alloc(size_t bytes, void **out);
+void compeg_host_free(void *ptr);
+int compeg_host_register(void *ptr, size_t bytes);
+int compeg_host_unregister(void *ptr);
 int compeg_batch_decode(compeg_batch *batch, void *hip_stream);
 /* Where the scans are preprocessed.  0 (default): on the host during
  * compeg_batch_upload, like the reference.  1: raw entropy-coded segments are

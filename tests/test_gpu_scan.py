@@ -145,3 +145,75 @@ def test_decoder_device_preprocess_hands_pathological_scans_to_the_host(ca, gpu)
             op = dec.start_decode(ca.ImageData(jpeg))
             op.wait()
             assert np.array_equal(dec.read_texture(256, 64), orc.ImageData(jpeg).decode()), run
+
+
+def _jpeg_set():
+    jpegs = [synth.make_jpeg(w, h, seed=180 + i, kind=k, quality=q, ri=ri)
+             for i, (w, h, k, q, ri) in enumerate([(640, 360, 0, 85, 4), (320, 240, 1, 95, 1), (1280, 720, 0, 70, 10),
+                                                   (64, 8, 0, 100, 2), (250, 70, 2, 85, 3), (1920, 1080, 0, 85, 4),
+                                                   (960, 720, 0, 85, 120)])]
+    jpegs.append(read_golden("parser", "mjpeg.jpg"))
+    return jpegs
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_batch_fed_from_pinned_bytes_reads_headers_only(ca, gpu, mode):
+    """compeg_batch_upload_jpegs with device preprocessing and the JPEG bytes in page-locked memory
+    (compeg_host_alloc / compeg_host_register): the host parses headers, the segments go up from where they lie --
+    the borrowed-bytes road of src/lib.rs:577-595,397-407 -- and the scan kernels check what the skipped walk
+    would have found.  Same pixels as the oracle; pageable bytes and a mix of both take the staged road."""
+    jpegs = _jpeg_set()
+    wants = [orc.ImageData(j).decode() for j in jpegs]
+    pinned = ca.HostBuffer(sum(len(j) + 64 for j in jpegs))
+    views = pinned.place(jpegs)
+    registered = np.frombuffer(bytearray(b"".join(jpegs)), dtype=np.uint8).copy()   # a caller-owned buffer, page-locked in place
+    ca.host_register(registered)
+    offs = np.cumsum([0] + [len(j) for j in jpegs])
+    reg_views = [registered[offs[i]:offs[i + 1]] for i in range(len(jpegs))]
+    try:
+        for name, src in (("pinned", views), ("registered", reg_views), ("pageable", jpegs),
+                          ("mixed", [v if i % 2 else j for i, (v, j) in enumerate(zip(views, jpegs))])):
+            batch = ca.Batch(gpu)
+            batch.set_device_preprocess(mode)
+            for _ in range(2):                       # (the second upload reuses arenas and the output)
+                batch.upload_jpegs(src, host_threads=4)
+                assert batch.host_fallbacks() == 0, name
+                batch.decode()
+                batch.wait()
+                for i, want in enumerate(wants):
+                    assert np.array_equal(batch.read_output(i), want), (name, i)
+    finally:
+        ca.host_unregister(registered)
+        pinned.close()
+
+
+def test_deferred_segment_end_is_checked_on_the_device(ca, gpu):
+    """The copy-free road takes a segment to run up to the file's final EOI.  Files where the reference's parser ends
+    it earlier (src/file.rs:163-201: any marker but RSTn) -- here: bytes behind the real EOI that themselves end in
+    FF D9 -- are caught by the scan kernels and parsed again in full; files the front-end rejects fail the call
+    with the reference's message."""
+    good = synth.make_jpeg(640, 360, seed=7, quality=85, ri=4)
+    tricky = good + b"trailing bytes \x12\x34" + b"\xff\xd9"
+    want_good, want_tricky = orc.ImageData(good).decode(), orc.ImageData(tricky).decode()
+    assert np.array_equal(want_good, want_tricky)          # (the reference stops at the first EOI)
+    pinned = ca.HostBuffer(4 * len(tricky) + 1024)
+    views = pinned.place([good, tricky, tricky, good])
+    try:
+        batch = ca.Batch(gpu)
+        batch.set_device_preprocess(1)
+        batch.upload_jpegs(views, host_threads=2)
+        assert batch.host_fallbacks() == 2
+        batch.decode()
+        batch.wait()
+        for i in range(4):
+            assert np.array_equal(batch.read_output(i), want_good), i
+        bad = bytearray(good)
+        bad[good.find(b"\xff\xc0") + 1] = 0xC2                  # SOF2: rejected like ImageData::new does
+        with pytest.raises(ca.Error) as e:
+            batch.upload_jpegs(pinned.place([good, bytes(bad)]), host_threads=2)
+        assert str(e.value).startswith("image 1: ")
+        with pytest.raises(orc.OracleError) as eo:
+            orc.ImageData(bytes(bad))
+        assert str(e.value) == "image 1: " + str(eo.value)
+    finally:
+        pinned.close()
