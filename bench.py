@@ -233,7 +233,8 @@ def bench_mjpeg_stream(compeg_amd, gpu, quality, steps, warmup, threads):
     return out
 
 
-def bench_config(compeg_amd, gpu, width, height, ri, quality, batch, steps, warmup, threads, distinct, label, flags=0):
+def bench_config(compeg_amd, gpu, width, height, ri, quality, batch, steps, warmup, threads, distinct, label, flags=0,
+                 sampling=(2, 1)):
     """One more single-GPU configuration of BASELINE.json, measured like the headline one: resident inputs, `steps`
     timed decodes of the whole batch, kernel time from the batch's HIP events, a spread of slots verified."""
     import numpy as np
@@ -241,11 +242,12 @@ def bench_config(compeg_amd, gpu, width, height, ri, quality, batch, steps, warm
     from tools import synth
 
     def one(i):
-        return synth.make_jpeg(width, height, seed=0xC0FFEE + i, kind=0, quality=quality, ri=ri, flags=flags)
+        return synth.make_jpeg(width, height, seed=0xC0FFEE + i, kind=0, quality=quality, ri=ri, flags=flags, sampling=sampling)
 
+    ext = tuple(sampling) != (2, 1)
     with ThreadPoolExecutor(threads) as ex:
         jpegs = list(ex.map(one, range(distinct)))
-    images = [compeg_amd.ImageData(j, copy=False) for j in jpegs]
+    images = [compeg_amd.ImageData(j, copy=False, allow_sampling=ext) for j in jpegs]
     b = compeg_amd.Batch(gpu)
     b.upload([images[i % distinct] for i in range(batch)], host_threads=threads)
     for _ in range(warmup):
@@ -263,7 +265,7 @@ def bench_config(compeg_amd, gpu, width, height, ri, quality, batch, steps, warm
     ok = True
     slots = sorted({0, batch - 1, batch // 2})
     for i in slots:
-        ok = ok and bool(np.array_equal(b.read_output(i), orc.ImageData(jpegs[i % distinct]).decode()))
+        ok = ok and bool(np.array_equal(b.read_output(i), orc.ImageData(jpegs[i % distinct], allow_sampling=ext).decode()))
     if not ok:
         raise SystemExit(f"bench: {label}: GPU output differs from the oracle")
     achieved = alg / (kernel_ms * 1e-3) / 1e9
@@ -414,46 +416,11 @@ def bench_end_to_end(compeg_amd, device, jpegs, images, threads, reps, ext):
             "host_fallbacks": dev_batches[0].host_fallbacks(),
             "what": "compeg_batch_upload_jpegs with device preprocessing from compeg_host_alloc'ed bytes: the host reads "
                     "headers only (what crosses PCIe: the raw entropy-coded segments + tables)"}
-        # ... and with two feeder threads, a batch each: the link never waits for one upload's last scan kernels,
-        # results and descriptors before the next upload's first segment leaves
-        import threading
-
-        more = [compeg_amd.Batch(g) for g in gpus]
-        for b in more:
-            b.set_device_preprocess(1)
-            b.upload_jpegs(views, host_threads=threads)          # (warm-up: allocations)
-            b.decode()
-            b.wait()
-
-        def feeder(pair, n):                                     # two batches of its own: the upload of one under the decode of the other
-            for r in range(n):
-                b = pair[r & 1]
-                b.wait()
-                b.upload_jpegs(views, host_threads=max(1, threads // 2))
-                b.decode()
-
-        for b in dev_batches:
-            b.wait()
-        per_thread = 2 * reps + 2
-        ts = [threading.Thread(target=feeder, args=((dev_batches[k], more[k]), per_thread)) for k in (0, 1)]
-        t_f = time.perf_counter()
-        for t in ts:
-            t.start()
-        for t in ts:
-            t.join()
-        for b in dev_batches + more:
-            b.wait()
-        t_f = (time.perf_counter() - t_f) / (2 * per_thread)
-        res["from_pinned_jpeg_bytes_device_scan_two_feeder_threads"] = {
-            "ms_per_batch": round(t_f * 1e3, 3), "mpix_s": round(pix / t_f / 1e6, 1),
-            "pcie_gbs": round(jpeg_bytes / t_f / 1e9, 2), "pcie_fraction_of_link": round(jpeg_bytes / t_f / 1e9 / PCIE_LINK_GBS, 3),
-            "batches_timed": 2 * per_thread,
-            "what": "the same road with two feeder threads, each alternating between two batches of its own (mean period over the whole run)"}
         ok = ok and all(bool(np.array_equal(dev_batches[k].read_output(i), orc.ImageData(jpegs[i]).decode()))
                         for k in (0, 1) for i in (0, len(jpegs) // 2, len(jpegs) - 1))
-        for b in dev_batches + more:
+        for b in dev_batches:
             b.wait()
-        del dev_batches, more
+        del dev_batches
         pinned.close()
     if not ok:
         raise SystemExit("bench: end_to_end output differs from the oracle")
@@ -659,6 +626,11 @@ def main():
             compeg_amd, gpu, 7680, 4320, 1, args.quality, 8, args.steps, args.warmup, threads, 4,
             "8 x 7680x4320 YUV 4:2:2 baseline JPEG, DRI=1 per step (BASELINE configs[4] frame), 4 distinct frames")
         extra["mjpeg stream 960x720 DRI=10"] = bench_mjpeg_stream(compeg_amd, gpu, args.quality, args.steps, args.warmup, threads)
+        # the extension layouts (opt-in, not what the reference accepts), fused kernels
+        for name, smp in (("4:4:4", (1, 1)), ("4:2:0", (2, 2))):
+            extra[f"extension {name}, 64 x 4K"] = bench_config(
+                compeg_amd, gpu, 3840, 2160, 4, args.quality, 64, args.steps, args.warmup, threads, 16,
+                f"64 x 3840x2160 YUV {name} baseline JPEG, DRI=4, 16 distinct frames (extension layout)", sampling=smp)
 
     feed_scaling = None
     if rank == 0 and world == 1 and args.host_feed_ranks and end_to_end is not None and not ext:

@@ -51,6 +51,7 @@ namespace compeg {
 #if defined(CG_EMUL_STATS)
 struct CoopStats {
     unsigned long intervals, rounds, direct, continued, serial, dead, zero, chase_steps, wave_steps, true_steps, true_max, hist[16], link_tries, link_ok, link_full_ok, link_none;
+    unsigned long dead_quarter[4], overrun; // quirk Q1's first dead data unit by quarter of its interval; walks that ended beyond their interval's words
 };
 inline CoopStats g_coop_stats{};
 #define CG_COOP_COUNT(field, n) (g_coop_stats.field += (n))
@@ -1913,8 +1914,10 @@ CG_DEV void coop_decode_quarter_422(const ImageDesc &d, const CoopShared &cs, co
         if (!Q_exists(li) || (state[li] & kCoopUnset))
             continue;
         const uint32_t first_dead = cs.dead_from[Q_il(li)];
-        if (LANES != 1 && Q_tl(li) == first_dead)
+        if (LANES != 1 && Q_tl(li) == first_dead) {
             CG_COOP_COUNT(dead, 1);
+            CG_COOP_COUNT(dead_quarter[q & 3u], 1);
+        }
         if (Q_tl(li) <= first_dead)
             continue;
         const uint32_t comp = comp_of_k(L[li].lane & 3u);

@@ -11,8 +11,9 @@ namespace compeg {
 // whose largest image has `max_intervals` restart intervals and `max_l2`
 // L2 entries; max_wave_words (largest scan span of 64 consecutive intervals)
 // sizes the per-wave scan window.
+// wave_cap: at most that many waves per workgroup (0: the kernel family's own limit)
 HuffLdsPlan plan_huffman(uint32_t max_intervals, uint32_t images, uint32_t max_l2,
-                         uint32_t max_wave_words, bool fused);
+                         uint32_t max_wave_words, bool fused, uint32_t wave_cap = 0);
 // Largest word span covered by any group of 64 consecutive restart intervals.
 uint32_t max_wave_span(const uint32_t *starts, size_t nstarts, size_t nwords, uint32_t intervals,
                        uint32_t group = kWave);
@@ -27,6 +28,10 @@ hipError_t launch_entropy(const ImageDesc *descs, uint32_t images, uint32_t max_
 // uniform: all images have max_intervals intervals and byte-identical LUTs (workgroups may then span images)
 hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t max_intervals,
                             const HuffLdsPlan &plan, hipStream_t stream, bool uniform = false);
+// Extension layouts (luma hs x vs = 1x1, 1x2, 2x2), fused like the 4:2:2 kernel; plan with wave_cap = fused_layout_wave_cap.
+uint32_t fused_layout_wave_cap(uint32_t hs, uint32_t vs);
+hipError_t launch_fused_layout(const ImageDesc *descs, uint32_t images, uint32_t max_intervals, const HuffLdsPlan &plan,
+                               uint32_t hs, uint32_t vs, hipStream_t stream);
 // Latency variant: one decoder wave + one transformer wave per 64 intervals.
 hipError_t launch_pair_422(const ImageDesc *descs, uint32_t images, uint32_t max_intervals,
                            const HuffLdsPlan &plan, hipStream_t stream);

@@ -162,6 +162,57 @@ entropy_samples_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, 
     entropy_kernel_body<true>(descs, l2_in_lds, window_words);
 }
 
+// Extension layouts, fused (kernels_body.h: decode_wave_fused_layout): one kernel per luma sampling.
+template <int HS, int VS>
+__device__ __forceinline__ void fused_layout_kernel_body(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const ImageDesc &d = descs[blockIdx.y];
+    const uint32_t first_interval = blockIdx.x * blockDim.x;
+    if (first_interval >= d.total_intervals)
+        return;
+    uint16_t *l1 = reinterpret_cast<uint16_t *>(smem);
+    uint16_t *l2 = l1 + kL1Entries;
+    const uint32_t wave_area = align16(window_words * 4u) + kWave * kDuSlotBytes;
+    uint8_t *wave_base = smem + align16((kL1Entries + l2_in_lds) * 2u);
+    const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x / kWave))), lane = threadIdx.x % kWave;
+    uint32_t *win = reinterpret_cast<uint32_t *>(wave_base + wave * wave_area);
+    const uint32_t wave_first = first_interval + wave * kWave;
+    uint32_t win_base = 0, win_len = 0;
+    if (wave_first < d.total_intervals)
+        wave_window(d, wave_first, window_words, win_base, win_len);
+    stage_luts_and_window(d, l1, l2, l2_in_lds, threadIdx.x, blockDim.x, win, win_base, win_len, lane);
+    __syncthreads();
+    if (wave_first >= d.total_intervals)
+        return;
+    HuffShared s;
+    s.l1 = l1;
+    s.l2 = l2;
+    s.l2_staged = umin(l2_in_lds, d.fast_off + 2u * kFastEntries);
+    s.win = win;
+    s.win_base = win_base;
+    s.win_len = win_len;
+    s.du_slots = reinterpret_cast<uint8_t *>(win) + align16(window_words * 4u);
+    decode_wave_fused_layout<HS, VS>(d, s, wave_first + lane, lane);
+}
+
+__global__ void __launch_bounds__(768)
+decode_fused_444_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words)
+{
+    fused_layout_kernel_body<1, 1>(descs, l2_in_lds, window_words);
+}
+__global__ void __launch_bounds__(768)
+decode_fused_440_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words)
+{
+    fused_layout_kernel_body<1, 2>(descs, l2_in_lds, window_words);
+}
+// (six data units of samples per lane: two waves to a SIMD)
+__global__ void __launch_bounds__(512)
+decode_fused_420_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words)
+{
+    fused_layout_kernel_body<2, 2>(descs, l2_in_lds, window_words);
+}
+
 // What a wave of the fused kernel does for its NEXT unit while it decodes the current one.  Vector memory
 // operations complete in order, stores included, so whatever waits for a load also waits for every store issued
 // before it: each step below sits where the wave's latest stores (the composite of an MCU) are an MCU old.
@@ -472,8 +523,10 @@ constexpr uint32_t kMaxWavesFused = 12; // 3 per SIMD: what 168 VGPRs allow
 constexpr uint32_t kMaxWavesSplit = 16; // entropy_kernel: 4 per SIMD
 } // namespace
 
+uint32_t fused_layout_wave_cap(uint32_t hs, uint32_t vs) { return hs == 2 && vs == 2 ? 8u : 12u; }
+
 HuffLdsPlan plan_huffman(uint32_t max_intervals, uint32_t images, uint32_t max_l2,
-                         uint32_t max_wave_words, bool fused)
+                         uint32_t max_wave_words, bool fused, uint32_t wave_cap)
 {
     HuffLdsPlan p;
     // everything behind L1: the L2 LUT and the two direct AC tables (at most 24 KB of LDS)
@@ -502,7 +555,7 @@ HuffLdsPlan plan_huffman(uint32_t max_intervals, uint32_t images, uint32_t max_l
     const uint32_t lds_per_cu = lim.lds_bytes, cu_count = lim.cus;
     const uint64_t total_waves = uint64_t((max_intervals + kWave - 1) / kWave) * images;
     const uint32_t fit = (lds_per_cu - tables) / wave_area;
-    const uint32_t most = std::max(1u, std::min(fit, fused ? kMaxWavesFused : kMaxWavesSplit));
+    const uint32_t most = std::max(1u, std::min(std::min(fit, fused ? kMaxWavesFused : kMaxWavesSplit), wave_cap ? wave_cap : 64u));
     const uint64_t per_cu = (total_waves + cu_count - 1u) / cu_count;
     uint32_t wpb = uint32_t(std::min<uint64_t>(std::max<uint64_t>(per_cu, 1u), most));
     // (every image rounds up to whole workgroups: a few more waves per workgroup can save a second round)
@@ -602,6 +655,33 @@ hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t ma
     hipLaunchKernelGGL(decode_fused_422_kernel, grid, dim3(threads), plan.total_bytes, stream, descs,
                        plan.l2_entries_in_lds, plan.window_words, grid.y == 1 && waves_per_image ? waves_per_image : 0u,
                        images);
+    return hipGetLastError();
+}
+
+hipError_t launch_fused_layout(const ImageDesc *descs, uint32_t images, uint32_t max_intervals, const HuffLdsPlan &plan,
+                               uint32_t hs, uint32_t vs, hipStream_t stream)
+{
+    if (images == 0 || max_intervals == 0)
+        return hipSuccess;
+    const uint32_t threads = plan.waves_per_block * kWave; // (planned with fused_layout_wave_cap)
+    if (threads > fused_layout_wave_cap(hs, vs) * kWave)
+        return hipErrorInvalidValue;
+    dim3 grid((max_intervals + threads - 1) / threads, images, 1);
+    const void *fn = hs == 1 && vs == 1   ? reinterpret_cast<const void *>(decode_fused_444_kernel)
+                     : hs == 1 && vs == 2 ? reinterpret_cast<const void *>(decode_fused_440_kernel)
+                     : hs == 2 && vs == 2 ? reinterpret_cast<const void *>(decode_fused_420_kernel)
+                                          : nullptr;
+    if (!fn)
+        return hipErrorInvalidValue;
+    const hipError_t attr = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(device_limits().lds_bytes));
+    if (attr != hipSuccess)
+        return attr;
+    if (hs == 1 && vs == 1)
+        hipLaunchKernelGGL(decode_fused_444_kernel, grid, dim3(threads), plan.total_bytes, stream, descs, plan.l2_entries_in_lds, plan.window_words);
+    else if (hs == 1)
+        hipLaunchKernelGGL(decode_fused_440_kernel, grid, dim3(threads), plan.total_bytes, stream, descs, plan.l2_entries_in_lds, plan.window_words);
+    else
+        hipLaunchKernelGGL(decode_fused_420_kernel, grid, dim3(threads), plan.total_bytes, stream, descs, plan.l2_entries_in_lds, plan.window_words);
     return hipGetLastError();
 }
 

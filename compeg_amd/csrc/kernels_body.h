@@ -1863,4 +1863,119 @@ CG_DEV void decode_wave_fused_422(const ImageDesc &d, const HuffShared &s, uint3
 }
 #endif // __HIPCC__
 
+// ---------------------------------------------------------------------------
+// The fused path for the extension layouts: 4:4:4, 4:4:0, 4:2:0
+// ---------------------------------------------------------------------------
+// The same single pass as decode_wave_fused_422 -- a lane per restart interval, coefficients through the lane's LDS
+// slot, samples in registers, nothing but RGBA leaves the chip -- for luma sampled HS x VS (1 or 2 each) against
+// chroma: HS * VS + 2 data units per MCU (luma blocks in raster order, Cb, Cr: the reference shader's own order,
+// src/huffman.wgsl:148-155), MCUs of 8 HS x 8 VS pixels.  The composite is the reference's finalize pass
+// (src/dct.wgsl:257-321; continued to 16-row MCUs as the oracle's orc_finalize_pass states it): the luma sample of
+// its block, chroma nearest neighbour.  Every lane stores its own MCU, 16 bytes (four pixels) at a time.  It replaces
+// the two-kernel route (entropy_samples_kernel + composite_generic_kernel) and its round trip of sample records.
+template <int HS, int VS>
+struct LayoutPixels {
+    static constexpr int kDus = HS * VS + 2;
+    uint32_t px[kDus][16]; // data unit k of the MCU being assembled, 4 samples per word
+    uint32_t mx, my;
+    bool active;
+};
+
+// The MCU a lane has finished: px -> RGBA.  Rows and 4-pixel groups unroll, so every sample word is a register.
+template <int HS, int VS>
+CG_DEV void composite_layout_mcu(const LayoutPixels<HS, VS> &t, const ImageDesc &d)
+{
+    constexpr int kDus = HS * VS + 2;
+    const uint32_t x0 = t.mx * (8u * HS), y0 = t.my * (8u * VS);
+    uint8_t *base = d.out + size_t(y0) * d.out_pitch + size_t(x0) * 4u;
+    const bool whole = x0 + 8u * HS <= d.out_w && y0 + 8u * VS <= d.out_h && (d.out_pitch & 15u) == 0u;
+#pragma unroll
+    for (int row = 0; row < 8 * VS; row++) {
+#pragma unroll
+        for (int g = 0; g < 2 * HS; g++) {
+            const uint32_t yw = t.px[(row >> 3) * HS + (g >> 1)][(row & 7) * 2 + (g & 1)];
+            const int cy = row / VS;
+            Vec4u o;
+            if (HS == 2) {
+                // two chroma samples, each under two pixels
+                const uint32_t cb = t.px[kDus - 2][cy * 2 + (g >> 1)] >> ((g & 1) * 16), cr = t.px[kDus - 1][cy * 2 + (g >> 1)] >> ((g & 1) * 16);
+                o = rgba_quad(yw, cb, cr);
+            } else {
+                o = rgba_quad4(yw, t.px[kDus - 2][cy * 2 + g], t.px[kDus - 1][cy * 2 + g]);
+            }
+            uint8_t *p = base + size_t(row) * d.out_pitch + size_t(g) * 16u;
+            if (whole) {
+                store_pixels<true>(p, o);
+            } else if (y0 + uint32_t(row) < d.out_h) {
+                // cut by the right / bottom edge (stores outside are dropped, like textureStore) or an unaligned pitch
+                const uint32_t x = x0 + uint32_t(g) * 4u;
+                auto *q = CG_GLOBAL(uint32_t, reinterpret_cast<uint32_t *>(p));
+                if (x < d.out_w)
+                    q[0] = o.x;
+                if (x + 1u < d.out_w)
+                    q[1] = o.y;
+                if (x + 2u < d.out_w)
+                    q[2] = o.z;
+                if (x + 3u < d.out_w)
+                    q[3] = o.w;
+            }
+        }
+    }
+}
+
+template <int HS, int VS>
+CG_DEV void decode_wave_fused_layout(const ImageDesc &d, const HuffShared &s, uint32_t interval, uint32_t lane)
+{
+    constexpr int kDus = HS * VS + 2;
+    const bool active = interval < d.total_intervals;
+    if (!active)
+        return; // (no cross-lane step in this body)
+    uint8_t *slot = s.du_slots + lane * kDuSlotBytes;
+    int16_t *slot16 = reinterpret_cast<int16_t *>(slot);
+    zero_slot(slot);
+    EntropyState e;
+    entropy_init(e, d, s, interval);
+    LayoutPixels<HS, VS> t;
+#pragma unroll
+    for (int k = 0; k < kDus; k++)
+#pragma unroll
+        for (int w = 0; w < 16; w++)
+            t.px[k][w] = 0u;
+    const uint32_t mcu0 = interval * d.restart_interval;
+    t.mx = mcu0 % d.width_mcus;
+    t.my = mcu0 / d.width_mcus;
+    t.active = true;
+    const uint32_t du_total = d.restart_interval * uint32_t(kDus);
+    uint32_t k = 0; // data unit inside the MCU
+#pragma unroll 1
+    for (uint32_t du = 0; du < du_total; du++) {
+        const uint32_t comp = k < uint32_t(HS * VS) ? 0u : k - uint32_t(HS * VS) + 1u;
+        const int32_t dc = entropy_data_unit(e, d, s, comp, slot16);
+        uint32_t rec[kRetained / 2];
+        take_slot(slot, rec);
+        idct_data_unit(rec, dc, d.quant[comp], t.px[kDus - 1]);
+        // (one copy of the IDCT; the blocks in front of the last are moved to their place: see pixel_transform)
+#pragma unroll
+        for (int j = 0; j < kDus - 1; j++) {
+            if (k == uint32_t(j)) {
+#pragma unroll
+                for (int w = 0; w < 16; w++)
+                    t.px[j][w] = t.px[kDus - 1][w];
+                CG_PLACE_MARK("; data unit in place");
+            }
+        }
+        if (k == uint32_t(kDus - 1)) {
+            composite_layout_mcu<HS, VS>(t, d);
+            t.mx++;
+            if (t.mx == d.width_mcus) {
+                t.mx = 0;
+                t.my++;
+            }
+            k = 0;
+        } else {
+            k++;
+        }
+    }
+}
+
 } // namespace compeg

@@ -155,13 +155,16 @@ CoopSpans coop_spans_exact(const uint32_t *starts, size_t nstarts, size_t nwords
 // Device preprocessing reports the largest word span of 64 consecutive intervals only: a group's share of it and
 // half as much again.  (A group that is longer than that still decodes: the walks that leave the window hand their
 // interval to the serial decoder.)
-CoopSpans coop_spans_estimate(uint32_t span_of_64, uint32_t restart_interval)
+// generous: span_of_64 is a measured maximum (batches), not itself an estimate with slack in it (a decoder's
+// blocking decode: twice the average span)
+CoopSpans coop_spans_estimate(uint32_t span_of_64, uint32_t restart_interval, bool generous)
 {
     CoopSpans sp{};
     for (uint32_t k = 0; k < 3u; k++) {
         const uint32_t ipw = coop_shape(restart_interval, 4u >> k).ipw;
         const uint64_t share = uint64_t(span_of_64) * ipw / kWave;
-        sp.words[k] = ipw >= uint32_t(kWave) ? span_of_64 : uint32_t(std::min<uint64_t>(span_of_64, share + share / 2 + 64));
+        sp.words[k] = ipw >= uint32_t(kWave) ? span_of_64
+                                             : uint32_t(std::min<uint64_t>(generous ? span_of_64 : 0x7fffffffu, share + (generous ? share / 2 : 0) + 64));
     }
     return sp;
 }
@@ -715,23 +718,30 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
                                                     md.total_restart_intervals);
     const bool fused = use_fused_pipeline() && is_422(img);
     // (the extension pipeline's first kernel carries the IDCT: planned like the fused kernel)
+    const uint32_t luma_h = md.components[0].hsample, luma_v = md.components[0].vsample;
     const HuffLdsPlan plan = plan_huffman(md.total_restart_intervals, 1, staged_lut_entries(img), span,
-                                          fused || !is_422(img));
+                                          fused || !is_422(img), is_422(img) ? 0u : fused_layout_wave_cap(luma_h, luma_v));
     last_span = span;
     last_plan = plan;
     trace.mark("plan");
     if (!is_422(img)) {
-        // extension layouts (4:4:4, 4:4:0, 4:2:0): entropy stage, IDCT in place, generic composite
-        CG_HIP(launch_entropy_samples(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals,
-                                      plan, stream));
-        CG_HIP(launch_generic_composite(reinterpret_cast<const ImageDesc *>(db), 1, out_w, out_h, stream));
+        // extension layouts (4:4:4, 4:4:0, 4:2:0): one fused kernel per layout (the development pipeline keeps the
+        // two-kernel route: entropy stage with the IDCT in place, generic composite)
+        if (use_fused_pipeline()) {
+            CG_HIP(launch_fused_layout(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals, plan, luma_h, luma_v, stream));
+            last_kernel = COMPEG_KERNEL_FUSED_LAYOUT;
+        } else {
+            CG_HIP(launch_entropy_samples(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals,
+                                          plan, stream));
+            CG_HIP(launch_generic_composite(reinterpret_cast<const ImageDesc *>(db), 1, out_w, out_h, stream));
+            last_kernel = COMPEG_KERNEL_GENERIC;
+        }
         coefficients_valid = false;
-        last_kernel = COMPEG_KERNEL_GENERIC;
     } else if (fused) {
         CoopPlan coop{};
         if (reinterpret_cast<const ImageDesc *>(hb)->coop_ok && use_coop_kernel(md.total_restart_intervals, 1, md.restart_interval)) {
             // (on the device path `dev_span` is itself an estimate, twice the average span of 64 intervals)
-            const CoopSpans spans = on_device ? coop_spans_estimate(dev_span, md.restart_interval)
+            const CoopSpans spans = on_device ? coop_spans_estimate(dev_span, md.restart_interval, false)
                                               : coop_spans_exact(scan.starts(), scan.nstarts(), scan.nwords(),
                                                                  md.total_restart_intervals, md.restart_interval);
             coop = plan_coop(md.total_restart_intervals, 1, md.restart_interval, staged_lut_entries(img), spans);
@@ -979,6 +989,8 @@ Status compeg_batch::upload(const ImageData *const *images, size_t n, int thread
 void compeg_batch::note_batch_properties(const ImageData *const *images, size_t n)
 {
     generic_layout = false;
+    layout_h = n ? images[0]->metadata.components[0].hsample : 0;
+    layout_v = n ? images[0]->metadata.components[0].vsample : 0;
     max_out_w = max_out_h = 0;
     // frames of one stream: the same number of restart intervals and byte-identical LUTs in every image
     // (the fused kernel's workgroups may then span image boundaries)
@@ -986,6 +998,8 @@ void compeg_batch::note_batch_properties(const ImageData *const *images, size_t 
     for (size_t i = 0; i < n; i++) {
         const ImageData &img = *images[i], &first = *images[0];
         generic_layout = generic_layout || !is_422(img);
+        if (img.metadata.components[0].hsample != layout_h || img.metadata.components[0].vsample != layout_v)
+            layout_h = layout_v = 0; // (mixed samplings in one batch)
         max_out_w = std::max(max_out_w, img.width);
         max_out_h = std::max(max_out_h, img.height);
         uniform = uniform && img.metadata.total_restart_intervals == first.metadata.total_restart_intervals &&
@@ -1652,7 +1666,7 @@ Status compeg_batch::upload_device_scan(size_t n, int threads, const FeedSource 
         } else {
             // (the kernels report the span of 64 intervals only: four times the average for a wave's group;
             // a group that is longer than that still decodes, its intervals one lane each)
-            coop_spans_max(coop_spans, coop_spans_estimate(span, coop_r));
+            coop_spans_max(coop_spans, coop_spans_estimate(span, coop_r, true));
         }
         algorithmic_bytes += 4ull * nwords + 4ull * expected + COMPEG_METADATA_BYTES +
                              COMPEG_HUFFMAN_L1_BYTES + img.l2.size() * 2 + 4ull * img.width * img.height;
@@ -1725,7 +1739,17 @@ Status compeg_batch::decode(hipStream_t stream)
     for (uint32_t at = 0; at < n; at += step) {
         const uint32_t m = std::min(step, n - at);
         const bool fused = use_fused_pipeline() && !generic_layout;
-        const HuffLdsPlan plan = plan_huffman(max_intervals, m, max_l2, max_span, fused || generic_layout);
+        const bool one_layout = generic_layout && layout_h != 0 && use_fused_pipeline();
+        const HuffLdsPlan plan = plan_huffman(max_intervals, m, max_l2, max_span, fused || generic_layout,
+                                              one_layout ? fused_layout_wave_cap(layout_h, layout_v) : 0u);
+        if (one_layout) {
+            // every image has the same extension layout: its fused kernel
+            last_kernel = at ? last_kernel : COMPEG_KERNEL_FUSED_LAYOUT;
+            CG_HIP(launch_fused_layout(dd + at, m, max_intervals, plan, layout_h, layout_v, stream));
+            if (timing && at == 0)
+                CG_HIP(hipEventRecord(ev[1], stream));
+            continue;
+        }
         if (generic_layout) {
             last_kernel = at ? last_kernel : COMPEG_KERNEL_GENERIC;
             CG_HIP(launch_entropy_samples(dd + at, m, max_intervals, plan, stream));

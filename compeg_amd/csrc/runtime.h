@@ -26,7 +26,7 @@ bool use_fused_pipeline();
 bool use_pair_kernel(uint32_t max_intervals, uint32_t images);
 bool use_coop_kernel(uint32_t max_intervals, uint32_t images, uint32_t restart_interval);
 CoopSpans coop_spans_exact(const uint32_t *starts, size_t nstarts, size_t nwords, uint32_t intervals, uint32_t restart_interval);
-CoopSpans coop_spans_estimate(uint32_t span_of_64, uint32_t restart_interval);
+CoopSpans coop_spans_estimate(uint32_t span_of_64, uint32_t restart_interval, bool generous);
 void coop_spans_max(CoopSpans &into, const CoopSpans &other);
 
 // Grow-only device allocation; contents are not preserved across growth
@@ -137,6 +137,7 @@ struct compeg_batch {
     uint32_t max_intervals = 0, max_dus = 0, max_l2 = 0, max_span = 0;
     // some image is not 4:2:2 (extension): the whole batch takes the three-kernel pipeline
     bool generic_layout = false;
+    uint32_t layout_h = 0, layout_v = 0; // luma sampling all images share (0: they differ)
     bool uniform = false; // same interval count and LUT bytes in every image (set by upload)
     // cooperative kernel: the restart interval all images share if every one of them qualifies (else 0), and the
     // largest word span of a wave's group of intervals

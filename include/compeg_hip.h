@@ -173,8 +173,9 @@ int compeg_decoder_last_stage_times(const compeg_decoder *dec, compeg_stage_time
 #define COMPEG_KERNEL_FUSED 1      /* decode_fused_422_kernel: a lane per restart interval, launches that fill the chip */
 #define COMPEG_KERNEL_PAIR 2       /* decode_pair_422_kernel: decoder wave + transformer wave per 64 intervals */
 #define COMPEG_KERNEL_COOP_TEAM 3  /* decode_coop_team_422_kernel: the lanes of a team work inside the intervals */
-#define COMPEG_KERNEL_GENERIC 4    /* entropy_samples_kernel + composite_generic_kernel (layouts other than 4:2:2) */
+#define COMPEG_KERNEL_GENERIC 4    /* entropy_samples_kernel + composite_generic_kernel (batches of mixed layouts) */
 #define COMPEG_KERNEL_SPLIT 5      /* entropy_kernel + idct_composite_kernel (development pipeline) */
+#define COMPEG_KERNEL_FUSED_LAYOUT 6 /* decode_fused_444 / _440 / _420_kernel (one layout other than 4:2:2) */
 int compeg_decoder_last_kernel(const compeg_decoder *dec);
 /* Extension: on != 0 moves the scan preprocessing of every following decode
  * from the host (the reference's data flow, default) to the device-side scan

@@ -47,7 +47,7 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
 {
     ImageData *img = nullptr;
     // mode 4 = the extension pipeline: any luma sampling is accepted
-    const unsigned parse_flags = (fused == 4 ? COMPEG_PARSE_ANY_LUMA_SAMPLING : 0u) |
+    const unsigned parse_flags = ((fused == 4 || fused == 6) ? COMPEG_PARSE_ANY_LUMA_SAMPLING : 0u) |
                                  (getenv("EMUL_STANDARD") ? COMPEG_PARSE_STANDARD_ENTROPY : 0u);
     Status s = ImageData::parse(jpeg, len, false, &img, parse_flags);
     if (!s.ok()) {
@@ -299,6 +299,19 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
             for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
                 stage_window(d, win, wb, wl, lane);
             HuffShared sh{sl1, sl2, umin(l2_in_lds, d.fast_off + 2u * kFastEntries), win, wb, wl, slots};
+            if (fused == 6) {
+                // decode_fused_444 / _440 / _420_kernel: a lane per interval from entropy decode to RGBA, no cross-lane step
+                const uint32_t hs = img->metadata.components[0].hsample, vs = img->metadata.components[0].vsample;
+                for (uint32_t lane = 0; lane < uint32_t(kWave); lane++) {
+                    if (hs == 1 && vs == 1)
+                        decode_wave_fused_layout<1, 1>(d, sh, wave_first + lane, lane);
+                    else if (hs == 1 && vs == 2)
+                        decode_wave_fused_layout<1, 2>(d, sh, wave_first + lane, lane);
+                    else if (hs == 2 && vs == 2)
+                        decode_wave_fused_layout<2, 2>(d, sh, wave_first + lane, lane);
+                }
+                continue;
+            }
             if (fused == 3 || fused == 4) {
                 // entropy_wave_to_records, data unit by data unit and phase by phase
                 std::vector<EntropyState> es(kWave);
@@ -335,6 +348,10 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
     if (dc_out)
         memcpy(dc_out, dc.data(), dc.size() * 4);
 
+    if (fused == 6) {
+        delete img;
+        return 0;
+    }
     if (fused == 4) {
         // ---- composite_generic_kernel (extension layouts; the records hold samples) ----
         for (uint32_t y = 0; y < tex_h; y++)
@@ -395,7 +412,7 @@ int main(int argc, char **argv)
 
     ImageData *probe = nullptr;
     const int mode = getenv("EMUL_FUSED") ? atoi(getenv("EMUL_FUSED")) : 0;
-    Status s = ImageData::parse(exact, jpeg.size(), false, &probe, mode == 4 ? COMPEG_PARSE_ANY_LUMA_SAMPLING : 0u);
+    Status s = ImageData::parse(exact, jpeg.size(), false, &probe, (mode == 4 || mode == 6) ? COMPEG_PARSE_ANY_LUMA_SAMPLING : 0u);
     if (!s.ok()) {
         printf("error: %s\n", s.message.c_str());
         free(exact);
@@ -434,6 +451,8 @@ int main(int argc, char **argv)
     if (cst.intervals)
         fprintf(stderr, "coop intervals=%lu rounds=%lu direct=%lu continued=%lu serial=%lu dead=%lu zero=%lu chase_steps=%lu wave_steps=%lu\n", cst.intervals,
                 cst.rounds, cst.direct, cst.continued, cst.serial, cst.dead, cst.zero, cst.chase_steps, cst.wave_steps);
+    if (cst.intervals && cst.dead)
+        fprintf(stderr, "coopdead q0=%lu q1=%lu q2=%lu q3=%lu\n", cst.dead_quarter[0], cst.dead_quarter[1], cst.dead_quarter[2], cst.dead_quarter[3]);
     if (cst.intervals && getenv("EMUL_COOP_HIST")) {
         fprintf(stderr, "cooplinks (first lane of each interval) tries=%lu ok=%lu only_full_match=%lu none=%lu\n", cst.link_tries, cst.link_ok, cst.link_full_ok, cst.link_none);
         fprintf(stderr, "coophist true_steps=%lu true_max=%lu hist(16 steps per bin):", cst.true_steps, cst.true_max);

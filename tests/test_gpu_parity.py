@@ -468,13 +468,40 @@ def test_extension_layouts(ca, gpu, sampling):
         data = ca.ImageData(j, allow_sampling=True)
         dec.decode_blocking(data)
         want, coef = orc.ImageData(j, allow_sampling=True).decode(want_coefficients=True)
+        assert dec.last_kernel() == "fused_layout"     # decode_fused_444 / _440 / _420_kernel: one pass, nothing but RGBA to HBM
         _assert_equal(dec.read_texture(w, h), want)
         assert np.array_equal(dec.read_coefficients(data.total_dus() if hasattr(data, "total_dus") else len(coef) // 32), coef)
+    # a batch of one layout: the same fused kernel (40 images: several workgroups per image, images of different sizes)
+    same = [jpegs[i % 4] for i in range(40)]
+    batch = ca.Batch(gpu)
+    batch.upload([ca.ImageData(j, allow_sampling=True) for j in same])
+    batch.decode()
+    batch.wait()
+    assert batch.last_kernel() == "fused_layout"
+    wants = [orc.ImageData(j, allow_sampling=True).decode() for j in jpegs]
+    for i in range(40):
+        _assert_equal(batch.read_output(i), wants[i % 4])
+    # corrupt streams in this layout (bit flips inside the scan)
+    rng = np.random.default_rng(17)
+    for it in range(4):
+        j = bytearray(jpegs[1])
+        scan_at = j.find(b"\xff\xda") + 14
+        for _ in range(int(rng.integers(1, 20))):
+            pos = int(rng.integers(scan_at, len(j) - 2))
+            if j[pos] != 0xFF and j[pos - 1] != 0xFF:
+                j[pos] ^= 1 << int(rng.integers(0, 8))
+                if j[pos] == 0xFF:
+                    j[pos] = 0xFE
+        dec = ca.Decoder(gpu)
+        dec.decode_blocking(ca.ImageData(bytes(j), allow_sampling=True))
+        _assert_equal(dec.read_texture(250, 70), orc.ImageData(bytes(j), allow_sampling=True).decode())
+    # layouts mixed in one batch: the two-kernel route (sample records, generic composite)
     mixed = jpegs[:3] + [synth.make_jpeg(320, 240, seed=305, ri=2)]
     batch = ca.Batch(gpu)
     batch.upload([ca.ImageData(j, allow_sampling=True) for j in mixed])
     batch.decode()
     batch.wait()
+    assert batch.last_kernel() == "generic"
     for i, j in enumerate(mixed):
         _assert_equal(batch.read_output(i), orc.ImageData(j, allow_sampling=True).decode())
 
@@ -696,6 +723,46 @@ def test_cooperative_kernel_window_estimate_too_small(ca, gpu, ri):
         if device:
             assert dec.last_kernel() == "coop_team"
         _assert_equal(dec.read_texture(w, h), want)
+
+
+# Seeds of synth.fill(64, 8, seed, kind=1): as one restart interval of four MCUs at quality 100, the reference's reader
+# runs dry at a DC code (quirk Q1) in quarter q of the interval -- MCU q -- and decodes zeros from there on.  Found
+# with the emulated kernel's counters (tests/test_kernel_emulation.py checks them); one such interval in a thousand.
+Q1_TILES = {0: (2336, 19408), 1: (860, 1469), 2: (1674, 7303), 3: (77, 6532)}
+
+
+def q1_frame(w, h, every=16):
+    """A smooth frame in which every `every`-th restart interval (64 x 8 pixels, DRI = 4) is one of the Q1 tiles."""
+    rgb = synth.fill(w, h, seed=5, kind=0, noise=0).copy()
+    per_row, n = w // 64, 0
+    for i in range(3, per_row * (h // 8), every):
+        seeds = Q1_TILES[n % 4]
+        y, x = (i // per_row) * 8, (i % per_row) * 64
+        rgb[y:y + 8, x:x + 64] = synth.fill(64, 8, seed=seeds[(n // 4) % 2], kind=1)
+        n += 1
+    return synth.encode(rgb, quality=100, ri=4), n
+
+
+def test_q1_underflow_in_every_quarter_under_the_walk(ca, gpu):
+    """Quirk Q1 inside the cooperative kernel's decoding-under-the-walk (DRI = 4, more than one team per workgroup):
+    the wave of quarter q finds the reference reader's underflow, the later quarters' lanes drop what they decoded
+    and take the zero-stream levels, the DC sums cross the quarters -- for underflows in each of the four quarters,
+    in one frame (272 teams) and in a two-frame launch."""
+    jpeg, tiles = q1_frame(2048, 1088)
+    assert tiles >= 250
+    want = orc.ImageData(jpeg).decode()
+    plain = orc.ImageData(jpeg, standard_entropy=True).decode()
+    assert (want != plain).any(axis=2).sum() > 20 * tiles          # (the underflows are there: whole MCUs differ)
+    dec, data, got = _decode(ca, gpu, jpeg)
+    assert dec.last_kernel() == "coop_team"
+    _assert_equal(got, want)
+    batch = ca.Batch(gpu)
+    batch.upload([ca.ImageData(jpeg)] * 2)
+    batch.decode()
+    batch.wait()
+    assert batch.last_kernel() == "coop_team"
+    for i in range(2):
+        _assert_equal(batch.read_output(i), want)
 
 
 def test_large_frames_clean_and_corrupt(ca, gpu):

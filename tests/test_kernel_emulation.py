@@ -47,7 +47,7 @@ def _run(runner, tmp_path, jpeg, fused, waves=1, window=2048, l2=12288, standard
     assert r.returncode == 0, r.stdout + r.stderr[-2000:]
     _, w, h, _ = r.stdout.split()
     for line in r.stderr.splitlines():
-        if line.startswith("stats ") or line.startswith("coop "):
+        if line.startswith("stats ") or line.startswith("coop ") or line.startswith("coopdead "):
             for kv in line.split()[1:]:
                 k, v = kv.split("=")
                 STATS[k] = STATS.get(k, 0) + int(v)
@@ -212,6 +212,20 @@ def test_emulated_reference_reader_underflow_on_valid_streams(runner, tmp_path):
     assert STATS.get("zero", 0) > 0
 
 
+def test_emulated_q1_underflow_in_every_quarter(runner, tmp_path):
+    """The tiles of tests/test_gpu_parity.py::Q1_TILES: the emulated team kernel (decoding by quarters) meets the
+    reference reader's underflow in each of the four quarters of an interval, and equals the oracle."""
+    import test_gpu_parity as gp
+    jpeg, tiles = gp.q1_frame(1024, 64, every=5)
+    want = orc.ImageData(jpeg).decode()
+    before = [STATS.get(f"q{q}", 0) for q in range(4)]
+    got = _run(runner, tmp_path, jpeg, 5, window=0, coop_passes=4)
+    assert np.array_equal(got, want)
+    assert all(STATS.get(f"q{q}", 0) > before[q] for q in range(4)), STATS
+    for fused in (1, 2):
+        assert np.array_equal(_run(runner, tmp_path, jpeg, fused), want)
+
+
 @pytest.mark.parametrize("sampling", [(1, 1), (2, 1), (1, 2), (2, 2)])
 def test_emulated_extension_layouts(runner, tmp_path, sampling):
     """4:4:4, 4:2:2, 4:4:0, 4:2:0 through the extension pipeline (entropy records, IDCT in place,
@@ -221,6 +235,9 @@ def test_emulated_extension_layouts(runner, tmp_path, sampling):
         want = orc.ImageData(jpeg, allow_sampling=True).decode()
         got = _run(runner, tmp_path, jpeg, 4)
         assert np.array_equal(got, want), f"{sampling} {w}x{h}: {(got != want).any(axis=2).sum()} pixels differ"
+        if sampling != (2, 1):   # the fused kernels of the extension layouts (decode_fused_444 / _440 / _420_kernel)
+            got = _run(runner, tmp_path, jpeg, 6, waves=3, window=300)
+            assert np.array_equal(got, want), f"fused {sampling} {w}x{h}: {(got != want).any(axis=2).sum()} pixels differ"
 
 
 def test_emulated_standard_entropy_extension(runner, tmp_path):
