@@ -29,9 +29,10 @@ hipError_t launch_entropy(const ImageDesc *descs, uint32_t images, uint32_t max_
 hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t max_intervals,
                             const HuffLdsPlan &plan, hipStream_t stream, bool uniform = false);
 // Extension layouts (luma hs x vs = 1x1, 1x2, 2x2), fused like the 4:2:2 kernel; plan with wave_cap = fused_layout_wave_cap.
-uint32_t fused_layout_wave_cap(uint32_t hs, uint32_t vs);
+// pairs: (8-pixel MCUs) every image of the launch has an even restart interval -- a lane composites its MCUs two at a time
+uint32_t fused_layout_wave_cap(uint32_t hs, uint32_t vs, bool pairs);
 hipError_t launch_fused_layout(const ImageDesc *descs, uint32_t images, uint32_t max_intervals, const HuffLdsPlan &plan,
-                               uint32_t hs, uint32_t vs, hipStream_t stream);
+                               uint32_t hs, uint32_t vs, bool pairs, hipStream_t stream);
 // Latency variant: one decoder wave + one transformer wave per 64 intervals.
 hipError_t launch_pair_422(const ImageDesc *descs, uint32_t images, uint32_t max_intervals,
                            const HuffLdsPlan &plan, hipStream_t stream);

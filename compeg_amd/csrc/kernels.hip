@@ -162,57 +162,6 @@ entropy_samples_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, 
     entropy_kernel_body<true>(descs, l2_in_lds, window_words);
 }
 
-// Extension layouts, fused (kernels_body.h: decode_wave_fused_layout): one kernel per luma sampling.
-template <int HS, int VS>
-__device__ __forceinline__ void fused_layout_kernel_body(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words)
-{
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const ImageDesc &d = descs[blockIdx.y];
-    const uint32_t first_interval = blockIdx.x * blockDim.x;
-    if (first_interval >= d.total_intervals)
-        return;
-    uint16_t *l1 = reinterpret_cast<uint16_t *>(smem);
-    uint16_t *l2 = l1 + kL1Entries;
-    const uint32_t wave_area = align16(window_words * 4u) + kWave * kDuSlotBytes;
-    uint8_t *wave_base = smem + align16((kL1Entries + l2_in_lds) * 2u);
-    const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x / kWave))), lane = threadIdx.x % kWave;
-    uint32_t *win = reinterpret_cast<uint32_t *>(wave_base + wave * wave_area);
-    const uint32_t wave_first = first_interval + wave * kWave;
-    uint32_t win_base = 0, win_len = 0;
-    if (wave_first < d.total_intervals)
-        wave_window(d, wave_first, window_words, win_base, win_len);
-    stage_luts_and_window(d, l1, l2, l2_in_lds, threadIdx.x, blockDim.x, win, win_base, win_len, lane);
-    __syncthreads();
-    if (wave_first >= d.total_intervals)
-        return;
-    HuffShared s;
-    s.l1 = l1;
-    s.l2 = l2;
-    s.l2_staged = umin(l2_in_lds, d.fast_off + 2u * kFastEntries);
-    s.win = win;
-    s.win_base = win_base;
-    s.win_len = win_len;
-    s.du_slots = reinterpret_cast<uint8_t *>(win) + align16(window_words * 4u);
-    decode_wave_fused_layout<HS, VS>(d, s, wave_first + lane, lane);
-}
-
-__global__ void __launch_bounds__(768)
-decode_fused_444_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words)
-{
-    fused_layout_kernel_body<1, 1>(descs, l2_in_lds, window_words);
-}
-__global__ void __launch_bounds__(768)
-decode_fused_440_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words)
-{
-    fused_layout_kernel_body<1, 2>(descs, l2_in_lds, window_words);
-}
-// (six data units of samples per lane: two waves to a SIMD)
-__global__ void __launch_bounds__(512)
-decode_fused_420_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words)
-{
-    fused_layout_kernel_body<2, 2>(descs, l2_in_lds, window_words);
-}
-
 // What a wave of the fused kernel does for its NEXT unit while it decodes the current one.  Vector memory
 // operations complete in order, stores included, so whatever waits for a load also waits for every store issued
 // before it: each step below sits where the wave's latest stores (the composite of an MCU) are an MCU old.
@@ -274,9 +223,10 @@ struct WindowAhead {
 // one stream): a one-dimensional grid over the waves of all images, workgroups span image boundaries (every
 // wave works from its own image's descriptor; the LUTs are staged from whichever images the workgroup's
 // threads belong to -- the same bytes), and only the batch's last workgroup is short.
-__global__ void __launch_bounds__(768)
-decode_fused_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words,
-                        uint32_t waves_per_image, uint32_t images)
+// (LAYOUT: a struct with the wave's body: Wave422 -- the reference's 4:2:2 -- or WaveLayout<HS, VS>, the extension layouts)
+template <class LAYOUT>
+__device__ __forceinline__ void fused_kernel_body(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words,
+                                                  uint32_t waves_per_image, uint32_t images)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x / kWave))), lane = threadIdx.x % kWave;
@@ -341,7 +291,7 @@ decode_fused_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds,
         ahead.lane = lane;
         ahead.win = win;
         ahead.sink = 0u;
-        decode_wave_fused_422(d, s, wave_first + lane, lane, ahead);
+        LAYOUT::decode(d, s, wave_first + lane, lane, ahead);
         if (!ahead.any)
             break;
         image = ahead.image;
@@ -349,6 +299,84 @@ decode_fused_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds,
         win_base = ahead.base;
         win_len = ahead.len;
     }
+}
+
+struct Wave422 {
+    template <class AHEAD>
+    static __device__ __forceinline__ void decode(const ImageDesc &d, const HuffShared &s, uint32_t interval, uint32_t lane, AHEAD &ahead)
+    {
+        decode_wave_fused_422(d, s, interval, lane, ahead);
+    }
+};
+__global__ void __launch_bounds__(768)
+decode_fused_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words,
+                        uint32_t waves_per_image, uint32_t images)
+{
+    fused_kernel_body<Wave422>(descs, l2_in_lds, window_words, waves_per_image, images);
+}
+// Extension layouts: decode_wave_fused_layout behind the plain prologue -- grid (workgroups per image,
+// images), no resident waves: inside the larger body above these kernels spill (4:2:0: 356 registers), alone they
+// do not (134 / 152 / 186 VGPRs).  Luma 1x1 (4:4:4), 1x2 (4:4:0) ...
+template <int HS, int VS, int MC>
+__device__ __forceinline__ void fused_layout_kernel_body(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const ImageDesc &d = descs[blockIdx.y];
+    const uint32_t first_interval = blockIdx.x * blockDim.x;
+    if (first_interval >= d.total_intervals)
+        return;
+    uint16_t *l1 = reinterpret_cast<uint16_t *>(smem);
+    uint16_t *l2 = l1 + kL1Entries;
+    const uint32_t wave_area = align16(window_words * 4u) + kWave * kDuSlotBytes;
+    uint8_t *wave_base = smem + align16((kL1Entries + l2_in_lds) * 2u);
+    const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x / kWave))), lane = threadIdx.x % kWave;
+    uint32_t *win = reinterpret_cast<uint32_t *>(wave_base + wave * wave_area);
+    const uint32_t wave_first = first_interval + wave * kWave;
+    uint32_t win_base = 0, win_len = 0;
+    if (wave_first < d.total_intervals)
+        wave_window(d, wave_first, window_words, win_base, win_len);
+    stage_luts_and_window(d, l1, l2, l2_in_lds, threadIdx.x, blockDim.x, win, win_base, win_len, lane);
+    __syncthreads();
+    if (wave_first >= d.total_intervals)
+        return; // the whole wave; lanes past the last interval of a partly used wave stay (quad exchange)
+    HuffShared s;
+    s.l1 = l1;
+    s.l2 = l2;
+    s.l2_staged = umin(l2_in_lds, d.fast_off + 2u * kFastEntries);
+    s.win = win;
+    s.win_base = win_base;
+    s.win_len = win_len;
+    s.du_slots = reinterpret_cast<uint8_t *>(win) + align16(window_words * 4u);
+    decode_wave_fused_layout<HS, VS, MC>(d, s, wave_first + lane, lane);
+}
+
+// (4:4:4 and 4:4:0: MCUs in pairs -- rows of 64 bytes -- where the restart interval is even: two waves to a SIMD;
+// singly otherwise)
+__global__ void __launch_bounds__(512)
+decode_fused_444_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words)
+{
+    fused_layout_kernel_body<1, 1, 2>(descs, l2_in_lds, window_words);
+}
+__global__ void __launch_bounds__(768)
+decode_fused_444_single_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words)
+{
+    fused_layout_kernel_body<1, 1, 1>(descs, l2_in_lds, window_words);
+}
+__global__ void __launch_bounds__(512)
+decode_fused_440_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words)
+{
+    fused_layout_kernel_body<1, 2, 2>(descs, l2_in_lds, window_words);
+}
+__global__ void __launch_bounds__(768)
+decode_fused_440_single_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words)
+{
+    fused_layout_kernel_body<1, 2, 1>(descs, l2_in_lds, window_words);
+}
+// ... and 2x2 (4:2:0: six data units of samples per lane, two waves to a SIMD)
+__global__ void __launch_bounds__(512)
+decode_fused_420_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words)
+{
+    fused_layout_kernel_body<2, 2, 1>(descs, l2_in_lds, window_words);
 }
 
 // Latency-oriented variant of the fused path for launches that cannot fill
@@ -523,7 +551,7 @@ constexpr uint32_t kMaxWavesFused = 12; // 3 per SIMD: what 168 VGPRs allow
 constexpr uint32_t kMaxWavesSplit = 16; // entropy_kernel: 4 per SIMD
 } // namespace
 
-uint32_t fused_layout_wave_cap(uint32_t hs, uint32_t vs) { return hs == 2 && vs == 2 ? 8u : 12u; }
+uint32_t fused_layout_wave_cap(uint32_t hs, uint32_t vs, bool pairs) { return (hs == 2 && vs == 2) || (hs == 1 && pairs) ? 8u : 12u; }
 
 HuffLdsPlan plan_huffman(uint32_t max_intervals, uint32_t images, uint32_t max_l2,
                          uint32_t max_wave_words, bool fused, uint32_t wave_cap)
@@ -619,11 +647,35 @@ hipError_t launch_entropy(const ImageDesc *descs, uint32_t images, uint32_t max_
     return hipGetLastError();
 }
 
+hipError_t launch_fused_layout(const ImageDesc *descs, uint32_t images, uint32_t max_intervals, const HuffLdsPlan &plan,
+                               uint32_t hs, uint32_t vs, bool pairs, hipStream_t stream)
+{
+    if (images == 0 || max_intervals == 0)
+        return hipSuccess;
+    using Kernel = void (*)(const ImageDesc *, uint32_t, uint32_t);
+    const Kernel kernel = hs == 1 && vs == 1   ? (pairs ? decode_fused_444_kernel : decode_fused_444_single_kernel)
+                          : hs == 1 && vs == 2 ? (pairs ? decode_fused_440_kernel : decode_fused_440_single_kernel)
+                          : hs == 2 && vs == 2 ? decode_fused_420_kernel
+                                               : nullptr;
+    if (!kernel || plan.waves_per_block > fused_layout_wave_cap(hs, vs, pairs))
+        return hipErrorInvalidValue;
+    const uint32_t threads = plan.waves_per_block * kWave;
+    dim3 grid((max_intervals + threads - 1) / threads, images, 1);
+    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                int(device_limits().lds_bytes));
+    if (attr != hipSuccess)
+        return attr;
+    hipLaunchKernelGGL(kernel, grid, dim3(threads), plan.total_bytes, stream, descs, plan.l2_entries_in_lds, plan.window_words);
+    return hipGetLastError();
+}
+
 hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t max_intervals,
                             const HuffLdsPlan &plan, hipStream_t stream, bool uniform)
 {
     if (images == 0 || max_intervals == 0)
         return hipSuccess;
+    const auto kernel = decode_fused_422_kernel;
+    const uint32_t wave_limit = kMaxWavesFused;
     const uint32_t threads = plan.waves_per_block * kWave;
     // uniform: every image has max_intervals intervals and the same LUT bytes -> workgroups may span images
     static const bool flat_allowed = [] {
@@ -642,46 +694,17 @@ hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t ma
         // (the CUs of the device the launch goes to: a wrong count would cost time, not results -- the waves' stride
         // is the grid's size whatever it is)
         const DeviceLimits lim = device_limits();
-        const uint32_t per_cu = std::max(1u, std::min(lim.lds_bytes / plan.total_bytes, kMaxWavesFused / plan.waves_per_block));
+        const uint32_t per_cu = std::max(1u, std::min(lim.lds_bytes / plan.total_bytes, wave_limit / plan.waves_per_block));
         const uint32_t cus = lim.cus;
         const uint64_t resident = uint64_t(cus) * per_cu;
         grid = dim3(uint32_t(resident_cap ? std::min(flat_groups, resident_cap > 1 ? uint64_t(resident_cap) : resident) : flat_groups), 1, 1);
     }
-    static const hipError_t attr = hipFuncSetAttribute(
-        reinterpret_cast<const void *>(decode_fused_422_kernel),
-        hipFuncAttributeMaxDynamicSharedMemorySize, int(device_limits().lds_bytes));
+    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                int(device_limits().lds_bytes));
     if (attr != hipSuccess)
         return attr;
-    hipLaunchKernelGGL(decode_fused_422_kernel, grid, dim3(threads), plan.total_bytes, stream, descs,
-                       plan.l2_entries_in_lds, plan.window_words, grid.y == 1 && waves_per_image ? waves_per_image : 0u,
-                       images);
-    return hipGetLastError();
-}
-
-hipError_t launch_fused_layout(const ImageDesc *descs, uint32_t images, uint32_t max_intervals, const HuffLdsPlan &plan,
-                               uint32_t hs, uint32_t vs, hipStream_t stream)
-{
-    if (images == 0 || max_intervals == 0)
-        return hipSuccess;
-    const uint32_t threads = plan.waves_per_block * kWave; // (planned with fused_layout_wave_cap)
-    if (threads > fused_layout_wave_cap(hs, vs) * kWave)
-        return hipErrorInvalidValue;
-    dim3 grid((max_intervals + threads - 1) / threads, images, 1);
-    const void *fn = hs == 1 && vs == 1   ? reinterpret_cast<const void *>(decode_fused_444_kernel)
-                     : hs == 1 && vs == 2 ? reinterpret_cast<const void *>(decode_fused_440_kernel)
-                     : hs == 2 && vs == 2 ? reinterpret_cast<const void *>(decode_fused_420_kernel)
-                                          : nullptr;
-    if (!fn)
-        return hipErrorInvalidValue;
-    const hipError_t attr = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(device_limits().lds_bytes));
-    if (attr != hipSuccess)
-        return attr;
-    if (hs == 1 && vs == 1)
-        hipLaunchKernelGGL(decode_fused_444_kernel, grid, dim3(threads), plan.total_bytes, stream, descs, plan.l2_entries_in_lds, plan.window_words);
-    else if (hs == 1)
-        hipLaunchKernelGGL(decode_fused_440_kernel, grid, dim3(threads), plan.total_bytes, stream, descs, plan.l2_entries_in_lds, plan.window_words);
-    else
-        hipLaunchKernelGGL(decode_fused_420_kernel, grid, dim3(threads), plan.total_bytes, stream, descs, plan.l2_entries_in_lds, plan.window_words);
+    hipLaunchKernelGGL(kernel, grid, dim3(threads), plan.total_bytes, stream, descs, plan.l2_entries_in_lds, plan.window_words,
+                       grid.y == 1 && waves_per_image ? waves_per_image : 0u, images);
     return hipGetLastError();
 }
 

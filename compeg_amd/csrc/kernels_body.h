@@ -1871,45 +1871,103 @@ CG_DEV void decode_wave_fused_422(const ImageDesc &d, const HuffShared &s, uint3
 // chroma: HS * VS + 2 data units per MCU (luma blocks in raster order, Cb, Cr: the reference shader's own order,
 // src/huffman.wgsl:148-155), MCUs of 8 HS x 8 VS pixels.  The composite is the reference's finalize pass
 // (src/dct.wgsl:257-321; continued to 16-row MCUs as the oracle's orc_finalize_pass states it): the luma sample of
-// its block, chroma nearest neighbour.  Every lane stores its own MCU, 16 bytes (four pixels) at a time.  It replaces
-// the two-kernel route (entropy_samples_kernel + composite_generic_kernel) and its round trip of sample records.
-template <int HS, int VS>
+// its block, chroma nearest neighbour.  It replaces the two-kernel route (entropy_samples_kernel +
+// composite_generic_kernel) and its round trip of sample records.
+// MC: MCUs a lane holds before it composites them -- 1, or 2 for the layouts with 8-pixel MCUs (their rows are 32
+// bytes; two neighbours of an interval make the 64-byte segments the write path takes twice as well; even restart
+// intervals only, so that a pair never straddles two intervals).
+template <int HS, int VS, int MC>
 struct LayoutPixels {
     static constexpr int kDus = HS * VS + 2;
-    uint32_t px[kDus][16]; // data unit k of the MCU being assembled, 4 samples per word
-    uint32_t mx, my;
+    uint32_t px[MC * kDus][16]; // data unit k of held MCU m at [m * kDus + k], 4 samples per word
+    uint32_t mx, my;            // the first held MCU
     bool active;
 };
 
-// The MCU a lane has finished: px -> RGBA.  Rows and 4-pixel groups unroll, so every sample word is a register.
-template <int HS, int VS>
-CG_DEV void composite_layout_mcu(const LayoutPixels<HS, VS> &t, const ImageDesc &d)
+// Four pixels of the lane's MCU group: row `row`, 4-pixel group `g` across the group's width (both unrolled: every
+// sample word is a register).
+template <int HS, int VS, int MC>
+CG_DEV Vec4u layout_pixels4(const LayoutPixels<HS, VS, MC> &t, int row, int g)
 {
     constexpr int kDus = HS * VS + 2;
-    const uint32_t x0 = t.mx * (8u * HS), y0 = t.my * (8u * VS);
-    uint8_t *base = d.out + size_t(y0) * d.out_pitch + size_t(x0) * 4u;
-    const bool whole = x0 + 8u * HS <= d.out_w && y0 + 8u * VS <= d.out_h && (d.out_pitch & 15u) == 0u;
+    const int m = g / (2 * HS), gg = g % (2 * HS), o = m * kDus;
+    const uint32_t yw = t.px[o + (row >> 3) * HS + (gg >> 1)][(row & 7) * 2 + (gg & 1)];
+    const int cy = row / VS;
+    if (HS == 2) // two chroma samples, each under two pixels
+        return rgba_quad(yw, t.px[o + kDus - 2][cy * 2 + (gg >> 1)] >> ((gg & 1) * 16), t.px[o + kDus - 1][cy * 2 + (gg >> 1)] >> ((gg & 1) * 16));
+    return rgba_quad4(yw, t.px[o + kDus - 2][cy * 2 + gg], t.px[o + kDus - 1][cy * 2 + gg]);
+}
+
+// Row `row` of the lane's MCU group into its slot: 2 HS MC pieces of 16 bytes.
+template <int HS, int VS, int MC>
+CG_DEV void layout_row_to_slot(const LayoutPixels<HS, VS, MC> &t, int row, uint8_t *slot)
+{
+    SlotVec *p = reinterpret_cast<SlotVec *>(slot);
 #pragma unroll
-    for (int row = 0; row < 8 * VS; row++) {
+    for (int g = 0; g < 2 * HS * MC; g++) {
+        const Vec4u o = layout_pixels4<HS, VS, MC>(t, row, g);
+        p[g] = SlotVec{o.x, o.y, o.z, o.w};
+    }
+}
+
+// The lane's share of row `row` of its quad's four MCU groups (composite_row_from_quad's counterpart): with 64-byte rows
+// (PIECES = 4) lane i stores piece i of each of the four rows; with 32-byte rows (PIECES = 2) lanes 0, 1 store the two
+// pieces of one group's row and lanes 2, 3 those of the next, twice -- a wave-wide store then writes whole rows of
+// MCU groups instead of 64 separate 16-byte pieces.
+template <int PIECES>
+CG_DEV void layout_row_from_quad(const ImageDesc &d, const uint8_t *wave_slots, uint32_t lane, uint32_t row,
+                                 uint8_t *const (&bases)[4], uint32_t whole_mask)
+{
+    const uint32_t quad = lane & ~3u, liq = lane & 3u;
 #pragma unroll
-        for (int g = 0; g < 2 * HS; g++) {
-            const uint32_t yw = t.px[(row >> 3) * HS + (g >> 1)][(row & 7) * 2 + (g & 1)];
-            const int cy = row / VS;
-            Vec4u o;
-            if (HS == 2) {
-                // two chroma samples, each under two pixels
-                const uint32_t cb = t.px[kDus - 2][cy * 2 + (g >> 1)] >> ((g & 1) * 16), cr = t.px[kDus - 1][cy * 2 + (g >> 1)] >> ((g & 1) * 16);
-                o = rgba_quad(yw, cb, cr);
-            } else {
-                o = rgba_quad4(yw, t.px[kDus - 2][cy * 2 + g], t.px[kDus - 1][cy * 2 + g]);
-            }
-            uint8_t *p = base + size_t(row) * d.out_pitch + size_t(g) * 16u;
-            if (whole) {
-                store_pixels<true>(p, o);
-            } else if (y0 + uint32_t(row) < d.out_h) {
-                // cut by the right / bottom edge (stores outside are dropped, like textureStore) or an unaligned pitch
-                const uint32_t x = x0 + uint32_t(g) * 4u;
-                auto *q = CG_GLOBAL(uint32_t, reinterpret_cast<uint32_t *>(p));
+    for (uint32_t j = 0; j < uint32_t(PIECES); j++) {
+        const uint32_t src = PIECES == 4 ? j : 2u * j + (liq >> 1), piece = PIECES == 4 ? liq : (liq & 1u);
+        const SlotVec v = reinterpret_cast<const SlotVec *>(wave_slots + (quad + src) * kDuSlotBytes)[piece];
+        uint8_t *base = src == 0u ? bases[0] : (src == 1u ? bases[1] : (src == 2u ? bases[2] : bases[3]));
+        if (whole_mask >> src & 1u)
+            store_pixels<true>(base + size_t(row) * d.out_pitch + piece * 16u, Vec4u{v.x, v.y, v.z, v.w});
+    }
+}
+
+// MCUs cut by the right / bottom edge of the output (stores outside it are dropped, like textureStore in the
+// reference), an unaligned pitch, or a pair whose second MCU begins the next MCU row: the owning lane stores them
+// pixel by pixel, each held MCU at its own place.
+template <int HS, int VS, int MC>
+CG_DEV void composite_layout_edge(const LayoutPixels<HS, VS, MC> &t, const ImageDesc &d)
+{
+    constexpr int kDus = HS * VS + 2;
+    // (rolled loops, the words selected without dynamic register indexing: unrolled, the 64 conversions of a 16 x 16
+    // MCU are hoisted over their stores' guards and the kernel spills)
+#pragma unroll 1
+    for (uint32_t m = 0; m < uint32_t(MC); m++) {
+        uint32_t mx = t.mx + m, my = t.my;
+        if (mx >= d.width_mcus) {
+            mx -= d.width_mcus;
+            my++;
+        }
+        const uint32_t x0 = mx * (8u * HS), y0 = my * (8u * VS);
+        uint8_t *base = d.out + size_t(y0) * d.out_pitch + size_t(x0) * 4u;
+#pragma unroll 1
+        for (uint32_t row = 0; row < uint32_t(8 * VS); row++) {
+            if (y0 + row >= d.out_h)
+                break;
+#pragma unroll 1
+            for (uint32_t g = 0; g < uint32_t(2 * HS); g++) {
+                const uint32_t yb = m * uint32_t(kDus) + (row >> 3) * uint32_t(HS) + (g >> 1), yi = (row & 7u) * 2u + (g & 1u);
+                const uint32_t cy = row / uint32_t(VS), ci = HS == 2 ? cy * 2u + (g >> 1) : cy * 2u + g;
+                uint32_t yw = 0, cbw = 0, crw = 0;
+#pragma unroll
+                for (uint32_t i = 0; i < 16; i++) {
+#pragma unroll
+                    for (uint32_t blk = 0; blk < uint32_t(MC * kDus); blk++) {
+                        yw = (i == yi && blk == yb) ? t.px[blk][i] : yw;
+                        cbw = (i == ci && blk == m * uint32_t(kDus) + uint32_t(kDus - 2)) ? t.px[blk][i] : cbw;
+                        crw = (i == ci && blk == m * uint32_t(kDus) + uint32_t(kDus - 1)) ? t.px[blk][i] : crw;
+                    }
+                }
+                const Vec4u o = HS == 2 ? rgba_quad(yw, cbw >> ((g & 1u) * 16u), crw >> ((g & 1u) * 16u)) : rgba_quad4(yw, cbw, crw);
+                const uint32_t x = x0 + g * 4u;
+                auto *q = CG_GLOBAL(uint32_t, reinterpret_cast<uint32_t *>(base + size_t(row) * d.out_pitch + size_t(g) * 16u));
                 if (x < d.out_w)
                     q[0] = o.x;
                 if (x + 1u < d.out_w)
@@ -1923,59 +1981,129 @@ CG_DEV void composite_layout_mcu(const LayoutPixels<HS, VS> &t, const ImageDesc 
     }
 }
 
-template <int HS, int VS>
-CG_DEV void decode_wave_fused_layout(const ImageDesc &d, const HuffShared &s, uint32_t interval, uint32_t lane)
+template <int HS, int VS, int MC>
+CG_DEV void layout_init(LayoutPixels<HS, VS, MC> &t, const ImageDesc &d, uint32_t interval, bool active)
 {
-    constexpr int kDus = HS * VS + 2;
-    const bool active = interval < d.total_intervals;
-    if (!active)
-        return; // (no cross-lane step in this body)
-    uint8_t *slot = s.du_slots + lane * kDuSlotBytes;
-    int16_t *slot16 = reinterpret_cast<int16_t *>(slot);
-    zero_slot(slot);
-    EntropyState e;
-    entropy_init(e, d, s, interval);
-    LayoutPixels<HS, VS> t;
 #pragma unroll
-    for (int k = 0; k < kDus; k++)
+    for (int k = 0; k < MC * (HS * VS + 2); k++)
 #pragma unroll
         for (int w = 0; w < 16; w++)
             t.px[k][w] = 0u;
     const uint32_t mcu0 = interval * d.restart_interval;
     t.mx = mcu0 % d.width_mcus;
     t.my = mcu0 / d.width_mcus;
-    t.active = true;
-    const uint32_t du_total = d.restart_interval * uint32_t(kDus);
-    uint32_t k = 0; // data unit inside the MCU
-#pragma unroll 1
-    for (uint32_t du = 0; du < du_total; du++) {
-        const uint32_t comp = k < uint32_t(HS * VS) ? 0u : k - uint32_t(HS * VS) + 1u;
-        const int32_t dc = entropy_data_unit(e, d, s, comp, slot16);
-        uint32_t rec[kRetained / 2];
-        take_slot(slot, rec);
-        idct_data_unit(rec, dc, d.quant[comp], t.px[kDus - 1]);
-        // (one copy of the IDCT; the blocks in front of the last are moved to their place: see pixel_transform)
+    t.active = active;
+}
+
+// One data unit: coefficients out of `slot` (cleared for reuse) and IDCT; place: m * kDus + k, its held MCU and
+// its place in it.  One copy of the IDCT in the instruction stream: it leaves its 16 words in the last block, the
+// blocks in front of it are moved to their place (see pixel_transform).
+template <int HS, int VS, int MC>
+CG_DEV void layout_transform(LayoutPixels<HS, VS, MC> &t, const ImageDesc &d, uint32_t comp, uint32_t place, uint8_t *slot, int32_t dc)
+{
+    constexpr int kBlocks = MC * (HS * VS + 2);
+    uint32_t rec[kRetained / 2];
+    take_slot(slot, rec);
+    idct_data_unit(rec, dc, d.quant[comp], t.px[kBlocks - 1]);
 #pragma unroll
-        for (int j = 0; j < kDus - 1; j++) {
-            if (k == uint32_t(j)) {
+    for (int j = 0; j < kBlocks - 1; j++) {
+        if (place == uint32_t(j)) {
 #pragma unroll
-                for (int w = 0; w < 16; w++)
-                    t.px[j][w] = t.px[kDus - 1][w];
-                CG_PLACE_MARK("; data unit in place");
-            }
-        }
-        if (k == uint32_t(kDus - 1)) {
-            composite_layout_mcu<HS, VS>(t, d);
-            t.mx++;
-            if (t.mx == d.width_mcus) {
-                t.mx = 0;
-                t.my++;
-            }
-            k = 0;
-        } else {
-            k++;
+            for (int w = 0; w < 16; w++)
+                t.px[j][w] = t.px[kBlocks - 1][w];
+            CG_PLACE_MARK("; data unit in place");
         }
     }
 }
+
+template <int HS, int VS, int MC>
+CG_DEV McuTarget layout_target(const LayoutPixels<HS, VS, MC> &t, const ImageDesc &d)
+{
+    const uint32_t x0 = t.mx * (8u * HS), y0 = t.my * (8u * VS);
+    McuTarget g;
+    g.base = d.out + size_t(y0) * d.out_pitch + size_t(x0) * 4u;
+    // (all held MCUs in one MCU row, inside the output)
+    g.whole = t.active && t.mx + uint32_t(MC) <= d.width_mcus && x0 + 8u * HS * MC <= d.out_w && y0 + 8u * VS <= d.out_h &&
+              (d.out_pitch & 15u) == 0u;
+    return g;
+}
+
+template <int HS, int VS, int MC>
+CG_DEV void layout_next_group(LayoutPixels<HS, VS, MC> &t, const ImageDesc &d)
+{
+    t.mx += uint32_t(MC);
+    if (t.mx >= d.width_mcus) {
+        t.mx -= d.width_mcus;
+        t.my++;
+    }
+}
+
+CG_DEV uint32_t layout_comp_of(uint32_t k, uint32_t luma_dus) { return k < luma_dus ? 0u : k - luma_dus + 1u; }
+
+#if defined(__HIPCC__)
+// The composite of the wave's 64 current MCU groups through the lanes' quads (composite_mcus_422's counterpart).
+template <int HS, int VS, int MC>
+CG_DEV void composite_layout_mcus(LayoutPixels<HS, VS, MC> &t, const ImageDesc &d, uint8_t *wave_slots, uint32_t lane)
+{
+    const McuTarget g = layout_target<HS, VS, MC>(t, d);
+    const uint64_t addr = reinterpret_cast<uint64_t>(g.base);
+    const uint32_t lo = uint32_t(addr), hi = uint32_t(addr >> 32), wh = g.whole ? 1u : 0u;
+    uint8_t *bases[4] = {
+        reinterpret_cast<uint8_t *>(uint64_t(quad_lane<0>(hi)) << 32 | quad_lane<0>(lo)),
+        reinterpret_cast<uint8_t *>(uint64_t(quad_lane<1>(hi)) << 32 | quad_lane<1>(lo)),
+        reinterpret_cast<uint8_t *>(uint64_t(quad_lane<2>(hi)) << 32 | quad_lane<2>(lo)),
+        reinterpret_cast<uint8_t *>(uint64_t(quad_lane<3>(hi)) << 32 | quad_lane<3>(lo)),
+    };
+    const uint32_t whole_mask = quad_lane<0>(wh) | quad_lane<1>(wh) << 1 | quad_lane<2>(wh) << 2 | quad_lane<3>(wh) << 3;
+    uint8_t *slot = wave_slots + lane * kDuSlotBytes;
+#pragma unroll
+    for (int row = 0; row < 8 * VS; row++) {
+        layout_row_to_slot<HS, VS, MC>(t, row, slot);
+        layout_row_from_quad<2 * HS * MC>(d, wave_slots, lane, uint32_t(row), bases, whole_mask);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    zero_slot(slot);
+    if (t.active && !g.whole)
+        composite_layout_edge<HS, VS, MC>(t, d);
+    layout_next_group<HS, VS, MC>(t, d);
+}
+
+// The whole path for 64 restart intervals, one per lane (decode_wave_fused_422's counterpart; tests/emul drives the
+// same steps lane by lane).  Lanes past the image's last interval decode that last interval once more and never
+// store an MCU of their own: they stay for their quad's exchange.  MC = 2: the restart interval is even.
+template <int HS, int VS, int MC>
+CG_DEV void decode_wave_fused_layout(const ImageDesc &d, const HuffShared &s, uint32_t interval, uint32_t lane)
+{
+    constexpr uint32_t kDus = uint32_t(HS * VS + 2), kBlocks = kDus * uint32_t(MC);
+    const bool active = interval < d.total_intervals;
+    interval = active ? interval : d.total_intervals - 1u;
+    uint8_t *slot = s.du_slots + lane * kDuSlotBytes;
+    int16_t *slot16 = reinterpret_cast<int16_t *>(slot);
+    zero_slot(slot);
+    EntropyState e;
+    entropy_init(e, d, s, interval);
+    LayoutPixels<HS, VS, MC> t;
+    layout_init<HS, VS, MC>(t, d, interval, active);
+    __builtin_amdgcn_s_setprio(CG_PRIO_ENTROPY);
+    const uint32_t du_total = d.restart_interval * kDus;
+    uint32_t place = 0, k = 0; // the data unit's block among the held MCUs', its place inside its MCU (wave-uniform)
+#pragma unroll 1
+    for (uint32_t du = 0; du < du_total; du++) {
+        const uint32_t comp = layout_comp_of(k, uint32_t(HS * VS));
+        const int32_t dc = entropy_data_unit(e, d, s, comp, slot16);
+        __builtin_amdgcn_s_setprio(CG_PRIO_IDCT);
+        layout_transform<HS, VS, MC>(t, d, comp, place, slot, dc);
+        k = k == kDus - 1u ? 0u : k + 1u;
+        if (place == kBlocks - 1u) {
+            __builtin_amdgcn_s_setprio(CG_PRIO_COMPOSITE);
+            composite_layout_mcus<HS, VS, MC>(t, d, s.du_slots, lane);
+            place = 0;
+        } else {
+            place++;
+        }
+        __builtin_amdgcn_s_setprio(CG_PRIO_ENTROPY);
+    }
+}
+#endif // __HIPCC__
 
 } // namespace compeg

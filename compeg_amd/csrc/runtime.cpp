@@ -719,8 +719,9 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     const bool fused = use_fused_pipeline() && is_422(img);
     // (the extension pipeline's first kernel carries the IDCT: planned like the fused kernel)
     const uint32_t luma_h = md.components[0].hsample, luma_v = md.components[0].vsample;
+    const bool mcu_pairs = luma_h == 1 && md.restart_interval % 2u == 0u;
     const HuffLdsPlan plan = plan_huffman(md.total_restart_intervals, 1, staged_lut_entries(img), span,
-                                          fused || !is_422(img), is_422(img) ? 0u : fused_layout_wave_cap(luma_h, luma_v));
+                                          fused || !is_422(img), is_422(img) ? 0u : fused_layout_wave_cap(luma_h, luma_v, mcu_pairs));
     last_span = span;
     last_plan = plan;
     trace.mark("plan");
@@ -728,7 +729,7 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
         // extension layouts (4:4:4, 4:4:0, 4:2:0): one fused kernel per layout (the development pipeline keeps the
         // two-kernel route: entropy stage with the IDCT in place, generic composite)
         if (use_fused_pipeline()) {
-            CG_HIP(launch_fused_layout(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals, plan, luma_h, luma_v, stream));
+            CG_HIP(launch_fused_layout(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals, plan, luma_h, luma_v, mcu_pairs, stream));
             last_kernel = COMPEG_KERNEL_FUSED_LAYOUT;
         } else {
             CG_HIP(launch_entropy_samples(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals,
@@ -991,6 +992,7 @@ void compeg_batch::note_batch_properties(const ImageData *const *images, size_t 
     generic_layout = false;
     layout_h = n ? images[0]->metadata.components[0].hsample : 0;
     layout_v = n ? images[0]->metadata.components[0].vsample : 0;
+    layout_even_ri = true;
     max_out_w = max_out_h = 0;
     // frames of one stream: the same number of restart intervals and byte-identical LUTs in every image
     // (the fused kernel's workgroups may then span image boundaries)
@@ -1000,6 +1002,7 @@ void compeg_batch::note_batch_properties(const ImageData *const *images, size_t 
         generic_layout = generic_layout || !is_422(img);
         if (img.metadata.components[0].hsample != layout_h || img.metadata.components[0].vsample != layout_v)
             layout_h = layout_v = 0; // (mixed samplings in one batch)
+        layout_even_ri = layout_even_ri && img.metadata.restart_interval % 2u == 0u;
         max_out_w = std::max(max_out_w, img.width);
         max_out_h = std::max(max_out_h, img.height);
         uniform = uniform && img.metadata.total_restart_intervals == first.metadata.total_restart_intervals &&
@@ -1740,12 +1743,13 @@ Status compeg_batch::decode(hipStream_t stream)
         const uint32_t m = std::min(step, n - at);
         const bool fused = use_fused_pipeline() && !generic_layout;
         const bool one_layout = generic_layout && layout_h != 0 && use_fused_pipeline();
+        const bool mcu_pairs = layout_h == 1 && layout_even_ri;
         const HuffLdsPlan plan = plan_huffman(max_intervals, m, max_l2, max_span, fused || generic_layout,
-                                              one_layout ? fused_layout_wave_cap(layout_h, layout_v) : 0u);
+                                              one_layout ? fused_layout_wave_cap(layout_h, layout_v, mcu_pairs) : 0u);
         if (one_layout) {
             // every image has the same extension layout: its fused kernel
             last_kernel = at ? last_kernel : COMPEG_KERNEL_FUSED_LAYOUT;
-            CG_HIP(launch_fused_layout(dd + at, m, max_intervals, plan, layout_h, layout_v, stream));
+            CG_HIP(launch_fused_layout(dd + at, m, max_intervals, plan, layout_h, layout_v, mcu_pairs, stream));
             if (timing && at == 0)
                 CG_HIP(hipEventRecord(ev[1], stream));
             continue;

@@ -40,6 +40,11 @@ static FILE *symbol_dump()
     return f;
 }
 
+template <int H, int V, int M>
+struct LayoutTag {
+    static constexpr int hs = H, vs = V, mc = M;
+};
+
 extern "C" __attribute__((visibility("default")))
 int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, uint32_t tex_h,
                 int16_t *ac_out, int32_t *dc_out, uint32_t waves_per_block, uint32_t window_words,
@@ -300,16 +305,71 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
                 stage_window(d, win, wb, wl, lane);
             HuffShared sh{sl1, sl2, umin(l2_in_lds, d.fast_off + 2u * kFastEntries), win, wb, wl, slots};
             if (fused == 6) {
-                // decode_fused_444 / _440 / _420_kernel: a lane per interval from entropy decode to RGBA, no cross-lane step
+                // decode_fused_444 / _440 / _420_kernel (decode_wave_fused_layout): the 64 lanes of a wave advance data
+                // unit by data unit, and through the quad exchange of the composite phase by phase
                 const uint32_t hs = img->metadata.components[0].hsample, vs = img->metadata.components[0].vsample;
-                for (uint32_t lane = 0; lane < uint32_t(kWave); lane++) {
-                    if (hs == 1 && vs == 1)
-                        decode_wave_fused_layout<1, 1>(d, sh, wave_first + lane, lane);
-                    else if (hs == 1 && vs == 2)
-                        decode_wave_fused_layout<1, 2>(d, sh, wave_first + lane, lane);
-                    else if (hs == 2 && vs == 2)
-                        decode_wave_fused_layout<2, 2>(d, sh, wave_first + lane, lane);
-                }
+                auto run = [&](auto tag) {
+                    constexpr int HS = decltype(tag)::hs, VS = decltype(tag)::vs, MC = decltype(tag)::mc;
+                    constexpr uint32_t kDus = uint32_t(HS * VS + 2), kBlocks = kDus * uint32_t(MC);
+                    std::vector<EntropyState> es(kWave);
+                    std::vector<LayoutPixels<HS, VS, MC>> ps(kWave);
+                    std::vector<McuTarget> tg(kWave);
+                    std::vector<int32_t> dcs(kWave);
+                    for (uint32_t lane = 0; lane < uint32_t(kWave); lane++) {
+                        zero_slot(slots + lane * kDuSlotBytes);
+                        const bool active = wave_first + lane < d.total_intervals;
+                        const uint32_t iv = active ? wave_first + lane : d.total_intervals - 1u;
+                        entropy_init(es[lane], d, sh, iv);
+                        layout_init<HS, VS, MC>(ps[lane], d, iv, active);
+                    }
+                    const uint32_t du_total = d.restart_interval * kDus;
+                    for (uint32_t du = 0, k = 0, place = 0; du < du_total; du++) {
+                        const uint32_t comp = layout_comp_of(k, uint32_t(HS * VS));
+                        for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
+                            dcs[lane] = entropy_data_unit(es[lane], d, sh, comp, reinterpret_cast<int16_t *>(slots + lane * kDuSlotBytes));
+                        for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
+                            layout_transform<HS, VS, MC>(ps[lane], d, comp, place, slots + lane * kDuSlotBytes, dcs[lane]);
+                        k = k == kDus - 1u ? 0u : k + 1u;
+                        if (place != kBlocks - 1u) {
+                            place++;
+                            continue;
+                        }
+                        place = 0;
+                        for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
+                            tg[lane] = layout_target<HS, VS, MC>(ps[lane], d);
+                        for (int row = 0; row < 8 * VS; row++) {
+                            for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
+                                layout_row_to_slot<HS, VS, MC>(ps[lane], row, slots + lane * kDuSlotBytes);
+                            for (uint32_t lane = 0; lane < uint32_t(kWave); lane++) {
+                                const uint32_t quad = lane & ~3u;
+                                uint8_t *bases[4];
+                                uint32_t whole_mask = 0;
+                                for (uint32_t j = 0; j < 4; j++) {
+                                    bases[j] = tg[quad + j].base;
+                                    whole_mask |= (tg[quad + j].whole ? 1u : 0u) << j;
+                                }
+                                layout_row_from_quad<2 * HS * MC>(d, slots, lane, uint32_t(row), bases, whole_mask);
+                            }
+                        }
+                        for (uint32_t lane = 0; lane < uint32_t(kWave); lane++) {
+                            zero_slot(slots + lane * kDuSlotBytes);
+                            if (ps[lane].active && !tg[lane].whole)
+                                composite_layout_edge<HS, VS, MC>(ps[lane], d);
+                            layout_next_group<HS, VS, MC>(ps[lane], d);
+                        }
+                    }
+                };
+                const bool pairs = hs == 1 && d.restart_interval % 2u == 0u; // (as the runtime dispatches)
+                if (hs == 1 && vs == 1 && pairs)
+                    run(LayoutTag<1, 1, 2>{});
+                else if (hs == 1 && vs == 1)
+                    run(LayoutTag<1, 1, 1>{});
+                else if (hs == 1 && vs == 2 && pairs)
+                    run(LayoutTag<1, 2, 2>{});
+                else if (hs == 1 && vs == 2)
+                    run(LayoutTag<1, 2, 1>{});
+                else if (hs == 2 && vs == 2)
+                    run(LayoutTag<2, 2, 1>{});
                 continue;
             }
             if (fused == 3 || fused == 4) {

@@ -459,7 +459,9 @@ print("split ok")
 def test_extension_layouts(ca, gpu, sampling):
     """4:4:4, 4:4:0 and 4:2:0 (opt-in): bit-exact against the oracle with the same
     extension, through the Decoder and -- mixed with a 4:2:2 image -- through a Batch."""
-    cases = [(640, 360, 0, 85, 4, 301), (250, 70, 1, 75, 3, 302), (33, 17, 2, 85, 1, 303), (1920, 1080, 0, 85, 8, 304)]
+    # (even restart intervals: the 8-pixel MCUs of 4:4:4 / 4:4:0 are composited in pairs; odd ones: singly)
+    cases = [(640, 360, 0, 85, 4, 301), (250, 70, 1, 75, 3, 302), (33, 17, 2, 85, 1, 303), (1920, 1080, 0, 85, 8, 304),
+             (250, 70, 0, 85, 2, 306), (33, 17, 1, 90, 6, 307)]
     jpegs = [synth.make_jpeg(w, h, seed=s, kind=k, quality=q, ri=ri, sampling=sampling) for (w, h, k, q, ri, s) in cases]
     for j, (w, h, *_) in zip(jpegs, cases):
         # a fresh decoder per image: texels behind a truncated last interval are only defined
@@ -472,7 +474,7 @@ def test_extension_layouts(ca, gpu, sampling):
         _assert_equal(dec.read_texture(w, h), want)
         assert np.array_equal(dec.read_coefficients(data.total_dus() if hasattr(data, "total_dus") else len(coef) // 32), coef)
     # a batch of one layout: the same fused kernel (40 images: several workgroups per image, images of different sizes)
-    same = [jpegs[i % 4] for i in range(40)]
+    same = [jpegs[i % 4] for i in range(40)]   # (restart intervals 4, 3, 1, 8: a batch with an odd one composites singly)
     batch = ca.Batch(gpu)
     batch.upload([ca.ImageData(j, allow_sampling=True) for j in same])
     batch.decode()

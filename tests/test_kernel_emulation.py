@@ -230,7 +230,10 @@ def test_emulated_q1_underflow_in_every_quarter(runner, tmp_path):
 def test_emulated_extension_layouts(runner, tmp_path, sampling):
     """4:4:4, 4:2:2, 4:4:0, 4:2:0 through the extension pipeline (entropy records, IDCT in place,
     generic composite) against the oracle with the same extension switched on."""
-    for (w, h, kind, q, ri, seed) in [(96, 48, 0, 90, 2, 91), (250, 70, 1, 75, 3, 92), (33, 17, 2, 85, 1, 93)]:
+    # (even restart intervals: 8-pixel MCUs in pairs, also across the end of an MCU row -- 250 and 33 pixels are 32 and 5
+    # MCUs -- and odd ones: singly)
+    for (w, h, kind, q, ri, seed) in [(96, 48, 0, 90, 2, 91), (250, 70, 1, 75, 3, 92), (33, 17, 2, 85, 1, 93), (250, 70, 0, 85, 4, 94),
+                                      (33, 17, 1, 90, 2, 95), (40, 24, 0, 85, 6, 96)]:
         jpeg = synth.make_jpeg(w, h, seed=seed, kind=kind, quality=q, ri=ri, sampling=sampling)
         want = orc.ImageData(jpeg, allow_sampling=True).decode()
         got = _run(runner, tmp_path, jpeg, 4)
