@@ -60,11 +60,18 @@ def run(seed=77, batches=40, log=print):
             if slots * w0 * h0 * 4 < (3 << 30):
                 items = [items[int(rng.integers(0, len(items)))] for _ in range(slots)]
         mode = int(rng.integers(0, 3))
-        as_bytes = bool(rng.integers(0, 2)) and mode == 0
+        as_bytes = bool(rng.integers(0, 2))
+        where = int(rng.integers(0, 3)) if as_bytes else 0   # the bytes: pageable, page-locked (the copy-free road), every other one
         batch = ca.Batch(gpu)
         batch.set_device_preprocess(mode)
+        pinned = None
         if as_bytes:
-            batch.upload_jpegs([j for j, _ in items], host_threads=int(rng.choice([1, 4, 8])))
+            srcs = [j for j, _ in items]
+            if where:
+                pinned = ca.HostBuffer(sum(len(j) + 64 for j in srcs))
+                views = pinned.place(srcs)
+                srcs = views if where == 1 else [v if i % 2 else j for i, (v, j) in enumerate(zip(views, srcs))]
+            batch.upload_jpegs(srcs, host_threads=int(rng.choice([1, 4, 8])))
         else:
             batch.upload([ca.ImageData(j) for j, _ in items], host_threads=int(rng.choice([1, 4, 8])))
         for rep in range(2):
@@ -75,8 +82,11 @@ def run(seed=77, batches=40, log=print):
                 n += 1
                 if not np.array_equal(got, want):
                     bad += 1
-                    log("MISMATCH batch", it, "image", i, "of", len(items), "mode", mode, "bytes" if as_bytes else "parsed", "rep", rep,
+                    log("MISMATCH batch", it, "image", i, "of", len(items), "mode", mode, ("bytes", "pinned bytes", "mixed bytes")[where] if as_bytes else "parsed", "rep", rep,
                         want.shape, int((got != want).any(axis=2).sum()), "pixels")
+        del batch
+        if pinned is not None:
+            pinned.close()
         if it % 10 == 9:
             log("batch", it, "outputs", n, "bad", bad, "%.0f s" % (time.time() - t0))
     return n, bad
