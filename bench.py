@@ -416,6 +416,38 @@ def bench_end_to_end(compeg_amd, device, jpegs, images, threads, reps, ext):
             "host_fallbacks": dev_batches[0].host_fallbacks(),
             "what": "compeg_batch_upload_jpegs with device preprocessing from compeg_host_alloc'ed bytes: the host reads "
                     "headers only (what crosses PCIe: the raw entropy-coded segments + tables)"}
+        # ... and the same with the upload in two steps (compeg_batch_upload_jpegs_begin / _end): the next batch's
+        # transfers are queued before this one's results are read and its descriptors made -- the link never idles
+        for b in dev_batches:
+            b.wait()
+        periods = []
+        dev_batches[0].upload_jpegs_begin(views, host_threads=threads)
+        t_prev = time.perf_counter()
+        n_iter = 2 * reps + 8                                    # (the first few periods are the pipeline filling)
+        for r in range(1, n_iter):
+            b, o = dev_batches[r & 1], dev_batches[(r + 1) & 1]
+            b.wait()                                             # its previous decode
+            b.upload_jpegs_begin(views, host_threads=threads)    # queued behind the other batch's transfers
+            o.upload_end()
+            o.decode()
+            t = time.perf_counter()
+            periods.append(t - t_prev)
+            t_prev = t
+        last = dev_batches[(n_iter - 1) & 1]
+        last.upload_end()
+        last.decode()
+        for b in dev_batches:
+            b.wait()
+        periods = periods[4:]
+        period = statistics.median(periods)
+        res["from_pinned_jpeg_bytes_device_scan_uploads_queued_ahead"] = {
+            "ms_per_batch": round(period * 1e3, 3), "mpix_s": round(pix / period / 1e6, 1),
+            "mean_ms_per_batch": round(statistics.mean(periods) * 1e3, 3),
+            "min_max_ms": [round(min(periods) * 1e3, 3), round(max(periods) * 1e3, 3)],
+            "pcie_gbs": round(jpeg_bytes / period / 1e9, 2), "pcie_fraction_of_link": round(jpeg_bytes / period / 1e9 / PCIE_LINK_GBS, 3),
+            "batches_timed": len(periods),
+            "what": "the copy-free road with compeg_batch_upload_jpegs_begin / _end: one feeder thread, two batches, the "
+                    "upload of one queued while the other's arrives, is finished and decoded"}
         ok = ok and all(bool(np.array_equal(dev_batches[k].read_output(i), orc.ImageData(jpegs[i]).decode()))
                         for k in (0, 1) for i in (0, len(jpegs) // 2, len(jpegs) - 1))
         for b in dev_batches:

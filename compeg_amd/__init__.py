@@ -365,6 +365,18 @@ class Batch:
         self._images = []
         check(lib.compeg_batch_upload_jpegs(self._h, jl.ptrs, jl.lens, jl.count, host_threads, flags))
 
+    def upload_jpegs_begin(self, jpegs, host_threads=0, allow_sampling=False, standard_entropy=False):
+        """compeg_batch_upload_jpegs_begin: returns when the transfers are queued; upload_end() (or decode()) finishes."""
+        jl = jpegs if isinstance(jpegs, JpegList) else JpegList(jpegs)
+        flags = (1 if allow_sampling else 0) | (2 if standard_entropy else 0)
+        self._images = []
+        self._feeding = jl   # (the bytes stay alive until the upload has ended)
+        check(lib.compeg_batch_upload_jpegs_begin(self._h, jl.ptrs, jl.lens, jl.count, host_threads, flags))
+
+    def upload_end(self):
+        check(lib.compeg_batch_upload_end(self._h))
+        self._feeding = None
+
     def set_device_preprocess(self, mode):
         """0 host (default), 1 scan kernels once at upload, 2 scan kernels in every decode."""
         check(lib.compeg_batch_set_device_preprocess(self._h, mode))

@@ -77,6 +77,8 @@ def _load():
         "compeg_batch_free": (None, [vp]),
         "compeg_batch_upload": (i, [vp, pvp, sz, i]),
         "compeg_batch_upload_jpegs": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_int, C.c_uint]),
+        "compeg_batch_upload_jpegs_begin": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_int, C.c_uint]),
+        "compeg_batch_upload_end": (i, [vp]),
         "compeg_batch_decode": (i, [vp, vp]),
         "compeg_batch_set_chunk": (i, [vp, u32]),
         "compeg_batch_set_device_preprocess": (i, [vp, i]),

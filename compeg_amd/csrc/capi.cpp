@@ -637,6 +637,30 @@ int compeg_batch_upload_jpegs(compeg_batch *batch, const uint8_t *const *jpegs, 
     });
 }
 
+int compeg_batch_upload_jpegs_begin(compeg_batch *batch, const uint8_t *const *jpegs, const size_t *lengths, size_t count,
+                                    int host_threads, unsigned flags)
+{
+    return guarded([&] {
+        if (!batch || ((!jpegs || !lengths) && count))
+            return fail(COMPEG_E_INVALID_ARG, "NULL argument");
+        for (size_t i = 0; i < count; i++)
+            if (!jpegs[i])
+                return fail(COMPEG_E_INVALID_ARG, "NULL image in batch");
+        Status s = batch->upload_jpegs(jpegs, lengths, count, host_threads, flags, true);
+        return s.ok() ? ok() : fail(s);
+    });
+}
+
+int compeg_batch_upload_end(compeg_batch *batch)
+{
+    return guarded([&] {
+        if (!batch)
+            return fail(COMPEG_E_INVALID_ARG, "batch is NULL");
+        Status s = batch->finish_upload();
+        return s.ok() ? ok() : fail(s);
+    });
+}
+
 int compeg_batch_decode(compeg_batch *batch, void *hip_stream)
 {
     return guarded([&] {

@@ -850,13 +850,35 @@ Status compeg::ScanBuffer::process_on_gpu(compeg_gpu *gpu, const uint8_t *scan, 
     return Status{};
 }
 
+// The streams the batches' host-to-device transfers run on: four per device, shared by every batch of the process, so
+// that the transfers of uploads begun one after the other (compeg_batch_upload_jpegs_begin) follow each other on the
+// link instead of sharing it -- the first upload's data arrives first.  (256 transfers of 1.6 MB: 43 GB/s on one
+// stream, 54-56 on two to four.)  Kept for the life of the process.
+hipError_t shared_copy_streams(int device, std::vector<hipStream_t> &out)
+{
+    static std::mutex m;
+    static std::vector<hipStream_t> pool[64];
+    std::lock_guard<std::mutex> lock(m);
+    if (device < 0 || device >= 64)
+        return hipErrorInvalidDevice;
+    while (pool[device].size() < 4) {
+        hipStream_t c = nullptr;
+        const hipError_t e = hipStreamCreateWithFlags(&c, hipStreamNonBlocking);
+        if (e != hipSuccess)
+            return e;
+        pool[device].push_back(c);
+    }
+    out = pool[device];
+    return hipSuccess;
+}
+
 compeg_batch::~compeg_batch()
 {
     (void)hipStreamSynchronize(last_stream);
-    for (hipStream_t c : copy_streams) {
+    if (gpu)
+        (void)hipStreamSynchronize(gpu->stream);
+    for (hipStream_t c : copy_streams)
         (void)hipStreamSynchronize(c);
-        (void)hipStreamDestroy(c);
-    }
     for (hipEvent_t e : events)
         (void)hipEventDestroy(e);
     if (gpu)
@@ -969,6 +991,7 @@ bool peek_item(const uint8_t *j, size_t len, unsigned flags, UploadItem &it)
 
 Status compeg_batch::upload(const ImageData *const *images, size_t n, int threads)
 {
+    (void)finish_upload();
     std::vector<UploadItem> items(n);
     for (size_t i = 0; i < n; i++)
         items[i] = item_of(*images[i]);
@@ -1077,11 +1100,7 @@ Status compeg_batch::upload_host(size_t n, int threads, const void *items_, cons
         all_covered = all_covered && items[i].covered;
     if (fresh_out || !all_covered)
         CG_HIP(hipMemsetAsync(out.ptr, 0, out.capacity, st)); // (the card does this while the host preprocesses)
-    while (copy_streams.size() < 4) {
-        hipStream_t c = nullptr;
-        CG_HIP(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
-        copy_streams.push_back(c);
-    }
+    CG_HIP(shared_copy_streams(gpu->device, copy_streams));
     CG_TRY(dev_descs.reserve(n * sizeof(ImageDesc) + 256));
     CG_TRY(stage.reserve(in_total + 256));
     uint8_t *hs = static_cast<uint8_t *>(stage.ptr);
@@ -1225,17 +1244,27 @@ Status compeg_batch::upload_host(size_t n, int threads, const void *items_, cons
 // in the same pass as its preprocessing: the layout of the batch is made from the files' headers and lengths
 // (upper bounds), so that nothing has to wait for all images to be parsed.  A file whose headers are unusual in
 // any way takes the plain road: parse everything (in parallel), then upload().
-Status compeg_batch::upload_jpegs(const uint8_t *const *jpegs, const size_t *lens, size_t n, int threads, unsigned flags)
+Status compeg_batch::upload_jpegs(const uint8_t *const *jpegs_in, const size_t *lens_in, size_t n, int threads, unsigned flags,
+                                  bool begin_only)
 {
-    std::vector<std::unique_ptr<ImageData>> fresh(n);
+    (void)finish_upload(); // (an earlier upload left half done: its transfers read the caller's bytes and the arena)
+    // (kept in the batch: an upload whose second step comes later -- finish_upload -- still needs them then)
+    feed_jpegs.assign(jpegs_in, jpegs_in + n);
+    feed_lens.assign(lens_in, lens_in + n);
+    feed_flags = flags;
+    feed_fresh.clear();
+    feed_fresh.resize(n);
+    const uint8_t *const *jpegs = feed_jpegs.data();
+    const size_t *lens = feed_lens.data();
+    std::vector<std::unique_ptr<ImageData>> &fresh = feed_fresh;
     std::vector<UploadItem> items(n);
     bool peeked = preprocess_mode == 0;
     for (size_t i = 0; i < n && peeked; i++)
         peeked = peek_item(jpegs[i], lens[i], flags, items[i]);
-    auto parse_one = [&](size_t i, Status &st) -> const ImageData * {
+    auto parse_one = [this](size_t i, Status &st) -> const ImageData * {
         ImageData *img = nullptr;
-        st = ImageData::parse(jpegs[i], lens[i], false, &img, flags);
-        fresh[i].reset(img);
+        st = ImageData::parse(feed_jpegs[i], feed_lens[i], false, &img, feed_flags);
+        feed_fresh[i].reset(img);
         if (!st.ok())
             st = Status::error(st.code, "image " + std::to_string(i) + ": " + st.message);
         return st.ok() ? img : nullptr;
@@ -1262,8 +1291,10 @@ Status compeg_batch::upload_jpegs(const uint8_t *const *jpegs, const size_t *len
             return st.ok() ? img : nullptr;
         };
         if (laid_out) {
-            s = upload_device_scan(n, threads, src.data(), nullptr, parse_headers, parse_one);
+            s = upload_device_scan(n, threads, src.data(), nullptr, parse_headers, parse_one, begin_only);
             done = s.ok() || s.message != kLayoutBoundExceeded;
+            if (s.ok() && pending_finish)
+                return s; // (finish_upload does the rest, and hands the parsed images over)
         }
         if (!done) {
             // (unusual headers: parse first, lay out afterwards)
@@ -1315,6 +1346,19 @@ Status compeg_batch::upload_jpegs(const uint8_t *const *jpegs, const size_t *len
     return s;
 }
 
+// The second step of an upload begun with begin_only (nothing to do after any other upload).
+Status compeg_batch::finish_upload()
+{
+    if (!pending_finish)
+        return Status{};
+    const std::function<Status()> finish = std::move(pending_finish);
+    pending_finish = nullptr;
+    Status s = finish();
+    parsed.swap(feed_fresh);
+    feed_fresh.clear();
+    return s;
+}
+
 // Device-side preprocessing: raw entropy-coded segments go to HBM as they are
 // and the scan kernels (scan_kernels.hip) produce words / start positions in
 // the reference layout.
@@ -1330,14 +1374,14 @@ Status compeg_batch::upload_jpegs(const uint8_t *const *jpegs, const size_t *len
 //   reparse  images whose segment end was left to the device (ImageData::scan_end_deferred) and turned out to end
 //            earlier (another marker inside: the scan kernels' flag bit 1) are parsed again in full through it
 Status compeg_batch::upload_device_scan(size_t n, int threads, const FeedSource *src, const ImageData *const *given,
-                                        const ImageSource &parse, const ImageSource &reparse)
+                                        const ImageSource &parse, const ImageSource &reparse, bool defer_finish)
 {
+    pending_finish = nullptr;
     CG_HIP(hipSetDevice(gpu->device));
     CG_HIP(hipStreamSynchronize(last_stream));
     count = 0;
     if (n > 65535)
         return Status::error(COMPEG_E_INVALID_ARG, "at most 65535 images per batch");
-    static const bool trace_on = getenv("COMPEG_TRACE_BATCH") != nullptr;
     const auto t_up0 = std::chrono::steady_clock::now();
     auto ms_since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_up0).count(); };
     std::vector<const ImageData *> images(n, nullptr);
@@ -1431,11 +1475,7 @@ Status compeg_batch::upload_device_scan(size_t n, int threads, const FeedSource 
     CG_TRY(scan_descs.reserve(n * sizeof(ScanDesc) + 256));
     hipStream_t st = gpu->stream;
     CG_TRY(dev_descs.reserve(n * sizeof(ImageDesc) + 256));
-    while (copy_streams.size() < kCopyStreams) {
-        hipStream_t c = nullptr;
-        CG_HIP(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
-        copy_streams.push_back(c);
-    }
+    CG_HIP(shared_copy_streams(gpu->device, copy_streams)); // (kCopyStreams of them)
     uint8_t *da = static_cast<uint8_t *>(scan_arena.ptr);
     CG_HIP(hipMemsetAsync(da + o_results, 0, n * kScanResultBytes, st));
     CG_TRY(stage.reserve((any_pageable ? staged_total : align_up(tables_bytes, 256)) + 256));
@@ -1576,116 +1616,168 @@ Status compeg_batch::upload_device_scan(size_t n, int threads, const FeedSource 
         CG_HIP(sent_status);
         return Status::error(COMPEG_E_INVALID_ARG, "batch upload failed");
     }
-    const double t_issued = ms_since();
-    CG_HIP(hipMemcpyAsync(da + o_tables, hs, tables_bytes, hipMemcpyHostToDevice, st));
-    // all results in one read-back: sizes and window spans for the decode descriptors
-    std::vector<uint32_t> res(n * (kScanResultBytes / 4));
-    CG_HIP(hipMemcpyAsync(res.data(), da + o_results, n * kScanResultBytes, hipMemcpyDeviceToHost, st));
+    // What is left -- waiting for the transfers and the scan kernels, the decode descriptors from their results -- is
+    // the upload's second step: at once, or (compeg_batch_upload_jpegs_begin / compeg_batch_upload_end) when the caller
+    // comes back for it, with the next batch's transfers queued behind these in the meantime.
+    struct Rest {
+        size_t n;
+        std::vector<Layout> lay;
+        std::vector<ScanDesc> sd;
+        std::vector<const ImageData *> images;
+        std::vector<uint8_t> pinned;
+        size_t runs, o_results, o_tables, tables_bytes;
+        unsigned nthreads;
+        double t_layout, t_issued;
+        std::chrono::steady_clock::time_point t_up0;
+        ImageSource reparse;
+    };
+    auto rest = std::make_shared<Rest>();
+    rest->n = n;
+    rest->lay = std::move(lay);
+    rest->sd = std::move(sd);
+    rest->images = std::move(images);
+    rest->pinned = std::move(pinned);
+    rest->runs = runs.size();
+    rest->o_results = o_results;
+    rest->o_tables = o_tables;
+    rest->tables_bytes = tables_bytes;
+    rest->nthreads = nthreads;
+    rest->t_layout = t_layout;
+    rest->t_issued = ms_since();
+    rest->t_up0 = t_up0;
+    rest->reparse = reparse;
+    auto finish = [this, rest]() -> Status {
+        const size_t n = rest->n;
+        std::vector<Layout> &lay = rest->lay;
+        std::vector<ScanDesc> &sd = rest->sd;
+        std::vector<const ImageData *> &images = rest->images;
+        const std::vector<uint8_t> &pinned = rest->pinned;
+        const size_t o_results = rest->o_results, o_tables = rest->o_tables, tables_bytes = rest->tables_bytes;
+        const unsigned nthreads = rest->nthreads;
+        const double t_layout = rest->t_layout, t_issued = rest->t_issued;
+        const ImageSource &reparse = rest->reparse;
+        const auto t_up0 = rest->t_up0;
+        auto ms_since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_up0).count(); };
+        static const bool trace_on = getenv("COMPEG_TRACE_BATCH") != nullptr;
+        CG_HIP(hipSetDevice(gpu->device));
+        hipStream_t st = gpu->stream;
+        uint8_t *da = static_cast<uint8_t *>(scan_arena.ptr), *hs = static_cast<uint8_t *>(stage.ptr);
+        struct RunsSize { size_t n; size_t size() const { return n; } } runs{rest->runs};
+        CG_HIP(hipMemcpyAsync(da + o_tables, hs, tables_bytes, hipMemcpyHostToDevice, st));
+        // all results in one read-back: sizes and window spans for the decode descriptors
+        std::vector<uint32_t> res(n * (kScanResultBytes / 4));
+        CG_HIP(hipMemcpyAsync(res.data(), da + o_results, n * kScanResultBytes, hipMemcpyDeviceToHost, st));
 
-    // (while the last quarter arrives: everything about the batch that needs the headers only)
-    max_tiles = 0;
-    max_intervals = max_dus = max_l2 = max_span = 0;
-    algorithmic_bytes = pixels = 0;
-    size_t out_total = 0;
-    bool all_covered = true;
-    for (size_t i = 0; i < n; i++) {
-        const ImageData &img = *images[i];
-        out_total += align_up(size_t(img.width) * 4 * img.height, 256);
-        max_tiles = std::max(max_tiles, sd[i].ntiles);
-        max_intervals = std::max(max_intervals, img.metadata.total_restart_intervals);
-        max_dus = std::max(max_dus, img.total_dus());
-        max_l2 = std::max<uint32_t>(max_l2, staged_lut_entries(img));
-        pixels += uint64_t(img.width) * img.height;
-        all_covered = all_covered && item_of(img).covered;
-    }
-    note_batch_properties(images.data(), n);
-    bool fresh_out = false;
-    CG_TRY(out.reserve(out_total + 256, &fresh_out));
-    // (texels no MCU covers read 0: see upload_host)
-    if (fresh_out || !all_covered)
-        CG_HIP(hipMemsetAsync(out.ptr, 0, out.capacity, st));
-    CG_HIP(hipStreamSynchronize(st));
-    const double t_arrived = ms_since();
-    last_stream = st;
+        // (while the last quarter arrives: everything about the batch that needs the headers only)
+        max_tiles = 0;
+        max_intervals = max_dus = max_l2 = max_span = 0;
+        algorithmic_bytes = pixels = 0;
+        size_t out_total = 0;
+        bool all_covered = true;
+        for (size_t i = 0; i < n; i++) {
+            const ImageData &img = *images[i];
+            out_total += align_up(size_t(img.width) * 4 * img.height, 256);
+            max_tiles = std::max(max_tiles, sd[i].ntiles);
+            max_intervals = std::max(max_intervals, img.metadata.total_restart_intervals);
+            max_dus = std::max(max_dus, img.total_dus());
+            max_l2 = std::max<uint32_t>(max_l2, staged_lut_entries(img));
+            pixels += uint64_t(img.width) * img.height;
+            all_covered = all_covered && item_of(img).covered;
+        }
+        note_batch_properties(images.data(), n);
+        bool fresh_out = false;
+        CG_TRY(out.reserve(out_total + 256, &fresh_out));
+        // (texels no MCU covers read 0: see upload_host)
+        if (fresh_out || !all_covered)
+            CG_HIP(hipMemsetAsync(out.ptr, 0, out.capacity, st));
+        CG_HIP(hipStreamSynchronize(st));
+        const double t_arrived = ms_since();
+        last_stream = st;
 
-    descs.assign(n, ImageDesc{});
-    out_offset.assign(n, 0);
-    host_fallbacks = 0;
-    size_t out_at = 0;
-    for (size_t i = 0; i < n; i++) {
-        const Layout &L = lay[i];
-        const uint32_t *r = &res[i * (kScanResultBytes / 4)];
-        uint32_t nwords = r[2], nstarts = std::min(r[0], sd[i].slots), span = r[4];
-        const bool ends_earlier = (r[3] & 2u) != 0u && images[i]->scan_end_deferred;
-        if (ends_earlier) {
-            // another marker inside what was taken for the segment: the reference's parser ends it there
-            // (src/file.rs:163-201) -- this image once more through the whole front-end
-            Status ps;
-            const ImageData *again = reparse ? reparse(i, ps) : nullptr;
-            if (!again)
-                return ps.ok() ? Status::error(COMPEG_E_MALFORMED, "entropy-coded segment ends early") : ps;
-            images[i] = again;
+        descs.assign(n, ImageDesc{});
+        out_offset.assign(n, 0);
+        host_fallbacks = 0;
+        size_t out_at = 0;
+        for (size_t i = 0; i < n; i++) {
+            const Layout &L = lay[i];
+            const uint32_t *r = &res[i * (kScanResultBytes / 4)];
+            uint32_t nwords = r[2], nstarts = std::min(r[0], sd[i].slots), span = r[4];
+            const bool ends_earlier = (r[3] & 2u) != 0u && images[i]->scan_end_deferred;
+            if (ends_earlier) {
+                // another marker inside what was taken for the segment: the reference's parser ends it there
+                // (src/file.rs:163-201) -- this image once more through the whole front-end
+                Status ps;
+                const ImageData *again = reparse ? reparse(i, ps) : nullptr;
+                if (!again)
+                    return ps.ok() ? Status::error(COMPEG_E_MALFORMED, "entropy-coded segment ends early") : ps;
+                images[i] = again;
+            }
+            const ImageData &img = *images[i];
+            const uint32_t expected = img.metadata.total_restart_intervals;
+            if ((r[3] & 1u) || ends_earlier) {
+                // pathological FF run (or see above): the host preprocessor (same output format) takes this image
+                ScanBuffer sb;
+                Status s = sb.process(img.scan_data(), img.scan_len, expected);
+                if (!s.ok() && s.code != COMPEG_E_COUNT_MISMATCH)
+                    return s;
+                nwords = uint32_t(sb.nwords());
+                nstarts = uint32_t(sb.nstarts());
+                if (nwords)
+                    CG_HIP(hipMemcpy(da + L.words, sb.words(), size_t(nwords) * 4, hipMemcpyHostToDevice));
+                if (nstarts)
+                    CG_HIP(hipMemcpy(da + L.starts, sb.starts(), size_t(nstarts) * 4, hipMemcpyHostToDevice));
+                span = max_wave_span(sb.starts(), nstarts, nwords, expected);
+                host_fallbacks++;
+            }
+            ImageDesc &d = descs[i];
+            fill_desc(img, d);
+            d.l1 = reinterpret_cast<const uint16_t *>(da + L.tables);
+            d.l2 = reinterpret_cast<const uint16_t *>(da + L.tables + COMPEG_HUFFMAN_L1_BYTES);
+            d.words = reinterpret_cast<const uint32_t *>(da + L.words);
+            d.starts = reinterpret_cast<const uint32_t *>(da + L.starts);
+            d.nwords = nwords;
+            d.nstarts = nstarts;
+            d.ac = nullptr;
+            d.dc = nullptr;
+            out_offset[i] = out_at;
+            d.out = static_cast<uint8_t *>(out.ptr) + out_at;
+            out_at += align_up(size_t(img.width) * 4 * img.height, 256);
+            d.out_w = img.width;
+            d.out_h = img.height;
+            d.out_pitch = img.width * 4;
+            max_span = std::max(max_span, span);
+            if (i == 0) {
+                coop_r = img.metadata.restart_interval;
+                coop_spans = CoopSpans{};
+            }
+            if (!d.coop_ok || img.metadata.restart_interval != coop_r) {
+                coop_r = 0;
+            } else {
+                // (the kernels report the span of 64 intervals only: four times the average for a wave's group;
+                // a group that is longer than that still decodes, its intervals one lane each)
+                coop_spans_max(coop_spans, coop_spans_estimate(span, coop_r, true));
+            }
+            algorithmic_bytes += 4ull * nwords + 4ull * expected + COMPEG_METADATA_BYTES +
+                                 COMPEG_HUFFMAN_L1_BYTES + img.l2.size() * 2 + 4ull * img.width * img.height;
         }
-        const ImageData &img = *images[i];
-        const uint32_t expected = img.metadata.total_restart_intervals;
-        if ((r[3] & 1u) || ends_earlier) {
-            // pathological FF run (or see above): the host preprocessor (same output format) takes this image
-            ScanBuffer sb;
-            Status s = sb.process(img.scan_data(), img.scan_len, expected);
-            if (!s.ok() && s.code != COMPEG_E_COUNT_MISMATCH)
-                return s;
-            nwords = uint32_t(sb.nwords());
-            nstarts = uint32_t(sb.nstarts());
-            if (nwords)
-                CG_HIP(hipMemcpy(da + L.words, sb.words(), size_t(nwords) * 4, hipMemcpyHostToDevice));
-            if (nstarts)
-                CG_HIP(hipMemcpy(da + L.starts, sb.starts(), size_t(nstarts) * 4, hipMemcpyHostToDevice));
-            span = max_wave_span(sb.starts(), nstarts, nwords, expected);
-            host_fallbacks++;
+        CG_TRY(make_walk_tables(gpu->stream, n));
+        CG_HIP(hipStreamSynchronize(gpu->stream));
+        count = n;
+        decodes_timed = 0;
+        if (trace_on) {
+            size_t direct = 0;
+            for (size_t i = 0; i < n; i++)
+                direct += pinned[i];
+            fprintf(stderr, "[compeg] batch upload, device scan (%zu images, %zu read where they are in %zu transfers, %u threads): layout=%.2f issued=%.2f arrived+scanned=%.2f total=%.2f ms\n",
+                    n, direct, runs.size(), nthreads, t_layout, t_issued, t_arrived, ms_since());
         }
-        ImageDesc &d = descs[i];
-        fill_desc(img, d);
-        d.l1 = reinterpret_cast<const uint16_t *>(da + L.tables);
-        d.l2 = reinterpret_cast<const uint16_t *>(da + L.tables + COMPEG_HUFFMAN_L1_BYTES);
-        d.words = reinterpret_cast<const uint32_t *>(da + L.words);
-        d.starts = reinterpret_cast<const uint32_t *>(da + L.starts);
-        d.nwords = nwords;
-        d.nstarts = nstarts;
-        d.ac = nullptr;
-        d.dc = nullptr;
-        out_offset[i] = out_at;
-        d.out = static_cast<uint8_t *>(out.ptr) + out_at;
-        out_at += align_up(size_t(img.width) * 4 * img.height, 256);
-        d.out_w = img.width;
-        d.out_h = img.height;
-        d.out_pitch = img.width * 4;
-        max_span = std::max(max_span, span);
-        if (i == 0) {
-            coop_r = img.metadata.restart_interval;
-            coop_spans = CoopSpans{};
-        }
-        if (!d.coop_ok || img.metadata.restart_interval != coop_r) {
-            coop_r = 0;
-        } else {
-            // (the kernels report the span of 64 intervals only: four times the average for a wave's group;
-            // a group that is longer than that still decodes, its intervals one lane each)
-            coop_spans_max(coop_spans, coop_spans_estimate(span, coop_r, true));
-        }
-        algorithmic_bytes += 4ull * nwords + 4ull * expected + COMPEG_METADATA_BYTES +
-                             COMPEG_HUFFMAN_L1_BYTES + img.l2.size() * 2 + 4ull * img.width * img.height;
+        return Status{};
+    };
+    if (defer_finish) {
+        pending_finish = finish;
+        return Status{};
     }
-    CG_TRY(make_walk_tables(gpu->stream, n));
-    CG_HIP(hipStreamSynchronize(gpu->stream));
-    count = n;
-    decodes_timed = 0;
-    if (trace_on) {
-        size_t direct = 0;
-        for (size_t i = 0; i < n; i++)
-            direct += pinned[i];
-        fprintf(stderr, "[compeg] batch upload, device scan (%zu images, %zu read where they are in %zu transfers, %u threads): layout=%.2f issued=%.2f arrived+scanned=%.2f total=%.2f ms\n",
-                n, direct, runs.size(), nthreads, t_layout, t_issued, t_arrived, ms_since());
-    }
-    return Status{};
+    return finish();
 }
 
 // Uploads the descriptors; in front of that, gives every image its walk tables if the cooperative kernel may
@@ -1718,6 +1810,7 @@ Status compeg_batch::make_walk_tables(hipStream_t stream, size_t n)
 
 Status compeg_batch::decode(hipStream_t stream)
 {
+    CG_TRY(finish_upload()); // (an upload begun with compeg_batch_upload_jpegs_begin and not ended yet)
     if (count == 0)
         return Status{};
     CG_HIP(hipSetDevice(gpu->device));

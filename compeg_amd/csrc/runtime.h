@@ -165,15 +165,15 @@ struct compeg_batch {
 
     // host-fed use (upload_jpegs): the images parsed from the caller's bytes, kept until the next upload
     std::vector<std::unique_ptr<compeg::ImageData>> parsed;
-    // H2D copies of an upload are spread over a few streams: 256 copies of 1.6 MB on one stream reach 43 GB/s
-    // on the target node, on two to four streams 54-56 (one copy of the whole arena: 57)
+    // the device's shared transfer streams (runtime.cpp: shared_copy_streams), not owned
     std::vector<hipStream_t> copy_streams;
 
     ~compeg_batch();
     compeg::Status upload(const compeg::ImageData *const *images, size_t n, int threads);
     // the same from JPEG bytes: ImageData::new for every image on the worker threads first (the bytes are
     // borrowed for the duration of the call)
-    compeg::Status upload_jpegs(const uint8_t *const *jpegs, const size_t *lens, size_t n, int threads, unsigned flags);
+    // begin_only: (device preprocessing from files) return as soon as the transfers are queued; finish_upload() completes it
+    compeg::Status upload_jpegs(const uint8_t *const *jpegs, const size_t *lens, size_t n, int threads, unsigned flags, bool begin_only = false);
     using ImageSource = std::function<const compeg::ImageData *(size_t index, compeg::Status &status)>;
     compeg::Status upload_host(size_t n, int threads, const void *items, const ImageSource &image_of);
     void note_batch_properties(const compeg::ImageData *const *images, size_t n);
@@ -182,7 +182,15 @@ struct compeg_batch {
         size_t len;
         uint32_t intervals;   // restart intervals its header announces
     };
+    // defer_finish: return when every transfer is queued; finish_upload() then does the rest (pending_finish)
     compeg::Status upload_device_scan(size_t n, int threads, const FeedSource *src, const compeg::ImageData *const *given,
-                                      const ImageSource &parse, const ImageSource &reparse);
+                                      const ImageSource &parse, const ImageSource &reparse, bool defer_finish = false);
+    std::function<compeg::Status()> pending_finish; // the second step of an upload begun with upload_jpegs(..., begin_only)
+    compeg::Status finish_upload();
+    // the caller's (pointer, length) lists and the images parsed from them, for an upload whose second step comes later
+    std::vector<const uint8_t *> feed_jpegs;
+    std::vector<size_t> feed_lens;
+    unsigned feed_flags = 0;
+    std::vector<std::unique_ptr<compeg::ImageData>> feed_fresh;
     compeg::Status decode(hipStream_t stream);
 };

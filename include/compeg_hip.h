@@ -255,6 +255,15 @@ int compeg_batch_upload_jpegs(compeg_batch *batch, const uint8_t *const *jpegs, 
  * once and written once); road 1: the headers only (the copy-free road above).  *seconds: wall time of all reps. */
 int compeg_host_feed_work(const uint8_t *const *jpegs, const size_t *lengths, size_t count, int host_threads, unsigned flags,
                           int road, int reps, double *seconds);
+/* compeg_batch_upload_jpegs in two steps, for a feeder that keeps the link busy.  _begin returns as soon as every
+ * transfer is queued (copy-free road: after a peek at the headers; on every other road it does the whole upload);
+ * _end waits for the transfers and the scan kernels and finishes the batch (compeg_batch_decode does it too if
+ * nobody has).  In between, the feeder begins the next batch's upload: its transfers queue up behind these, and the
+ * link does not idle while this batch's results are read and its descriptors made.  The bytes must stay valid
+ * and unchanged until _end returns; the batch must not be touched otherwise between the two. */
+int compeg_batch_upload_jpegs_begin(compeg_batch *batch, const uint8_t *const *jpegs, const size_t *lengths, size_t count,
+                                    int host_threads, unsigned flags);
+int compeg_batch_upload_end(compeg_batch *batch);
 int compeg_host_alloc(size_t bytes, void **out);
 void compeg_host_free(void *ptr);
 int compeg_host_register(void *ptr, size_t bytes);

@@ -106,6 +106,9 @@ extern "C" {
     pub fn compeg_host_free(ptr: *mut c_void);
     pub fn compeg_host_register(ptr: *mut c_void, bytes: usize) -> c_int;
     pub fn compeg_host_unregister(ptr: *mut c_void) -> c_int;
+    pub fn compeg_batch_upload_jpegs_begin(batch: *mut compeg_batch, jpegs: *const *const u8, lengths: *const usize,
+                                           count: usize, host_threads: c_int, flags: c_uint) -> c_int;
+    pub fn compeg_batch_upload_end(batch: *mut compeg_batch) -> c_int;
     pub fn compeg_batch_decode(batch: *mut compeg_batch, hip_stream: *mut c_void) -> c_int;
     pub fn compeg_batch_set_device_preprocess(batch: *mut compeg_batch, mode: c_int) -> c_int;
     pub fn compeg_batch_host_fallbacks(batch: *const compeg_batch) -> usize;

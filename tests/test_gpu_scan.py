@@ -217,3 +217,45 @@ def test_deferred_segment_end_is_checked_on_the_device(ca, gpu):
         assert str(e.value) == "image 1: " + str(eo.value)
     finally:
         pinned.close()
+
+
+def test_upload_in_two_steps_keeps_the_link_busy(ca, gpu):
+    """compeg_batch_upload_jpegs_begin / _end: the second batch's transfers are queued while the first one's arrive;
+    decode() ends a begun upload by itself; a new upload on a batch ends the begun one first.  Same pixels."""
+    jpegs = _jpeg_set()
+    wants = [orc.ImageData(j).decode() for j in jpegs]
+    pinned = ca.HostBuffer(2 * sum(len(j) + 64 for j in jpegs))
+    views_a = ca.JpegList(pinned.place(jpegs + jpegs[::-1])[:len(jpegs)])
+    views_b = ca.JpegList(pinned.place(jpegs + jpegs[::-1])[len(jpegs):])
+    g2 = ca.Gpu.open(0)
+    a, b = ca.Batch(gpu), ca.Batch(g2)
+    try:
+        for batch in (a, b):
+            batch.set_device_preprocess(1)
+        for rep in range(3):
+            a.upload_jpegs_begin(views_a, host_threads=4)
+            b.upload_jpegs_begin(views_b, host_threads=4)         # queued behind a's
+            a.upload_end()
+            a.decode()
+            b.decode()                                            # (ends b's upload itself)
+            a.wait()
+            b.wait()
+            for i, want in enumerate(wants):
+                assert np.array_equal(a.read_output(i), want), (rep, i)
+                assert np.array_equal(b.read_output(len(jpegs) - 1 - i), want), (rep, i)
+        a.upload_jpegs_begin(views_a, host_threads=2)
+        a.upload_jpegs(views_b, host_threads=2)                   # a whole new upload: the begun one is ended first
+        a.decode()
+        a.wait()
+        for i, want in enumerate(wants):
+            assert np.array_equal(a.read_output(len(jpegs) - 1 - i), want), i
+        # pageable bytes and host preprocessing: _begin does the whole upload, _end has nothing left to do
+        c = ca.Batch(gpu)
+        c.upload_jpegs_begin(jpegs, host_threads=2)
+        c.upload_end()
+        c.decode()
+        c.wait()
+        assert np.array_equal(c.read_output(0), wants[0])
+    finally:
+        del a, b
+        pinned.close()

@@ -38,3 +38,26 @@ for label, with_decode in (("uploads alone", False), ("uploads under the other b
     ts = np.array(ts[2:]) * 1e3
     print(f"{label}: upload median {np.median(ts):.2f} ms (min {ts.min():.2f}, max {ts.max():.2f}) = {nbytes / np.median(ts) / 1e6:.1f} GB/s over PCIe, "
           f"{n * 3840 * 2160 / np.median(ts) / 1e6:.0f} Gpixel/s", flush=True)
+
+# uploads in two steps, the next one queued ahead: where the feeder's time goes
+for b in bs:
+    b.wait()
+bs[0].upload_jpegs_begin(views, host_threads=8)
+rows = []
+t_prev = time.perf_counter()
+for r in range(1, 14):
+    b, o = bs[r & 1], bs[(r + 1) & 1]
+    t0 = time.perf_counter(); b.wait()
+    t1 = time.perf_counter(); b.upload_jpegs_begin(views, host_threads=8)
+    t2 = time.perf_counter(); o.upload_end()
+    t3 = time.perf_counter(); o.decode()
+    t4 = time.perf_counter()
+    rows.append((t1 - t0, t2 - t1, t3 - t2, t4 - t3, t4 - t_prev))
+    t_prev = t4
+last = bs[14 & 1]
+last.upload_end(); last.decode()
+for b in bs:
+    b.wait()
+print("queued ahead, per iteration [ms]: wait(decode)  begin  end  decode()  period")
+for w in rows:
+    print("   " + "  ".join(f"{v * 1e3:7.2f}" for v in w))
