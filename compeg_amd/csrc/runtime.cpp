@@ -146,8 +146,10 @@ CoopSpans coop_spans_exact(const uint32_t *starts, size_t nstarts, size_t nwords
     CoopSpans sp{};
     for (uint32_t k = 0; k < 3u; k++) {
         const uint32_t ipw = coop_shape(restart_interval, 4u >> k).ipw;
-        sp.words[k] = (k && ipw == coop_shape(restart_interval, 4u >> (k - 1u)).ipw)
-                          ? sp.words[k - 1u] : max_wave_span(starts, nstarts, nwords, intervals, ipw);
+        // (a smaller group's span is no larger: where the larger group fits the kernel's ordinary window already, its
+        // figure serves as the bound and the pass over the start positions is saved)
+        const bool reuse = k && (ipw == coop_shape(restart_interval, 4u >> (k - 1u)).ipw || sp.words[k - 1u] <= 1024u);
+        sp.words[k] = reuse ? sp.words[k - 1u] : max_wave_span(starts, nstarts, nwords, intervals, ipw);
     }
     return sp;
 }
@@ -678,19 +680,27 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     const size_t n_words = on_device ? dev_nwords : scan.nwords();
     const size_t n_starts = on_device ? dev_nstarts : scan.nstarts();
     const bool pull = !on_device && pull_copies(); // everything the host path uploads sits in pinned memory
-    if (!blob_uploaded) {
+    // The rest of the preprocessed scan, the start positions, descriptor + tables: one launch for the three (each alone
+    // is a launch and a PCIe round trip of its own).  A large rest leaves on its own first -- the card fetches it
+    // while the host makes descriptor and tables.
+    size_t rest_at = shipped, rest_bytes = pull && n_words * 4 > shipped ? n_words * 4 - shipped : 0;
+    if (pull && rest_bytes > (256u << 10)) {
+        CG_HIP(launch_pull(static_cast<uint8_t *>(words.ptr) + rest_at, scan.data() + rest_at, rest_bytes, stream));
+        rest_bytes = 0;
+    }
+    trace.mark("copies");
+    if (!blob_uploaded)
         write_blob(on_device ? dev_words : words.ptr, on_device ? dev_starts : starts.ptr, n_words, n_starts);
-        if (pull)
-            CG_HIP(launch_pull(db, hb, blob_bytes, stream));
-        else
-            CG_HIP(hipMemcpyAsync(db, hb, blob_bytes, hipMemcpyHostToDevice, stream));
+    if (pull) {
+        void *const dsts[3] = {static_cast<uint8_t *>(words.ptr) + rest_at, starts.ptr, db};
+        const void *const srcs[3] = {scan.data() + rest_at, scan.starts(), hb};
+        const size_t sizes[3] = {rest_bytes, n_starts * 4, blob_uploaded ? 0 : blob_bytes};
+        CG_HIP(launch_pull3(dsts, srcs, sizes, stream));
+    } else if (!blob_uploaded) {
+        CG_HIP(hipMemcpyAsync(db, hb, blob_bytes, hipMemcpyHostToDevice, stream));
     }
     trace.mark("tables");
     if (pull) {
-        CG_HIP(launch_pull(starts.ptr, scan.starts(), n_starts * 4, stream));
-        if (n_words * 4 > shipped)
-            CG_HIP(launch_pull(static_cast<uint8_t *>(words.ptr) + shipped, scan.data() + shipped,
-                               n_words * 4 - shipped, stream));
     } else if (!on_device) {
         if (n_starts)
             CG_HIP(hipMemcpyAsync(starts.ptr, scan.starts(), n_starts * 4, hipMemcpyHostToDevice, stream));
@@ -703,7 +713,6 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     last_md = md;
     last_desc_dev = db;
     have_last = true;
-    trace.mark("copies");
 
     last_kernel = COMPEG_KERNEL_NONE;
     if (total_dus == 0) {

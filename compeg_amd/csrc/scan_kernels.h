@@ -33,6 +33,8 @@ uint32_t scan_tiles(uint32_t len);
 // dst (device) <- pinned_src (pinned host memory), both 16-byte aligned and readable / writable up to the
 // next multiple of 16 bytes; the copy is a kernel on `stream`
 hipError_t launch_pull(void *dst, const void *pinned_src, size_t bytes, hipStream_t stream);
+// three such transfers in one launch (a transfer of 0 bytes is skipped)
+hipError_t launch_pull3(void *const dst[3], const void *const pinned_src[3], const size_t bytes[3], hipStream_t stream);
 // with_span: one more small kernel leaves in result[4] what max_wave_span() computes on the host (the decode
 // kernels' LDS window is sized from it)
 hipError_t launch_scan(const ScanDesc *descs, uint32_t images, uint32_t max_tiles, hipStream_t stream,

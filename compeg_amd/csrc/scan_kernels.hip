@@ -43,6 +43,7 @@ struct Chunk {
     uint32_t n;        // how many of them lie inside the segment
     uint32_t kept;     // bit i: byte i contributes one output byte (itself; FF for an FF 00 pair)
     uint32_t marker;   // bit i: byte i is the first byte of an FF xx pair that ends an interval
+    uint32_t foreign;  // bit i: byte i follows an FF and is neither 00, RSTn nor FF: a marker that ends the segment
 };
 
 __device__ __forceinline__ uint32_t byte_of(const uint32_t (&w)[4], uint32_t i)
@@ -73,7 +74,7 @@ __device__ uint32_t ff_run_before_slow(const ScanDesc &d, uint32_t pos)
 __device__ __forceinline__ void load_classify(const ScanDesc &d, uint32_t g, Chunk &c)
 {
     c.n = g < d.len ? min(kBytesPerThread, d.len - g) : 0u;
-    c.kept = c.marker = 0u;
+    c.kept = c.marker = c.foreign = 0u;
     c.w[0] = c.w[1] = c.w[2] = c.w[3] = 0u;
     uint32_t next = 0; // the byte behind the chunk
     if (c.n) {
@@ -96,18 +97,22 @@ __device__ __forceinline__ void load_classify(const ScanDesc &d, uint32_t g, Chu
 
     // Bit-parallel classification on 16-bit masks (bit i = byte i).
     // F: byte is FF.  Z: byte is 00.
-    uint32_t F = 0, Z = 0;
+    uint32_t F = 0, Z = 0, R = 0;
     for (int k = 0; k < 4; k++) {
-        const uint32_t x = c.w[k], nx = ~x;
+        const uint32_t x = c.w[k], nx = ~x, rx = (x ^ 0xd0d0d0d0u) & 0xf8f8f8f8u;
         // exact per-byte "== 0" tests, result in bit 7 of every byte
         const uint32_t zf = ~(((nx & 0x7f7f7f7fu) + 0x7f7f7f7fu) | nx) & 0x80808080u; // bytes of x equal to FF
         const uint32_t zz = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;   // bytes of x equal to 00
+        const uint32_t zr = ~(((rx & 0x7f7f7f7fu) + 0x7f7f7f7fu) | rx) & 0x80808080u; // bytes D0 .. D7 (RSTn)
         // gather bits 7, 15, 23, 31 into a nibble
         F |= (((zf >> 7) * 0x00204081u) >> 21 & 0xfu) << (4 * k);
         Z |= (((zz >> 7) * 0x00204081u) >> 21 & 0xfu) << (4 * k);
+        R |= (((zr >> 7) * 0x00204081u) >> 21 & 0xfu) << (4 * k);
     }
     const uint32_t valid = c.n >= 16u ? 0xffffu : ((1u << c.n) - 1u);
     F &= valid;
+    // (the byte in front of the chunk: FF iff the run in front of it is not empty -- computed above, r)
+    c.foreign = ((F << 1) | (r ? 1u : 0u)) & ~F & ~Z & ~R & valid;
     // Lead FFs are the FFs at even distance from the start of their run (a run
     // that continues from the previous chunk starts "odd" when r is odd).
     const uint32_t starts = F & ~(F << 1);
@@ -244,16 +249,8 @@ __global__ void __launch_bounds__(kThreads) count_kernel(const ScanDesc *descs)
     // entropy-coded segment in the reference's parser (src/file.rs:163-201).  A segment whose end was taken from the
     // file's final EOI without walking it on the host (borrowed, copy-free uploads: runtime.cpp) must not hold one:
     // flag bit 1 sends the image back to the host front-end.
-    if (c.n) {
-        uint32_t prev_ff = g > 0u && d.raw[g - 1u] == 0xffu ? 1u : 0u, foreign = 0u;
-        for (uint32_t i = 0; i < c.n; i++) {
-            const uint32_t b = byte_of(c.w, i);
-            foreign |= prev_ff & uint32_t(b != 0xffu && b != 0u && (b & 0xf8u) != 0xd0u);
-            prev_ff = b == 0xffu ? 1u : 0u;
-        }
-        if (foreign)
-            atomicOr(&d.result[3], 2u);
-    }
+    if (c.foreign)
+        atomicOr(&d.result[3], 2u);
     Stretch total;
     block_exclusive_scan(stretch_of(c), lds, total);
     if (threadIdx.x == 0)
@@ -428,7 +425,42 @@ __global__ void __launch_bounds__(kThreads) pull_kernel(PullVec *__restrict__ ds
         dst[i] = __builtin_nontemporal_load(src + i);
 }
 
+// Up to three transfers in one launch (the tail of a single decode's uploads: the rest of the scan, the start
+// positions, descriptor + tables -- each alone is a launch and a PCIe round trip of its own).
+struct PullSegs {
+    PullVec *dst[3];
+    const PullVec *src[3];
+    uint32_t n16[3];
+};
+__global__ void __launch_bounds__(kThreads) pull3_kernel(PullSegs segs)
+{
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < segs.n16[k]; i += gridDim.x * kThreads)
+            segs.dst[k][i] = __builtin_nontemporal_load(segs.src[k] + i);
+}
+
 } // namespace
+
+hipError_t launch_pull3(void *const dst[3], const void *const pinned_src[3], const size_t bytes[3], hipStream_t stream)
+{
+    PullSegs segs{};
+    size_t most = 0;
+    for (int k = 0; k < 3; k++) {
+        const size_t n16 = (bytes[k] + 15) / 16;
+        if (n16 > 0xffffffffu)
+            return hipErrorInvalidValue;
+        segs.dst[k] = static_cast<PullVec *>(dst[k]);
+        segs.src[k] = static_cast<const PullVec *>(pinned_src[k]);
+        segs.n16[k] = uint32_t(n16);
+        most = std::max(most, n16);
+    }
+    if (most == 0)
+        return hipSuccess;
+    const uint32_t blocks = uint32_t(std::min<size_t>((most + kThreads - 1) / kThreads, 48));
+    hipLaunchKernelGGL(pull3_kernel, dim3(blocks), dim3(kThreads), 0, stream, segs);
+    return hipGetLastError();
+}
 
 hipError_t launch_pull(void *dst, const void *pinned_src, size_t bytes, hipStream_t stream)
 {

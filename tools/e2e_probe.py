@@ -14,7 +14,8 @@ def main():
     jpeg = synth.make_jpeg(w, h, seed=0xC0FFEE, quality=85, ri=ri)
     img = compeg_amd.ImageData(jpeg)
     gpu = compeg_amd.Gpu.open()
-    for mode in (False, True):   # (the profile timeline reads the tail of the second pass)
+    modes = {"host": (False,), "device": (True,)}.get(sys.argv[1] if len(sys.argv) > 1 else "", (False, True))
+    for mode in modes:   # (the profile timeline reads the tail of the last pass)
         dec = compeg_amd.Decoder(gpu)
         dec.set_device_preprocess(mode)
         for _ in range(3):
