@@ -654,6 +654,7 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
         }
     }
     size_t shipped = 0; // bytes of the preprocessed scan already on their way
+    bool blob_prebuilt = false;
     if (!on_device) {
         // the output's worst case (scan.rs:38-44), so that pieces can leave while the scan is running
         CG_TRY(words.reserve(ScanBuffer::output_capacity(img.scan_len)));
@@ -662,6 +663,12 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
         ScanBuffer::Progress ship;
         if (pull_copies())
             ship = [&](size_t final_bytes) {
+                if (final_bytes == 0 && !blob_prebuilt) {
+                    // (the scan's first round is under way on the helpers: what does not depend on it; the two
+                    // counts follow below)
+                    write_blob(words.ptr, starts.ptr, 0, 0);
+                    blob_prebuilt = true;
+                }
                 if (final_bytes > shipped && ship_error == hipSuccess)
                     ship_error = launch_pull(static_cast<uint8_t *>(words.ptr) + shipped, scan.data() + shipped,
                                              final_bytes - shipped, stream);
@@ -684,13 +691,21 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     // is a launch and a PCIe round trip of its own).  A large rest leaves on its own first -- the card fetches it
     // while the host makes descriptor and tables.
     size_t rest_at = shipped, rest_bytes = pull && n_words * 4 > shipped ? n_words * 4 - shipped : 0;
-    if (pull && rest_bytes > (256u << 10)) {
+    size_t rest_alone = blob_prebuilt ? size_t(-1) : size_t(256u << 10); // (nothing left to make: one launch for all)
+    if (const char *e = lab_env("COMPEG_REST_ALONE")) // experiment knob: bytes
+        rest_alone = size_t(atol(e));
+    if (pull && rest_bytes > rest_alone) {
         CG_HIP(launch_pull(static_cast<uint8_t *>(words.ptr) + rest_at, scan.data() + rest_at, rest_bytes, stream));
         rest_bytes = 0;
     }
     trace.mark("copies");
-    if (!blob_uploaded)
+    if (blob_prebuilt) {
+        ImageDesc &d = *reinterpret_cast<ImageDesc *>(hb);
+        d.nwords = uint32_t(n_words);
+        d.nstarts = uint32_t(n_starts);
+    } else if (!blob_uploaded) {
         write_blob(on_device ? dev_words : words.ptr, on_device ? dev_starts : starts.ptr, n_words, n_starts);
+    }
     if (pull) {
         void *const dsts[3] = {static_cast<uint8_t *>(words.ptr) + rest_at, starts.ptr, db};
         const void *const srcs[3] = {scan.data() + rest_at, scan.starts(), hb};

@@ -1,6 +1,7 @@
 // Host scan preprocessor (see scan.h): the reference's byte-serial loop (src/scan.rs:33-128) as a
 // vector copy between 0xFF bytes, optionally shared by several threads; byte-identical output.
 #include "scan.h"
+#include "lab.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -300,9 +301,11 @@ void ScanBuffer::copy(void *dst, const void *src, size_t bytes)
 
 // false: not worth it or not possible (the caller takes the one-thread loop)
 //
-// With a progress callback the segment is taken in two rounds, each one shared by all threads, and the
-// callback hears about the output of the first round as soon as it is in place: the decoder ships it while
-// the second round is being scanned (one 4K frame: 144 -> 135 us for the blocking decode).
+// With a progress callback the segment is taken in rounds, each one shared by all threads, and the callback hears
+// about the output of a round as soon as it is in place: the decoder ships it while the next round is being scanned.
+// The callback runs on the calling thread as the first thing of its share of the next round, so that the helpers
+// never wait for the launches it makes; in the first round it is called with 0 ("nothing yet: prepare what does not
+// depend on the scan").
 bool ScanBuffer::process_with_team(const uint8_t *scan, size_t len, uint32_t expected, uint8_t *out, uint32_t *starts,
                                    size_t slots, size_t &wp_out, size_t &ri_out, const Progress &progress)
 {
@@ -311,8 +314,16 @@ bool ScanBuffer::process_with_team(const uint8_t *scan, size_t len, uint32_t exp
     if (len < n * (64u << 10))
         return false;
     size_t rounds = 1;
-    if (progress)
-        rounds = len >= 2 * n * (64u << 10) ? 2 : 1; // (three rounds measured no better than two)
+    if (progress) {
+        size_t want = 2; // (a round costs two rendezvous of the team: three or four rounds measured 4-15 us slower)
+        if (const char *e = lab_env("COMPEG_SCAN_ROUNDS")) // experiment knob
+            want = size_t(std::max(1, atoi(e)));
+        rounds = std::max<size_t>(1, std::min(want, len / (n * (48u << 10))));
+    }
+    // the calling thread's share of a round, in quarters of a helper's
+    size_t own = 4; // (a smaller share for the thread that makes the launches measured no better)
+    if (const char *e = lab_env("COMPEG_SCAN_OWN")) // experiment knob
+        own = size_t(std::max(0, std::min(4, atoi(e))));
     // a cut that falls inside an FF xx pair moves behind the partner byte
     auto cut = [&](size_t at) {
         if (at == 0 || at >= len)
@@ -327,14 +338,18 @@ bool ScanBuffer::process_with_team(const uint8_t *scan, size_t len, uint32_t exp
     size_t interval = 0, start_word = 0, bytes = 0; // the output's cursor: open interval, its start word, bytes in it
     for (size_t r = 0; r < rounds; r++) {
         const size_t lo = len / rounds * r, hi = r + 1 == rounds ? len : len / rounds * (r + 1);
+        const size_t shares = own + 4 * (n - 1); // (in quarters of a helper's piece)
         for (size_t k = 0; k <= n; k++) {
-            const size_t at = cut(k == n ? hi : lo + (hi - lo) / n * k);
+            const size_t at = cut(k == n ? hi : lo + (hi - lo) / shares * (k ? own + 4 * (k - 1) : 0));
             if (k < n)
                 team.pieces[k].begin = at;
             if (k > 0)
                 team.pieces[k - 1].end = at;
         }
+        const size_t reported = (start_word * 4 + bytes) & ~size_t(15);
         team.run([&](unsigned k) {
+            if (k == 0 && progress)
+                progress(r ? reported : 0);
             ScanTeam::Piece &p = team.pieces[k];
             const size_t range = p.end - p.begin;
             if (p.out.size() < range + range / 3 + 80)
@@ -387,8 +402,6 @@ bool ScanBuffer::process_with_team(const uint8_t *scan, size_t len, uint32_t exp
                     starts[global & mask] = uint32_t(body / 4 + (p.starts[j] - first));
             }
         });
-        if (progress && r + 1 < rounds)
-            progress((start_word * 4 + bytes) & ~size_t(15));
     }
     wp_out = start_word * 4 + bytes;
     ri_out = interval + 1;
