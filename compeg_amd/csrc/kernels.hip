@@ -551,7 +551,11 @@ constexpr uint32_t kMaxWavesFused = 12; // 3 per SIMD: what 168 VGPRs allow
 constexpr uint32_t kMaxWavesSplit = 16; // entropy_kernel: 4 per SIMD
 } // namespace
 
-uint32_t fused_layout_wave_cap(uint32_t hs, uint32_t vs, bool pairs) { return (hs == 2 && vs == 2) || (hs == 1 && pairs) ? 8u : 12u; }
+// Waves per workgroup of the extension-layout kernels (their registers allow two waves per SIMD): 4:2:0 eight -- its
+// windows leave room for one workgroup per CU; the paired 8-pixel-MCU kernels four, two workgroups per CU (64 x 4K,
+// 4:4:4 / 4:4:0: 1.095 / 0.864 ms per launch against 1.144 / 0.896 with one workgroup of eight; three or five waves,
+// i.e. nine or ten per CU, are slower than either).
+uint32_t fused_layout_wave_cap(uint32_t hs, uint32_t vs, bool pairs) { return hs == 2 && vs == 2 ? 8u : (hs == 1 && pairs ? 4u : 12u); }
 
 HuffLdsPlan plan_huffman(uint32_t max_intervals, uint32_t images, uint32_t max_l2,
                          uint32_t max_wave_words, bool fused, uint32_t wave_cap)
