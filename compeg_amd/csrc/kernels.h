@@ -26,8 +26,9 @@ hipError_t launch_huffman(const ImageDesc *descs, uint32_t images, uint32_t max_
 hipError_t launch_entropy(const ImageDesc *descs, uint32_t images, uint32_t max_intervals,
                           const HuffLdsPlan &plan, hipStream_t stream);
 // uniform: all images have max_intervals intervals and byte-identical LUTs (workgroups may then span images)
+// one_mcu_intervals: every image's restart interval is one MCU (the kernel whose rows leave wave-wide)
 hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t max_intervals,
-                            const HuffLdsPlan &plan, hipStream_t stream, bool uniform = false);
+                            const HuffLdsPlan &plan, hipStream_t stream, bool uniform = false, bool one_mcu_intervals = false);
 // Extension layouts (luma hs x vs = 1x1, 1x2, 2x2), fused like the 4:2:2 kernel; plan with wave_cap = fused_layout_wave_cap.
 // pairs: (8-pixel MCUs) every image of the launch has an even restart interval -- a lane composites its MCUs two at a time
 uint32_t fused_layout_wave_cap(uint32_t hs, uint32_t vs, bool pairs);

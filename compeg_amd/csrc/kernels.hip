@@ -301,18 +301,28 @@ __device__ __forceinline__ void fused_kernel_body(const ImageDesc *__restrict__ 
     }
 }
 
+template <bool WIDE>
 struct Wave422 {
     template <class AHEAD>
     static __device__ __forceinline__ void decode(const ImageDesc &d, const HuffShared &s, uint32_t interval, uint32_t lane, AHEAD &ahead)
     {
-        decode_wave_fused_422(d, s, interval, lane, ahead);
+        decode_wave_fused_422<AHEAD, WIDE>(d, s, interval, lane, ahead);
     }
 };
 __global__ void __launch_bounds__(768)
 decode_fused_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words,
                         uint32_t waves_per_image, uint32_t images)
 {
-    fused_kernel_body<Wave422>(descs, l2_in_lds, window_words, waves_per_image, images);
+    fused_kernel_body<Wave422<false>>(descs, l2_in_lds, window_words, waves_per_image, images);
+}
+// The same for launches whose every restart interval is one MCU (BASELINE configs[4]: 8K, DRI = 1): consecutive lanes
+// hold consecutive MCUs, and the rows of sixteen of them leave in one piece of 1 KB (composite_row_from_wave).  A
+// kernel of its own: as a branch inside the one above the second exchange costs it two spilled registers.
+__global__ void __launch_bounds__(768)
+decode_fused_422_mcu_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words,
+                            uint32_t waves_per_image, uint32_t images)
+{
+    fused_kernel_body<Wave422<true>>(descs, l2_in_lds, window_words, waves_per_image, images);
 }
 // Extension layouts: decode_wave_fused_layout behind the plain prologue -- grid (workgroups per image,
 // images), no resident waves: inside the larger body above these kernels spill (4:2:0: 356 registers), alone they
@@ -674,11 +684,15 @@ hipError_t launch_fused_layout(const ImageDesc *descs, uint32_t images, uint32_t
 }
 
 hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t max_intervals,
-                            const HuffLdsPlan &plan, hipStream_t stream, bool uniform)
+                            const HuffLdsPlan &plan, hipStream_t stream, bool uniform, bool one_mcu_intervals)
 {
     if (images == 0 || max_intervals == 0)
         return hipSuccess;
-    const auto kernel = decode_fused_422_kernel;
+    static const bool wide_allowed = [] {
+        const char *e = lab_env("COMPEG_WIDE"); // experiment knob: 0 = the quad exchange for every restart interval
+        return e ? atoi(e) != 0 : true;
+    }();
+    const auto kernel = one_mcu_intervals && wide_allowed ? decode_fused_422_mcu_kernel : decode_fused_422_kernel;
     const uint32_t wave_limit = kMaxWavesFused;
     const uint32_t threads = plan.waves_per_block * kWave;
     // uniform: every image has max_intervals intervals and the same LUT bytes -> workgroups may span images

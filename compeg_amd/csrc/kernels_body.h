@@ -1435,6 +1435,23 @@ CG_DEV void composite_row_from_quad(const ImageDesc &d, const uint8_t *wave_slot
     }
 }
 
+// The same for a restart interval of one MCU, where the wave's lanes hold 64 consecutive MCUs: store t of a row
+// takes the MCUs of lanes 16 t .. 16 t + 15, lane l piece l & 3 of the MCU of lane 16 t + (l >> 2) -- 1 KB in one
+// piece wherever those sixteen MCUs lie in one MCU row (64-byte segments 256 bytes apart are what every longer
+// interval leaves the write path with).
+// bases[t], bit t of whole_mask: of the MCU of lane 16 t + (lane >> 2).
+CG_DEV void composite_row_from_wave(const ImageDesc &d, const uint8_t *wave_slots, uint32_t lane, uint32_t row,
+                                    uint8_t *const (&bases)[4], uint32_t whole_mask)
+{
+    const uint32_t piece = lane & 3u, sub = lane >> 2;
+#pragma unroll
+    for (uint32_t t = 0; t < 4; t++) {
+        const SlotVec v = reinterpret_cast<const SlotVec *>(wave_slots + (16u * t + sub) * kDuSlotBytes)[piece];
+        if (whole_mask >> t & 1u)
+            store_pixels<true>(bases[t] + size_t(row) * d.out_pitch + piece * 16u, Vec4u{v.x, v.y, v.z, v.w});
+    }
+}
+
 // An MCU cut by the right / bottom edge of the output (stores outside it are
 // dropped, like textureStore in the reference) or an unaligned pitch: the
 // owning lane stores it pixel by pixel.
@@ -1724,13 +1741,26 @@ CG_DEV uint32_t quad_lane(uint32_t v)
 #endif
 }
 
+// value of lane 16 T + (lane >> 2) of the wave
+template <int T>
+CG_DEV uint32_t wave_lane(uint32_t v, uint32_t lane)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return uint32_t(__builtin_amdgcn_ds_bpermute(int((16u * T + (lane >> 2)) * 4u), int(v)));
+#else
+    (void)lane;
+    return v; // host pass of hipcc: never executed
+#endif
+}
+
 // The composite of the wave's 64 current MCUs; every lane of the wave calls
 // this together (tests/emul drives the same steps lane by lane).
 // wave_slots: the 64 slots the data units came through.
 // QUADS = false: every lane stores its own MCU, 16 bytes at a time -- less
 // latency (no LDS round trip per row) for launches that leave the vector
 // memory path idle anyway (the paired kernel).
-template <bool QUADS>
+// WIDE: every interval of the launch is one MCU (composite_row_from_wave).
+template <bool QUADS, bool WIDE = false>
 CG_DEV void composite_mcus_422(PixelState &t, const ImageDesc &d, uint8_t *wave_slots, uint32_t lane)
 {
     const McuTarget g = mcu_target(t, d);
@@ -1752,6 +1782,37 @@ CG_DEV void composite_mcus_422(PixelState &t, const ImageDesc &d, uint8_t *wave_
     }
     const uint64_t addr = reinterpret_cast<uint64_t>(g.base);
     const uint32_t lo = uint32_t(addr), hi = uint32_t(addr >> 32), wh = g.whole ? 1u : 0u;
+    uint8_t *slot = wave_slots + lane * kDuSlotBytes;
+    if (WIDE) {
+        // consecutive lanes, consecutive MCUs: rows leave in pieces of 1 KB (composite_row_from_wave)
+        uint8_t *from[4] = {
+            reinterpret_cast<uint8_t *>(uint64_t(wave_lane<0>(hi, lane)) << 32 | wave_lane<0>(lo, lane)),
+            reinterpret_cast<uint8_t *>(uint64_t(wave_lane<1>(hi, lane)) << 32 | wave_lane<1>(lo, lane)),
+            reinterpret_cast<uint8_t *>(uint64_t(wave_lane<2>(hi, lane)) << 32 | wave_lane<2>(lo, lane)),
+            reinterpret_cast<uint8_t *>(uint64_t(wave_lane<3>(hi, lane)) << 32 | wave_lane<3>(lo, lane)),
+        };
+        const uint32_t mask = wave_lane<0>(wh, lane) | wave_lane<1>(wh, lane) << 1 | wave_lane<2>(wh, lane) << 2 | wave_lane<3>(wh, lane) << 3;
+        if (__builtin_amdgcn_ballot_w64(mask != 0xfu) == 0u) {
+#pragma unroll
+            for (uint32_t row = 0; row < 8; row++) {
+                composite_row_to_slot(t.px, row, slot);
+                composite_row_from_wave(d, wave_slots, lane, row, from, 0xfu);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (uint32_t row = 0; row < 8; row++) {
+                composite_row_to_slot(t.px, row, slot);
+                composite_row_from_wave(d, wave_slots, lane, row, from, mask);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        zero_slot(slot);
+        if (t.active && !g.whole)
+            composite_edge_mcu(d, t.px, t.mx, t.my);
+        pixel_next_mcu(t, d);
+        return;
+    }
     uint8_t *bases[4] = {
         reinterpret_cast<uint8_t *>(uint64_t(quad_lane<0>(hi)) << 32 | quad_lane<0>(lo)),
         reinterpret_cast<uint8_t *>(uint64_t(quad_lane<1>(hi)) << 32 | quad_lane<1>(lo)),
@@ -1759,7 +1820,6 @@ CG_DEV void composite_mcus_422(PixelState &t, const ImageDesc &d, uint8_t *wave_
         reinterpret_cast<uint8_t *>(uint64_t(quad_lane<3>(hi)) << 32 | quad_lane<3>(lo)),
     };
     const uint32_t whole_mask = quad_lane<0>(wh) | quad_lane<1>(wh) << 1 | quad_lane<2>(wh) << 2 | quad_lane<3>(wh) << 3;
-    uint8_t *slot = wave_slots + lane * kDuSlotBytes;
     // (rows stay apart in the schedule: interleaving them only costs registers)
     if (__builtin_amdgcn_ballot_w64(whole_mask != 0xfu) == 0u) {
         // the common case, all 64 MCUs inside the output: unconditional stores
@@ -1796,7 +1856,7 @@ struct NothingAhead {
     CG_DEV void decoded(uint32_t, uint32_t) {}
 };
 
-template <class AHEAD>
+template <class AHEAD, bool WIDE = false>
 CG_DEV void decode_wave_fused_422(const ImageDesc &d, const HuffShared &s, uint32_t interval, uint32_t lane, AHEAD &ahead)
 {
     // A lane past the image's last interval decodes that last interval once
@@ -1840,7 +1900,7 @@ CG_DEV void decode_wave_fused_422(const ImageDesc &d, const HuffShared &s, uint3
         CG_STAMP(t_idct);
         if (k == 3u) {
             __builtin_amdgcn_s_setprio(CG_PRIO_COMPOSITE);
-            composite_mcus_422<true>(t, d, s.du_slots, lane);
+            composite_mcus_422<true, WIDE>(t, d, s.du_slots, lane);
             CG_STAMP(t_comp);
         }
         __builtin_amdgcn_s_setprio(CG_PRIO_ENTROPY);

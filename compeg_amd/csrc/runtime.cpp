@@ -795,7 +795,7 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
             last_kernel = COMPEG_KERNEL_PAIR;
         } else {
             CG_HIP(launch_fused_422(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals,
-                                    plan, stream));
+                                    plan, stream, false, md.restart_interval == 1u));
             last_kernel = COMPEG_KERNEL_FUSED;
         }
         coefficients_valid = false;
@@ -1040,6 +1040,7 @@ void compeg_batch::note_batch_properties(const ImageData *const *images, size_t 
     layout_h = n ? images[0]->metadata.components[0].hsample : 0;
     layout_v = n ? images[0]->metadata.components[0].vsample : 0;
     layout_even_ri = true;
+    one_mcu_intervals = n > 0;
     max_out_w = max_out_h = 0;
     // frames of one stream: the same number of restart intervals and byte-identical LUTs in every image
     // (the fused kernel's workgroups may then span image boundaries)
@@ -1050,6 +1051,7 @@ void compeg_batch::note_batch_properties(const ImageData *const *images, size_t 
         if (img.metadata.components[0].hsample != layout_h || img.metadata.components[0].vsample != layout_v)
             layout_h = layout_v = 0; // (mixed samplings in one batch)
         layout_even_ri = layout_even_ri && img.metadata.restart_interval % 2u == 0u;
+        one_mcu_intervals = one_mcu_intervals && img.metadata.restart_interval == 1u;
         max_out_w = std::max(max_out_w, img.width);
         max_out_h = std::max(max_out_h, img.height);
         uniform = uniform && img.metadata.total_restart_intervals == first.metadata.total_restart_intervals &&
@@ -1888,7 +1890,7 @@ Status compeg_batch::decode(hipStream_t stream)
             else if (use_pair_kernel(max_intervals, m))
                 CG_HIP(launch_pair_422(dd + at, m, max_intervals, plan, stream));
             else
-                CG_HIP(launch_fused_422(dd + at, m, max_intervals, plan, stream, uniform));
+                CG_HIP(launch_fused_422(dd + at, m, max_intervals, plan, stream, uniform, one_mcu_intervals));
             if (at == 0)
                 last_kernel = coop.usable ? COMPEG_KERNEL_COOP_TEAM : (use_pair_kernel(max_intervals, m) ? COMPEG_KERNEL_PAIR : COMPEG_KERNEL_FUSED);
             if (timing && at == 0)

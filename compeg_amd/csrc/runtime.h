@@ -139,6 +139,7 @@ struct compeg_batch {
     bool generic_layout = false;
     uint32_t layout_h = 0, layout_v = 0; // luma sampling all images share (0: they differ)
     bool layout_even_ri = false;         // ... and every restart interval is even
+    bool one_mcu_intervals = false;      // every restart interval is one MCU
     bool uniform = false; // same interval count and LUT bytes in every image (set by upload)
     // cooperative kernel: the restart interval all images share if every one of them qualifies (else 0), and the
     // largest word span of a wave's group of intervals

@@ -261,10 +261,15 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
                         uint8_t *bases[4];
                         uint32_t whole_mask = 0;
                         for (uint32_t j = 0; j < 4; j++) {
-                            bases[j] = tg[quad + j].base;
-                            whole_mask |= (tg[quad + j].whole ? 1u : 0u) << j;
+                            // (a restart interval of one MCU: the rows leave wave-wide, composite_row_from_wave)
+                            const uint32_t from = d.restart_interval == 1u ? 16u * j + (lane >> 2) : quad + j;
+                            bases[j] = tg[from].base;
+                            whole_mask |= (tg[from].whole ? 1u : 0u) << j;
                         }
-                        composite_row_from_quad(d, set_slots, lane, row, bases, whole_mask);
+                        if (d.restart_interval == 1u)
+                            composite_row_from_wave(d, set_slots, lane, row, bases, whole_mask);
+                        else
+                            composite_row_from_quad(d, set_slots, lane, row, bases, whole_mask);
                     }
                 }
                 for (uint32_t lane = 0; lane < uint32_t(kWave); lane++) {

@@ -291,12 +291,14 @@ def test_full_size_8k_dri1_roundtrip_properties(ca, gpu):
     _assert_equal(got, want)
 
 
-def test_fused_kernel_ragged_batch(ca, gpu):
+@pytest.mark.parametrize("every_ri", [0, 1])
+def test_fused_kernel_ragged_batch(ca, gpu, every_ri):
     """A batch big enough for the throughput kernel (more than 1024 waves) of images whose
     geometry exercises its corner cases: MCUs cut by the right and bottom edge (stored by
     their own lane), a last wave with unused lanes (they only help their quad store), an
-    interval count that is not a multiple of the restart interval."""
-    shapes = [(1000, 1000, 3), (1016, 990, 5), (1000, 1004, 4)]
+    interval count that is not a multiple of the restart interval.  every_ri = 1: the kernel for
+    launches of one-MCU intervals, whose rows leave wave-wide (sixteen MCUs to a store)."""
+    shapes = [(1000, 1000, every_ri or 3), (1016, 990, every_ri or 5), (1000, 1004, every_ri or 4)]
     jpegs = [synth.make_jpeg(w, h, seed=200 + i, kind=i % 3, quality=80, ri=ri)
              for i, (w, h, ri) in enumerate(shapes * 11)]
     images = [ca.ImageData(j) for j in jpegs]

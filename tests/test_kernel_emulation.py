@@ -72,6 +72,7 @@ def _check(runner, tmp_path, jpeg, **kw):
 CASES = [
     (64, 8, 0, 100, 1, 1), (320, 200, 0, 85, 4, 2), (128, 64, 1, 95, 1, 3), (250, 70, 0, 50, 3, 4),
     (33, 17, 0, 90, 1, 5), (256, 64, 2, 85, 7, 6), (96, 48, 1, 100, 0, 7),
+    (500, 40, 0, 85, 1, 8),   # DRI = 1 over several waves, right edge cut: the rows that leave wave-wide
 ]
 
 
