@@ -146,6 +146,8 @@ struct HuffLdsPlan {
     uint32_t window_words;      // per-wave scan window
     uint32_t waves_per_block;
     uint32_t total_bytes;
+    uint32_t waves_that_fit;    // waves with such a window one CU's LDS holds
+    bool window_cut;            // some wave's intervals are longer than the window (the rest: global reads)
 };
 
 } // namespace compeg

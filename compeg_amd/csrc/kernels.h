@@ -29,6 +29,18 @@ hipError_t launch_entropy(const ImageDesc *descs, uint32_t images, uint32_t max_
 // one_mcu_intervals: every image's restart interval is one MCU (the kernel whose rows leave wave-wide)
 hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t max_intervals,
                             const HuffLdsPlan &plan, hipStream_t stream, bool uniform = false, bool one_mcu_intervals = false);
+// The batch kernel with the window in its streamed form (kernels_body.h: decode_wave_fused_422_stream), for launches
+// whose whole-interval windows would leave a CU fewer than its twelve waves.
+struct StreamPlan {
+    uint32_t rows = 0, waves_per_block = 0, l2_entries_in_lds = 0, total_bytes = 0;
+    uint32_t waves_per_image = 0; // != 0: the flat grid (uniform launches)
+};
+// uniform: all images have max_intervals intervals and byte-identical LUTs (workgroups may then span images)
+StreamPlan plan_stream(uint32_t max_intervals, uint32_t images, uint32_t max_l2, uint32_t mcu_words, bool uniform);
+// (plan: plan_huffman's for the same launch)
+bool stream_plan_preferred(const HuffLdsPlan &plan, uint32_t max_intervals, uint32_t images);
+hipError_t launch_fused_422_stream(const ImageDesc *descs, uint32_t images, uint32_t max_intervals, const StreamPlan &plan,
+                                   hipStream_t stream);
 // Extension layouts (luma hs x vs = 1x1, 1x2, 2x2), fused like the 4:2:2 kernel; plan with wave_cap = fused_layout_wave_cap.
 // pairs: (8-pixel MCUs) every image of the launch has an even restart interval -- a lane composites its MCUs two at a time
 uint32_t fused_layout_wave_cap(uint32_t hs, uint32_t vs, bool pairs);

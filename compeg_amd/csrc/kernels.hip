@@ -389,6 +389,52 @@ decode_fused_420_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds,
     fused_layout_kernel_body<2, 2, 1>(descs, l2_in_lds, window_words);
 }
 
+// The batch kernel for restart intervals too long for whole-interval windows (decode_wave_fused_422_stream: `rows`
+// words of every lane's stream at a time, fetched by LDS-DMA MCU by MCU).  Plain grid (workgroups per image,
+// images): the units are long, the prologue is a small share of them.
+__global__ void __launch_bounds__(768)
+decode_fused_422_stream_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t rows, uint32_t waves_per_image,
+                               uint32_t images)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x / kWave))), lane = threadIdx.x % kWave;
+    // Two grid shapes, as in decode_fused_422_kernel: (workgroups per image, images), or -- waves_per_image != 0:
+    // every image has that many waves and the same LUT bytes -- one dimension over the waves of all images, so
+    // that small images (a 960x720 frame with DRI = 30 is three waves) still make workgroups of twelve.
+    uint32_t image = blockIdx.y, wave_first = (blockIdx.x * (blockDim.x / kWave) + wave) * kWave;
+    bool has_work = true;
+    if (waves_per_image) {
+        const uint32_t flat = blockIdx.x * (blockDim.x / kWave) + wave;
+        image = flat / waves_per_image;
+        wave_first = (flat % waves_per_image) * kWave;
+        has_work = image < images;
+        image = has_work ? image : images - 1u; // (it still helps staging the LUTs)
+    }
+    image = uint32_t(__builtin_amdgcn_readfirstlane(int(image)));
+    wave_first = uint32_t(__builtin_amdgcn_readfirstlane(int(wave_first)));
+    const ImageDesc &d = descs[image];
+    if (!waves_per_image && blockIdx.x * blockDim.x >= d.total_intervals)
+        return; // the whole workgroup
+    uint16_t *l1 = reinterpret_cast<uint16_t *>(smem);
+    uint16_t *l2 = l1 + kL1Entries;
+    const uint32_t wave_area = rows * kWave * 4u + kWave * kDuSlotBytes;
+    uint8_t *wave_base = smem + align16((kL1Entries + l2_in_lds) * 2u);
+    uint32_t *win = reinterpret_cast<uint32_t *>(wave_base + wave * wave_area);
+    stage_luts_and_window(d, l1, l2, l2_in_lds, threadIdx.x, blockDim.x, win, 0u, 0u, lane);
+    __syncthreads();
+    if (!has_work || wave_first >= d.total_intervals)
+        return; // the whole wave; lanes past the last interval of a partly used wave stay (quad exchange)
+    HuffShared s;
+    s.l1 = l1;
+    s.l2 = l2;
+    s.l2_staged = umin(l2_in_lds, d.fast_off + 2u * kFastEntries);
+    s.win = win;
+    s.win_base = 0u;
+    s.win_len = 0u; // (no whole-interval window: the reference reader's words come from global memory)
+    s.du_slots = reinterpret_cast<uint8_t *>(win) + rows * kWave * 4u;
+    decode_wave_fused_422_stream(d, s, rows, wave_first + lane, lane);
+}
+
 // Latency-oriented variant of the fused path for launches that cannot fill
 // the chip (a single 4K frame with DRI=4 is 254 waves for 1024 SIMDs): every
 // workgroup is a PAIR of waves working on the same 64 restart intervals.
@@ -570,7 +616,7 @@ uint32_t fused_layout_wave_cap(uint32_t hs, uint32_t vs, bool pairs) { return hs
 HuffLdsPlan plan_huffman(uint32_t max_intervals, uint32_t images, uint32_t max_l2,
                          uint32_t max_wave_words, bool fused, uint32_t wave_cap)
 {
-    HuffLdsPlan p;
+    HuffLdsPlan p{};
     // everything behind L1: the L2 LUT and the two direct AC tables (at most 24 KB of LDS)
     p.l2_entries_in_lds = max_l2 < 12288u ? (max_l2 + 1u) & ~1u : 12288u;
     const uint32_t tables = (((kL1Entries + p.l2_entries_in_lds) * 2u) + 15u) & ~15u;
@@ -582,6 +628,7 @@ HuffLdsPlan plan_huffman(uint32_t max_intervals, uint32_t images, uint32_t max_l
     uint32_t w = max_wave_words + kDuWordSlack + 4u;
     if (w < 256u)
         w = 256u;
+    p.window_cut = w > 6144u;
     if (w > 6144u)
         w = 6144u;
     if (const char *e = lab_env("COMPEG_WINDOW_CAP")) // experiment knob (words)
@@ -597,6 +644,7 @@ HuffLdsPlan plan_huffman(uint32_t max_intervals, uint32_t images, uint32_t max_l
     const uint32_t lds_per_cu = lim.lds_bytes, cu_count = lim.cus;
     const uint64_t total_waves = uint64_t((max_intervals + kWave - 1) / kWave) * images;
     const uint32_t fit = (lds_per_cu - tables) / wave_area;
+    p.waves_that_fit = fit;
     const uint32_t most = std::max(1u, std::min(std::min(fit, fused ? kMaxWavesFused : kMaxWavesSplit), wave_cap ? wave_cap : 64u));
     const uint64_t per_cu = (total_waves + cu_count - 1u) / cu_count;
     uint32_t wpb = uint32_t(std::min<uint64_t>(std::max<uint64_t>(per_cu, 1u), most));
@@ -723,6 +771,70 @@ hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t ma
         return attr;
     hipLaunchKernelGGL(kernel, grid, dim3(threads), plan.total_bytes, stream, descs, plan.l2_entries_in_lds, plan.window_words,
                        grid.y == 1 && waves_per_image ? waves_per_image : 0u, images);
+    return hipGetLastError();
+}
+
+// Where whole-interval windows are longer than a window can be, or leave a CU fewer than eight of its twelve waves
+// and fewer than the launch would put there (256 frames of 960x720, whole windows / streamed, ms per launch: DRI 6
+// 0.335 / 0.412 -- nine waves fit --, 8 0.397 / 0.336, 10 0.469 / 0.366, 16 1.22 / 0.42, 30 1.14 / 0.64, 60 2.2 / 1.18).
+bool stream_plan_preferred(const HuffLdsPlan &plan, uint32_t max_intervals, uint32_t images)
+{
+    const uint64_t waves = uint64_t((max_intervals + kWave - 1) / kWave) * images;
+    const uint32_t cus = device_limits().cus;
+    const uint64_t per_cu = std::min<uint64_t>(kMaxWavesFused, (waves + cus - 1u) / cus);
+    return plan.window_cut || (plan.waves_that_fit < 8u && per_cu > plan.waves_that_fit);
+}
+
+// Rows for the streamed window: room for `mcu_words` (the launch's average MCU, rounded up) four times over and
+// the words a reader holds beyond, as many as leave the CU its twelve waves, never fewer than sixteen.
+StreamPlan plan_stream(uint32_t max_intervals, uint32_t images, uint32_t max_l2, uint32_t mcu_words, bool uniform)
+{
+    StreamPlan p;
+    p.l2_entries_in_lds = max_l2 < 12288u ? (max_l2 + 1u) & ~1u : 12288u;
+    const uint32_t tables = (((kL1Entries + p.l2_entries_in_lds) * 2u) + 15u) & ~15u;
+    const DeviceLimits lim = device_limits();
+    uint32_t rows = std::max(16u, std::min(64u, 3u * mcu_words + 4u));
+    if (const char *e = lab_env("COMPEG_STREAM_ROWS")) // experiment knob
+        rows = uint32_t(std::max(4, std::min(128, atoi(e))));
+    const uint32_t wave_area = rows * kWave * 4u + kWave * kDuSlotBytes;
+    const uint32_t waves_per_image = (max_intervals + kWave - 1) / kWave;
+    const uint64_t total_waves = uint64_t(waves_per_image) * images;
+    // Waves per workgroup: one CU's share of the launch (a launch smaller than the chip spreads over all of its CUs:
+    // 256 frames of 960x720 with DRI = 30 are 768 waves), at most what the LDS holds and twelve; the per-image grid
+    // never more than an image has.  (Workgroups smaller than the share, two to a CU, measured no better.)
+    const uint32_t fit = std::max(1u, (lim.lds_bytes - tables) / wave_area);
+    uint32_t best = uint32_t(std::min<uint64_t>(std::max<uint64_t>((total_waves + lim.cus - 1) / lim.cus, 1u), std::min(fit, kMaxWavesFused)));
+    if (!uniform)
+        best = std::min(best, std::max(1u, waves_per_image));
+    if (const char *e = lab_env("COMPEG_WPB")) // experiment knob
+        best = uint32_t(atoi(e));
+    p.rows = rows;
+    p.waves_per_block = best;
+    p.total_bytes = tables + best * wave_area;
+    p.waves_per_image = uniform ? waves_per_image : 0u;
+    if (getenv("COMPEG_VERBOSE"))
+        fprintf(stderr, "[compeg] stream plan: images=%u intervals=%u waves/block=%u rows=%u lds=%u B%s\n", images, max_intervals, best,
+                rows, p.total_bytes, uniform ? " flat" : "");
+    return p;
+}
+
+hipError_t launch_fused_422_stream(const ImageDesc *descs, uint32_t images, uint32_t max_intervals, const StreamPlan &plan,
+                                   hipStream_t stream)
+{
+    if (images == 0 || max_intervals == 0)
+        return hipSuccess;
+    const uint32_t threads = plan.waves_per_block * kWave;
+    dim3 grid((max_intervals + threads - 1) / threads, images, 1);
+    const uint64_t flat_groups = (uint64_t(plan.waves_per_image) * images + plan.waves_per_block - 1) / plan.waves_per_block;
+    const bool flat = plan.waves_per_image != 0u && flat_groups <= 0x7fffffffu;
+    if (flat)
+        grid = dim3(uint32_t(flat_groups), 1, 1);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(decode_fused_422_stream_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(device_limits().lds_bytes));
+    if (attr != hipSuccess)
+        return attr;
+    hipLaunchKernelGGL(decode_fused_422_stream_kernel, grid, dim3(threads), plan.total_bytes, stream, descs,
+                       plan.l2_entries_in_lds, plan.rows, flat ? plan.waves_per_image : 0u, images);
     return hipGetLastError();
 }
 

@@ -891,9 +891,10 @@ CG_DEV int32_t decode_dc_diff(PrefetchReader &r, const ImageDesc &d, const HuffS
 // padding.  ZRL advances 17 positions (quirk Q2).
 // AC coefficients of one data unit, reference-exact reader (see fast_ac for
 // the path normally taken).
+// pos0: the zig-zag position to go on from (a data unit begun in fast mode: fast_ac<true>).
 template <bool FAST>
 CG_DEV void decode_ac_loop(PrefetchReader &r, const ImageDesc &d, const HuffShared &s,
-                           uint32_t ac_off, int16_t *slot16)
+                           uint32_t ac_off, int16_t *slot16, uint32_t pos0 = 1u)
 {
     // Software-pipelined: the LUT lookup of the next symbol is issued as soon
     // as the bit position after the current one is known; magnitude
@@ -903,7 +904,7 @@ CG_DEV void decode_ac_loop(PrefetchReader &r, const ImageDesc &d, const HuffShar
     // position 64): reader state is committed only if decoding continues, so
     // the DC code that follows sees exactly the reference's un-refilled
     // reader (quirk Q1).
-    uint32_t pos = 1u;
+    uint32_t pos = pos0;
     reader_refill<FAST>(r, d, s);
     uint32_t e = lut_lookup<FAST>(d, s, ac_off, reader_cur(r));
     bool done;
@@ -971,6 +972,13 @@ struct EntropyState {
     uint32_t ref_left;    // fast mode: the reference reader's `left` at the coming DC code
     bool fast;
     int32_t pred0, pred1, pred2;
+    // The streamed form of the window (decode_wave_fused_422_stream; nothing of it exists in the other kernels): the
+    // lane reads its own column of the wave's rows -- row j, 64 words apart, holds the lane's stream word
+    // r.next_word + j as it lies in memory (LSB-first: swapped when it is merged) --, wlimit is the first row that does
+    // not hold one, and a lane that ran into it finishes its data unit with the reference reader and comes back to
+    // fast mode when the rows are staged next (resume).
+    const uint32_t *wlimit;
+    bool resume;
 };
 
 // tests/emul counts how often the rare paths run (to prove the tests reach them)
@@ -1043,32 +1051,59 @@ CG_DEV void entropy_init(EntropyState &e, const ImageDesc &d, const HuffShared &
     e.wptr = s.win + (e.fast ? rel : 0u);
 }
 
+// STREAM (decode_wave_fused_422_stream): index of the stream word e.wptr points at -- its row in the lane's column
+// (s.win + lane; a column's rows are 64 words apart) behind the word of row 0.
+CG_DEV uint32_t stream_word_index(const EntropyState &e, const HuffShared &s, uint32_t lane)
+{
+    return e.r.next_word + uint32_t(e.wptr - (s.win + lane)) / uint32_t(kWave);
+}
+
 // Fast -> exact: drop what was loaded ahead of the reference.
-CG_DEV void leave_fast_mode(EntropyState &e, const ImageDesc &d, const HuffShared &s)
+template <bool STREAM = false>
+CG_DEV void leave_fast_mode(EntropyState &e, const ImageDesc &d, const HuffShared &s, uint32_t lane = 0u)
 {
     PrefetchReader &r = e.r;
     if (d.standard_entropy)
         e.ref_left = r.left; // nothing to drop: the standard reader is topped up in front of DC codes too
     const uint32_t ahead = (r.left - e.ref_left) >> 5; // 0 or 1 word
-    r.next_word = s.win_base + uint32_t(e.wptr - s.win) - ahead;
-    if (ahead)
+    if (STREAM) {
+        // (the rows hold the words as they lie in memory and a row behind the limit holds anything: both readers'
+        // word in flight is read again, through the reference reader's fetch)
+        r.next_word = stream_word_index(e, s, lane) - ahead;
         r.pre = fetch_word_pf<false>(d, s, r.next_word);
+    } else {
+        r.next_word = s.win_base + uint32_t(e.wptr - s.win) - ahead;
+        if (ahead)
+            r.pre = fetch_word_pf<false>(d, s, r.next_word);
+    }
     r.buf &= ~uint64_t(0) << (64u - e.ref_left);
     r.left = e.ref_left;
     e.fast = false;
 }
 
+// STREAM, inside a data unit, behind its DC code (where the reference reader tops up in front of every symbol: from
+// there on both readers hold the same bits): the lane has reached its last staged row.
+CG_DEV void stream_leave_inside(EntropyState &e, const ImageDesc &d, const HuffShared &s, uint32_t lane)
+{
+    PrefetchReader &r = e.r;
+    r.next_word = stream_word_index(e, s, lane);
+    r.pre = fetch_word_pf<false>(d, s, r.next_word);
+    e.fast = false;
+    e.resume = true;
+}
+
 // Branch-free top-up: merges the stream word in flight when fewer than 32
 // bits are left (0 <= left <= 63) and puts the next one in flight.
+template <bool STREAM = false>
 CG_DEV void fast_refill(EntropyState &e)
 {
     PrefetchReader &r = e.r;
     const uint32_t t = r.left - 32u;
     const uint32_t f = t >> 31;                         // 1 when left < 32
-    const uint32_t w = r.pre & uint32_t(int32_t(t) >> 31);
+    const uint32_t w = (STREAM ? bswap32(r.pre) : r.pre) & uint32_t(int32_t(t) >> 31);
     r.buf |= (uint64_t(w) << 32) >> (r.left & 63u);     // w == 0 when left >= 32
     r.left += f << 5;
-    e.wptr += f;
+    e.wptr += STREAM ? f * uint32_t(kWave) : f;
 #if CG_EXP == 12
     r.pre = uint32_t(reinterpret_cast<uintptr_t>(e.wptr)) * 2654435761u;
 #else
@@ -1118,13 +1153,18 @@ __device__ unsigned long long g_ac_stamps[4];
 #define CG_AC_STAMP(x)
 #endif
 
-CG_DEV void fast_ac(EntropyState &e, const ImageDesc &d, const HuffShared &s, uint32_t ac_off,
-                    uint32_t fast_base, int16_t *slot16)
+// Returns the zig-zag position of the coefficient decoded last: 63 or more at the data unit's end; STREAM: less when
+// the lane's word in flight is no staged one (e.wptr at e.wlimit) -- whatever was consumed up to there was stream.
+template <bool STREAM = false>
+CG_DEV uint32_t fast_ac(EntropyState &e, const ImageDesc &d, const HuffShared &s, uint32_t ac_off,
+                        uint32_t fast_base, int16_t *slot16)
 {
     CG_AC_STAMP(const uint64_t ts0 = __builtin_readcyclecounter(); uint64_t tw = 0; uint32_t its = 0;)
     PrefetchReader &r = e.r;
     const uint16_t *tab = s.l2 + fast_base;
-    fast_refill(e);
+    if (STREAM && e.wptr >= e.wlimit)
+        return 0u;
+    fast_refill<STREAM>(e);
     uint32_t ent = lds_read_u16_early(tab + (reader_cur(r) >> (32u - kFastBits)));
     uint32_t at = 0u, tot = 0u; // at: zig-zag position of the coefficient decoded last
     // Software-pipelined like the exact loop, but nothing is speculative:
@@ -1136,7 +1176,7 @@ CG_DEV void fast_ac(EntropyState &e, const ImageDesc &d, const HuffShared &s, ui
     // completion is never waited for.
     int16_t *pend_at = slot16 + kRetained; // the slot's padding
     int16_t pend_val = 0;
-    while (at < 63u) {
+    while (at < 63u && (!STREAM || e.wptr < e.wlimit)) {
         CG_AC_STAMP(const uint64_t tw0 = __builtin_readcyclecounter();)
         lds_reads_done(ent, r.pre);
         CG_AC_STAMP(tw += __builtin_readcyclecounter() - tw0; its++;)
@@ -1163,7 +1203,7 @@ CG_DEV void fast_ac(EntropyState &e, const ImageDesc &d, const HuffShared &s, ui
         const uint32_t cur = reader_cur(r);
         r.buf <<= tot;
         r.left -= tot;
-        fast_refill(e);
+        fast_refill<STREAM>(e);
 #if CG_EXP == 11 || CG_EXP == 12
         ent = reader_cur(r) >> 30;
 #else
@@ -1189,24 +1229,42 @@ CG_DEV void fast_ac(EntropyState &e, const ImageDesc &d, const HuffShared &s, ui
         atomicAdd(&g_ac_stamps[3], 1ull);
     })
     e.ref_left = 32u + ((r.left + tot) & 31u) - tot;
+    return at;
 }
 
 // One data unit: DC difference + AC coefficients into `slot16` (zeroed by the
 // consumer); returns the dequantised DC term.  comp is wave-uniform.
+// STREAM: the wave's window in its streamed form (EntropyState); lane = the caller's.
+template <bool STREAM = false>
 CG_DEV int32_t entropy_data_unit(EntropyState &e, const ImageDesc &d, const HuffShared &s, uint32_t comp,
-                                 int16_t *slot16)
+                                 int16_t *slot16, uint32_t lane = 0u)
 {
     const uint32_t dc_off = d.dc_table[comp] * 256u, ac_off = d.ac_table[comp] * 256u;
     int32_t diff = 0;
     bool decoded = false;
-    if (e.fast) {
+    if (!STREAM && e.fast) {
         const uint32_t rel = uint32_t(e.wptr - s.win);
         if (s.win_len - rel < kDuWordSlack) { // rel < win_len holds in fast mode
             CG_COUNT(left_window);
             leave_fast_mode(e, d, s);
         }
     }
-    if (e.fast) {
+    if (STREAM && e.fast) {
+        if (fast_dc(e, d, s, dc_off, diff)) {
+            const uint32_t at = fast_ac<true>(e, d, s, ac_off, d.fast_off + d.fast_table[comp] * kFastEntries, slot16);
+            CG_COUNT(fast_dus);
+            if (at < 63u) {
+                // the staged rows end inside this data unit: the reference reader takes the rest of it
+                CG_COUNT(left_window);
+                stream_leave_inside(e, d, s, lane);
+                decode_ac_loop<false>(e.r, d, s, ac_off, slot16, at + 1u);
+            }
+            decoded = true;
+        } else {
+            CG_COUNT(left_underflow);
+            leave_fast_mode<true>(e, d, s, lane);
+        }
+    } else if (e.fast) {
         if (fast_dc(e, d, s, dc_off, diff)) {
 #if CG_EXP == 3 // diagnostic build: the AC loop twice (idempotent: same coefficients, same final state)
             {
@@ -1729,6 +1787,83 @@ CG_DEV void pixel_next_mcu(PixelState &t, const ImageDesc &d)
     }
 }
 
+// ---- the window in its streamed form: restart intervals of any length ----
+// A wave's window (above) holds its 64 intervals whole: 64 x DRI MCUs of stream, 17 KB with DRI = 10, beyond what
+// the LDS has with DRI = 16 -- the waves per CU go, then the window itself.  Here a lane has `nrows` words of its
+// own stream staged at any time, whatever the interval's length: row j of the wave's rows (64 words, one per lane)
+// holds word j behind each lane's own position, fetched by LDS-DMA (one global_load_lds_dword a row: per-lane source,
+// lane-linear destination) after the last data unit of every MCU and landed under that data unit's IDCT.  The fast
+// reader walks down its lane's column (EntropyState); a lane that reaches its last row inside an MCU finishes the
+// MCU's data units with the reference reader from global memory and is back in fast mode with the next rows.
+
+// Row j of `rows` := word `first + j` of every lane's stream, j < nrows (asynchronous on the device: vmcnt).
+// (first <= d.nwords; the words behind an image's last are readable -- runtime.cpp pads its buffers -- and never used)
+CG_DEV void stream_stage_rows(const ImageDesc &d, uint32_t *rows, uint32_t nrows, uint32_t first, uint32_t lane)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)lane;
+    uint32_t voff = first * 4u, m0 = uint32_t(reinterpret_cast<uintptr_t>(rows));
+    const uint32_t *base = d.words;
+#pragma unroll 1
+    for (uint32_t j = 0; j < nrows; j++) {
+        uint32_t keep;
+        // (M0: the LDS address the wave's 64 words go to; compiler-reserved, hence written, used and put back in
+        // one statement)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"(m0), "s"(base)
+                     : "memory");
+        voff += 4u;
+        m0 += uint32_t(kWave) * 4u;
+    }
+#else
+    for (uint32_t j = 0; j < nrows; j++)
+        rows[j * uint32_t(kWave) + lane] = first + j < d.nwords ? d.words[first + j] : 0xfeedf00du;
+#endif
+}
+
+CG_DEV void stream_rows_landed()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
+// The lane's rows anew from the word it has in flight; lanes in fast mode go on in it, lanes that left it for want
+// of rows come back (at a data unit's boundary the reference reader's state is a fast-mode state), lanes whose reader
+// has underflowed (Q1) stay with the reference reader.
+CG_DEV void stream_restage(EntropyState &e, const ImageDesc &d, const HuffShared &s, uint32_t nrows, uint32_t lane)
+{
+    const uint32_t word = e.fast ? stream_word_index(e, s, lane) : e.r.next_word;
+    const uint32_t first = umin(word, d.nwords);
+    stream_stage_rows(d, const_cast<uint32_t *>(s.win), nrows, first, lane);
+    const bool back = !e.fast && e.resume && e.r.left < 64u; // (>= 2^31: the reference reader has underflowed since)
+    if (back) {
+        e.ref_left = e.r.left;
+        e.r.pre = bswap32(e.r.pre); // (as it lies in memory, like the rows)
+    }
+    if (e.fast || back) {
+        e.r.next_word = word; // fast mode: the word of row 0
+        e.wptr = s.win + lane;
+        e.wlimit = s.win + lane + umin(nrows, d.nwords - first) * uint32_t(kWave);
+        e.fast = true;
+    }
+    e.resume = false;
+}
+
+// The reference reader at the interval's start (two words from global memory), then the first rows and fast mode.
+CG_DEV void stream_lane_init(EntropyState &e, const ImageDesc &d, const HuffShared &s, uint32_t nrows, uint32_t interval, uint32_t lane)
+{
+    reader_init(e.r, d, s, interval < d.nstarts ? CG_GLOBAL(const uint32_t, d.starts)[interval] : 0u);
+    reader_refill<false>(e.r, d, s); // left == 32: also a valid fast-mode state
+    e.pred0 = e.pred1 = e.pred2 = 0;
+    e.ref_left = 32u;
+    e.fast = false;
+    e.resume = fast_tables_usable(d, s);
+    e.wptr = e.wlimit = s.win + lane;
+    stream_restage(e, d, s, nrows, lane);
+}
+
 #if defined(__HIPCC__)
 // value of lane j of the caller's quad
 template <int J>
@@ -1920,6 +2055,41 @@ CG_DEV void decode_wave_fused_422(const ImageDesc &d, const HuffShared &s, uint3
 {
     NothingAhead none;
     decode_wave_fused_422(d, s, interval, lane, none);
+}
+
+CG_DEV void decode_wave_fused_422_stream(const ImageDesc &d, const HuffShared &s, uint32_t nrows, uint32_t interval, uint32_t lane)
+{
+    const bool active = interval < d.total_intervals;
+    interval = active ? interval : d.total_intervals - 1u;
+    uint8_t *slot = s.du_slots + lane * kDuSlotBytes;
+    int16_t *slot16 = reinterpret_cast<int16_t *>(slot);
+    zero_slot(slot);
+
+    EntropyState e;
+    PixelState t;
+    stream_lane_init(e, d, s, nrows, interval, lane);
+    pixel_init(t, d, interval, active);
+    stream_rows_landed();
+    __builtin_amdgcn_s_setprio(CG_PRIO_ENTROPY);
+
+    const uint32_t du_total = d.restart_interval * 4u;
+#pragma unroll 1
+    for (uint32_t du = 0; du < du_total; du++) {
+        const uint32_t k = du & 3u;
+        const uint32_t comp = k < 2u ? 0u : k - 1u; // Y0 Y1 Cb Cr (wave-uniform)
+        const int32_t dc = entropy_data_unit<true>(e, d, s, comp, slot16, lane);
+        if (k == 3u && du + 1u < du_total)
+            stream_restage(e, d, s, nrows, lane); // (lands under this data unit's IDCT)
+        __builtin_amdgcn_s_setprio(CG_PRIO_IDCT);
+        pixel_transform(t, d, comp, k, slot, dc);
+        if (k == 3u) {
+            // (the rows before the stores: whatever waits for a load waits for every store in front of it as well)
+            stream_rows_landed();
+            __builtin_amdgcn_s_setprio(CG_PRIO_COMPOSITE);
+            composite_mcus_422<true>(t, d, s.du_slots, lane);
+        }
+        __builtin_amdgcn_s_setprio(CG_PRIO_ENTROPY);
+    }
 }
 #endif // __HIPCC__
 

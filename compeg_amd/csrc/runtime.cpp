@@ -123,6 +123,20 @@ bool use_pair_kernel(uint32_t max_intervals, uint32_t images)
 
 // ... and of those, the ones whose images qualify (ImageDesc::coop_ok, one restart interval for the whole
 // launch) take the cooperative kernel, which spends the idle lanes inside the intervals (coop_body.h).
+// The batch kernel with the window in its streamed form (kernels.h) instead of whole-interval windows.
+// Readable bytes behind the words of the last image of a buffer: the streamed window's rows are fetched without a
+// look at where a scan ends (up to 64 words beyond its last; never used).
+constexpr size_t kStreamSlackBytes = 1024;
+
+bool use_stream_kernel(const HuffLdsPlan &plan, uint32_t max_intervals, uint32_t images)
+{
+    static const int forced = [] {
+        const char *e = lab_env("COMPEG_STREAM"); // experiment knob: 0 / 1
+        return e ? atoi(e) : -1;
+    }();
+    return forced >= 0 ? forced != 0 : stream_plan_preferred(plan, max_intervals, images);
+}
+
 bool use_coop_kernel(uint32_t max_intervals, uint32_t images, uint32_t restart_interval)
 {
     static const int forced = [] {
@@ -429,7 +443,7 @@ Status compeg_decoder::preprocess_on_device(const ImageData &img, hipStream_t st
     const size_t o_res = 0, o_desc = take(sizeof(ScanDesc)), o_blob = take(before_submit ? blob_bytes : 0),
                  o_raw = take(size_t(len) + 64), o_ts = take(size_t(ntiles) * kScanTileStateBytes + 32),
                  o_st = take(size_t(slots) * 4), o_w = take(size_t(len) + len / 3 + 64);
-    CG_TRY(scan_arena.reserve(total));
+    CG_TRY(scan_arena.reserve(total + kStreamSlackBytes)); // (words are the arena's last part)
     CG_TRY(raw_stage.reserve(o_raw + len + 64));
     uint8_t *da = static_cast<uint8_t *>(scan_arena.ptr), *hs = static_cast<uint8_t *>(raw_stage.ptr);
     ScanDesc s;
@@ -657,7 +671,7 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     bool blob_prebuilt = false;
     if (!on_device) {
         // the output's worst case (scan.rs:38-44), so that pieces can leave while the scan is running
-        CG_TRY(words.reserve(ScanBuffer::output_capacity(img.scan_len)));
+        CG_TRY(words.reserve(ScanBuffer::output_capacity(img.scan_len) + kStreamSlackBytes));
         CG_TRY(starts.reserve(ScanBuffer::start_slots(md.total_restart_intervals) * 4 + 16));
         hipError_t ship_error = hipSuccess;
         ScanBuffer::Progress ship;
@@ -789,6 +803,12 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
             }
             CG_HIP(launch_coop_422(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals, coop, stream));
             last_kernel = COMPEG_KERNEL_COOP_TEAM;
+        } else if (use_stream_kernel(plan, md.total_restart_intervals, 1)) {
+            const uint64_t mcus = std::max<uint64_t>(1u, uint64_t(md.total_restart_intervals) * std::max(1u, uint32_t(md.restart_interval)));
+            const StreamPlan sp = plan_stream(md.total_restart_intervals, 1, staged_lut_entries(img),
+                                              uint32_t((img.scan_len / 4u + mcus - 1u) / mcus), true);
+            CG_HIP(launch_fused_422_stream(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals, sp, stream));
+            last_kernel = COMPEG_KERNEL_FUSED_STREAM;
         } else if (use_pair_kernel(md.total_restart_intervals, 1)) {
             CG_HIP(launch_pair_422(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals,
                                    plan, stream));
@@ -1041,6 +1061,7 @@ void compeg_batch::note_batch_properties(const ImageData *const *images, size_t 
     layout_v = n ? images[0]->metadata.components[0].vsample : 0;
     layout_even_ri = true;
     one_mcu_intervals = n > 0;
+    uint64_t scan_bytes = 0, mcus = 0;
     max_out_w = max_out_h = 0;
     // frames of one stream: the same number of restart intervals and byte-identical LUTs in every image
     // (the fused kernel's workgroups may then span image boundaries)
@@ -1052,12 +1073,15 @@ void compeg_batch::note_batch_properties(const ImageData *const *images, size_t 
             layout_h = layout_v = 0; // (mixed samplings in one batch)
         layout_even_ri = layout_even_ri && img.metadata.restart_interval % 2u == 0u;
         one_mcu_intervals = one_mcu_intervals && img.metadata.restart_interval == 1u;
+        scan_bytes += img.scan_len;
+        mcus += uint64_t(img.metadata.total_restart_intervals) * std::max(1u, uint32_t(img.metadata.restart_interval));
         max_out_w = std::max(max_out_w, img.width);
         max_out_h = std::max(max_out_h, img.height);
         uniform = uniform && img.metadata.total_restart_intervals == first.metadata.total_restart_intervals &&
                   img.l2 == first.l2 && img.ac_fast == first.ac_fast && img.dc_fast == first.dc_fast &&
                   memcmp(img.l1, first.l1, sizeof img.l1) == 0;
     }
+    stream_mcu_words = uint32_t((scan_bytes / 4u + std::max<uint64_t>(mcus, 1u) - 1u) / std::max<uint64_t>(mcus, 1u));
 }
 
 // Host path of an upload.  image_of(i, status) hands out image i -- parsing it first when the batch is fed with
@@ -1106,7 +1130,7 @@ Status compeg_batch::upload_host(size_t n, int threads, const void *items_, cons
     }
 
     const bool fused = use_fused_pipeline() && !any_generic;
-    CG_TRY(inputs.reserve(in_total + 256));
+    CG_TRY(inputs.reserve(in_total + kStreamSlackBytes));
     const bool stamps = lab_env("COMPEG_STAMPS") != nullptr; // diagnostic builds park cycle stamps in dc
     if (!fused) { // the fused kernel keeps coefficients on chip
         CG_TRY(ac.reserve(ac_total + 256));
@@ -1497,7 +1521,7 @@ Status compeg_batch::upload_device_scan(size_t n, int threads, const FeedSource 
         L.staged = staged_total; // (used by pageable sources)
         staged_total += align_up(len + 64, 256);
     }
-    CG_TRY(scan_arena.reserve(total + 256));
+    CG_TRY(scan_arena.reserve(total + kStreamSlackBytes));
     CG_TRY(scan_descs.reserve(n * sizeof(ScanDesc) + 256));
     hipStream_t st = gpu->stream;
     CG_TRY(dev_descs.reserve(n * sizeof(ImageDesc) + 256));
@@ -1885,14 +1909,19 @@ Status compeg_batch::decode(hipStream_t stream)
             CoopPlan coop{};
             if (coop_r && use_coop_kernel(max_intervals, m, coop_r))
                 coop = plan_coop(max_intervals, m, coop_r, max_l2, coop_spans);
+            const bool streamed = !coop.usable && use_stream_kernel(plan, max_intervals, m);
             if (coop.usable)
                 CG_HIP(launch_coop_422(dd + at, m, max_intervals, coop, stream));
+            else if (streamed)
+                CG_HIP(launch_fused_422_stream(dd + at, m, max_intervals, plan_stream(max_intervals, m, max_l2, stream_mcu_words, uniform), stream));
             else if (use_pair_kernel(max_intervals, m))
                 CG_HIP(launch_pair_422(dd + at, m, max_intervals, plan, stream));
             else
                 CG_HIP(launch_fused_422(dd + at, m, max_intervals, plan, stream, uniform, one_mcu_intervals));
             if (at == 0)
-                last_kernel = coop.usable ? COMPEG_KERNEL_COOP_TEAM : (use_pair_kernel(max_intervals, m) ? COMPEG_KERNEL_PAIR : COMPEG_KERNEL_FUSED);
+                last_kernel = coop.usable ? COMPEG_KERNEL_COOP_TEAM
+                              : streamed  ? COMPEG_KERNEL_FUSED_STREAM
+                                          : (use_pair_kernel(max_intervals, m) ? COMPEG_KERNEL_PAIR : COMPEG_KERNEL_FUSED);
             if (timing && at == 0)
                 CG_HIP(hipEventRecord(ev[1], stream));
             continue;

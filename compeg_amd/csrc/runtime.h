@@ -140,6 +140,7 @@ struct compeg_batch {
     uint32_t layout_h = 0, layout_v = 0; // luma sampling all images share (0: they differ)
     bool layout_even_ri = false;         // ... and every restart interval is even
     bool one_mcu_intervals = false;      // every restart interval is one MCU
+    uint32_t stream_mcu_words = 0;       // the batch's average MCU in stream words, rounded up (plan_stream)
     bool uniform = false; // same interval count and LUT bytes in every image (set by upload)
     // cooperative kernel: the restart interval all images share if every one of them qualifies (else 0), and the
     // largest word span of a wave's group of intervals

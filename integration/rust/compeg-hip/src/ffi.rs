@@ -32,6 +32,7 @@ pub const COMPEG_KERNEL_COOP_TEAM: c_int = 3;
 pub const COMPEG_KERNEL_GENERIC: c_int = 4;
 pub const COMPEG_KERNEL_SPLIT: c_int = 5;
 pub const COMPEG_KERNEL_FUSED_LAYOUT: c_int = 6;
+pub const COMPEG_KERNEL_FUSED_STREAM: c_int = 7;
 
 extern "C" {
     pub fn compeg_last_error() -> *const c_char;

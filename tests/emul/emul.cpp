@@ -182,7 +182,12 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
         return 0;
     }
 
-    if (fused == 1 || fused == 2) {
+    if (fused == 1 || fused == 2 || fused == 7) {
+        // (7: decode_fused_422_stream_kernel -- `window_words` rows of every lane's stream instead of the wave's window)
+        const bool stream = fused == 7;
+        const uint32_t nrows = window_words ? window_words : 16u;
+        if (stream)
+            window_words = nrows * kWave;
         // ---- decode_fused_422_kernel (one slot set) / decode_pair_422_kernel (two sets, decoder role and
         // transformer role): the 64 lanes of a wave advance data unit by data unit, and through the quad
         // exchange of the composite phase by phase, as the wave does on the GPU ----
@@ -202,7 +207,8 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
             for (uint32_t tid = 0; tid < 128; tid++)
                 stage_luts(d, sl1, sl2, l2_in_lds, tid, 128);
             uint32_t wb = 0, wl = 0;
-            wave_window(d, first, window_words, wb, wl);
+            if (!stream)
+                wave_window(d, first, window_words, wb, wl);
             for (uint32_t i = 0; i < wl; i++)
                 win[i] = wb + i < d.nwords ? bswap32(d.words[wb + i]) : 0u;
             for (uint32_t i = 0; i < nsets * kWave; i++)
@@ -213,7 +219,9 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
             std::vector<McuTarget> tg(kWave);
             for (uint32_t lane = 0; lane < uint32_t(kWave); lane++) {
                 const bool active = first + lane < d.total_intervals;
-                if (active)
+                if (active && stream)
+                    stream_lane_init(es[lane], d, sh, nrows, first + lane, lane);
+                else if (active)
                     entropy_init(es[lane], d, sh, first + lane);
                 pixel_init(ps[lane], d, active ? first + lane : 0u, active);
             }
@@ -225,8 +233,11 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
                 for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
                     if (ps[lane].active) {
                         g_emul_stats.lane_symbols = 0;
-                        dcs[set * kWave + lane] = entropy_data_unit(
-                            es[lane], d, sh, comp, reinterpret_cast<int16_t *>(set_slots + lane * kDuSlotBytes));
+                        int16_t *slot16 = reinterpret_cast<int16_t *>(set_slots + lane * kDuSlotBytes);
+                        dcs[set * kWave + lane] = stream ? entropy_data_unit<true>(es[lane], d, sh, comp, slot16, lane)
+                                                         : entropy_data_unit(es[lane], d, sh, comp, slot16);
+                        if (stream && k == 3u && du + 1u < du_total)
+                            stream_restage(es[lane], d, sh, nrows, lane);
                         step_max = std::max(step_max, g_emul_stats.lane_symbols);
                         if (FILE *dump = symbol_dump())
                             fprintf(dump, "%lu%c", g_emul_stats.lane_symbols, lane == uint32_t(kWave) - 1 ? '\n' : ' ');

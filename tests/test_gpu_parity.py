@@ -320,6 +320,46 @@ def test_fused_kernel_ragged_batch(ca, gpu, every_ri):
         assert np.array_equal(dev.read_output(i), batch.read_output(i))
 
 
+@pytest.mark.parametrize("ri,uniform", [(10, True), (16, True), (30, True), (120, False), (16, False)])
+def test_batch_kernel_with_streamed_windows(ca, gpu, ri, uniform):
+    """Batches whose restart intervals are too long for whole-interval windows (64 intervals of DRI MCUs per wave)
+    go to decode_fused_422_stream_kernel: every lane's stream staged MCU by MCU.  Frames of one stream (the flat
+    grid) and mixed images (a grid row per image; ragged edges, a corrupt scan among them)."""
+    if uniform:
+        jpegs = [synth.make_jpeg(960, 720, seed=900 + i + ri, kind=i % 3, quality=85, ri=ri) for i in range(96)]
+    else:
+        shapes = [(1000, 1000), (1016, 990), (936, 1004), (1280, 720)]
+        jpegs = [synth.make_jpeg(w, h, seed=950 + i + ri, kind=i % 3, quality=(70, 85, 95)[i % 3], ri=ri)
+                 for i, (w, h) in enumerate(shapes * 30)]
+        bad = bytearray(jpegs[5])
+        at = bad.find(b"\xff\xda") + 14
+        rng = np.random.default_rng(ri)
+        for _ in range(40):
+            pos = int(rng.integers(at, len(bad) - 2))
+            if bad[pos] != 0xFF and bad[pos - 1] != 0xFF:
+                bad[pos] ^= 1 << int(rng.integers(0, 8))
+                if bad[pos] == 0xFF:
+                    bad[pos] = 0xFE
+        jpegs[5] = bytes(bad)
+    images = [ca.ImageData(j) for j in jpegs]
+    batch = ca.Batch(gpu)
+    batch.upload(images)
+    batch.decode()
+    batch.wait()
+    assert batch.last_kernel() == "fused_stream"
+    for i in list(range(0, len(jpegs), 7)) + [5, len(jpegs) - 1]:
+        _assert_equal(batch.read_output(i), orc.ImageData(jpegs[i]).decode())
+    # the same with the scan preprocess on the device (the descriptors' word counts are patched in there)
+    dev = ca.Batch(gpu)
+    dev.set_device_preprocess(2)
+    dev.upload(images)
+    dev.decode()
+    dev.wait()
+    assert dev.last_kernel() == "fused_stream"
+    for i in (0, 5, len(jpegs) - 1):
+        assert np.array_equal(dev.read_output(i), batch.read_output(i))
+
+
 def test_uniform_batch_spans_images_with_its_workgroups(ca, gpu):
     """Frames of one stream (same interval count, same LUT bytes): the throughput kernel runs a one-dimensional
     grid over the waves of all images; 112.5 waves per image, so workgroups and even the image's last wave are

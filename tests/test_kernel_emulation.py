@@ -59,6 +59,11 @@ def _check(runner, tmp_path, jpeg, **kw):
     for fused in (1, 2, 3, 0):   # fused kernel, paired-wave kernel, two-kernel pipeline, reference-style split kernels
         got = _run(runner, tmp_path, jpeg, fused, **kw)
         assert np.array_equal(got, want), f"fused={fused}: {(got != want).any(axis=2).sum()} pixels differ"
+    # the fused kernel with its window in the streamed form: rows enough for an MCU; far too few (lanes keep running
+    # out of them inside data units and come back with the next rows)
+    for rows in (16, 3):
+        got = _run(runner, tmp_path, jpeg, 7, **dict(kw, window=rows))
+        assert np.array_equal(got, want), f"streamed window, {rows} rows: {(got != want).any(axis=2).sum()} pixels differ"
     # the cooperative kernel, with the window the runtime would plan and with the test's (possibly cut short: the
     # walks that leave it hand their interval to the serial decoder)
     for window in sorted({0, kw.get("window", 0)}):
@@ -110,6 +115,36 @@ def test_emulated_cooperative_kernel_any_restart_interval(runner, tmp_path, ri):
         for passes in (4, 1):
             got = _run(runner, tmp_path, bytes(j), 5, window=0, coop_passes=passes)
             assert got is not None and np.array_equal(got, want), (ri, it, passes)
+
+
+@pytest.mark.parametrize("ri", [1, 2, 4, 7, 10, 16, 30, 120, 0])
+def test_emulated_streamed_window_any_restart_interval(runner, tmp_path, ri):
+    """decode_fused_422_stream_kernel's body: every lane's rows staged MCU by MCU, whatever the interval's length;
+    lanes that reach their last row inside a data unit finish it with the reference reader and come back."""
+    STATS.clear()
+    for (w, h, kind, q, seed) in [(320, 64, 0, 85, 1), (256, 48, 1, 95, 2), (200, 40, 2, 100, 3)]:
+        jpeg = synth.make_jpeg(w, h, seed=seed + ri, kind=kind, quality=q, ri=ri)
+        want = orc.ImageData(jpeg).decode()
+        for rows in (2, 5, 12, 40):
+            got = _run(runner, tmp_path, jpeg, 7, window=rows)
+            assert np.array_equal(got, want), (ri, w, h, rows, int((got != want).any(axis=2).sum()))
+    assert STATS.get("left_window", 0) > 0 and STATS.get("fast_dus", 0) > 0, STATS
+    # corrupt streams
+    rng = np.random.default_rng(100 + ri)
+    base = synth.make_jpeg(320, 64, seed=9, kind=0, quality=80, ri=ri)
+    scan_at = base.find(b"\xff\xda") + 14
+    for it in range(4):
+        j = bytearray(base)
+        for _ in range(int(rng.integers(1, 12))):
+            pos = int(rng.integers(scan_at, len(j) - 2))
+            if j[pos] != 0xFF and j[pos - 1] != 0xFF:
+                j[pos] ^= 1 << int(rng.integers(0, 8))
+                if j[pos] == 0xFF:
+                    j[pos] = 0xFE
+        want = orc.ImageData(bytes(j)).decode()
+        for rows in (3, 16):
+            got = _run(runner, tmp_path, bytes(j), 7, window=rows)
+            assert np.array_equal(got, want), (ri, it, rows)
 
 
 @pytest.mark.parametrize("waves,window,l2", [(4, 64, 512), (2, 80, 0), (1, 4, 0), (3, 300, 1024), (2, 2048, 3000),
