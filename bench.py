@@ -682,7 +682,9 @@ def main():
         fused = which not in ("split", "generic")
         if fused:
             # one kernel does the whole path; the event pair brackets exactly its launches
-            name = {"fused": "decode_fused_422_kernel", "pair": "decode_pair_422_kernel", "coop_team": "decode_coop_team_422_kernel",
+            name = {"fused": "decode_fused_422_mcu_kernel" if args.ri == 1 else "decode_fused_422_kernel",
+                    "fused_stream": "decode_fused_422_stream_kernel",
+                    "pair": "decode_pair_422_kernel", "coop_team": "decode_coop_team_422_kernel",
                     "fused_layout": {(1, 1): "decode_fused_444_kernel", (1, 2): "decode_fused_440_kernel",
                                      (2, 2): "decode_fused_420_kernel"}.get(args.sampling_hv, "decode_fused_layout_kernel")}[which]
             kernels_ms = {name: round(ev_total_ms / max(n_timed, 1), 4)}

@@ -393,8 +393,8 @@ decode_fused_420_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds,
 // words of every lane's stream at a time, fetched by LDS-DMA MCU by MCU).  Plain grid (workgroups per image,
 // images): the units are long, the prologue is a small share of them.
 __global__ void __launch_bounds__(768)
-decode_fused_422_stream_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t rows, uint32_t waves_per_image,
-                               uint32_t images)
+decode_fused_422_stream_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t rows, uint32_t stage_after,
+                               uint32_t waves_per_image, uint32_t images)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x / kWave))), lane = threadIdx.x % kWave;
@@ -432,7 +432,7 @@ decode_fused_422_stream_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_
     s.win_base = 0u;
     s.win_len = 0u; // (no whole-interval window: the reference reader's words come from global memory)
     s.du_slots = reinterpret_cast<uint8_t *>(win) + rows * kWave * 4u;
-    decode_wave_fused_422_stream(d, s, rows, wave_first + lane, lane);
+    decode_wave_fused_422_stream(d, s, rows, stage_after, wave_first + lane, lane);
 }
 
 // Latency-oriented variant of the fused path for launches that cannot fill
@@ -793,9 +793,21 @@ StreamPlan plan_stream(uint32_t max_intervals, uint32_t images, uint32_t max_l2,
     p.l2_entries_in_lds = max_l2 < 12288u ? (max_l2 + 1u) & ~1u : 12288u;
     const uint32_t tables = (((kL1Entries + p.l2_entries_in_lds) * 2u) + 15u) & ~15u;
     const DeviceLimits lim = device_limits();
-    uint32_t rows = std::max(16u, std::min(64u, 3u * mcu_words + 4u));
+    // How often the rows are staged anew -- behind every MCU, behind its luma and its chroma data units, behind every
+    // data unit -- and how many: three times what a lane reads on average between two stagings (luma: 0.7 of an
+    // MCU's words at most; one data unit: 0.45) and the words a reader holds beyond.  The coarsest step whose rows
+    // leave a CU its twelve waves (or all but one of them); where none does (10 bit per pixel), every MCU and at most 64
+    // rows.  (256 x 960x720, DRI = 10, ms per launch by step: 1.7 bit per pixel 0.361 / 0.370 / 0.381; 4.6 bit 1.04 /
+    // 1.08 / 0.73; 10 bit 1.48 / 1.54 / 1.62.)
+    const uint32_t most_rows = ((lim.lds_bytes - tables) / kMaxWavesFused - kWave * kDuSlotBytes) / (kWave * 4u);
+    const uint32_t need[3] = {3u * mcu_words + 4u, 3u * ((7u * mcu_words + 9u) / 10u) + 4u, 3u * ((9u * mcu_words + 19u) / 20u) + 4u};
+    uint32_t step = need[0] <= most_rows ? 0u : (need[1] <= most_rows ? 1u : (need[2] <= most_rows + 6u ? 2u : 0u));
+    if (const char *e = lab_env("COMPEG_STREAM_STEP")) // experiment knob: 0 / 1 / 2
+        step = uint32_t(std::max(0, std::min(2, atoi(e))));
+    uint32_t rows = std::max(12u, std::min(64u, need[step]));
     if (const char *e = lab_env("COMPEG_STREAM_ROWS")) // experiment knob
         rows = uint32_t(std::max(4, std::min(128, atoi(e))));
+    p.stage_after = step == 0u ? 0x8u : (step == 1u ? 0xau : 0xfu);
     const uint32_t wave_area = rows * kWave * 4u + kWave * kDuSlotBytes;
     const uint32_t waves_per_image = (max_intervals + kWave - 1) / kWave;
     const uint64_t total_waves = uint64_t(waves_per_image) * images;
@@ -813,8 +825,8 @@ StreamPlan plan_stream(uint32_t max_intervals, uint32_t images, uint32_t max_l2,
     p.total_bytes = tables + best * wave_area;
     p.waves_per_image = uniform ? waves_per_image : 0u;
     if (getenv("COMPEG_VERBOSE"))
-        fprintf(stderr, "[compeg] stream plan: images=%u intervals=%u waves/block=%u rows=%u lds=%u B%s\n", images, max_intervals, best,
-                rows, p.total_bytes, uniform ? " flat" : "");
+        fprintf(stderr, "[compeg] stream plan: images=%u intervals=%u waves/block=%u rows=%u staged behind data units %#x lds=%u B%s\n", images,
+                max_intervals, best, rows, p.stage_after, p.total_bytes, uniform ? " flat" : "");
     return p;
 }
 
@@ -834,7 +846,7 @@ hipError_t launch_fused_422_stream(const ImageDesc *descs, uint32_t images, uint
     if (attr != hipSuccess)
         return attr;
     hipLaunchKernelGGL(decode_fused_422_stream_kernel, grid, dim3(threads), plan.total_bytes, stream, descs,
-                       plan.l2_entries_in_lds, plan.rows, flat ? plan.waves_per_image : 0u, images);
+                       plan.l2_entries_in_lds, plan.rows, plan.stage_after, flat ? plan.waves_per_image : 0u, images);
     return hipGetLastError();
 }
 

@@ -2057,7 +2057,9 @@ CG_DEV void decode_wave_fused_422(const ImageDesc &d, const HuffShared &s, uint3
     decode_wave_fused_422(d, s, interval, lane, none);
 }
 
-CG_DEV void decode_wave_fused_422_stream(const ImageDesc &d, const HuffShared &s, uint32_t nrows, uint32_t interval, uint32_t lane)
+// stage_after: bit k -- the rows are staged anew behind data unit k of every MCU (Y0 Y1 Cb Cr); bit 3 always.
+CG_DEV void decode_wave_fused_422_stream(const ImageDesc &d, const HuffShared &s, uint32_t nrows, uint32_t stage_after, uint32_t interval,
+                                         uint32_t lane)
 {
     const bool active = interval < d.total_intervals;
     interval = active ? interval : d.total_intervals - 1u;
@@ -2078,13 +2080,15 @@ CG_DEV void decode_wave_fused_422_stream(const ImageDesc &d, const HuffShared &s
         const uint32_t k = du & 3u;
         const uint32_t comp = k < 2u ? 0u : k - 1u; // Y0 Y1 Cb Cr (wave-uniform)
         const int32_t dc = entropy_data_unit<true>(e, d, s, comp, slot16, lane);
-        if (k == 3u && du + 1u < du_total)
+        const bool stage = ((stage_after | 8u) >> k & 1u) != 0u && du + 1u < du_total; // (wave-uniform)
+        if (stage)
             stream_restage(e, d, s, nrows, lane); // (lands under this data unit's IDCT)
         __builtin_amdgcn_s_setprio(CG_PRIO_IDCT);
         pixel_transform(t, d, comp, k, slot, dc);
-        if (k == 3u) {
-            // (the rows before the stores: whatever waits for a load waits for every store in front of it as well)
+        // (the rows before the stores: whatever waits for a load waits for every store in front of it as well)
+        if (stage)
             stream_rows_landed();
+        if (k == 3u) {
             __builtin_amdgcn_s_setprio(CG_PRIO_COMPOSITE);
             composite_mcus_422<true>(t, d, s.du_slots, lane);
         }

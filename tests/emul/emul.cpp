@@ -186,6 +186,7 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
         // (7: decode_fused_422_stream_kernel -- `window_words` rows of every lane's stream instead of the wave's window)
         const bool stream = fused == 7;
         const uint32_t nrows = window_words ? window_words : 16u;
+        const uint32_t stage_after = getenv("EMUL_STREAM_STAGE") ? uint32_t(strtoul(getenv("EMUL_STREAM_STAGE"), nullptr, 0)) : 8u;
         if (stream)
             window_words = nrows * kWave;
         // ---- decode_fused_422_kernel (one slot set) / decode_pair_422_kernel (two sets, decoder role and
@@ -236,7 +237,7 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
                         int16_t *slot16 = reinterpret_cast<int16_t *>(set_slots + lane * kDuSlotBytes);
                         dcs[set * kWave + lane] = stream ? entropy_data_unit<true>(es[lane], d, sh, comp, slot16, lane)
                                                          : entropy_data_unit(es[lane], d, sh, comp, slot16);
-                        if (stream && k == 3u && du + 1u < du_total)
+                        if (stream && ((stage_after | 8u) >> k & 1u) && du + 1u < du_total)
                             stream_restage(es[lane], d, sh, nrows, lane);
                         step_max = std::max(step_max, g_emul_stats.lane_symbols);
                         if (FILE *dump = symbol_dump())

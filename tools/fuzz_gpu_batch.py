@@ -23,6 +23,7 @@ def run(seed=77, batches=40, log=print):
     rng = np.random.default_rng(seed)
     gpu = ca.Gpu.open()
     bad = n = 0
+    kernels = {}
     t0 = time.time()
     for it in range(batches):
         count = int(rng.integers(1, 7))
@@ -77,6 +78,7 @@ def run(seed=77, batches=40, log=print):
         for rep in range(2):
             batch.decode()
             batch.wait()
+            kernels[batch.last_kernel()] = kernels.get(batch.last_kernel(), 0) + 1
             for i, (_, want) in enumerate(items):
                 got = batch.read_output(i)
                 n += 1
@@ -88,7 +90,7 @@ def run(seed=77, batches=40, log=print):
         if pinned is not None:
             pinned.close()
         if it % 10 == 9:
-            log("batch", it, "outputs", n, "bad", bad, "%.0f s" % (time.time() - t0))
+            log("batch", it, "outputs", n, "bad", bad, "%.0f s" % (time.time() - t0), "decodes by kernel", kernels)
     return n, bad
 
 
