@@ -234,6 +234,12 @@ def bench_mjpeg_stream(compeg_amd, gpu, quality, steps, warmup, threads):
     out["batch_256"] = bench_config(compeg_amd, gpu, 960, 720, 10, quality, 256, steps, warmup, threads, 64,
                                     "256 x 960x720 YUV 4:2:2 baseline JPEG, DRI=10, no DHT, 64 distinct frames",
                                     flags=synth.NO_DHT)
+    # the same stream with a restart interval per MCU row (60 MCUs), as many encoders write it: 90 intervals a frame
+    # -- 360 waves for the chip's 3072 in a batch of 256 frames, 1440 in one of 1024
+    for frames in (256, 1024):
+        out[f"batch_{frames}_row_intervals"] = bench_config(
+            compeg_amd, gpu, 960, 720, 60, quality, frames, max(3, steps // 2), warmup, threads, 32,
+            f"{frames} x 960x720 YUV 4:2:2 baseline JPEG, DRI=60 (one restart interval per MCU row), 32 distinct frames")
     return out
 
 
