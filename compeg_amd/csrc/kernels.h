@@ -34,7 +34,8 @@ hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t ma
 struct StreamPlan {
     uint32_t rows = 0, waves_per_block = 0, l2_entries_in_lds = 0, total_bytes = 0;
     uint32_t waves_per_image = 0; // != 0: the flat grid (uniform launches)
-    uint32_t stage_after = 8;     // bit k: rows staged anew behind data unit k of an MCU
+    uint32_t stage_after = 8;     // bit k: rows may be staged anew behind data unit k of an MCU ...
+    uint32_t stage_below = 0;     // ... and are, when some lane has fewer staged words than this in front of it
 };
 // uniform: all images have max_intervals intervals and byte-identical LUTs (workgroups may then span images)
 StreamPlan plan_stream(uint32_t max_intervals, uint32_t images, uint32_t max_l2, uint32_t mcu_words, bool uniform);

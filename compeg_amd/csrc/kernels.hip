@@ -394,7 +394,7 @@ decode_fused_420_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds,
 // images): the units are long, the prologue is a small share of them.
 __global__ void __launch_bounds__(768)
 decode_fused_422_stream_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t rows, uint32_t stage_after,
-                               uint32_t waves_per_image, uint32_t images)
+                               uint32_t stage_below, uint32_t waves_per_image, uint32_t images)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x / kWave))), lane = threadIdx.x % kWave;
@@ -432,7 +432,21 @@ decode_fused_422_stream_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_
     s.win_base = 0u;
     s.win_len = 0u; // (no whole-interval window: the reference reader's words come from global memory)
     s.du_slots = reinterpret_cast<uint8_t *>(win) + rows * kWave * 4u;
-    decode_wave_fused_422_stream(d, s, rows, stage_after, wave_first + lane, lane);
+    if (!waves_per_image) {
+        decode_wave_fused_422_stream(d, s, rows, stage_after, stage_below, wave_first + lane, lane);
+        return;
+    }
+    // The flat grid is no larger than what is resident at once; a wave goes on to further units of 64 intervals on its
+    // own (rows and slots are its own, the tables are every image's): no CU waits for the slowest wave of a workgroup.
+    const uint32_t stride = gridDim.x * (blockDim.x / kWave), units = waves_per_image * images;
+    for (uint32_t flat = blockIdx.x * (blockDim.x / kWave) + wave;;) {
+        decode_wave_fused_422_stream(descs[image], s, rows, stage_after, stage_below, wave_first + lane, lane);
+        flat += stride; // (wave-uniform)
+        if (flat >= units)
+            break;
+        image = uint32_t(__builtin_amdgcn_readfirstlane(int(flat / waves_per_image)));
+        wave_first = uint32_t(__builtin_amdgcn_readfirstlane(int((flat % waves_per_image) * kWave)));
+    }
 }
 
 // Latency-oriented variant of the fused path for launches that cannot fill
@@ -808,6 +822,12 @@ StreamPlan plan_stream(uint32_t max_intervals, uint32_t images, uint32_t max_l2,
     if (const char *e = lab_env("COMPEG_STREAM_ROWS")) // experiment knob
         rows = uint32_t(std::max(4, std::min(128, atoi(e))));
     p.stage_after = step == 0u ? 0x8u : (step == 1u ? 0xau : 0xfu);
+    // staged anew when a lane has less than one of those averages and the reader's words in front of it (256 x
+    // 960x720 DRI = 10, 2048 frames, ms per launch: always 3.01, below 14 words 2.73, below 10 2.67, below 7 2.66; a fetch
+    // ahead into the L2 for the next staging, never waited for, changed nothing)
+    p.stage_below = std::min(rows, (need[step] - 4u) / 3u + 3u);
+    if (const char *e = lab_env("COMPEG_STREAM_BELOW")) // experiment knob
+        p.stage_below = uint32_t(std::max(0, atoi(e)));
     const uint32_t wave_area = rows * kWave * 4u + kWave * kDuSlotBytes;
     const uint32_t waves_per_image = (max_intervals + kWave - 1) / kWave;
     const uint64_t total_waves = uint64_t(waves_per_image) * images;
@@ -825,8 +845,8 @@ StreamPlan plan_stream(uint32_t max_intervals, uint32_t images, uint32_t max_l2,
     p.total_bytes = tables + best * wave_area;
     p.waves_per_image = uniform ? waves_per_image : 0u;
     if (getenv("COMPEG_VERBOSE"))
-        fprintf(stderr, "[compeg] stream plan: images=%u intervals=%u waves/block=%u rows=%u staged behind data units %#x lds=%u B%s\n", images,
-                max_intervals, best, rows, p.stage_after, p.total_bytes, uniform ? " flat" : "");
+        fprintf(stderr, "[compeg] stream plan: images=%u intervals=%u waves/block=%u rows=%u staged behind data units %#x below %u words lds=%u B%s\n",
+                images, max_intervals, best, rows, p.stage_after, p.stage_below, p.total_bytes, uniform ? " flat" : "");
     return p;
 }
 
@@ -839,14 +859,18 @@ hipError_t launch_fused_422_stream(const ImageDesc *descs, uint32_t images, uint
     dim3 grid((max_intervals + threads - 1) / threads, images, 1);
     const uint64_t flat_groups = (uint64_t(plan.waves_per_image) * images + plan.waves_per_block - 1) / plan.waves_per_block;
     const bool flat = plan.waves_per_image != 0u && flat_groups <= 0x7fffffffu;
-    if (flat)
-        grid = dim3(uint32_t(flat_groups), 1, 1);
+    if (flat) {
+        // at most as many workgroups as are resident at once; their waves loop over the rest (see the kernel)
+        const DeviceLimits lim = device_limits();
+        const uint32_t per_cu = std::max(1u, std::min(lim.lds_bytes / plan.total_bytes, kMaxWavesFused / plan.waves_per_block));
+        grid = dim3(uint32_t(std::min<uint64_t>(flat_groups, uint64_t(lim.cus) * per_cu)), 1, 1);
+    }
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(decode_fused_422_stream_kernel),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(device_limits().lds_bytes));
     if (attr != hipSuccess)
         return attr;
     hipLaunchKernelGGL(decode_fused_422_stream_kernel, grid, dim3(threads), plan.total_bytes, stream, descs,
-                       plan.l2_entries_in_lds, plan.rows, plan.stage_after, flat ? plan.waves_per_image : 0u, images);
+                       plan.l2_entries_in_lds, plan.rows, plan.stage_after, plan.stage_below, flat ? plan.waves_per_image : 0u, images);
     return hipGetLastError();
 }
 

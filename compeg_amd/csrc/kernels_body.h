@@ -1787,6 +1787,16 @@ CG_DEV void pixel_next_mcu(PixelState &t, const ImageDesc &d)
     }
 }
 
+// true in every lane if `v` is in any (the host build runs lanes one after the other: tests/emul decides for the wave)
+CG_DEV bool wave_any(bool v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ballot_w64(v) != 0u;
+#else
+    return v;
+#endif
+}
+
 // ---- the window in its streamed form: restart intervals of any length ----
 // A wave's window (above) holds its 64 intervals whole: 64 x DRI MCUs of stream, 17 KB with DRI = 10, beyond what
 // the LDS has with DRI = 16 -- the waves per CU go, then the window itself.  Here a lane has `nrows` words of its
@@ -1849,6 +1859,18 @@ CG_DEV void stream_restage(EntropyState &e, const ImageDesc &d, const HuffShared
         e.fast = true;
     }
     e.resume = false;
+}
+
+// Would new rows help this lane?  It has fewer than `below` staged words in front of it and the scan goes on behind
+// them, or it waits for rows to come back to fast mode.  (The wave stages when any lane says so: fewer, larger
+// fetches -- a line of the scan is then fetched once or twice, not once per MCU.)
+CG_DEV bool stream_wants_rows(const EntropyState &e, const ImageDesc &d, const HuffShared &s, uint32_t lane, uint32_t below)
+{
+    if (!e.fast)
+        return e.resume && e.r.left < 64u;
+    const uint32_t left = uint32_t(e.wlimit - e.wptr) / uint32_t(kWave);
+    const uint32_t end_word = e.r.next_word + uint32_t(e.wlimit - (s.win + lane)) / uint32_t(kWave);
+    return left < below && end_word < d.nwords;
 }
 
 // The reference reader at the interval's start (two words from global memory), then the first rows and fast mode.
@@ -2057,9 +2079,10 @@ CG_DEV void decode_wave_fused_422(const ImageDesc &d, const HuffShared &s, uint3
     decode_wave_fused_422(d, s, interval, lane, none);
 }
 
-// stage_after: bit k -- the rows are staged anew behind data unit k of every MCU (Y0 Y1 Cb Cr); bit 3 always.
-CG_DEV void decode_wave_fused_422_stream(const ImageDesc &d, const HuffShared &s, uint32_t nrows, uint32_t stage_after, uint32_t interval,
-                                         uint32_t lane)
+// stage_after: bit k -- the rows may be staged anew behind data unit k of every MCU (Y0 Y1 Cb Cr); bit 3 always.
+// stage_below: ... and are, when some lane has fewer words than that in front of it (stream_wants_rows).
+CG_DEV void decode_wave_fused_422_stream(const ImageDesc &d, const HuffShared &s, uint32_t nrows, uint32_t stage_after, uint32_t stage_below,
+                                         uint32_t interval, uint32_t lane)
 {
     const bool active = interval < d.total_intervals;
     interval = active ? interval : d.total_intervals - 1u;
@@ -2080,7 +2103,9 @@ CG_DEV void decode_wave_fused_422_stream(const ImageDesc &d, const HuffShared &s
         const uint32_t k = du & 3u;
         const uint32_t comp = k < 2u ? 0u : k - 1u; // Y0 Y1 Cb Cr (wave-uniform)
         const int32_t dc = entropy_data_unit<true>(e, d, s, comp, slot16, lane);
-        const bool stage = ((stage_after | 8u) >> k & 1u) != 0u && du + 1u < du_total; // (wave-uniform)
+        bool stage = ((stage_after | 8u) >> k & 1u) != 0u && du + 1u < du_total; // (wave-uniform)
+        if (stage)
+            stage = wave_any(stream_wants_rows(e, d, s, lane, stage_below));
         if (stage)
             stream_restage(e, d, s, nrows, lane); // (lands under this data unit's IDCT)
         __builtin_amdgcn_s_setprio(CG_PRIO_IDCT);

@@ -187,6 +187,7 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
         const bool stream = fused == 7;
         const uint32_t nrows = window_words ? window_words : 16u;
         const uint32_t stage_after = getenv("EMUL_STREAM_STAGE") ? uint32_t(strtoul(getenv("EMUL_STREAM_STAGE"), nullptr, 0)) : 8u;
+        const uint32_t stage_below = getenv("EMUL_STREAM_BELOW") ? uint32_t(strtoul(getenv("EMUL_STREAM_BELOW"), nullptr, 0)) : nrows;
         if (stream)
             window_words = nrows * kWave;
         // ---- decode_fused_422_kernel (one slot set) / decode_pair_422_kernel (two sets, decoder role and
@@ -237,12 +238,20 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
                         int16_t *slot16 = reinterpret_cast<int16_t *>(set_slots + lane * kDuSlotBytes);
                         dcs[set * kWave + lane] = stream ? entropy_data_unit<true>(es[lane], d, sh, comp, slot16, lane)
                                                          : entropy_data_unit(es[lane], d, sh, comp, slot16);
-                        if (stream && ((stage_after | 8u) >> k & 1u) && du + 1u < du_total)
-                            stream_restage(es[lane], d, sh, nrows, lane);
+
                         step_max = std::max(step_max, g_emul_stats.lane_symbols);
                         if (FILE *dump = symbol_dump())
                             fprintf(dump, "%lu%c", g_emul_stats.lane_symbols, lane == uint32_t(kWave) - 1 ? '\n' : ' ');
                     }
+                if (stream && ((stage_after | 8u) >> k & 1u) && du + 1u < du_total) {
+                    // (the wave's decision, then every lane's rows)
+                    bool any = false;
+                    for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
+                        any = any || (ps[lane].active && stream_wants_rows(es[lane], d, sh, lane, stage_below));
+                    for (uint32_t lane = 0; lane < uint32_t(kWave) && any; lane++)
+                        if (ps[lane].active)
+                            stream_restage(es[lane], d, sh, nrows, lane);
+                }
                 g_emul_stats.wave_steps++;
                 g_emul_stats.wave_step_symbols += step_max;
                 if (last_nz_hist()) { // analysis only: the highest zig-zag position any lane of the wave has filled

@@ -26,7 +26,7 @@ def runner():
 STATS = {}   # rare-path counters of the emulated kernels, summed over every run of this module
 
 
-def _run(runner, tmp_path, jpeg, fused, waves=1, window=2048, l2=12288, standard=False, coop_passes=1, stage=8):
+def _run(runner, tmp_path, jpeg, fused, waves=1, window=2048, l2=12288, standard=False, coop_passes=1, stage=8, below=None):
     p = tmp_path / "in.jpg"
     p.write_bytes(jpeg)
     env = dict(os.environ)
@@ -35,7 +35,10 @@ def _run(runner, tmp_path, jpeg, fused, waves=1, window=2048, l2=12288, standard
     # a walk covers the whole restart intervals of 4 x 64 data units (a team; small intervals through the walk tables),
     # of 2 x 64 (dense streams) or of 64 (also: a lone wave's geometry, every interval walked speculatively)
     env["EMUL_COOP_PASSES"] = str(coop_passes)
-    env["EMUL_STREAM_STAGE"] = str(stage)   # (streamed window: behind which data units of an MCU the rows are staged)
+    env["EMUL_STREAM_STAGE"] = str(stage)   # (streamed window: behind which data units of an MCU the rows are staged ...
+    env.pop("EMUL_STREAM_BELOW", None)
+    if below is not None:
+        env["EMUL_STREAM_BELOW"] = str(below)   # ... when some lane has fewer words than this left; default: always)
     if standard:
         env["EMUL_STANDARD"] = "1"
     if fused:
@@ -126,9 +129,9 @@ def test_emulated_streamed_window_any_restart_interval(runner, tmp_path, ri):
     for (w, h, kind, q, seed) in [(320, 64, 0, 85, 1), (256, 48, 1, 95, 2), (200, 40, 2, 100, 3)]:
         jpeg = synth.make_jpeg(w, h, seed=seed + ri, kind=kind, quality=q, ri=ri)
         want = orc.ImageData(jpeg).decode()
-        for rows, stage in ((2, 8), (5, 0xa), (12, 0xf), (40, 8), (3, 0xf)):
-            got = _run(runner, tmp_path, jpeg, 7, window=rows, stage=stage)
-            assert np.array_equal(got, want), (ri, w, h, rows, stage, int((got != want).any(axis=2).sum()))
+        for rows, stage, below in ((2, 8, None), (5, 0xa, 3), (12, 0xf, 6), (40, 8, 20), (3, 0xf, 0), (24, 8, 10)):
+            got = _run(runner, tmp_path, jpeg, 7, window=rows, stage=stage, below=below)
+            assert np.array_equal(got, want), (ri, w, h, rows, stage, below, int((got != want).any(axis=2).sum()))
     assert STATS.get("left_window", 0) > 0 and STATS.get("fast_dus", 0) > 0, STATS
     # corrupt streams
     rng = np.random.default_rng(100 + ri)
