@@ -291,6 +291,21 @@ def test_full_size_8k_dri1_roundtrip_properties(ca, gpu):
     _assert_equal(got, want)
 
 
+def test_single_large_frame_with_long_intervals_takes_the_streamed_windows(ca, gpu):
+    """One 8K frame with DRI = 32: too many data units for the cooperative kernel, 64 intervals too long for a
+    whole-interval window -- the decoder's launch goes to decode_fused_422_stream_kernel, with the host's
+    preprocessing and with the device's (word counts patched into the descriptor behind the launch's planning)."""
+    jpeg = synth.make_jpeg(7680, 4320, seed=71, ri=32, quality=75)
+    want = orc.ImageData(jpeg).decode()
+    data = ca.ImageData(jpeg)
+    for device in (False, True):
+        dec = ca.Decoder(gpu)
+        dec.set_device_preprocess(device)
+        dec.decode_blocking(data)
+        assert dec.last_kernel() == "fused_stream"
+        _assert_equal(dec.read_texture(7680, 4320), want)
+
+
 @pytest.mark.parametrize("every_ri", [0, 1])
 def test_fused_kernel_ragged_batch(ca, gpu, every_ri):
     """A batch big enough for the throughput kernel (more than 1024 waves) of images whose
