@@ -36,13 +36,17 @@ struct StreamPlan {
     uint32_t waves_per_image = 0; // != 0: the flat grid (uniform launches)
     uint32_t stage_after = 8;     // bit k: rows may be staged anew behind data unit k of an MCU ...
     uint32_t stage_below = 0;     // ... and are, when some lane has fewer staged words than this in front of it
+    uint32_t cu_waves = 12;       // waves of the kernel a CU holds
 };
 // uniform: all images have max_intervals intervals and byte-identical LUTs (workgroups may then span images)
-StreamPlan plan_stream(uint32_t max_intervals, uint32_t images, uint32_t max_l2, uint32_t mcu_words, bool uniform);
+// cu_waves / group_waves: 0 (4:2:2: twelve waves a CU, in one workgroup), or what the layout's kernel holds
+StreamPlan plan_stream(uint32_t max_intervals, uint32_t images, uint32_t max_l2, uint32_t mcu_words, bool uniform, uint32_t cu_waves = 0,
+                       uint32_t group_waves = 0);
 // (plan: plan_huffman's for the same launch)
-bool stream_plan_preferred(const HuffLdsPlan &plan, uint32_t max_intervals, uint32_t images);
+bool stream_plan_preferred(const HuffLdsPlan &plan, uint32_t max_intervals, uint32_t images, uint32_t cu_waves = 0, uint32_t group_waves = 0);
+// (hs, vs: the luma sampling all images of the launch share: 2x1, or an extension layout's -- paired kernels for 1x1 / 1x2)
 hipError_t launch_fused_422_stream(const ImageDesc *descs, uint32_t images, uint32_t max_intervals, const StreamPlan &plan,
-                                   hipStream_t stream);
+                                   hipStream_t stream, uint32_t hs = 2, uint32_t vs = 1);
 // Extension layouts (luma hs x vs = 1x1, 1x2, 2x2), fused like the 4:2:2 kernel; plan with wave_cap = fused_layout_wave_cap.
 // pairs: (8-pixel MCUs) every image of the launch has an even restart interval -- a lane composites its MCUs two at a time
 uint32_t fused_layout_wave_cap(uint32_t hs, uint32_t vs, bool pairs);

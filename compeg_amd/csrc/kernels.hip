@@ -392,9 +392,10 @@ decode_fused_420_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds,
 // The batch kernel for restart intervals too long for whole-interval windows (decode_wave_fused_422_stream: `rows`
 // words of every lane's stream at a time, fetched by LDS-DMA MCU by MCU).  Plain grid (workgroups per image,
 // images): the units are long, the prologue is a small share of them.
-__global__ void __launch_bounds__(768)
-decode_fused_422_stream_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t rows, uint32_t stage_after,
-                               uint32_t stage_below, uint32_t waves_per_image, uint32_t images)
+// (WAVE: a struct with the wave's body -- Wave422Stream, or WaveLayoutStream<HS, VS, MC> for the extension layouts)
+template <class WAVE>
+__device__ __forceinline__ void fused_stream_kernel_body(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t rows,
+                                                         uint32_t stage_after, uint32_t stage_below, uint32_t waves_per_image, uint32_t images)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x / kWave))), lane = threadIdx.x % kWave;
@@ -433,20 +434,61 @@ decode_fused_422_stream_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_
     s.win_len = 0u; // (no whole-interval window: the reference reader's words come from global memory)
     s.du_slots = reinterpret_cast<uint8_t *>(win) + rows * kWave * 4u;
     if (!waves_per_image) {
-        decode_wave_fused_422_stream(d, s, rows, stage_after, stage_below, wave_first + lane, lane);
+        WAVE::decode(d, s, rows, stage_after, stage_below, wave_first + lane, lane);
         return;
     }
     // The flat grid is no larger than what is resident at once; a wave goes on to further units of 64 intervals on its
     // own (rows and slots are its own, the tables are every image's): no CU waits for the slowest wave of a workgroup.
     const uint32_t stride = gridDim.x * (blockDim.x / kWave), units = waves_per_image * images;
     for (uint32_t flat = blockIdx.x * (blockDim.x / kWave) + wave;;) {
-        decode_wave_fused_422_stream(descs[image], s, rows, stage_after, stage_below, wave_first + lane, lane);
+        WAVE::decode(descs[image], s, rows, stage_after, stage_below, wave_first + lane, lane);
         flat += stride; // (wave-uniform)
         if (flat >= units)
             break;
         image = uint32_t(__builtin_amdgcn_readfirstlane(int(flat / waves_per_image)));
         wave_first = uint32_t(__builtin_amdgcn_readfirstlane(int((flat % waves_per_image) * kWave)));
     }
+}
+
+struct Wave422Stream {
+    static __device__ __forceinline__ void decode(const ImageDesc &d, const HuffShared &s, uint32_t rows, uint32_t stage_after,
+                                                  uint32_t stage_below, uint32_t interval, uint32_t lane)
+    {
+        decode_wave_fused_422_stream(d, s, rows, stage_after, stage_below, interval, lane);
+    }
+};
+template <int HS, int VS, int MC>
+struct WaveLayoutStream {
+    static __device__ __forceinline__ void decode(const ImageDesc &d, const HuffShared &s, uint32_t rows, uint32_t stage_after,
+                                                  uint32_t stage_below, uint32_t interval, uint32_t lane)
+    {
+        decode_wave_fused_layout<HS, VS, MC, true>(d, s, interval, lane, rows, stage_after, stage_below);
+    }
+};
+__global__ void __launch_bounds__(768)
+decode_fused_422_stream_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t rows, uint32_t stage_after,
+                               uint32_t stage_below, uint32_t waves_per_image, uint32_t images)
+{
+    fused_stream_kernel_body<Wave422Stream>(descs, l2_in_lds, rows, stage_after, stage_below, waves_per_image, images);
+}
+// ... and of the extension layouts' kernels (4:4:4 / 4:4:0 in pairs -- even restart intervals --, 4:2:0)
+__global__ void __launch_bounds__(512)
+decode_fused_444_stream_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t rows, uint32_t stage_after,
+                               uint32_t stage_below, uint32_t waves_per_image, uint32_t images)
+{
+    fused_stream_kernel_body<WaveLayoutStream<1, 1, 2>>(descs, l2_in_lds, rows, stage_after, stage_below, waves_per_image, images);
+}
+__global__ void __launch_bounds__(512)
+decode_fused_440_stream_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t rows, uint32_t stage_after,
+                               uint32_t stage_below, uint32_t waves_per_image, uint32_t images)
+{
+    fused_stream_kernel_body<WaveLayoutStream<1, 2, 2>>(descs, l2_in_lds, rows, stage_after, stage_below, waves_per_image, images);
+}
+__global__ void __launch_bounds__(512)
+decode_fused_420_stream_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t rows, uint32_t stage_after,
+                               uint32_t stage_below, uint32_t waves_per_image, uint32_t images)
+{
+    fused_stream_kernel_body<WaveLayoutStream<2, 2, 1>>(descs, l2_in_lds, rows, stage_after, stage_below, waves_per_image, images);
 }
 
 // Latency-oriented variant of the fused path for launches that cannot fill
@@ -791,18 +833,36 @@ hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t ma
 // Where whole-interval windows are longer than a window can be, or leave a CU fewer than eight of its twelve waves
 // and fewer than the launch would put there (256 frames of 960x720, whole windows / streamed, ms per launch: DRI 6
 // 0.335 / 0.412 -- nine waves fit --, 8 0.397 / 0.336, 10 0.469 / 0.366, 16 1.22 / 0.42, 30 1.14 / 0.64, 60 2.2 / 1.18).
-bool stream_plan_preferred(const HuffLdsPlan &plan, uint32_t max_intervals, uint32_t images)
+bool stream_plan_preferred(const HuffLdsPlan &plan, uint32_t max_intervals, uint32_t images, uint32_t cu_waves, uint32_t group_waves)
 {
+    const DeviceLimits lim = device_limits();
     const uint64_t waves = uint64_t((max_intervals + kWave - 1) / kWave) * images;
-    const uint32_t cus = device_limits().cus;
-    const uint64_t per_cu = std::min<uint64_t>(kMaxWavesFused, (waves + cus - 1u) / cus);
-    return plan.window_cut || (plan.waves_that_fit < 8u && per_cu > plan.waves_that_fit);
+    if (!cu_waves) {
+        const uint64_t per_cu = std::min<uint64_t>(kMaxWavesFused, (waves + lim.cus - 1u) / lim.cus);
+        return plan.window_cut || (plan.waves_that_fit < 8u && per_cu > plan.waves_that_fit);
+    }
+    // the extension layouts' kernels (cu_waves of them on a CU, in workgroups of at most group_waves, each with the
+    // tables of its own): streamed wherever whole windows cost the CU a wave the launch would put there
+    group_waves = group_waves ? std::min(group_waves, cu_waves) : cu_waves;
+    const uint32_t groups = cu_waves / group_waves;
+    const uint32_t tables = (((kL1Entries + plan.l2_entries_in_lds) * 2u) + 15u) & ~15u;
+    const uint32_t wave_area = ((plan.window_words * 4u + 15u) & ~15u) + kWave * kDuSlotBytes;
+    const uint32_t room = lim.lds_bytes / groups > tables ? lim.lds_bytes / groups - tables : 0u;
+    const uint32_t fit = groups * std::min(group_waves, room / wave_area);
+    const uint64_t per_cu = std::min<uint64_t>(cu_waves, (waves + lim.cus - 1u) / lim.cus);
+    return plan.window_cut || (fit < cu_waves && per_cu > fit);
 }
 
 // Rows for the streamed window: room for `mcu_words` (the launch's average MCU, rounded up) four times over and
 // the words a reader holds beyond, as many as leave the CU its twelve waves, never fewer than sixteen.
-StreamPlan plan_stream(uint32_t max_intervals, uint32_t images, uint32_t max_l2, uint32_t mcu_words, bool uniform)
+StreamPlan plan_stream(uint32_t max_intervals, uint32_t images, uint32_t max_l2, uint32_t mcu_words, bool uniform, uint32_t cu_waves,
+                       uint32_t group_waves)
 {
+    // cu_waves: waves a CU holds of this kernel (twelve; eight of the extension layouts'); group_waves: the most a
+    // workgroup has (the paired layout kernels: four, two workgroups to a CU -- fused_layout_wave_cap)
+    cu_waves = cu_waves ? cu_waves : kMaxWavesFused;
+    group_waves = group_waves ? std::min(group_waves, cu_waves) : cu_waves;
+    const uint32_t groups_per_cu = cu_waves / group_waves;
     StreamPlan p;
     p.l2_entries_in_lds = max_l2 < 12288u ? (max_l2 + 1u) & ~1u : 12288u;
     const uint32_t tables = (((kL1Entries + p.l2_entries_in_lds) * 2u) + 15u) & ~15u;
@@ -813,7 +873,7 @@ StreamPlan plan_stream(uint32_t max_intervals, uint32_t images, uint32_t max_l2,
     // leave a CU its twelve waves (or all but one of them); where none does (10 bit per pixel), every MCU and at most 64
     // rows.  (256 x 960x720, DRI = 10, ms per launch by step: 1.7 bit per pixel 0.361 / 0.370 / 0.381; 4.6 bit 1.04 /
     // 1.08 / 0.73; 10 bit 1.48 / 1.54 / 1.62.)
-    const uint32_t most_rows = ((lim.lds_bytes - tables) / kMaxWavesFused - kWave * kDuSlotBytes) / (kWave * 4u);
+    const uint32_t most_rows = ((lim.lds_bytes - groups_per_cu * tables) / cu_waves - kWave * kDuSlotBytes) / (kWave * 4u);
     const uint32_t need[3] = {3u * mcu_words + 4u, 3u * ((7u * mcu_words + 9u) / 10u) + 4u, 3u * ((9u * mcu_words + 19u) / 20u) + 4u};
     uint32_t step = need[0] <= most_rows ? 0u : (need[1] <= most_rows ? 1u : (need[2] <= most_rows + 6u ? 2u : 0u));
     if (const char *e = lab_env("COMPEG_STREAM_STEP")) // experiment knob: 0 / 1 / 2
@@ -834,8 +894,8 @@ StreamPlan plan_stream(uint32_t max_intervals, uint32_t images, uint32_t max_l2,
     // Waves per workgroup: one CU's share of the launch (a launch smaller than the chip spreads over all of its CUs:
     // 256 frames of 960x720 with DRI = 30 are 768 waves), at most what the LDS holds and twelve; the per-image grid
     // never more than an image has.  (Workgroups smaller than the share, two to a CU, measured no better.)
-    const uint32_t fit = std::max(1u, (lim.lds_bytes - tables) / wave_area);
-    uint32_t best = uint32_t(std::min<uint64_t>(std::max<uint64_t>((total_waves + lim.cus - 1) / lim.cus, 1u), std::min(fit, kMaxWavesFused)));
+    const uint32_t fit = std::max(1u, (lim.lds_bytes / groups_per_cu - tables) / wave_area);
+    uint32_t best = uint32_t(std::min<uint64_t>(std::max<uint64_t>((total_waves + lim.cus - 1) / lim.cus, 1u), std::min(fit, group_waves)));
     if (!uniform)
         best = std::min(best, std::max(1u, waves_per_image));
     if (const char *e = lab_env("COMPEG_WPB")) // experiment knob
@@ -844,6 +904,7 @@ StreamPlan plan_stream(uint32_t max_intervals, uint32_t images, uint32_t max_l2,
     p.waves_per_block = best;
     p.total_bytes = tables + best * wave_area;
     p.waves_per_image = uniform ? waves_per_image : 0u;
+    p.cu_waves = cu_waves;
     if (getenv("COMPEG_VERBOSE"))
         fprintf(stderr, "[compeg] stream plan: images=%u intervals=%u waves/block=%u rows=%u staged behind data units %#x below %u words lds=%u B%s\n",
                 images, max_intervals, best, rows, p.stage_after, p.stage_below, p.total_bytes, uniform ? " flat" : "");
@@ -851,10 +912,18 @@ StreamPlan plan_stream(uint32_t max_intervals, uint32_t images, uint32_t max_l2,
 }
 
 hipError_t launch_fused_422_stream(const ImageDesc *descs, uint32_t images, uint32_t max_intervals, const StreamPlan &plan,
-                                   hipStream_t stream)
+                                   hipStream_t stream, uint32_t hs, uint32_t vs)
 {
     if (images == 0 || max_intervals == 0)
         return hipSuccess;
+    using Kernel = void (*)(const ImageDesc *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t);
+    const Kernel kernel = hs == 2 && vs == 1   ? decode_fused_422_stream_kernel
+                          : hs == 1 && vs == 1 ? decode_fused_444_stream_kernel
+                          : hs == 1 && vs == 2 ? decode_fused_440_stream_kernel
+                          : hs == 2 && vs == 2 ? decode_fused_420_stream_kernel
+                                               : nullptr;
+    if (!kernel)
+        return hipErrorInvalidValue;
     const uint32_t threads = plan.waves_per_block * kWave;
     dim3 grid((max_intervals + threads - 1) / threads, images, 1);
     const uint64_t flat_groups = (uint64_t(plan.waves_per_image) * images + plan.waves_per_block - 1) / plan.waves_per_block;
@@ -862,14 +931,14 @@ hipError_t launch_fused_422_stream(const ImageDesc *descs, uint32_t images, uint
     if (flat) {
         // at most as many workgroups as are resident at once; their waves loop over the rest (see the kernel)
         const DeviceLimits lim = device_limits();
-        const uint32_t per_cu = std::max(1u, std::min(lim.lds_bytes / plan.total_bytes, kMaxWavesFused / plan.waves_per_block));
+        const uint32_t per_cu = std::max(1u, std::min(lim.lds_bytes / plan.total_bytes, plan.cu_waves / plan.waves_per_block));
         grid = dim3(uint32_t(std::min<uint64_t>(flat_groups, uint64_t(lim.cus) * per_cu)), 1, 1);
     }
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(decode_fused_422_stream_kernel),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(device_limits().lds_bytes));
+    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                int(device_limits().lds_bytes));
     if (attr != hipSuccess)
         return attr;
-    hipLaunchKernelGGL(decode_fused_422_stream_kernel, grid, dim3(threads), plan.total_bytes, stream, descs,
+    hipLaunchKernelGGL(kernel, grid, dim3(threads), plan.total_bytes, stream, descs,
                        plan.l2_entries_in_lds, plan.rows, plan.stage_after, plan.stage_below, flat ? plan.waves_per_image : 0u, images);
     return hipGetLastError();
 }

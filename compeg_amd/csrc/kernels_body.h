@@ -2330,8 +2330,12 @@ CG_DEV void composite_layout_mcus(LayoutPixels<HS, VS, MC> &t, const ImageDesc &
 // The whole path for 64 restart intervals, one per lane (decode_wave_fused_422's counterpart; tests/emul drives the
 // same steps lane by lane).  Lanes past the image's last interval decode that last interval once more and never
 // store an MCU of their own: they stay for their quad's exchange.  MC = 2: the restart interval is even.
-template <int HS, int VS, int MC>
-CG_DEV void decode_wave_fused_layout(const ImageDesc &d, const HuffShared &s, uint32_t interval, uint32_t lane)
+// STREAM: the window in its streamed form (decode_wave_fused_422_stream): nrows words of every lane's stream, staged
+// anew behind an MCU's last data unit -- stage_after other than 8: behind every data unit -- when a lane has fewer than
+// stage_below in front of it.
+template <int HS, int VS, int MC, bool STREAM = false>
+CG_DEV void decode_wave_fused_layout(const ImageDesc &d, const HuffShared &s, uint32_t interval, uint32_t lane, uint32_t nrows = 0u,
+                                     uint32_t stage_after = 8u, uint32_t stage_below = 0u)
 {
     constexpr uint32_t kDus = uint32_t(HS * VS + 2), kBlocks = kDus * uint32_t(MC);
     const bool active = interval < d.total_intervals;
@@ -2340,18 +2344,30 @@ CG_DEV void decode_wave_fused_layout(const ImageDesc &d, const HuffShared &s, ui
     int16_t *slot16 = reinterpret_cast<int16_t *>(slot);
     zero_slot(slot);
     EntropyState e;
-    entropy_init(e, d, s, interval);
+    if (STREAM)
+        stream_lane_init(e, d, s, nrows, interval, lane);
+    else
+        entropy_init(e, d, s, interval);
     LayoutPixels<HS, VS, MC> t;
     layout_init<HS, VS, MC>(t, d, interval, active);
+    if (STREAM)
+        stream_rows_landed();
     __builtin_amdgcn_s_setprio(CG_PRIO_ENTROPY);
     const uint32_t du_total = d.restart_interval * kDus;
     uint32_t place = 0, k = 0; // the data unit's block among the held MCUs', its place inside its MCU (wave-uniform)
 #pragma unroll 1
     for (uint32_t du = 0; du < du_total; du++) {
         const uint32_t comp = layout_comp_of(k, uint32_t(HS * VS));
-        const int32_t dc = entropy_data_unit(e, d, s, comp, slot16);
+        const int32_t dc = STREAM ? entropy_data_unit<true>(e, d, s, comp, slot16, lane) : entropy_data_unit(e, d, s, comp, slot16);
+        bool stage = STREAM && (k == kDus - 1u || stage_after != 8u) && du + 1u < du_total; // (wave-uniform)
+        if (stage)
+            stage = wave_any(stream_wants_rows(e, d, s, lane, stage_below));
+        if (stage)
+            stream_restage(e, d, s, nrows, lane); // (lands under this data unit's IDCT)
         __builtin_amdgcn_s_setprio(CG_PRIO_IDCT);
         layout_transform<HS, VS, MC>(t, d, comp, place, slot, dc);
+        if (stage)
+            stream_rows_landed(); // (in front of the composite's stores)
         k = k == kDus - 1u ? 0u : k + 1u;
         if (place == kBlocks - 1u) {
             __builtin_amdgcn_s_setprio(CG_PRIO_COMPOSITE);

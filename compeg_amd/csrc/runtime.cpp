@@ -128,14 +128,19 @@ bool use_pair_kernel(uint32_t max_intervals, uint32_t images)
 // look at where a scan ends (up to 64 words beyond its last; never used).
 constexpr size_t kStreamSlackBytes = 1024;
 
-bool use_stream_kernel(const HuffLdsPlan &plan, uint32_t max_intervals, uint32_t images)
+bool use_stream_kernel(const HuffLdsPlan &plan, uint32_t max_intervals, uint32_t images, uint32_t cu_waves = 0, uint32_t group_waves = 0)
 {
     static const int forced = [] {
         const char *e = lab_env("COMPEG_STREAM"); // experiment knob: 0 / 1
         return e ? atoi(e) : -1;
     }();
-    return forced >= 0 ? forced != 0 : stream_plan_preferred(plan, max_intervals, images);
+    return forced >= 0 ? forced != 0 : stream_plan_preferred(plan, max_intervals, images, cu_waves, group_waves);
 }
+
+// The extension layouts' kernels: waves a CU holds (their registers: two to a SIMD) and the most a workgroup has
+// (fused_layout_wave_cap); a streamed form exists for 4:2:0 and for 4:4:4 / 4:4:0 with even restart intervals.
+constexpr uint32_t kLayoutCuWaves = 8;
+bool layout_has_stream_kernel(uint32_t hs, uint32_t vs, bool pairs) { return (hs == 2 && vs == 2) || (hs == 1 && pairs); }
 
 bool use_coop_kernel(uint32_t max_intervals, uint32_t images, uint32_t restart_interval)
 {
@@ -766,7 +771,14 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     if (!is_422(img)) {
         // extension layouts (4:4:4, 4:4:0, 4:2:0): one fused kernel per layout (the development pipeline keeps the
         // two-kernel route: entropy stage with the IDCT in place, generic composite)
-        if (use_fused_pipeline()) {
+        if (use_fused_pipeline() && layout_has_stream_kernel(luma_h, luma_v, mcu_pairs) &&
+            use_stream_kernel(plan, md.total_restart_intervals, 1, kLayoutCuWaves, fused_layout_wave_cap(luma_h, luma_v, mcu_pairs))) {
+            const uint64_t mcus = std::max<uint64_t>(1u, uint64_t(md.total_restart_intervals) * std::max(1u, uint32_t(md.restart_interval)));
+            const StreamPlan sp = plan_stream(md.total_restart_intervals, 1, staged_lut_entries(img), uint32_t((img.scan_len / 4u + mcus - 1u) / mcus),
+                                              true, kLayoutCuWaves, fused_layout_wave_cap(luma_h, luma_v, mcu_pairs));
+            CG_HIP(launch_fused_422_stream(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals, sp, stream, luma_h, luma_v));
+            last_kernel = COMPEG_KERNEL_FUSED_STREAM;
+        } else if (use_fused_pipeline()) {
             CG_HIP(launch_fused_layout(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals, plan, luma_h, luma_v, mcu_pairs, stream));
             last_kernel = COMPEG_KERNEL_FUSED_LAYOUT;
         } else {
@@ -1890,9 +1902,16 @@ Status compeg_batch::decode(hipStream_t stream)
         const HuffLdsPlan plan = plan_huffman(max_intervals, m, max_l2, max_span, fused || generic_layout,
                                               one_layout ? fused_layout_wave_cap(layout_h, layout_v, mcu_pairs) : 0u);
         if (one_layout) {
-            // every image has the same extension layout: its fused kernel
-            last_kernel = at ? last_kernel : COMPEG_KERNEL_FUSED_LAYOUT;
-            CG_HIP(launch_fused_layout(dd + at, m, max_intervals, plan, layout_h, layout_v, mcu_pairs, stream));
+            // every image has the same extension layout: its fused kernel, whole windows or streamed
+            const bool streamed = layout_has_stream_kernel(layout_h, layout_v, mcu_pairs) && use_stream_kernel(plan, max_intervals, m, kLayoutCuWaves, fused_layout_wave_cap(layout_h, layout_v, mcu_pairs));
+            last_kernel = at ? last_kernel : (streamed ? COMPEG_KERNEL_FUSED_STREAM : COMPEG_KERNEL_FUSED_LAYOUT);
+            if (streamed)
+                CG_HIP(launch_fused_422_stream(dd + at, m, max_intervals,
+                                               plan_stream(max_intervals, m, max_l2, stream_mcu_words, uniform, kLayoutCuWaves,
+                                                           fused_layout_wave_cap(layout_h, layout_v, mcu_pairs)),
+                                               stream, layout_h, layout_v));
+            else
+                CG_HIP(launch_fused_layout(dd + at, m, max_intervals, plan, layout_h, layout_v, mcu_pairs, stream));
             if (timing && at == 0)
                 CG_HIP(hipEventRecord(ev[1], stream));
             continue;

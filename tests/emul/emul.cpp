@@ -308,6 +308,12 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
 
     // ---- huffman_kernel ----
     l2_in_lds &= ~1u;
+    // (fused == 6 with EMUL_STREAM_ROWS: the layout kernels' streamed form -- that many rows of every lane's stream)
+    const uint32_t lay_rows = fused == 6 && getenv("EMUL_STREAM_ROWS") ? uint32_t(std::max(1, atoi(getenv("EMUL_STREAM_ROWS")))) : 0u;
+    const uint32_t lay_stage = getenv("EMUL_STREAM_STAGE") ? uint32_t(strtoul(getenv("EMUL_STREAM_STAGE"), nullptr, 0)) : 8u;
+    const uint32_t lay_below = getenv("EMUL_STREAM_BELOW") ? uint32_t(strtoul(getenv("EMUL_STREAM_BELOW"), nullptr, 0)) : lay_rows;
+    if (lay_rows)
+        window_words = lay_rows * kWave;
     const uint32_t threads = waves_per_block * kWave;
     const uint32_t wave_area = align16(window_words * 4u) + kWave * kDuSlotBytes;
     const uint32_t lds_bytes = align16((kL1Entries + l2_in_lds) * 2u) + waves_per_block * wave_area;
@@ -326,7 +332,8 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
             if (wave_first >= d.total_intervals)
                 continue;
             uint32_t wb = 0, wl = 0;
-            wave_window(d, wave_first, window_words, wb, wl);
+            if (!lay_rows)
+                wave_window(d, wave_first, window_words, wb, wl);
             for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
                 stage_window(d, win, wb, wl, lane);
             HuffShared sh{sl1, sl2, umin(l2_in_lds, d.fast_off + 2u * kFastEntries), win, wb, wl, slots};
@@ -345,14 +352,27 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
                         zero_slot(slots + lane * kDuSlotBytes);
                         const bool active = wave_first + lane < d.total_intervals;
                         const uint32_t iv = active ? wave_first + lane : d.total_intervals - 1u;
-                        entropy_init(es[lane], d, sh, iv);
+                        if (lay_rows)
+                            stream_lane_init(es[lane], d, sh, lay_rows, iv, lane);
+                        else
+                            entropy_init(es[lane], d, sh, iv);
                         layout_init<HS, VS, MC>(ps[lane], d, iv, active);
                     }
                     const uint32_t du_total = d.restart_interval * kDus;
                     for (uint32_t du = 0, k = 0, place = 0; du < du_total; du++) {
                         const uint32_t comp = layout_comp_of(k, uint32_t(HS * VS));
-                        for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
-                            dcs[lane] = entropy_data_unit(es[lane], d, sh, comp, reinterpret_cast<int16_t *>(slots + lane * kDuSlotBytes));
+                        for (uint32_t lane = 0; lane < uint32_t(kWave); lane++) {
+                            int16_t *slot16 = reinterpret_cast<int16_t *>(slots + lane * kDuSlotBytes);
+                            dcs[lane] = lay_rows ? entropy_data_unit<true>(es[lane], d, sh, comp, slot16, lane)
+                                                 : entropy_data_unit(es[lane], d, sh, comp, slot16);
+                        }
+                        if (lay_rows && (k == kDus - 1u || lay_stage != 8u) && du + 1u < du_total) {
+                            bool any = false; // (the wave's decision, then every lane's rows)
+                            for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
+                                any = any || stream_wants_rows(es[lane], d, sh, lane, lay_below);
+                            for (uint32_t lane = 0; lane < uint32_t(kWave) && any; lane++)
+                                stream_restage(es[lane], d, sh, lay_rows, lane);
+                        }
                         for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
                             layout_transform<HS, VS, MC>(ps[lane], d, comp, place, slots + lane * kDuSlotBytes, dcs[lane]);
                         k = k == kDus - 1u ? 0u : k + 1u;

@@ -513,6 +513,40 @@ print("split ok")
 
 
 @pytest.mark.parametrize("sampling", [(1, 1), (1, 2), (2, 2)])
+def test_extension_layouts_with_streamed_windows(ca, gpu, sampling):
+    """The extension layouts' kernels in their streamed form (decode_fused_444 / _440 / _420_stream_kernel): long
+    restart intervals and dense streams, where whole-interval windows cost a CU its waves -- a uniform batch (flat
+    grid), a mixed-size one with a corrupt scan (a grid row per image), one large frame through the Decoder."""
+    uniform = [synth.make_jpeg(960, 720, seed=700 + i, kind=i % 3, quality=85, ri=16, sampling=sampling) for i in range(64)]
+    shapes = [(1000, 600), (1016, 590), (936, 604), (1280, 720)]
+    mixed = [synth.make_jpeg(w, h, seed=760 + i, kind=i % 3, quality=(85, 95)[i % 2], ri=(8, 16, 40)[i % 3], sampling=sampling)
+             for i, (w, h) in enumerate(shapes * 16)]
+    bad = bytearray(mixed[3])
+    at = bad.find(b"\xff\xda") + 14
+    rng = np.random.default_rng(5)
+    for _ in range(40):
+        pos = int(rng.integers(at, len(bad) - 2))
+        if bad[pos] != 0xFF and bad[pos - 1] != 0xFF:
+            bad[pos] ^= 1 << int(rng.integers(0, 8))
+            if bad[pos] == 0xFF:
+                bad[pos] = 0xFE
+    mixed[3] = bytes(bad)
+    for jpegs in (uniform, mixed):
+        batch = ca.Batch(gpu)
+        batch.upload([ca.ImageData(j, allow_sampling=True) for j in jpegs])
+        batch.decode()
+        batch.wait()
+        assert batch.last_kernel() == "fused_stream"
+        for i in list(range(0, len(jpegs), 9)) + [3, len(jpegs) - 1]:
+            _assert_equal(batch.read_output(i), orc.ImageData(jpegs[i], allow_sampling=True).decode())
+    big = synth.make_jpeg(3840, 2160, seed=799, quality=90, ri=48, sampling=sampling)
+    dec = ca.Decoder(gpu)
+    dec.decode_blocking(ca.ImageData(big, allow_sampling=True))
+    assert dec.last_kernel() == "fused_stream"
+    _assert_equal(dec.read_texture(3840, 2160), orc.ImageData(big, allow_sampling=True).decode())
+
+
+@pytest.mark.parametrize("sampling", [(1, 1), (1, 2), (2, 2)])
 def test_extension_layouts(ca, gpu, sampling):
     """4:4:4, 4:4:0 and 4:2:0 (opt-in): bit-exact against the oracle with the same
     extension, through the Decoder and -- mixed with a 4:2:2 image -- through a Batch."""

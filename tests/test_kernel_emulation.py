@@ -26,7 +26,8 @@ def runner():
 STATS = {}   # rare-path counters of the emulated kernels, summed over every run of this module
 
 
-def _run(runner, tmp_path, jpeg, fused, waves=1, window=2048, l2=12288, standard=False, coop_passes=1, stage=8, below=None):
+def _run(runner, tmp_path, jpeg, fused, waves=1, window=2048, l2=12288, standard=False, coop_passes=1, stage=8, below=None,
+         layout_rows=None):
     p = tmp_path / "in.jpg"
     p.write_bytes(jpeg)
     env = dict(os.environ)
@@ -37,6 +38,9 @@ def _run(runner, tmp_path, jpeg, fused, waves=1, window=2048, l2=12288, standard
     env["EMUL_COOP_PASSES"] = str(coop_passes)
     env["EMUL_STREAM_STAGE"] = str(stage)   # (streamed window: behind which data units of an MCU the rows are staged ...
     env.pop("EMUL_STREAM_BELOW", None)
+    env.pop("EMUL_STREAM_ROWS", None)
+    if layout_rows is not None:
+        env["EMUL_STREAM_ROWS"] = str(layout_rows)   # (fused = 6: the layout kernels' streamed form)
     if below is not None:
         env["EMUL_STREAM_BELOW"] = str(below)   # ... when some lane has fewer words than this left; default: always)
     if standard:
@@ -281,6 +285,11 @@ def test_emulated_extension_layouts(runner, tmp_path, sampling):
         if sampling != (2, 1):   # the fused kernels of the extension layouts (decode_fused_444 / _440 / _420_kernel)
             got = _run(runner, tmp_path, jpeg, 6, waves=3, window=300)
             assert np.array_equal(got, want), f"fused {sampling} {w}x{h}: {(got != want).any(axis=2).sum()} pixels differ"
+            # ... and their streamed form (the odd restart intervals too: the body is the same, only the GPU library
+            # has no kernel of it for them): rows enough; too few; staged behind every data unit
+            for rows, stage, below in ((24, 8, 24), (3, 8, 2), (6, 0xf, 3)):
+                got = _run(runner, tmp_path, jpeg, 6, waves=2, layout_rows=rows, stage=stage, below=below)
+                assert np.array_equal(got, want), f"streamed {sampling} {w}x{h} rows {rows}: {(got != want).any(axis=2).sum()} pixels differ"
 
 
 def test_emulated_standard_entropy_extension(runner, tmp_path):
