@@ -19,7 +19,12 @@ RUNNER = os.path.join(EMUL_DIR, "emul_runner")
 
 @pytest.fixture(scope="module")
 def runner():
-    subprocess.check_call(["make", "-C", EMUL_DIR, "-s"])
+    # (one build at a time: under pytest-xdist every worker comes here, and two makes writing one binary leave a
+    # truncated file behind)
+    import fcntl
+    with open(os.path.join(EMUL_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        subprocess.check_call(["make", "-C", EMUL_DIR, "-s"])
     return RUNNER
 
 
