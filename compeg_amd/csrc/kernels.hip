@@ -900,9 +900,16 @@ StreamPlan plan_stream(uint32_t max_intervals, uint32_t images, uint32_t max_l2,
         best = std::min(best, std::max(1u, waves_per_image));
     if (const char *e = lab_env("COMPEG_WPB")) // experiment knob
         best = uint32_t(atoi(e));
+    // With LDS to spare at that size, more rows: the stagings get rarer by as much as they get larger, and every
+    // one of them waits for the stores in front of it (sparse streams, short MCU steps -- 256 x 1080p q50 DRI = 16:
+    // 0.90 ms with 12 rows, 0.83 with the 27 that fit).
+    const uint32_t spare_rows = best ? ((lim.lds_bytes / groups_per_cu - tables) / best - kWave * kDuSlotBytes) / (kWave * 4u) : rows;
+    if (!lab_env("COMPEG_STREAM_ROWS") && spare_rows > rows)
+        rows = std::min(64u, spare_rows);
+    const uint32_t area = rows * kWave * 4u + kWave * kDuSlotBytes;
     p.rows = rows;
     p.waves_per_block = best;
-    p.total_bytes = tables + best * wave_area;
+    p.total_bytes = tables + best * area;
     p.waves_per_image = uniform ? waves_per_image : 0u;
     p.cu_waves = cu_waves;
     if (getenv("COMPEG_VERBOSE"))
