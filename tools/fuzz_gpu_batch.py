@@ -30,12 +30,17 @@ def run(seed=77, batches=40, log=print):
         same = bool(rng.integers(0, 2))
         w0, h0 = SIZES[int(rng.integers(0, len(SIZES)))]
         ri0 = int(rng.choice([1, 2, 4, 4, 8, 16, 3, 10, 30, 7, 120]))
+        # one batch in four is of an extension layout (the fused layout kernels, whole windows or streamed), one in
+        # eight mixes layouts (the two-kernel route)
+        ext = int(rng.integers(0, 8))
+        smp0 = [(1, 1), (1, 2), (2, 2)][ext % 3] if ext < 2 else (2, 1)
         items = []
         for i in range(count):
             w, h = (w0, h0) if same else SIZES[int(rng.integers(0, len(SIZES)))]
             ri = ri0 if same or rng.integers(0, 2) else int(rng.choice([1, 2, 4, 8]))
+            smp = [(2, 1), (1, 1), (1, 2), (2, 2)][int(rng.integers(0, 4))] if ext == 2 else smp0
             j = bytearray(synth.make_jpeg(w, h, seed=int(rng.integers(1, 1 << 30)), kind=int(rng.integers(0, 3)),
-                                          quality=int(rng.choice([50, 85, 95])), ri=ri))
+                                          quality=int(rng.choice([50, 85, 95])), ri=ri, sampling=smp))
             if rng.integers(0, 4) == 0:
                 scan_at = j.find(b"\xff\xda") + 14
                 for _ in range(int(rng.integers(1, 30))):
@@ -46,7 +51,7 @@ def run(seed=77, batches=40, log=print):
                             j[pos] = 0xFE
             j = bytes(j)
             try:
-                items.append((j, orc.ImageData(j).decode()))
+                items.append((j, orc.ImageData(j, allow_sampling=True).decode()))
             except orc.OracleError:
                 pass
         if not items:
@@ -55,7 +60,7 @@ def run(seed=77, batches=40, log=print):
             # a long uniform batch: the same few frames over and over until the launch has more units of 64 intervals
             # than the chip holds waves, by a random fraction of a round -- the throughput kernel's resident waves then
             # take a second, third ... unit each (quantisers and content differ per slot, sizes and tables do not)
-            par = ca.ImageData(items[0][0]).parallelism()
+            par = ca.ImageData(items[0][0], allow_sampling=True).parallelism()
             waves = (par + 63) // 64
             slots = int((3072 * float(rng.uniform(1.02, 2.6))) // waves) + 1
             if slots * w0 * h0 * 4 < (3 << 30):
@@ -72,9 +77,9 @@ def run(seed=77, batches=40, log=print):
                 pinned = ca.HostBuffer(sum(len(j) + 64 for j in srcs))
                 views = pinned.place(srcs)
                 srcs = views if where == 1 else [v if i % 2 else j for i, (v, j) in enumerate(zip(views, srcs))]
-            batch.upload_jpegs(srcs, host_threads=int(rng.choice([1, 4, 8])))
+            batch.upload_jpegs(srcs, host_threads=int(rng.choice([1, 4, 8])), allow_sampling=True)
         else:
-            batch.upload([ca.ImageData(j) for j, _ in items], host_threads=int(rng.choice([1, 4, 8])))
+            batch.upload([ca.ImageData(j, allow_sampling=True) for j, _ in items], host_threads=int(rng.choice([1, 4, 8])))
         for rep in range(2):
             batch.decode()
             batch.wait()
