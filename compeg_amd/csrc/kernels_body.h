@@ -1802,9 +1802,10 @@ CG_DEV bool wave_any(bool v)
 // the LDS has with DRI = 16 -- the waves per CU go, then the window itself.  Here a lane has `nrows` words of its
 // own stream staged at any time, whatever the interval's length: row j of the wave's rows (64 words, one per lane)
 // holds word j behind each lane's own position, fetched by LDS-DMA (one global_load_lds_dword a row: per-lane source,
-// lane-linear destination) after the last data unit of every MCU and landed under that data unit's IDCT.  The fast
-// reader walks down its lane's column (EntropyState); a lane that reaches its last row inside an MCU finishes the
-// MCU's data units with the reference reader from global memory and is back in fast mode with the next rows.
+// lane-linear destination) behind the last data unit of an MCU -- when some lane is running short
+// (stream_wants_rows) -- and landed under that data unit's IDCT.  The fast reader walks down its lane's column
+// (EntropyState); a lane that reaches its last row inside a data unit finishes it, and the MCU, with the reference
+// reader from global memory and is back in fast mode with the next rows.
 
 // Row j of `rows` := word `first + j` of every lane's stream, j < nrows (asynchronous on the device: vmcnt).
 // (first <= d.nwords; the words behind an image's last are readable -- runtime.cpp pads its buffers -- and never used)
