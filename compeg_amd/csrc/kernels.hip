@@ -919,7 +919,7 @@ StreamPlan plan_stream(uint32_t max_intervals, uint32_t images, uint32_t max_l2,
     return p;
 }
 
-hipError_t launch_fused_422_stream(const ImageDesc *descs, uint32_t images, uint32_t max_intervals, const StreamPlan &plan,
+hipError_t launch_fused_stream(const ImageDesc *descs, uint32_t images, uint32_t max_intervals, const StreamPlan &plan,
                                    hipStream_t stream, uint32_t hs, uint32_t vs)
 {
     if (images == 0 || max_intervals == 0)

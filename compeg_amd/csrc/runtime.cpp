@@ -776,7 +776,7 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
             const uint64_t mcus = std::max<uint64_t>(1u, uint64_t(md.total_restart_intervals) * std::max(1u, uint32_t(md.restart_interval)));
             const StreamPlan sp = plan_stream(md.total_restart_intervals, 1, staged_lut_entries(img), uint32_t((img.scan_len / 4u + mcus - 1u) / mcus),
                                               true, kLayoutCuWaves, fused_layout_wave_cap(luma_h, luma_v, mcu_pairs));
-            CG_HIP(launch_fused_422_stream(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals, sp, stream, luma_h, luma_v));
+            CG_HIP(launch_fused_stream(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals, sp, stream, luma_h, luma_v));
             last_kernel = COMPEG_KERNEL_FUSED_STREAM;
         } else if (use_fused_pipeline()) {
             CG_HIP(launch_fused_layout(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals, plan, luma_h, luma_v, mcu_pairs, stream));
@@ -819,7 +819,7 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
             const uint64_t mcus = std::max<uint64_t>(1u, uint64_t(md.total_restart_intervals) * std::max(1u, uint32_t(md.restart_interval)));
             const StreamPlan sp = plan_stream(md.total_restart_intervals, 1, staged_lut_entries(img),
                                               uint32_t((img.scan_len / 4u + mcus - 1u) / mcus), true);
-            CG_HIP(launch_fused_422_stream(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals, sp, stream));
+            CG_HIP(launch_fused_stream(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals, sp, stream));
             last_kernel = COMPEG_KERNEL_FUSED_STREAM;
         } else if (use_pair_kernel(md.total_restart_intervals, 1)) {
             CG_HIP(launch_pair_422(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals,
@@ -1906,7 +1906,7 @@ Status compeg_batch::decode(hipStream_t stream)
             const bool streamed = layout_has_stream_kernel(layout_h, layout_v, mcu_pairs) && use_stream_kernel(plan, max_intervals, m, kLayoutCuWaves, fused_layout_wave_cap(layout_h, layout_v, mcu_pairs));
             last_kernel = at ? last_kernel : (streamed ? COMPEG_KERNEL_FUSED_STREAM : COMPEG_KERNEL_FUSED_LAYOUT);
             if (streamed)
-                CG_HIP(launch_fused_422_stream(dd + at, m, max_intervals,
+                CG_HIP(launch_fused_stream(dd + at, m, max_intervals,
                                                plan_stream(max_intervals, m, max_l2, stream_mcu_words, uniform, kLayoutCuWaves,
                                                            fused_layout_wave_cap(layout_h, layout_v, mcu_pairs)),
                                                stream, layout_h, layout_v));
@@ -1932,7 +1932,7 @@ Status compeg_batch::decode(hipStream_t stream)
             if (coop.usable)
                 CG_HIP(launch_coop_422(dd + at, m, max_intervals, coop, stream));
             else if (streamed)
-                CG_HIP(launch_fused_422_stream(dd + at, m, max_intervals, plan_stream(max_intervals, m, max_l2, stream_mcu_words, uniform), stream));
+                CG_HIP(launch_fused_stream(dd + at, m, max_intervals, plan_stream(max_intervals, m, max_l2, stream_mcu_words, uniform), stream));
             else if (use_pair_kernel(max_intervals, m))
                 CG_HIP(launch_pair_422(dd + at, m, max_intervals, plan, stream));
             else

@@ -176,7 +176,8 @@ int compeg_decoder_last_stage_times(const compeg_decoder *dec, compeg_stage_time
 #define COMPEG_KERNEL_GENERIC 4    /* entropy_samples_kernel + composite_generic_kernel (batches of mixed layouts) */
 #define COMPEG_KERNEL_SPLIT 5      /* entropy_kernel + idct_composite_kernel (development pipeline) */
 #define COMPEG_KERNEL_FUSED_LAYOUT 6 /* decode_fused_444 / _440 / _420_kernel (one layout other than 4:2:2) */
-#define COMPEG_KERNEL_FUSED_STREAM 7 /* decode_fused_422_stream_kernel: the batch kernel for long restart intervals */
+#define COMPEG_KERNEL_FUSED_STREAM 7 /* decode_fused_422 / _444 / _440 / _420_stream_kernel: the batch kernels with streamed
+                                       windows (long restart intervals, dense streams) */
 int compeg_decoder_last_kernel(const compeg_decoder *dec);
 /* Extension: on != 0 moves the scan preprocessing of every following decode
  * from the host (the reference's data flow, default) to the device-side scan
