@@ -88,6 +88,15 @@ struct alignas(16) Vec4u {
 template <bool STREAM>
 CG_DEV void store_pixels(uint8_t *p, const Vec4u &v)
 {
+#if defined(COMPEG_LAB) && defined(CG_STORE_POLICY) && defined(__HIP_DEVICE_COMPILE__)
+    // laboratory build: the cache-policy bits of the composite's stores by hand (sc0 / sc1 / nt), -DCG_STORE_POLICY="..."
+    if (STREAM) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 val{v.x, v.y, v.z, v.w};
+        asm volatile("global_store_dwordx4 %0, %1, off " CG_STORE_POLICY ::"v"(p), "v"(val) : "memory");
+        return;
+    }
+#endif
 #if CG_NT_STORES && defined(__HIP_DEVICE_COMPILE__)
     if (STREAM) {
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
