@@ -1988,6 +1988,22 @@ CG_DEV void composite_mcus_422(PixelState &t, const ImageDesc &d, uint8_t *wave_
     };
     const uint32_t whole_mask = quad_lane<0>(wh) | quad_lane<1>(wh) << 1 | quad_lane<2>(wh) << 2 | quad_lane<3>(wh) << 3;
     // (rows stay apart in the schedule: interleaving them only costs registers)
+#if CG_EXP == 15 // diagnostic build (wrong picture, the same bytes): an MCU at an even place stores nothing, the odd one
+                 // behind it stores its rows twice -- to its neighbour's place and its own, back to back: what the
+                 // write path does with the two halves of a 128-byte line arriving together (held MCUs)
+    if (__builtin_amdgcn_ballot_w64(whole_mask != 0xfu) == 0u) {
+        uint8_t *left[4] = {bases[0] - 64, bases[1] - 64, bases[2] - 64, bases[3] - 64};
+#pragma unroll
+        for (uint32_t row = 0; row < 8; row++) {
+            composite_row_to_slot(t.px, row, slot);
+            if (t.mx & 1u) {
+                composite_row_from_quad(d, wave_slots, lane, row, left, 0xfu);
+                composite_row_from_quad(d, wave_slots, lane, row, bases, 0xfu);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else
+#endif
     if (__builtin_amdgcn_ballot_w64(whole_mask != 0xfu) == 0u) {
         // the common case, all 64 MCUs inside the output: unconditional stores
 #pragma unroll
