@@ -309,7 +309,10 @@ struct Wave422 {
         decode_wave_fused_422<AHEAD, WIDE>(d, s, interval, lane, ahead);
     }
 };
-__global__ void __launch_bounds__(768)
+#if !defined(CG_FUSED_BOUNDS) || !defined(COMPEG_LAB)
+#define CG_FUSED_BOUNDS 768 // (laboratory builds: 512 = two waves to a SIMD and their registers)
+#endif
+__global__ void __launch_bounds__(CG_FUSED_BOUNDS)
 decode_fused_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words,
                         uint32_t waves_per_image, uint32_t images)
 {
