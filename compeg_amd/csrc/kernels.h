@@ -27,8 +27,11 @@ hipError_t launch_entropy(const ImageDesc *descs, uint32_t images, uint32_t max_
                           const HuffLdsPlan &plan, hipStream_t stream);
 // uniform: all images have max_intervals intervals and byte-identical LUTs (workgroups may then span images)
 // one_mcu_intervals: every image's restart interval is one MCU (the kernel whose rows leave wave-wide)
+// queue: four bytes of device memory of the caller's (or null): the counter the resident waves of a uniform launch
+// draw their units from (zeroed here, in stream order)
 hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t max_intervals,
-                            const HuffLdsPlan &plan, hipStream_t stream, bool uniform = false, bool one_mcu_intervals = false);
+                            const HuffLdsPlan &plan, hipStream_t stream, bool uniform = false, bool one_mcu_intervals = false,
+                            uint32_t *queue = nullptr);
 // The batch kernel with the window in its streamed form (kernels_body.h: decode_wave_fused_422_stream), for launches
 // whose whole-interval windows would leave a CU fewer than its twelve waves.
 struct StreamPlan {

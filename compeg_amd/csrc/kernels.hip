@@ -168,6 +168,11 @@ entropy_samples_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, 
 //   data unit 0        the two interval starts that bound the next window are asked for;
 //   last MCU but one   one word of every 128-byte line of that window is touched (into the L2);
 //   last data unit     decoded: the window is free -- the next one is staged in front of the last IDCT and composite.
+//
+// Which unit is the next: with a queue (a counter in global memory, zeroed in front of the launch) the one the wave
+// draws -- asked for at data unit 0, looked at at data unit 1, the starts asked for there --, so that waves that
+// get through their units faster take more of them and the launch's last units are shared out (256 1080p frames are
+// 8160 units for 3072 waves: 2.66 each, i.e. three for all by turns); without one, every stride-th.
 struct WindowAhead {
     // (an index, not a pointer: a pointer carried around the units' loop is no longer visibly derived from the
     // kernel's restrict argument, and every descriptor field would be read with vector loads)
@@ -178,15 +183,29 @@ struct WindowAhead {
     uint32_t window_words, lane;
     uint32_t *win;
     uint32_t raw_base, raw_end, base, len, sink;
+    uint32_t *queue;     // null: `next` is known from the start
+    uint32_t next, drawn, stride, units, waves_per_image;
 
     __device__ __forceinline__ void at(uint32_t du, uint32_t du_total)
     {
+        if (queue) {
+            if (du == 0u && lane == 0u)
+                drawn = atomicAdd(queue, 1u);
+            if (du == 1u) {
+                next = stride + uint32_t(__builtin_amdgcn_readfirstlane(int(drawn))); // (the units below stride: the waves' first)
+                any = next < units;
+                if (any) {
+                    image = uint32_t(__builtin_amdgcn_readfirstlane(int(next / waves_per_image)));
+                    first = uint32_t(__builtin_amdgcn_readfirstlane(int((next % waves_per_image) * kWave)));
+                }
+            }
+        }
         if (!any)
             return;
         const ImageDesc *dn = descs + image;
-        if (du == 0u)
+        if (du == (queue ? 1u : 0u))
             wave_window_fetch(*dn, first, raw_base, raw_end);
-        if (du_total >= 8u && du == du_total - 8u) {
+        if (du_total >= 8u && du == (du_total >= 10u ? du_total - 8u : 2u)) {
             uint32_t b, l;
             wave_window_from(*dn, raw_base, raw_end, window_words, b, l);
             const uint32_t have = dn->nwords > b ? umin(l, dn->nwords - b) : 0u;
@@ -194,7 +213,7 @@ struct WindowAhead {
             for (uint32_t v = lane * 32u; v < have; v += kWave * 32u)
                 sink ^= words[b + v];
         }
-        if (du_total >= 8u && du == du_total - 5u)
+        if (du_total >= 8u && du == (du_total >= 10u ? du_total - 5u : 5u))
             asm volatile("" ::"v"(sink)); // (the touches' results: never looked at; the register is free from here)
     }
 
@@ -226,7 +245,7 @@ struct WindowAhead {
 // (LAYOUT: a struct with the wave's body: Wave422 -- the reference's 4:2:2 -- or WaveLayout<HS, VS>, the extension layouts)
 template <class LAYOUT>
 __device__ __forceinline__ void fused_kernel_body(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words,
-                                                  uint32_t waves_per_image, uint32_t images)
+                                                  uint32_t waves_per_image, uint32_t images, uint32_t *queue)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x / kWave))), lane = threadIdx.x % kWave;
@@ -281,7 +300,12 @@ __device__ __forceinline__ void fused_kernel_body(const ImageDesc *__restrict__ 
         flat += stride; // (wave-uniform)
         WindowAhead ahead;
         ahead.descs = descs;
-        ahead.any = waves_per_image && flat < units;
+        ahead.queue = waves_per_image ? queue : nullptr;
+        ahead.stride = stride;
+        ahead.units = units;
+        ahead.waves_per_image = waves_per_image;
+        ahead.next = ahead.drawn = 0u;
+        ahead.any = waves_per_image && !ahead.queue && flat < units;
         ahead.image = ahead.first = 0u;
         if (ahead.any) {
             ahead.image = uint32_t(__builtin_amdgcn_readfirstlane(int(flat / waves_per_image)));
@@ -314,18 +338,18 @@ struct Wave422 {
 #endif
 __global__ void __launch_bounds__(CG_FUSED_BOUNDS)
 decode_fused_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words,
-                        uint32_t waves_per_image, uint32_t images)
+                        uint32_t waves_per_image, uint32_t images, uint32_t *queue)
 {
-    fused_kernel_body<Wave422<false>>(descs, l2_in_lds, window_words, waves_per_image, images);
+    fused_kernel_body<Wave422<false>>(descs, l2_in_lds, window_words, waves_per_image, images, queue);
 }
 // The same for launches whose every restart interval is one MCU (BASELINE configs[4]: 8K, DRI = 1): consecutive lanes
 // hold consecutive MCUs, and the rows of sixteen of them leave in one piece of 1 KB (composite_row_from_wave).  A
 // kernel of its own: as a branch inside the one above the second exchange costs it two spilled registers.
 __global__ void __launch_bounds__(768)
 decode_fused_422_mcu_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words,
-                            uint32_t waves_per_image, uint32_t images)
+                            uint32_t waves_per_image, uint32_t images, uint32_t *queue)
 {
-    fused_kernel_body<Wave422<true>>(descs, l2_in_lds, window_words, waves_per_image, images);
+    fused_kernel_body<Wave422<true>>(descs, l2_in_lds, window_words, waves_per_image, images, queue);
 }
 // Extension layouts: decode_wave_fused_layout behind the plain prologue -- grid (workgroups per image,
 // images), no resident waves: inside the larger body above these kernels spill (4:2:0: 356 registers), alone they
@@ -792,7 +816,7 @@ hipError_t launch_fused_layout(const ImageDesc *descs, uint32_t images, uint32_t
 }
 
 hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t max_intervals,
-                            const HuffLdsPlan &plan, hipStream_t stream, bool uniform, bool one_mcu_intervals)
+                            const HuffLdsPlan &plan, hipStream_t stream, bool uniform, bool one_mcu_intervals, uint32_t *queue)
 {
     if (images == 0 || max_intervals == 0)
         return hipSuccess;
@@ -829,8 +853,24 @@ hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t ma
                                                 int(device_limits().lds_bytes));
     if (attr != hipSuccess)
         return attr;
+    const bool flat = grid.y == 1 && waves_per_image;
+    static const bool queue_allowed = [] {
+        const char *e = lab_env("COMPEG_QUEUE"); // experiment knob: 0 = every wave takes every stride-th unit
+        return e ? atoi(e) != 0 : true;
+    }();
+    // the units' queue: where the waves have more than one unit each, and units of more than one MCU a lane (with
+    // DRI = 1 the draw and the later request for the starts cost more than the sharing brings: 8 x 8K 0.426 against
+    // 0.397 ms; 256 x 4K DRI = 4 2.74 against 2.86, 300 x 720p 0.46 against 0.51, 256 x 1080p DRI = 6 0.84 against 0.91)
+    uint32_t *q = flat && queue_allowed && queue && !one_mcu_intervals && uint64_t(waves_per_image) * images > uint64_t(grid.x) * plan.waves_per_block
+                      ? queue
+                      : nullptr;
+    if (q) {
+        const hipError_t z = hipMemsetAsync(q, 0, sizeof(uint32_t), stream);
+        if (z != hipSuccess)
+            return z;
+    }
     hipLaunchKernelGGL(kernel, grid, dim3(threads), plan.total_bytes, stream, descs, plan.l2_entries_in_lds, plan.window_words,
-                       grid.y == 1 && waves_per_image ? waves_per_image : 0u, images);
+                       flat ? waves_per_image : 0u, images, q);
     return hipGetLastError();
 }
 

@@ -1887,6 +1887,7 @@ Status compeg_batch::decode(hipStream_t stream)
         }
         ev = events.data() + decodes_timed * 3;
     }
+    CG_TRY(unit_queue.reserve(256));
     const ImageDesc *dd = static_cast<const ImageDesc *>(dev_descs.ptr);
     const uint32_t n = uint32_t(count);
     const uint32_t step = chunk ? std::min(chunk, n) : n;
@@ -1936,7 +1937,7 @@ Status compeg_batch::decode(hipStream_t stream)
             else if (use_pair_kernel(max_intervals, m))
                 CG_HIP(launch_pair_422(dd + at, m, max_intervals, plan, stream));
             else
-                CG_HIP(launch_fused_422(dd + at, m, max_intervals, plan, stream, uniform, one_mcu_intervals));
+                CG_HIP(launch_fused_422(dd + at, m, max_intervals, plan, stream, uniform, one_mcu_intervals, static_cast<uint32_t *>(unit_queue.ptr)));
             if (at == 0)
                 last_kernel = coop.usable ? COMPEG_KERNEL_COOP_TEAM
                               : streamed  ? COMPEG_KERNEL_FUSED_STREAM
