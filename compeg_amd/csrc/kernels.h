@@ -49,7 +49,7 @@ StreamPlan plan_stream(uint32_t max_intervals, uint32_t images, uint32_t max_l2,
 bool stream_plan_preferred(const HuffLdsPlan &plan, uint32_t max_intervals, uint32_t images, uint32_t cu_waves = 0, uint32_t group_waves = 0);
 // (hs, vs: the luma sampling all images of the launch share: 2x1, or an extension layout's -- paired kernels for 1x1 / 1x2)
 hipError_t launch_fused_stream(const ImageDesc *descs, uint32_t images, uint32_t max_intervals, const StreamPlan &plan,
-                                   hipStream_t stream, uint32_t hs = 2, uint32_t vs = 1);
+                                   hipStream_t stream, uint32_t hs = 2, uint32_t vs = 1, uint32_t *queue = nullptr);
 // Extension layouts (luma hs x vs = 1x1, 1x2, 2x2), fused like the 4:2:2 kernel; plan with wave_cap = fused_layout_wave_cap.
 // pairs: (8-pixel MCUs) every image of the launch has an even restart interval -- a lane composites its MCUs two at a time
 uint32_t fused_layout_wave_cap(uint32_t hs, uint32_t vs, bool pairs);

@@ -422,7 +422,8 @@ decode_fused_420_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds,
 // (WAVE: a struct with the wave's body -- Wave422Stream, or WaveLayoutStream<HS, VS, MC> for the extension layouts)
 template <class WAVE>
 __device__ __forceinline__ void fused_stream_kernel_body(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t rows,
-                                                         uint32_t stage_after, uint32_t stage_below, uint32_t waves_per_image, uint32_t images)
+                                                         uint32_t stage_after, uint32_t stage_below, uint32_t waves_per_image, uint32_t images,
+                                                         uint32_t *queue)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x / kWave))), lane = threadIdx.x % kWave;
@@ -466,10 +467,14 @@ __device__ __forceinline__ void fused_stream_kernel_body(const ImageDesc *__rest
     }
     // The flat grid is no larger than what is resident at once; a wave goes on to further units of 64 intervals on its
     // own (rows and slots are its own, the tables are every image's): no CU waits for the slowest wave of a workgroup.
+    // (which units: drawn from the queue, if there is one, at a unit's start and looked at at its end -- see WindowAhead)
     const uint32_t stride = gridDim.x * (blockDim.x / kWave), units = waves_per_image * images;
     for (uint32_t flat = blockIdx.x * (blockDim.x / kWave) + wave;;) {
+        uint32_t drawn = 0u;
+        if (queue && lane == 0u)
+            drawn = atomicAdd(queue, 1u);
         WAVE::decode(descs[image], s, rows, stage_after, stage_below, wave_first + lane, lane);
-        flat += stride; // (wave-uniform)
+        flat = queue ? stride + uint32_t(__builtin_amdgcn_readfirstlane(int(drawn))) : flat + stride; // (wave-uniform)
         if (flat >= units)
             break;
         image = uint32_t(__builtin_amdgcn_readfirstlane(int(flat / waves_per_image)));
@@ -494,28 +499,28 @@ struct WaveLayoutStream {
 };
 __global__ void __launch_bounds__(768)
 decode_fused_422_stream_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t rows, uint32_t stage_after,
-                               uint32_t stage_below, uint32_t waves_per_image, uint32_t images)
+                               uint32_t stage_below, uint32_t waves_per_image, uint32_t images, uint32_t *queue)
 {
-    fused_stream_kernel_body<Wave422Stream>(descs, l2_in_lds, rows, stage_after, stage_below, waves_per_image, images);
+    fused_stream_kernel_body<Wave422Stream>(descs, l2_in_lds, rows, stage_after, stage_below, waves_per_image, images, queue);
 }
 // ... and of the extension layouts' kernels (4:4:4 / 4:4:0 in pairs -- even restart intervals --, 4:2:0)
 __global__ void __launch_bounds__(512)
 decode_fused_444_stream_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t rows, uint32_t stage_after,
-                               uint32_t stage_below, uint32_t waves_per_image, uint32_t images)
+                               uint32_t stage_below, uint32_t waves_per_image, uint32_t images, uint32_t *queue)
 {
-    fused_stream_kernel_body<WaveLayoutStream<1, 1, 2>>(descs, l2_in_lds, rows, stage_after, stage_below, waves_per_image, images);
+    fused_stream_kernel_body<WaveLayoutStream<1, 1, 2>>(descs, l2_in_lds, rows, stage_after, stage_below, waves_per_image, images, queue);
 }
 __global__ void __launch_bounds__(512)
 decode_fused_440_stream_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t rows, uint32_t stage_after,
-                               uint32_t stage_below, uint32_t waves_per_image, uint32_t images)
+                               uint32_t stage_below, uint32_t waves_per_image, uint32_t images, uint32_t *queue)
 {
-    fused_stream_kernel_body<WaveLayoutStream<1, 2, 2>>(descs, l2_in_lds, rows, stage_after, stage_below, waves_per_image, images);
+    fused_stream_kernel_body<WaveLayoutStream<1, 2, 2>>(descs, l2_in_lds, rows, stage_after, stage_below, waves_per_image, images, queue);
 }
 __global__ void __launch_bounds__(512)
 decode_fused_420_stream_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t rows, uint32_t stage_after,
-                               uint32_t stage_below, uint32_t waves_per_image, uint32_t images)
+                               uint32_t stage_below, uint32_t waves_per_image, uint32_t images, uint32_t *queue)
 {
-    fused_stream_kernel_body<WaveLayoutStream<2, 2, 1>>(descs, l2_in_lds, rows, stage_after, stage_below, waves_per_image, images);
+    fused_stream_kernel_body<WaveLayoutStream<2, 2, 1>>(descs, l2_in_lds, rows, stage_after, stage_below, waves_per_image, images, queue);
 }
 
 // Latency-oriented variant of the fused path for launches that cannot fill
@@ -963,11 +968,11 @@ StreamPlan plan_stream(uint32_t max_intervals, uint32_t images, uint32_t max_l2,
 }
 
 hipError_t launch_fused_stream(const ImageDesc *descs, uint32_t images, uint32_t max_intervals, const StreamPlan &plan,
-                                   hipStream_t stream, uint32_t hs, uint32_t vs)
+                                   hipStream_t stream, uint32_t hs, uint32_t vs, uint32_t *queue)
 {
     if (images == 0 || max_intervals == 0)
         return hipSuccess;
-    using Kernel = void (*)(const ImageDesc *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t);
+    using Kernel = void (*)(const ImageDesc *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t *);
     const Kernel kernel = hs == 2 && vs == 1   ? decode_fused_422_stream_kernel
                           : hs == 1 && vs == 1 ? decode_fused_444_stream_kernel
                           : hs == 1 && vs == 2 ? decode_fused_440_stream_kernel
@@ -989,8 +994,15 @@ hipError_t launch_fused_stream(const ImageDesc *descs, uint32_t images, uint32_t
                                                 int(device_limits().lds_bytes));
     if (attr != hipSuccess)
         return attr;
+    // the units' queue (launch_fused_422): where the resident waves have more than one unit each
+    uint32_t *q = flat && queue && flat_groups > grid.x && !lab_env("COMPEG_NO_QUEUE") ? queue : nullptr;
+    if (q) {
+        const hipError_t z = hipMemsetAsync(q, 0, sizeof(uint32_t), stream);
+        if (z != hipSuccess)
+            return z;
+    }
     hipLaunchKernelGGL(kernel, grid, dim3(threads), plan.total_bytes, stream, descs,
-                       plan.l2_entries_in_lds, plan.rows, plan.stage_after, plan.stage_below, flat ? plan.waves_per_image : 0u, images);
+                       plan.l2_entries_in_lds, plan.rows, plan.stage_after, plan.stage_below, flat ? plan.waves_per_image : 0u, images, q);
     return hipGetLastError();
 }
 

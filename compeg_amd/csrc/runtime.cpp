@@ -1910,7 +1910,7 @@ Status compeg_batch::decode(hipStream_t stream)
                 CG_HIP(launch_fused_stream(dd + at, m, max_intervals,
                                                plan_stream(max_intervals, m, max_l2, stream_mcu_words, uniform, kLayoutCuWaves,
                                                            fused_layout_wave_cap(layout_h, layout_v, mcu_pairs)),
-                                               stream, layout_h, layout_v));
+                                               stream, layout_h, layout_v, static_cast<uint32_t *>(unit_queue.ptr)));
             else
                 CG_HIP(launch_fused_layout(dd + at, m, max_intervals, plan, layout_h, layout_v, mcu_pairs, stream));
             if (timing && at == 0)
@@ -1933,7 +1933,8 @@ Status compeg_batch::decode(hipStream_t stream)
             if (coop.usable)
                 CG_HIP(launch_coop_422(dd + at, m, max_intervals, coop, stream));
             else if (streamed)
-                CG_HIP(launch_fused_stream(dd + at, m, max_intervals, plan_stream(max_intervals, m, max_l2, stream_mcu_words, uniform), stream));
+                CG_HIP(launch_fused_stream(dd + at, m, max_intervals, plan_stream(max_intervals, m, max_l2, stream_mcu_words, uniform), stream, 2, 1,
+                                           static_cast<uint32_t *>(unit_queue.ptr)));
             else if (use_pair_kernel(max_intervals, m))
                 CG_HIP(launch_pair_422(dd + at, m, max_intervals, plan, stream));
             else
