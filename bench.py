@@ -689,7 +689,8 @@ def main():
         if fused:
             # one kernel does the whole path; the event pair brackets exactly its launches
             name = {"fused": "decode_fused_422_mcu_kernel" if args.ri == 1 else "decode_fused_422_kernel",
-                    "fused_stream": "decode_fused_422_stream_kernel",
+                    "fused_stream": {(1, 1): "decode_fused_444_stream_kernel", (1, 2): "decode_fused_440_stream_kernel",
+                                     (2, 2): "decode_fused_420_stream_kernel"}.get(args.sampling_hv, "decode_fused_422_stream_kernel"),
                     "pair": "decode_pair_422_kernel", "coop_team": "decode_coop_team_422_kernel",
                     "fused_layout": {(1, 1): "decode_fused_444_kernel", (1, 2): "decode_fused_440_kernel",
                                      (2, 2): "decode_fused_420_kernel"}.get(args.sampling_hv, "decode_fused_layout_kernel")}[which]
