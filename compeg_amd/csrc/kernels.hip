@@ -183,8 +183,8 @@ struct WindowAhead {
     uint32_t window_words, lane;
     uint32_t *win;
     uint32_t raw_base, raw_end, base, len, sink;
-    uint32_t *queue;     // null: `next` is known from the start
-    uint32_t next, drawn, stride, units, waves_per_image;
+    uint32_t *queue;     // null: `next` is known from the start (and with a queue: inside a group of units drawn together)
+    uint32_t next, drawn, stride, units, waves_per_image, group;
 
     __device__ __forceinline__ void at(uint32_t du, uint32_t du_total)
     {
@@ -192,7 +192,8 @@ struct WindowAhead {
             if (du == 0u && lane == 0u)
                 drawn = atomicAdd(queue, 1u);
             if (du == 1u) {
-                next = stride + uint32_t(__builtin_amdgcn_readfirstlane(int(drawn))); // (the units below stride: the waves' first)
+                // (the groups below stride: the waves' first)
+                next = (stride + uint32_t(__builtin_amdgcn_readfirstlane(int(drawn)))) * group;
                 any = next < units;
                 if (any) {
                     image = uint32_t(__builtin_amdgcn_readfirstlane(int(next / waves_per_image)));
@@ -243,16 +244,20 @@ struct WindowAhead {
 // wave works from its own image's descriptor; the LUTs are staged from whichever images the workgroup's
 // threads belong to -- the same bytes), and only the batch's last workgroup is short.
 // (LAYOUT: a struct with the wave's body: Wave422 -- the reference's 4:2:2 -- or WaveLayout<HS, VS>, the extension layouts)
-template <class LAYOUT>
+// (GROUP: units a wave draws from the queue at a time)
+template <class LAYOUT, uint32_t GROUP>
 __device__ __forceinline__ void fused_kernel_body(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words,
                                                   uint32_t waves_per_image, uint32_t images, uint32_t *queue)
 {
+    constexpr uint32_t group = GROUP;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x / kWave))), lane = threadIdx.x % kWave;
     uint32_t image = blockIdx.y, wave_first = (blockIdx.x * (blockDim.x / kWave) + wave) * kWave;
     bool has_work = true;
     if (waves_per_image) {
-        const uint32_t flat = blockIdx.x * (blockDim.x / kWave) + wave; // wave-uniform
+        // (with a queue a wave's units come in groups of `group` consecutive ones -- short units, DRI = 1 --: its first
+        // group is the one of its place in the grid)
+        const uint32_t flat = (blockIdx.x * (blockDim.x / kWave) + wave) * (queue ? group : 1u); // wave-uniform
         image = flat / waves_per_image;
         wave_first = (flat % waves_per_image) * kWave;
         has_work = image < images;
@@ -286,7 +291,8 @@ __device__ __forceinline__ void fused_kernel_body(const ImageDesc *__restrict__ 
     // no CU waiting for the slowest wave of a workgroup between two units -- a wave stages its next window itself
     // (WindowAhead).
     const uint32_t stride = gridDim.x * (blockDim.x / kWave), units = waves_per_image * images;
-    uint32_t flat = blockIdx.x * (blockDim.x / kWave) + wave;
+    const uint32_t per_draw = waves_per_image && queue ? group : 1u;
+    uint32_t flat = (blockIdx.x * (blockDim.x / kWave) + wave) * per_draw;
     for (;;) {
         const ImageDesc &d = descs[image];
         HuffShared s;
@@ -297,15 +303,19 @@ __device__ __forceinline__ void fused_kernel_body(const ImageDesc *__restrict__ 
         s.win_base = win_base;
         s.win_len = win_len;
         s.du_slots = slots;
-        flat += stride; // (wave-uniform)
+        // the next unit: the one behind this inside a group, else drawn (WindowAhead) or, without a queue, every stride-th
+        // (groups begin at multiples of their size: the place inside one is the unit's index modulo that)
+        const bool draw = waves_per_image && queue && flat % per_draw == per_draw - 1u;
+        flat += waves_per_image && queue ? 1u : stride; // (wave-uniform; drawn: overwritten below)
         WindowAhead ahead;
         ahead.descs = descs;
-        ahead.queue = waves_per_image ? queue : nullptr;
+        ahead.queue = draw ? queue : nullptr;
         ahead.stride = stride;
         ahead.units = units;
         ahead.waves_per_image = waves_per_image;
+        ahead.group = per_draw;
         ahead.next = ahead.drawn = 0u;
-        ahead.any = waves_per_image && !ahead.queue && flat < units;
+        ahead.any = waves_per_image && !draw && flat < units;
         ahead.image = ahead.first = 0u;
         if (ahead.any) {
             ahead.image = uint32_t(__builtin_amdgcn_readfirstlane(int(flat / waves_per_image)));
@@ -318,12 +328,17 @@ __device__ __forceinline__ void fused_kernel_body(const ImageDesc *__restrict__ 
         LAYOUT::decode(d, s, wave_first + lane, lane, ahead);
         if (!ahead.any)
             break;
+        if (draw)
+            flat = ahead.next;
         image = ahead.image;
         wave_first = ahead.first;
         win_base = ahead.base;
         win_len = ahead.len;
     }
 }
+
+// units of one MCU a lane (DRI = 1) are drawn from the queue four at a time (launch_fused_422)
+constexpr uint32_t kMcuQueueGroup = 4;
 
 template <bool WIDE>
 struct Wave422 {
@@ -340,7 +355,7 @@ __global__ void __launch_bounds__(CG_FUSED_BOUNDS)
 decode_fused_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words,
                         uint32_t waves_per_image, uint32_t images, uint32_t *queue)
 {
-    fused_kernel_body<Wave422<false>>(descs, l2_in_lds, window_words, waves_per_image, images, queue);
+    fused_kernel_body<Wave422<false>, 1>(descs, l2_in_lds, window_words, waves_per_image, images, queue);
 }
 // The same for launches whose every restart interval is one MCU (BASELINE configs[4]: 8K, DRI = 1): consecutive lanes
 // hold consecutive MCUs, and the rows of sixteen of them leave in one piece of 1 KB (composite_row_from_wave).  A
@@ -349,7 +364,7 @@ __global__ void __launch_bounds__(768)
 decode_fused_422_mcu_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words,
                             uint32_t waves_per_image, uint32_t images, uint32_t *queue)
 {
-    fused_kernel_body<Wave422<true>>(descs, l2_in_lds, window_words, waves_per_image, images, queue);
+    fused_kernel_body<Wave422<true>, kMcuQueueGroup>(descs, l2_in_lds, window_words, waves_per_image, images, queue);
 }
 // Extension layouts: decode_wave_fused_layout behind the plain prologue -- grid (workgroups per image,
 // images), no resident waves: inside the larger body above these kernels spill (4:2:0: 356 registers), alone they
@@ -863,10 +878,11 @@ hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t ma
         const char *e = lab_env("COMPEG_QUEUE"); // experiment knob: 0 = every wave takes every stride-th unit
         return e ? atoi(e) != 0 : true;
     }();
-    // the units' queue: where the waves have more than one unit each, and units of more than one MCU a lane (with
-    // DRI = 1 the draw and the later request for the starts cost more than the sharing brings: 8 x 8K 0.426 against
-    // 0.397 ms; 256 x 4K DRI = 4 2.74 against 2.86, 300 x 720p 0.46 against 0.51, 256 x 1080p DRI = 6 0.84 against 0.91)
-    uint32_t *q = flat && queue_allowed && queue && !one_mcu_intervals && uint64_t(waves_per_image) * images > uint64_t(grid.x) * plan.waves_per_block
+    // The units' queue: where the waves have more than one draw each.  Units of one MCU a lane (DRI = 1) are drawn four
+    // at a time: one by one the draw and the later request for the starts cost more than the sharing brings (8 x 8K:
+    // 0.426 against 0.397 ms without a queue; 256 x 4K DRI = 4 2.74 against 2.86, 300 x 720p 0.46 against 0.51).
+    const uint32_t group = one_mcu_intervals && wide_allowed ? kMcuQueueGroup : 1u;
+    uint32_t *q = flat && queue_allowed && queue && uint64_t(waves_per_image) * images > uint64_t(grid.x) * plan.waves_per_block * group
                       ? queue
                       : nullptr;
     if (q) {
