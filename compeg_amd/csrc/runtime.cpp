@@ -937,6 +937,8 @@ compeg_batch::~compeg_batch()
         (void)hipStreamSynchronize(c);
     for (hipEvent_t e : events)
         (void)hipEventDestroy(e);
+    if (decode_done)
+        (void)hipEventDestroy(decode_done);
     if (gpu)
         compeg_gpu_release(gpu);
 }
@@ -1888,6 +1890,12 @@ Status compeg_batch::decode(hipStream_t stream)
         ev = events.data() + decodes_timed * 3;
     }
     CG_TRY(unit_queue.reserve(256));
+    // One batch, one set of device buffers and one units' queue: a decode recorded on another stream than the
+    // previous one waits for that one (two launches drawing from one queue would each decode part of the units).
+    if (!decode_done)
+        CG_HIP(hipEventCreateWithFlags(&decode_done, hipEventDisableTiming));
+    if (decode_recorded && stream != last_stream)
+        CG_HIP(hipStreamWaitEvent(stream, decode_done, 0));
     const ImageDesc *dd = static_cast<const ImageDesc *>(dev_descs.ptr);
     const uint32_t n = uint32_t(count);
     const uint32_t step = chunk ? std::min(chunk, n) : n;
@@ -1957,6 +1965,8 @@ Status compeg_batch::decode(hipStream_t stream)
         CG_HIP(hipEventRecord(ev[2], stream));
         decodes_timed++;
     }
+    CG_HIP(hipEventRecord(decode_done, stream));
+    decode_recorded = true;
     last_stream = stream;
     return Status{};
 }

@@ -132,6 +132,8 @@ struct compeg_batch {
     compeg::DeviceBuffer dev_descs, inputs, ac, dc, out;
     compeg::DeviceBuffer walk_tables; // the cooperative kernel's (kernels.h), made at upload when it may run
     compeg::DeviceBuffer unit_queue;  // the counter a uniform launch's resident waves draw their units from (kernels.h)
+    hipEvent_t decode_done = nullptr; // behind the last decode (one on another stream waits for it)
+    bool decode_recorded = false;
     compeg::Status make_walk_tables(hipStream_t stream, size_t n); // (behind the descriptors' upload; n images)
     compeg::PinnedBuffer stage; // host copy of the input arena (kept between uploads: pinning is slow)
     std::vector<size_t> out_offset;

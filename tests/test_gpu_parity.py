@@ -639,6 +639,19 @@ batch.decode(stream.cuda_stream)
 with torch.cuda.stream(stream):
     bview = torch.as_tensor(batch.output(0), device="cuda")
     assert np.array_equal(bview.cpu().numpy(), want)
+# a uniform batch with more units than resident waves (they draw their units from the batch's queue), decoded on two
+# streams in a row: the second decode waits for the first, each is whole
+frames = [synth.make_jpeg(960, 540, seed=410 + i, ri=2) for i in range(4)]
+big = ca.Batch(g)
+big.upload([ca.ImageData(frames[i %% 4]) for i in range(104)])
+other = torch.cuda.Stream()
+big.decode(stream.cuda_stream)
+big.decode(other.cuda_stream)
+other.synchronize()
+assert big.last_kernel() == "fused"
+wants = [orc.ImageData(j).decode() for j in frames]
+for i in (0, 1, 50, 103):
+    assert np.array_equal(torch.as_tensor(big.output(i), device="cuda").cpu().numpy(), wants[i %% 4])
 print("zero-copy ok")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
