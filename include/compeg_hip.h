@@ -234,7 +234,8 @@ void compeg_batch_free(compeg_batch *batch);
 int compeg_batch_upload(compeg_batch *batch, const compeg_image *const *images, size_t count,
                         int host_threads);
 /* Records the decode of every uploaded image on hip_stream (NULL = the gpu's
- * stream) and returns without waiting. */
+ * stream) and returns without waiting.  Decodes of one batch recorded on different
+ * streams are ordered one behind the other (the batch's device buffers are one set). */
 /* The same from JPEG bytes (host-fed use): `ImageData::new` for every image -- on the worker threads, it walks the
  * whole entropy-coded segment -- then what compeg_batch_upload does.  flags: COMPEG_PARSE_*.  The bytes are
  * borrowed until the call returns.  An image the front-end rejects fails the whole call with its error text,
