@@ -663,6 +663,12 @@ idct_composite_kernel(const ImageDesc *__restrict__ descs)
     composite_422(d, wave_px, first_mcu, total_mcus, lane);
 }
 
+#if defined(CG_STREAM_DEBUG)
+hipError_t read_stream_debug(unsigned long long out[4])
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stream_debug), sizeof(unsigned long long) * 4);
+}
+#endif
 #if defined(CG_AC_STAMPS)
 hipError_t read_ac_stamps(unsigned long long out[4], bool reset)
 {
@@ -938,12 +944,16 @@ StreamPlan plan_stream(uint32_t max_intervals, uint32_t images, uint32_t max_l2,
     // leave a CU its twelve waves (or all but one of them); where none does (10 bit per pixel), every MCU and at most 64
     // rows.  (256 x 960x720, DRI = 10, ms per launch by step: 1.7 bit per pixel 0.361 / 0.370 / 0.381; 4.6 bit 1.04 /
     // 1.08 / 0.73; 10 bit 1.48 / 1.54 / 1.62.)
-    const uint32_t most_rows = ((lim.lds_bytes - groups_per_cu * tables) / cu_waves - kWave * kDuSlotBytes) / (kWave * 4u);
+    // (several workgroups to a CU: a little less than the arithmetic says -- three of 54 272 bytes did not share a CU)
+    const uint32_t lds_room = lim.lds_bytes - (groups_per_cu > 1u ? groups_per_cu * 2048u : 0u);
+    const uint32_t most_rows = ((lds_room - groups_per_cu * tables) / cu_waves - kWave * kDuSlotBytes) / (kWave * 4u);
     const uint32_t need[3] = {3u * mcu_words + 4u, 3u * ((7u * mcu_words + 9u) / 10u) + 4u, 3u * ((9u * mcu_words + 19u) / 20u) + 4u};
     uint32_t step = need[0] <= most_rows ? 0u : (need[1] <= most_rows ? 1u : (need[2] <= most_rows + 6u ? 2u : 0u));
     if (const char *e = lab_env("COMPEG_STREAM_STEP")) // experiment knob: 0 / 1 / 2
         step = uint32_t(std::max(0, std::min(2, atoi(e))));
     uint32_t rows = std::max(12u, std::min(64u, need[step]));
+    if (groups_per_cu > 1u)
+        rows = std::min(rows, std::max(12u, most_rows)); // (so that the workgroups do share the CU)
     if (const char *e = lab_env("COMPEG_STREAM_ROWS")) // experiment knob
         rows = uint32_t(std::max(4, std::min(128, atoi(e))));
     p.stage_after = step == 0u ? 0x8u : (step == 1u ? 0xau : 0xfu);
@@ -959,7 +969,7 @@ StreamPlan plan_stream(uint32_t max_intervals, uint32_t images, uint32_t max_l2,
     // Waves per workgroup: one CU's share of the launch (a launch smaller than the chip spreads over all of its CUs:
     // 256 frames of 960x720 with DRI = 30 are 768 waves), at most what the LDS holds and twelve; the per-image grid
     // never more than an image has.  (Workgroups smaller than the share, two to a CU, measured no better.)
-    const uint32_t fit = std::max(1u, (lim.lds_bytes / groups_per_cu - tables) / wave_area);
+    const uint32_t fit = std::max(1u, (lds_room / groups_per_cu - tables) / wave_area);
     uint32_t best = uint32_t(std::min<uint64_t>(std::max<uint64_t>((total_waves + lim.cus - 1) / lim.cus, 1u), std::min(fit, group_waves)));
     if (!uniform)
         best = std::min(best, std::max(1u, waves_per_image));
@@ -968,7 +978,7 @@ StreamPlan plan_stream(uint32_t max_intervals, uint32_t images, uint32_t max_l2,
     // With LDS to spare at that size, more rows: the stagings get rarer by as much as they get larger, and every
     // one of them waits for the stores in front of it (sparse streams, short MCU steps -- 256 x 1080p q50 DRI = 16:
     // 0.90 ms with 12 rows, 0.83 with the 27 that fit).
-    const uint32_t spare_rows = best ? ((lim.lds_bytes / groups_per_cu - tables) / best - kWave * kDuSlotBytes) / (kWave * 4u) : rows;
+    const uint32_t spare_rows = best ? ((lds_room / groups_per_cu - tables) / best - kWave * kDuSlotBytes) / (kWave * 4u) : rows;
     if (!lab_env("COMPEG_STREAM_ROWS") && spare_rows > rows)
         rows = std::min(64u, spare_rows);
     const uint32_t area = rows * kWave * 4u + kWave * kDuSlotBytes;

@@ -295,7 +295,7 @@ def test_single_large_frame_with_long_intervals_takes_the_streamed_windows(ca, g
     """One 8K frame with DRI = 32: too many data units for the cooperative kernel, 64 intervals too long for a
     whole-interval window -- the decoder's launch goes to decode_fused_422_stream_kernel, with the host's
     preprocessing and with the device's (word counts patched into the descriptor behind the launch's planning)."""
-    jpeg = synth.make_jpeg(7680, 4320, seed=71, ri=32, quality=75)
+    jpeg = synth.make_jpeg(7680, 4320, seed=71, ri=32, quality=75, kind=0)
     want = orc.ImageData(jpeg).decode()
     data = ca.ImageData(jpeg)
     for device in (False, True):
@@ -341,10 +341,13 @@ def test_batch_kernel_with_streamed_windows(ca, gpu, ri, uniform):
     go to decode_fused_422_stream_kernel: every lane's stream staged MCU by MCU.  Frames of one stream (the flat
     grid) and mixed images (a grid row per image; ragged edges, a corrupt scan among them)."""
     if uniform:
-        jpegs = [synth.make_jpeg(960, 720, seed=900 + i + ri, kind=i % 3, quality=85, ri=ri) for i in range(96)]
+        # (kind 0: photograph-like, 1.7 bit per pixel -- streams beyond 3 bit per pixel keep whole-interval windows)
+        # (DRI = 10: whole windows would still fit -- six waves a CU --, the launch has to want more than that)
+        frames = [synth.make_jpeg(960, 720, seed=900 + i + ri, kind=0, quality=85, ri=ri) for i in range(32)]
+        jpegs = [frames[i % 32] for i in range(320 if ri == 10 else 96)]
     else:
         shapes = [(1000, 1000), (1016, 990), (936, 1004), (1280, 720)]
-        jpegs = [synth.make_jpeg(w, h, seed=950 + i + ri, kind=i % 3, quality=(70, 85, 95)[i % 3], ri=ri)
+        jpegs = [synth.make_jpeg(w, h, seed=950 + i + ri, kind=0, quality=(70, 85, 90)[i % 3], ri=ri)
                  for i, (w, h) in enumerate(shapes * 30)]
         bad = bytearray(jpegs[5])
         at = bad.find(b"\xff\xda") + 14
@@ -517,9 +520,10 @@ def test_extension_layouts_with_streamed_windows(ca, gpu, sampling):
     """The extension layouts' kernels in their streamed form (decode_fused_444 / _440 / _420_stream_kernel): long
     restart intervals and dense streams, where whole-interval windows cost a CU its waves -- a uniform batch (flat
     grid), a mixed-size one with a corrupt scan (a grid row per image), one large frame through the Decoder."""
-    uniform = [synth.make_jpeg(960, 720, seed=700 + i, kind=i % 3, quality=85, ri=16, sampling=sampling) for i in range(64)]
+    frames = [synth.make_jpeg(960, 720, seed=700 + i, kind=0, quality=85, ri=16, sampling=sampling) for i in range(16)]
+    uniform = [frames[i % 16] for i in range(240)]   # (a launch that wants more waves a CU than whole windows leave it)
     shapes = [(1000, 600), (1016, 590), (936, 604), (1280, 720)]
-    mixed = [synth.make_jpeg(w, h, seed=760 + i, kind=i % 3, quality=(85, 95)[i % 2], ri=(8, 16, 40)[i % 3], sampling=sampling)
+    mixed = [synth.make_jpeg(w, h, seed=760 + i, kind=0, quality=(75, 85)[i % 2], ri=(8, 16, 40)[i % 3], sampling=sampling)
              for i, (w, h) in enumerate(shapes * 16)]
     bad = bytearray(mixed[3])
     at = bad.find(b"\xff\xda") + 14
@@ -539,7 +543,7 @@ def test_extension_layouts_with_streamed_windows(ca, gpu, sampling):
         assert batch.last_kernel() == "fused_stream"
         for i in list(range(0, len(jpegs), 9)) + [3, len(jpegs) - 1]:
             _assert_equal(batch.read_output(i), orc.ImageData(jpegs[i], allow_sampling=True).decode())
-    big = synth.make_jpeg(3840, 2160, seed=799, quality=90, ri=48, sampling=sampling)
+    big = synth.make_jpeg(3840, 2160, seed=799, quality=85, ri=48, sampling=sampling)
     dec = ca.Decoder(gpu)
     dec.decode_blocking(ca.ImageData(big, allow_sampling=True))
     assert dec.last_kernel() == "fused_stream"

@@ -68,6 +68,21 @@ def run(seed=77, batches=40, log=print):
         mode = int(rng.integers(0, 3)) if ext > 2 else 0   # (device preprocessing of a batch: 4:2:2 only)
         as_bytes = bool(rng.integers(0, 2))
         where = int(rng.integers(0, 3)) if as_bytes else 0   # the bytes: pageable, page-locked (the copy-free road), every other one
+        threads = int(rng.choice([1, 4, 8]))
+        only = os.environ.get("FUZZ_ONLY")   # (replaying one batch of a seed: everything drawn, nothing else run)
+        if only is not None and it != int(only):
+            continue
+        if only is not None and os.environ.get("FUZZ_DUMP"):
+            import pickle
+            uniq = {}
+            for j, _ in items:
+                uniq.setdefault(j, len(uniq))
+            with open(os.environ["FUZZ_DUMP"], "wb") as f:
+                pickle.dump({"jpegs": list(uniq), "order": [uniq[j] for j, _ in items], "mode": mode, "as_bytes": as_bytes, "where": where,
+                             "threads": threads}, f)
+        if only is not None:
+            log("batch", it, "images", len(items), "first", items[0][1].shape, "mode", mode, "as bytes", as_bytes, "where", where, "threads", threads,
+                "ri0", ri0, "ext", ext, "same", same)
         batch = ca.Batch(gpu)
         batch.set_device_preprocess(mode)
         pinned = None
@@ -77,9 +92,9 @@ def run(seed=77, batches=40, log=print):
                 pinned = ca.HostBuffer(sum(len(j) + 64 for j in srcs))
                 views = pinned.place(srcs)
                 srcs = views if where == 1 else [v if i % 2 else j for i, (v, j) in enumerate(zip(views, srcs))]
-            batch.upload_jpegs(srcs, host_threads=int(rng.choice([1, 4, 8])), allow_sampling=True)
+            batch.upload_jpegs(srcs, host_threads=threads, allow_sampling=True)
         else:
-            batch.upload([ca.ImageData(j, allow_sampling=True) for j, _ in items], host_threads=int(rng.choice([1, 4, 8])))
+            batch.upload([ca.ImageData(j, allow_sampling=True) for j, _ in items], host_threads=threads)
         for rep in range(2):
             batch.decode()
             batch.wait()
