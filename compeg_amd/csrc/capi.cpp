@@ -558,12 +558,6 @@ int compeg_decoder_read_coefficients(compeg_decoder *dec, int32_t *host, size_t 
     });
 }
 
-#if defined(CG_STREAM_DEBUG)
-extern "C" __attribute__((visibility("default"))) int compeg_debug_stream(unsigned long long *out)
-{
-    return compeg::read_stream_debug(out) == hipSuccess ? 0 : -1;
-}
-#endif
 #if defined(CG_AC_STAMPS)
 extern "C" __attribute__((visibility("default"))) int compeg_debug_ac_stamps(unsigned long long *out, int reset)
 {

@@ -92,8 +92,5 @@ hipError_t launch_generic_composite(const ImageDesc *descs, uint32_t images, uin
 // diagnostic build: AC-loop cycle counters (kernels_body.h)
 hipError_t read_ac_stamps(unsigned long long out[4], bool reset);
 #endif
-#if defined(CG_STREAM_DEBUG)
-hipError_t read_stream_debug(unsigned long long out[4]); // diagnostic build: stream_stage_rows' counters
-#endif
 
 } // namespace compeg

@@ -663,12 +663,6 @@ idct_composite_kernel(const ImageDesc *__restrict__ descs)
     composite_422(d, wave_px, first_mcu, total_mcus, lane);
 }
 
-#if defined(CG_STREAM_DEBUG)
-hipError_t read_stream_debug(unsigned long long out[4])
-{
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stream_debug), sizeof(unsigned long long) * 4);
-}
-#endif
 #if defined(CG_AC_STAMPS)
 hipError_t read_ac_stamps(unsigned long long out[4], bool reset)
 {

@@ -1098,11 +1098,7 @@ CG_DEV void stream_leave_inside(EntropyState &e, const ImageDesc &d, const HuffS
     r.next_word = stream_word_index(e, s, lane);
     r.pre = fetch_word_pf<false>(d, s, r.next_word);
     e.fast = false;
-#if defined(CG_STREAM_RESUME)
     e.resume = true;
-#else
-    e.resume = false;
-#endif
 }
 
 // Branch-free top-up: merges the stream word in flight when fewer than 32
@@ -1820,79 +1816,29 @@ CG_DEV bool wave_any(bool v)
 // (EntropyState); a lane that reaches its last row inside a data unit finishes it, and the MCU, with the reference
 // reader from global memory and is back in fast mode with the next rows.
 
-// Row j of `rows` := word `first + j` of every lane's stream, j < nrows (asynchronous on the device: vmcnt).
+// Row j of `rows` := word `first + j` of every lane's stream, j < nrows.
 // (first <= d.nwords; the words behind an image's last are readable -- runtime.cpp pads its buffers -- and never used)
 //
-// On the device: LDS-DMA, one global_load_lds_dword a row (per-lane source, the wave's 64 words to M0 + offset + 4 lane).
-// M0 has to stay as it is until the load has left the wave's queue, which with 64 scattered lanes a load can be a long
-// time after its issue (found by the GPU fuzz: with M0 set and put back around every load, whole waves read rows that
-// had gone elsewhere, the more the more rows).  So: sixteen rows to one M0, told apart by the instruction's offset --
-// which moves source and destination alike: row j's source address is 252 j short of where it would be, against an
-// address base moved down by 4096 --, and a full wait in front of every further sixteen.  M0 stays behind changed:
-// nothing else in these kernels uses it (tests/test_code_objects.py looks).
-#if defined(__HIP_DEVICE_COMPILE__)
-#define CG_GLDS_ROW(J) \
-    "global_load_lds_dword %[voff], %[base] offset:" #J "*256\n\t" \
-    "s_cmp_eq_u32 %[n], " #J "+1\n\t" \
-    "s_cbranch_scc1 9f\n\t" \
-    "v_add_u32 %[voff], 0xffffff04, %[voff]\n\t"
-#endif
-#if defined(CG_STREAM_DEBUG) && defined(__HIPCC__)
-__device__ unsigned long long g_stream_debug[4]; // diagnostic build: [0] stagings, [1] of them with lanes switched off
-#endif
+// Through registers: loads, then LDS writes.  The first form fetched the rows by LDS-DMA (global_load_lds_dword: no
+// registers, landing under the IDCT) and was as fast, not faster (256 x 960x720 DRI = 10: 0.351 ms this way, 0.359
+// that way); in dense streams the GPU fuzz found a few images in a thousand wrong with it, other ones on every run,
+// and none with this -- with M0 held still per sixteen rows, the in-flight count under its six bits and a stand-alone
+// stress of the staging clean, the cause was not found (profiles/r03/NOTES.md).
 CG_DEV void stream_stage_rows(const ImageDesc &d, uint32_t *rows, uint32_t nrows, uint32_t first, uint32_t lane)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    (void)lane;
-#if defined(CG_STREAM_DEBUG)
-    {
-        const unsigned long long ex = __builtin_amdgcn_read_exec();
-        if (__builtin_amdgcn_mbcnt_hi(unsigned(ex >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(ex), 0u)) == 0u) {
-            atomicAdd(&g_stream_debug[0], 1ull);
-            if (ex != ~0ull)
-                atomicAdd(&g_stream_debug[1], 1ull);
-        }
-    }
-#endif
-    // (the wave's count of vector memory operations in flight has six bits: the composite's 32 stores may still be there)
-#if defined(CG_STAGE_DRAIN)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#else
-    asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
-#endif
-    const uint8_t *base = reinterpret_cast<const uint8_t *>(d.words) - 4096;
-    uint32_t m0 = uint32_t(reinterpret_cast<uintptr_t>(rows));
-#pragma unroll 1
-    for (uint32_t j = 0; j < nrows; j += 16u) {
-        uint32_t voff = (first + j) * 4u + 4096u, n = umin(16u, nrows - j);
-        if (j)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the loads that still need the old M0)
-        asm volatile("s_mov_b32 m0, %[m0]\n\t"
-                     "s_nop 0\n\t" //
-                     CG_GLDS_ROW(0) CG_GLDS_ROW(1) CG_GLDS_ROW(2) CG_GLDS_ROW(3) CG_GLDS_ROW(4) CG_GLDS_ROW(5) CG_GLDS_ROW(6)
-                         CG_GLDS_ROW(7) CG_GLDS_ROW(8) CG_GLDS_ROW(9) CG_GLDS_ROW(10) CG_GLDS_ROW(11) CG_GLDS_ROW(12)
-                             CG_GLDS_ROW(13) CG_GLDS_ROW(14) CG_GLDS_ROW(15) "9:"
-                     : [voff] "+v"(voff)
-                     : [m0] "s"(m0), [base] "s"(base), [n] "s"(n)
-                     : "memory", "scc");
-        m0 += 16u * uint32_t(kWave) * 4u;
-    }
+    auto *words = CG_GLOBAL(const uint32_t, d.words);
+#pragma unroll 8
+    for (uint32_t j = 0; j < nrows; j++)
+        CG_LDS(uint32_t, rows)[j * uint32_t(kWave) + lane] = words[first + j];
 #else
     for (uint32_t j = 0; j < nrows; j++)
         rows[j * uint32_t(kWave) + lane] = first + j < d.nwords ? d.words[first + j] : 0xfeedf00du;
 #endif
 }
 
-CG_DEV void stream_rows_landed()
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-#if defined(CG_LANDED_EXTRA)
-    asm volatile("s_waitcnt vmcnt(0)\n\t" CG_LANDED_EXTRA ::: "memory");
-#else
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-#endif
-}
+// (the LDS-DMA form waited here for its rows; kept as the place where a staging is complete)
+CG_DEV void stream_rows_landed() {}
 
 // The lane's rows anew from the word it has in flight; lanes in fast mode go on in it, lanes that left it for want
 // of rows come back (at a data unit's boundary the reference reader's state is a fast-mode state), lanes whose reader
@@ -1908,11 +1854,6 @@ CG_DEV void stream_restage(EntropyState &e, const ImageDesc &d, const HuffShared
         e.r.pre = word < d.nwords ? CG_GLOBAL(const uint32_t, d.words)[word] : 0u;
     }
     stream_stage_rows(d, const_cast<uint32_t *>(s.win), nrows, first, lane);
-    // Back to fast mode only from the state stream_lane_init leaves (an interval's first rows).  Coming back in the
-    // middle of an interval -- lanes that ran out of rows inside a data unit -- is written and passes the emulation,
-    // but on the GPU the fuzz found whole waves wrong after it in dense streams (8 bit per pixel), a few images in
-    // 1463, not the same ones twice; without it none.  Until that is understood such a lane stays with the reference
-    // reader to its interval's end: stream_leave_inside does not set e.resume (-DCG_STREAM_RESUME: it does, for the search).
     const bool back = !e.fast && e.resume && e.r.left < 64u; // (>= 2^31: the reference reader has underflowed since)
     if (back) {
         e.ref_left = e.r.left;

@@ -128,15 +128,6 @@ bool use_pair_kernel(uint32_t max_intervals, uint32_t images)
 // look at where a scan ends (up to 64 words beyond its last; never used).
 constexpr size_t kStreamSlackBytes = 1024;
 
-// Streams the streamed-window kernels are not given: beyond 12 words an MCU (about 3 bit per pixel with 4:2:2).  In
-// dense streams -- lanes reaching their last staged row inside data units all the time -- the GPU fuzz found a batch
-// (1463 frames of 640x360, 5-8 bit per pixel) in which a few images in a thousand come out wrong, not the same ones
-// twice; the staging itself holds under a stress test and the emulation passes, the cause is not found
-// (profiles/r03/NOTES.md).  Until it is, such streams keep whole-interval windows: slower, right.
-constexpr uint32_t kStreamMostMcuWords = 12;
-// (the same density for the extension layouts' MCUs of 64, 128 or 256 pixels)
-uint32_t stream_most_mcu_words(uint32_t hs, uint32_t vs) { return kStreamMostMcuWords * hs * vs / 2u; }
-
 bool use_stream_kernel(const HuffLdsPlan &plan, uint32_t max_intervals, uint32_t images, uint32_t cu_waves = 0, uint32_t group_waves = 0)
 {
     static const int forced = [] {
@@ -781,7 +772,6 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
         // extension layouts (4:4:4, 4:4:0, 4:2:0): one fused kernel per layout (the development pipeline keeps the
         // two-kernel route: entropy stage with the IDCT in place, generic composite)
         if (use_fused_pipeline() && layout_has_stream_kernel(luma_h, luma_v, mcu_pairs) &&
-            img.scan_len / 4u <= uint64_t(stream_most_mcu_words(luma_h, luma_v)) * md.total_restart_intervals * std::max(1u, uint32_t(md.restart_interval)) &&
             use_stream_kernel(plan, md.total_restart_intervals, 1, kLayoutCuWaves, fused_layout_wave_cap(luma_h, luma_v, mcu_pairs))) {
             const uint64_t mcus = std::max<uint64_t>(1u, uint64_t(md.total_restart_intervals) * std::max(1u, uint32_t(md.restart_interval)));
             const StreamPlan sp = plan_stream(md.total_restart_intervals, 1, staged_lut_entries(img), uint32_t((img.scan_len / 4u + mcus - 1u) / mcus),
@@ -825,8 +815,7 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
             }
             CG_HIP(launch_coop_422(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals, coop, stream));
             last_kernel = COMPEG_KERNEL_COOP_TEAM;
-        } else if (img.scan_len / 4u <= uint64_t(kStreamMostMcuWords) * md.total_restart_intervals * std::max(1u, uint32_t(md.restart_interval)) &&
-                   use_stream_kernel(plan, md.total_restart_intervals, 1)) {
+        } else if (use_stream_kernel(plan, md.total_restart_intervals, 1)) {
             const uint64_t mcus = std::max<uint64_t>(1u, uint64_t(md.total_restart_intervals) * std::max(1u, uint32_t(md.restart_interval)));
             const StreamPlan sp = plan_stream(md.total_restart_intervals, 1, staged_lut_entries(img),
                                               uint32_t((img.scan_len / 4u + mcus - 1u) / mcus), true);
@@ -1927,7 +1916,7 @@ Status compeg_batch::decode(hipStream_t stream)
                                               one_layout ? fused_layout_wave_cap(layout_h, layout_v, mcu_pairs) : 0u);
         if (one_layout) {
             // every image has the same extension layout: its fused kernel, whole windows or streamed
-            const bool streamed = layout_has_stream_kernel(layout_h, layout_v, mcu_pairs) && stream_mcu_words <= stream_most_mcu_words(layout_h, layout_v) && use_stream_kernel(plan, max_intervals, m, kLayoutCuWaves, fused_layout_wave_cap(layout_h, layout_v, mcu_pairs));
+            const bool streamed = layout_has_stream_kernel(layout_h, layout_v, mcu_pairs) && use_stream_kernel(plan, max_intervals, m, kLayoutCuWaves, fused_layout_wave_cap(layout_h, layout_v, mcu_pairs));
             last_kernel = at ? last_kernel : (streamed ? COMPEG_KERNEL_FUSED_STREAM : COMPEG_KERNEL_FUSED_LAYOUT);
             if (streamed)
                 CG_HIP(launch_fused_stream(dd + at, m, max_intervals,
@@ -1955,10 +1944,9 @@ Status compeg_batch::decode(hipStream_t stream)
             // Images of different sizes (a grid row per image, workgroups that wait for their slowest wave): the
             // streamed form in workgroups of four waves, three to a CU, which the hardware shares out as they finish --
             // 256 frames of four sizes 550 -> 630 Gpixel/s, 1024 small ones 344 -> 444; not below DRI = 3 (606 -> 559).
-            const bool sparse = stream_mcu_words <= kStreamMostMcuWords || lab_env("COMPEG_STREAM");
-            const bool small_groups = sparse && !coop.usable && !uniform && min_restart_interval >= 3u && m == n &&
+            const bool small_groups = !coop.usable && !uniform && min_restart_interval >= 3u && m == n &&
                                       total_waves > uint64_t(12u) * 256u && !lab_env("COMPEG_NO_SMALL_GROUPS");
-            const bool streamed = sparse && !coop.usable && (small_groups || use_stream_kernel(plan, max_intervals, m));
+            const bool streamed = !coop.usable && (small_groups || use_stream_kernel(plan, max_intervals, m));
             if (coop.usable)
                 CG_HIP(launch_coop_422(dd + at, m, max_intervals, coop, stream));
             else if (streamed)
