@@ -432,8 +432,8 @@ decode_fused_420_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds,
 }
 
 // The batch kernel for restart intervals too long for whole-interval windows (decode_wave_fused_422_stream: `rows`
-// words of every lane's stream at a time, fetched by LDS-DMA MCU by MCU).  Plain grid (workgroups per image,
-// images): the units are long, the prologue is a small share of them.
+// words of every lane's stream at a time, staged MCU by MCU).  A grid row per image, or -- frames of one stream --
+// the flat grid with resident waves that draw their units from the queue.
 // (WAVE: a struct with the wave's body -- Wave422Stream, or WaveLayoutStream<HS, VS, MC> for the extension layouts)
 template <class WAVE>
 __device__ __forceinline__ void fused_stream_kernel_body(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t rows,

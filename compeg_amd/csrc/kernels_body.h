@@ -1810,9 +1810,8 @@ CG_DEV bool wave_any(bool v)
 // A wave's window (above) holds its 64 intervals whole: 64 x DRI MCUs of stream, 17 KB with DRI = 10, beyond what
 // the LDS has with DRI = 16 -- the waves per CU go, then the window itself.  Here a lane has `nrows` words of its
 // own stream staged at any time, whatever the interval's length: row j of the wave's rows (64 words, one per lane)
-// holds word j behind each lane's own position, fetched by LDS-DMA (one global_load_lds_dword a row: per-lane source,
-// lane-linear destination) behind the last data unit of an MCU -- when some lane is running short
-// (stream_wants_rows) -- and landed under that data unit's IDCT.  The fast reader walks down its lane's column
+// holds word j behind each lane's own position, staged (stream_stage_rows) behind the last data unit of an MCU -- when
+// some lane is running short (stream_wants_rows).  The fast reader walks down its lane's column
 // (EntropyState); a lane that reaches its last row inside a data unit finishes it, and the MCU, with the reference
 // reader from global memory and is back in fast mode with the next rows.
 
