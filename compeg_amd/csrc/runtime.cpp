@@ -1056,9 +1056,6 @@ Status compeg_batch::upload(const ImageData *const *images, size_t n, int thread
     if (preprocess_mode != 0) {
         if (!use_fused_pipeline())
             return Status::error(COMPEG_E_INVALID_ARG, "device preprocessing needs the fused pipeline");
-        for (size_t i = 0; i < n; i++)
-            if (!items[i].is422)
-                return Status::error(COMPEG_E_UNSUPPORTED, "device preprocessing of a batch supports 4:2:2 images only");
         std::vector<FeedSource> src(n);
         for (size_t i = 0; i < n; i++)
             src[i] = FeedSource{images[i]->scan_data(), images[i]->scan_len, images[i]->metadata.total_restart_intervals};
@@ -1347,7 +1344,7 @@ Status compeg_batch::upload_jpegs(const uint8_t *const *jpegs_in, const size_t *
         bool laid_out = true;
         std::vector<FeedSource> src(n);
         for (size_t i = 0; i < n && laid_out; i++) {
-            laid_out = peek_item(jpegs[i], lens[i], flags, items[i]) && items[i].is422;
+            laid_out = peek_item(jpegs[i], lens[i], flags, items[i]);
             src[i] = FeedSource{jpegs[i], lens[i], items[i].intervals};
         }
         auto parse_headers = [&](size_t i, Status &st) -> const ImageData * {
@@ -1379,8 +1376,6 @@ Status compeg_batch::upload_jpegs(const uint8_t *const *jpegs_in, const size_t *
                 if (!results[i].ok())
                     return results[i];
                 ptrs[i] = fresh[i].get();
-                if (!is_422(*ptrs[i]))
-                    return Status::error(COMPEG_E_UNSUPPORTED, "device preprocessing of a batch supports 4:2:2 images only");
                 src[i] = FeedSource{ptrs[i]->scan_data(), ptrs[i]->scan_len, ptrs[i]->metadata.total_restart_intervals};
             }
             s = upload_device_scan(n, threads, src.data(), ptrs.data(), nullptr, parse_one);
@@ -1572,10 +1567,9 @@ Status compeg_batch::upload_device_scan(size_t n, int threads, const FeedSource 
                 return;
             if (!given) {
                 images[i] = parse(i, results[i]);
-                if (!images[i] || table_blob_bytes(*images[i]) > kUnparsedTablesCap || !is_422(*images[i])) {
+                if (!images[i] || table_blob_bytes(*images[i]) > kUnparsedTablesCap) {
                     if (images[i] && results[i].ok())
-                        results[i] = is_422(*images[i]) ? Status::error(COMPEG_E_INVALID_ARG, kLayoutBoundExceeded)
-                                                        : Status::error(COMPEG_E_UNSUPPORTED, "device preprocessing of a batch supports 4:2:2 images only");
+                        results[i] = Status::error(COMPEG_E_INVALID_ARG, kLayoutBoundExceeded);
                     images[i] = nullptr;
                     failed.store(true, std::memory_order_relaxed);
                 }
@@ -1753,6 +1747,16 @@ Status compeg_batch::upload_device_scan(size_t n, int threads, const FeedSource 
             all_covered = all_covered && item_of(img).covered;
         }
         note_batch_properties(images.data(), n);
+        // (extension layouts: the coefficient records of their kernels, as in upload_host)
+        size_t ac_total = 0, dc_total = 0;
+        for (size_t i = 0; i < n && generic_layout; i++) {
+            ac_total += size_t(images[i]->total_dus()) * kRetained * 2;
+            dc_total += size_t(images[i]->total_dus()) * 4;
+        }
+        if (generic_layout) {
+            CG_TRY(ac.reserve(ac_total + 256));
+            CG_TRY(dc.reserve(dc_total + 256));
+        }
         bool fresh_out = false;
         CG_TRY(out.reserve(out_total + 256, &fresh_out));
         // (texels no MCU covers read 0: see upload_host)
@@ -1765,7 +1769,7 @@ Status compeg_batch::upload_device_scan(size_t n, int threads, const FeedSource 
         descs.assign(n, ImageDesc{});
         out_offset.assign(n, 0);
         host_fallbacks = 0;
-        size_t out_at = 0;
+        size_t out_at = 0, ac_at = 0, dc_at = 0;
         for (size_t i = 0; i < n; i++) {
             const Layout &L = lay[i];
             const uint32_t *r = &res[i * (kScanResultBytes / 4)];
@@ -1805,8 +1809,10 @@ Status compeg_batch::upload_device_scan(size_t n, int threads, const FeedSource 
             d.starts = reinterpret_cast<const uint32_t *>(da + L.starts);
             d.nwords = nwords;
             d.nstarts = nstarts;
-            d.ac = nullptr;
-            d.dc = nullptr;
+            d.ac = generic_layout ? reinterpret_cast<int16_t *>(static_cast<uint8_t *>(ac.ptr) + ac_at) : nullptr;
+            d.dc = generic_layout ? reinterpret_cast<int32_t *>(static_cast<uint8_t *>(dc.ptr) + dc_at) : nullptr;
+            ac_at += size_t(img.total_dus()) * kRetained * 2;
+            dc_at += size_t(img.total_dus()) * 4;
             out_offset[i] = out_at;
             d.out = static_cast<uint8_t *>(out.ptr) + out_at;
             out_at += align_up(size_t(img.width) * 4 * img.height, 256);

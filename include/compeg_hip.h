@@ -276,9 +276,8 @@ int compeg_batch_decode(compeg_batch *batch, void *hip_stream);
  * compeg_batch_upload, like the reference.  1: raw entropy-coded segments are
  * uploaded and preprocessed once by the scan kernels.  2: like 1, and every
  * compeg_batch_decode re-runs the scan kernels first, i.e. a decode covers the
- * whole path from raw scan bytes in HBM to RGBA.  Set before upload.  Modes 1 and 2
- * take 4:2:2 images (the reference's subset); an upload of an extension layout
- * (COMPEG_PARSE_ANY_LUMA_SAMPLING) in those modes fails with COMPEG_E_UNSUPPORTED. */
+ * whole path from raw scan bytes in HBM to RGBA.  Set before upload.  Every layout
+ * the front-end accepts (the extension layouts of COMPEG_PARSE_ANY_LUMA_SAMPLING too). */
 int compeg_batch_set_device_preprocess(compeg_batch *batch, int mode);
 /* Images of the last upload that the scan kernels handed back to the host. */
 size_t compeg_batch_host_fallbacks(const compeg_batch *batch);

@@ -259,3 +259,58 @@ def test_upload_in_two_steps_keeps_the_link_busy(ca, gpu):
     finally:
         del a, b
         pinned.close()
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_device_preprocessing_of_extension_layouts(ca, gpu, mode):
+    """Rows f1 x f3: batches of 4:4:4 / 4:4:0 / 4:2:0 images with the scan kernels' preprocessing -- parsed images
+    (compeg_batch_upload), JPEG bytes in pageable and page-locked memory (headers only on the host) -- through the
+    layouts' fused kernels, their streamed form, and, layouts mixed with 4:2:2, the two-kernel route.  Same pixels as
+    the oracle with the same extension; stuffed bytes and ragged edges among the images."""
+    for sampling in ((1, 1), (1, 2), (2, 2)):
+        cases = [(640, 360, 0, 85, 4, 311), (250, 70, 1, 75, 3, 312), (33, 17, 2, 85, 1, 313), (1000, 600, 1, 95, 8, 314)]
+        jpegs = [synth.make_jpeg(w, h, seed=s, kind=k, quality=q, ri=ri, sampling=sampling) for (w, h, k, q, ri, s) in cases]
+        wants = [orc.ImageData(j, allow_sampling=True).decode() for j in jpegs]
+        same = [jpegs[i % 4] for i in range(40)]
+        batch = ca.Batch(gpu)
+        batch.set_device_preprocess(mode)
+        batch.upload([ca.ImageData(j, allow_sampling=True) for j in same])
+        assert batch.host_fallbacks() == 0
+        batch.decode()
+        batch.wait()
+        # (the scan kernels report window spans less exactly than the host: the dense image may ask for streamed windows)
+        assert batch.last_kernel() in ("fused_layout", "fused_stream")
+        for i in range(40):
+            assert np.array_equal(batch.read_output(i), wants[i % 4]), (sampling, i)
+        pinned = ca.HostBuffer(sum(len(j) + 64 for j in same))
+        try:
+            for name, src in (("pageable", same), ("pinned", pinned.place(same))):
+                batch.upload_jpegs(src, host_threads=4, allow_sampling=True)
+                assert batch.host_fallbacks() == 0, name
+                batch.decode()
+                batch.wait()
+                assert batch.last_kernel() in ("fused_layout", "fused_stream")
+                for i in range(40):
+                    assert np.array_equal(batch.read_output(i), wants[i % 4]), (sampling, name, i)
+        finally:
+            pinned.close()
+        # long restart intervals: the layout's streamed form
+        frames = [synth.make_jpeg(960, 720, seed=720 + i, kind=0, quality=85, ri=16, sampling=sampling) for i in range(8)]
+        uniform = [frames[i % 8] for i in range(240)]
+        batch.upload_jpegs(uniform, host_threads=8, allow_sampling=True)
+        batch.decode()
+        batch.wait()
+        assert batch.last_kernel() == "fused_stream"
+        for i in (0, 1, 7, 100, 239):
+            assert np.array_equal(batch.read_output(i), orc.ImageData(uniform[i], allow_sampling=True).decode()), (sampling, i)
+        # layouts mixed in one batch
+        mixed = jpegs[:3] + [synth.make_jpeg(320, 240, seed=315, ri=2)]
+        batch.upload_jpegs(mixed, host_threads=2, allow_sampling=True)
+        batch.decode()
+        batch.wait()
+        assert batch.last_kernel() == "generic"
+        for i, j in enumerate(mixed):
+            assert np.array_equal(batch.read_output(i), orc.ImageData(j, allow_sampling=True).decode()), (sampling, i)
+    # without the flag the front-end rejects the layout, as the reference does (src/lib.rs:650)
+    with pytest.raises(ca.Error):
+        batch.upload_jpegs([synth.make_jpeg(64, 64, seed=1, ri=2, sampling=(2, 2))], host_threads=1)

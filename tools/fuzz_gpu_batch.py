@@ -65,7 +65,7 @@ def run(seed=77, batches=40, log=print):
             slots = int((3072 * float(rng.uniform(1.02, 2.6))) // waves) + 1
             if slots * w0 * h0 * 4 < (3 << 30):
                 items = [items[int(rng.integers(0, len(items)))] for _ in range(slots)]
-        mode = int(rng.integers(0, 3)) if ext > 2 else 0   # (device preprocessing of a batch: 4:2:2 only)
+        mode = int(rng.integers(0, 3))
         as_bytes = bool(rng.integers(0, 2))
         where = int(rng.integers(0, 3)) if as_bytes else 0   # the bytes: pageable, page-locked (the copy-free road), every other one
         threads = int(rng.choice([1, 4, 8]))
