@@ -1622,78 +1622,114 @@ CG_DEV void coop_decode_round_422(const ImageDesc &d, const CoopShared &cs, cons
     }
     CG_WAVE_SYNC();
     CG_COOP_STAMP(3);
-#if defined(__HIP_DEVICE_COMPILE__)
-    // the earlier rounds' sums and "dead from" are final
-    if (cs.flags) {
-        while (__hip_atomic_load(cs.flags + kTeamDecoded, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < r)
-            __builtin_amdgcn_s_sleep(2);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
-#endif
-    CG_EACH_LANE
-    {
-        if (state[li] & kCoopUnset)
-            continue;
-        // an interval that turned out to need the serial decoder after all: what its lanes decoded is dropped
-        if ((cs.verdict[L[li].il] & 0xffu) == kVerdictSerial) {
-            state[li] = kCoopUnset;
-            continue;
-        }
-        // quirk Q1: behind the first data unit whose DC code underflows the reference reader, the interval decodes
-        // from zeros -- whatever those lanes have decoded from the walk's states is replaced (this round's lanes
-        // or an earlier round's may have found it)
-        const uint32_t first_dead = cs.dead_from[L[li].il];
-        if (LANES != 1 && L[li].tl == first_dead)
-            CG_COOP_COUNT(dead, 1);
-        if (L[li].tl <= first_dead)
-            continue;
-        const uint32_t comp = comp_of_k(L[li].lane & 3u);
-        uint8_t *slot = s.du_slots + L[li].lane * kDuSlotBytes;
-        zero_slot(slot);
-        copy_zero_levels(d, comp, reinterpret_cast<int16_t *>(slot));
-        cs.diffs[L[li].lane] = zero_diff(d, comp);
-        state[li] |= kCoopZero;
-        if (LANES != 1)
-            CG_COOP_COUNT(zero, 1);
-    }
-    CG_WAVE_SYNC();
-    // DC prediction (src/huffman.wgsl:137,170): the sum of the differences of the component's data units up to this
-    // one, inside the interval; i32 wrap like the reference.  The part of the interval in earlier rounds: cs.carry.
+    // What a round needs of the rounds before it: for the interval its first data units continue, if any (`head`), the
+    // DC sums up to the round's start (cs.carry), Q1's "dead from" and the verdict -- all of them round r - 1's to
+    // publish (bit r - 1 of the team's flag word).  What it owes the round behind it: the sums at its own end; where
+    // the interval of its last data unit begins inside the round (`tail_own`: always so up to 16 MCUs an interval) they
+    // are known before any waiting.  So the rounds of short intervals do not queue up behind each other: everything
+    // is worked out from what the wave itself has decoded, published, and only the head's carry-in is added behind
+    // the wait -- repeated in full in the rare case that the wait brings a Q1 event of the head's interval.
+    const uint32_t first_n = r * uint32_t(kWave), last_n = umin(first_n + uint32_t(kWave), g.dus) - 1u;
+    uint32_t head_il, head_tl, tail_il, tail_tl;
+    coop_du_of(g, first_n, head_il, head_tl);
+    coop_du_of(g, last_n, tail_il, tail_tl);
+    const bool head = head_tl != 0u, tail_own = tail_tl <= last_n - first_n;
+    (void)head_il;
+    (void)tail_il;
+    bool fixed[LANES];
     uint32_t sum[LANES];
-    CG_EACH_LANE
-    {
-        sum[li] = 0u;
-        if (state[li] & kCoopUnset)
-            continue;
-        const uint32_t lane = L[li].lane, k = lane & 3u, base = lane & ~3u;
-        const uint32_t before = L[li].tl - (lane & 3u); // the interval's data units in front of this lane's MCU
-        uint32_t acc = 0u, from = base - before;       // (lane of the interval's first data unit, if in this round)
-        if (before > base) {
-            // the interval began in an earlier round
-            acc = cs.carry[4u * (r - 1u) + comp_of_k(k)];
-            from = 0u;
-        }
-        const int32_t *df = cs.diffs;
-        for (uint32_t l = from; l < base; l += 4u)
-            acc += k < 2u ? uint32_t(df[l]) + uint32_t(df[l + 1u]) : uint32_t(df[l + k]);
-        acc += k == 1u ? uint32_t(df[base]) + uint32_t(df[base + 1u]) : uint32_t(df[base + k]);
-        sum[li] = acc;
-        dc[li] = int32_t(acc * sel3(comp_of_k(k), t.dc_quant[0], t.dc_quant[1], t.dc_quant[2]));
-    }
-    CG_EACH_LANE
-    {
-        // (the round's last MCU: lanes 61 .. 63 hold the sums of Y, Cb, Cr up to the round's end)
-        if (!(state[li] & kCoopUnset) && L[li].lane >= uint32_t(kWave) - 3u)
-            cs.carry[4u * r + (L[li].lane - (uint32_t(kWave) - 3u))] = sum[li];
-    }
-    CG_WAVE_SYNC();
+    for (int pass = 0; pass < 2; pass++) {
+        const bool last_pass = pass == 1 || !head;
+        if (pass == 1) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (cs.flags) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if ((LANES == 1 ? my_lane : 0u) == 0u)
-            __hip_atomic_store(cs.flags + kTeamDecoded, r + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
+            if (cs.flags) {
+                while (!(__hip_atomic_load(cs.flags + kTeamDecoded, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & (1u << ((r - 1u) & 31u))))
+                    __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
 #endif
+        }
+        CG_EACH_LANE
+        {
+            fixed[li] = false;
+            if (state[li] & kCoopUnset)
+                continue;
+            // an interval that turned out to need the serial decoder after all: what its lanes decoded is dropped
+            if ((cs.verdict[L[li].il] & 0xffu) == kVerdictSerial) {
+                state[li] = kCoopUnset;
+                continue;
+            }
+            // quirk Q1: behind the first data unit whose DC code underflows the reference reader, the interval decodes
+            // from zeros -- whatever those lanes have decoded from the walk's states is replaced (this round's lanes
+            // or an earlier round's may have found it; "dead from" only ever falls)
+            const uint32_t first_dead = cs.dead_from[L[li].il];
+            if (LANES != 1 && last_pass && L[li].tl == first_dead)
+                CG_COOP_COUNT(dead, 1);
+            if (L[li].tl <= first_dead || (state[li] & kCoopZero))
+                continue;
+            const uint32_t comp = comp_of_k(L[li].lane & 3u);
+            uint8_t *slot = s.du_slots + L[li].lane * kDuSlotBytes;
+            zero_slot(slot);
+            copy_zero_levels(d, comp, reinterpret_cast<int16_t *>(slot));
+            cs.diffs[L[li].lane] = zero_diff(d, comp);
+            state[li] |= kCoopZero;
+            fixed[li] = true;
+            if (LANES != 1)
+                CG_COOP_COUNT(zero, 1);
+        }
+        CG_WAVE_SYNC();
+        // DC prediction (src/huffman.wgsl:137,170): the sum of the differences of the component's data units up to this
+        // one, inside the interval; i32 wrap like the reference.  The part of the interval in earlier rounds: cs.carry.
+        if (pass == 0 || coop_any<LANES>(fixed)) {
+            CG_EACH_LANE
+            {
+                sum[li] = 0u;
+                if (state[li] & kCoopUnset)
+                    continue;
+                const uint32_t lane = L[li].lane, k = lane & 3u, base = lane & ~3u;
+                const uint32_t before = L[li].tl - (lane & 3u); // the interval's data units in front of this lane's MCU
+                const uint32_t from = before > base ? 0u : base - before; // (lane of the interval's first data unit in this round)
+                uint32_t acc = 0u;
+                const int32_t *df = cs.diffs;
+                for (uint32_t l = from; l < base; l += 4u)
+                    acc += k < 2u ? uint32_t(df[l]) + uint32_t(df[l + 1u]) : uint32_t(df[l + k]);
+                acc += k == 1u ? uint32_t(df[base]) + uint32_t(df[base + 1u]) : uint32_t(df[base + k]);
+                sum[li] = acc;
+            }
+        }
+        if (last_pass && head) {
+            // (the interval began in an earlier round)
+            CG_EACH_LANE
+            {
+                const uint32_t lane = L[li].lane;
+                if (!(state[li] & kCoopUnset) && L[li].tl - (lane & 3u) > (lane & ~3u))
+                    sum[li] += cs.carry[4u * (r - 1u) + comp_of_k(lane & 3u)];
+            }
+        }
+        if (tail_own ? pass == 0 : last_pass) {
+            CG_EACH_LANE
+            {
+                // (the round's last MCU: lanes 61 .. 63 hold the sums of Y, Cb, Cr up to the round's end)
+                if (!(state[li] & kCoopUnset) && L[li].lane >= uint32_t(kWave) - 3u)
+                    cs.carry[4u * r + (L[li].lane - (uint32_t(kWave) - 3u))] = sum[li];
+            }
+            CG_WAVE_SYNC();
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (cs.flags) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if ((LANES == 1 ? my_lane : 0u) == 0u)
+                    __hip_atomic_fetch_or(cs.flags + kTeamDecoded, 1u << (r & 31u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+#endif
+        }
+        if (last_pass)
+            break;
+    }
+    CG_EACH_LANE
+    {
+        if (!(state[li] & kCoopUnset))
+            dc[li] = int32_t(sum[li] * sel3(comp_of_k(L[li].lane & 3u), t.dc_quant[0], t.dc_quant[1], t.dc_quant[2]));
+    }
     CG_COOP_STAMP(4);
     uint32_t px[LANES][16];
     CG_EACH_LANE

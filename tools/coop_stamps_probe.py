@@ -21,10 +21,12 @@ dec = ca.Decoder(gpu)
 for _ in range(3):
     dec.decode_blocking(img)
 team = os.environ.get("COMPEG_COOP_TEAM", "1") != "0"
-ipw = 64 // (4 * ri)
-waves = (img.parallelism() + ipw - 1) // ipw
 if team:
-    waves = (waves + 3) // 4 * 4
+    per_team = max(1, 256 // (4 * ri))          # (coop_shape: a team of four waves takes 4 x 64 data units' worth of intervals)
+    waves = (img.parallelism() + per_team - 1) // per_team * 4
+else:
+    ipw = max(1, 64 // (4 * ri))
+    waves = (img.parallelism() + ipw - 1) // ipw
 full = np.zeros((waves, 16), dtype=np.uint64)
 assert lib.compeg_debug_read_dc(dec._h, full.ctypes.data, full.nbytes) == 0
 buf = full[:, :8]
