@@ -39,6 +39,9 @@ def parse_args():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--prime-seconds", type=float, default=PRIME_SECONDS,
+                   help="untimed decodes for this long in front of the warmup steps (a card out of idle runs its launches "
+                        "5-20 %% longer for 30-40 ms); 0 = none")
     p.add_argument("--batch", type=int, default=256,
                    help="images per GPU per step (256 = one GPU's share of BASELINE config 4: "
                         "2048 4K frames over 8 GPUs)")
@@ -552,7 +555,7 @@ def main():
     # the same decodes, untimed, for PRIME_SECONDS in front of the --warmup steps, so that the timed steps are those
     # of a card that is being fed -- reported as "clock_prime" in the line.
     prime_decodes, t_prime = 0, time.perf_counter()
-    while time.perf_counter() - t_prime < PRIME_SECONDS:
+    while time.perf_counter() - t_prime < args.prime_seconds:
         batch.decode()
         batch.wait()
         prime_decodes += 1
@@ -736,7 +739,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "clock_prime": {"seconds": PRIME_SECONDS, "decodes": prime_decodes,
+            "clock_prime": {"seconds": args.prime_seconds, "decodes": prime_decodes,
                             "what": "untimed decodes in front of the warmup steps: the card's launches get shorter for 30-40 ms after idle"},
             "ms_per_step": round(ms_per_step, 4),
             "ms_per_frame": round(ms_per_step / args.batch, 5),
