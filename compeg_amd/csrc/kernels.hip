@@ -840,11 +840,11 @@ hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t ma
 {
     if (images == 0 || max_intervals == 0)
         return hipSuccess;
-    static const bool wide_allowed = [] {
-        const char *e = lab_env("COMPEG_WIDE"); // experiment knob: 0 = the quad exchange for every restart interval
-        return e ? atoi(e) != 0 : true;
+    static const int wide_knob = [] {
+        const char *e = lab_env("COMPEG_WIDE"); // experiment knob: 0 = the quad exchange for every restart interval, 2 = the wave-wide one
+        return e ? atoi(e) : 1;
     }();
-    const auto kernel = one_mcu_intervals && wide_allowed ? decode_fused_422_mcu_kernel : decode_fused_422_kernel;
+    const auto kernel = (one_mcu_intervals && wide_knob != 0) || wide_knob == 2 ? decode_fused_422_mcu_kernel : decode_fused_422_kernel;
     const uint32_t wave_limit = kMaxWavesFused;
     const uint32_t threads = plan.waves_per_block * kWave;
     // uniform: every image has max_intervals intervals and the same LUT bytes -> workgroups may span images
@@ -881,7 +881,7 @@ hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t ma
     // The units' queue: where the waves have more than one draw each.  Units of one MCU a lane (DRI = 1) are drawn four
     // at a time: one by one the draw and the later request for the starts cost more than the sharing brings (8 x 8K:
     // 0.426 against 0.397 ms without a queue; 256 x 4K DRI = 4 2.74 against 2.86, 300 x 720p 0.46 against 0.51).
-    const uint32_t group = one_mcu_intervals && wide_allowed ? kMcuQueueGroup : 1u;
+    const uint32_t group = kernel == decode_fused_422_mcu_kernel ? kMcuQueueGroup : 1u;
     uint32_t *q = flat && queue_allowed && queue && uint64_t(waves_per_image) * images > uint64_t(grid.x) * plan.waves_per_block * group
                       ? queue
                       : nullptr;
