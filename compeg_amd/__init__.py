@@ -25,7 +25,7 @@ __all__ = ["Gpu", "Decoder", "DecodeOp", "ImageData", "ScanBuffer", "Batch", "Te
 
 
 # compeg_decoder_last_kernel / compeg_batch_last_kernel (include/compeg_hip.h: COMPEG_KERNEL_*)
-KERNEL_NAMES = ("none", "fused", "pair", "coop_team", "generic", "split", "fused_layout", "fused_stream")
+KERNEL_NAMES = ("none", "fused", "pair", "coop_team", "generic", "split", "fused_layout", "fused_stream", "walk_mcu")
 
 
 def version():

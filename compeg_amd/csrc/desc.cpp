@@ -50,6 +50,32 @@ void fill_desc(const ImageData &img, ImageDesc &d)
         d.dc_fast_table[c] = (cm.dchuff == 0 || cm.dchuff == 2) ? cm.dchuff >> 1 : 2;
     }
     fill_coop(img, d);
+    // The walk + lane-per-MCU route (device_types.h: ImageDesc::mcu_ok): 4:2:2, the direct tables for every component,
+    // and no DC category above 15 in the DC tables the components use -- every consume is then shorter than 32 bits,
+    // so the reference reader's state at an MCU's start is a position and its `left`, or "run dry" (quirk Q1), and
+    // nothing else.  (At most 2^18 MCUs an interval: a reader that has run dry keeps its wrapped `left` above 64 for
+    // 2^32 bits.)
+    d.total_mcus = img.total_mcus();
+    const bool is422 = md.dus_per_mcu == 4 && md.components[0].hsample == 2 && md.components[0].vsample == 1 &&
+                       md.components[1].hsample == 1 && md.components[1].vsample == 1 &&
+                       md.components[2].hsample == 1 && md.components[2].vsample == 1;
+    bool ok = is422 && md.restart_interval != 0 && md.restart_interval <= (1u << 18) && d.total_mcus != 0;
+    for (uint32_t c = 0; c < 3 && ok; c++) {
+        ok = d.fast_table[c] < 2 && d.dc_fast_table[c] < 2;
+        const uint16_t *l1 = img.l1 + size_t(d.dc_table[c] & 3u) * 256;
+        for (uint32_t i = 0; i < 256 && ok; i++) {
+            const uint16_t e = l1[i];
+            if (!(e & 0x8000u)) {
+                ok = (e & 0xffu) <= 15u;
+                continue;
+            }
+            for (uint32_t j = 0; j < 256 && ok; j++) {
+                const size_t idx = size_t(e & 0x7fffu) + j;
+                ok = idx >= img.l2.size() || (img.l2[idx] & 0xffu) <= 15u;
+            }
+        }
+    }
+    d.mcu_ok = ok ? 1u : 0u;
 }
 
 // What the cooperative kernel needs to know beyond the tables (coop_body.h): whether the image qualifies, and

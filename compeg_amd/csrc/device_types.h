@@ -85,6 +85,18 @@ constexpr CoopShape coop_shape(uint32_t restart_interval, uint32_t waves)
 // access phase on different banks.
 constexpr int kDuSlotBytes = 80;
 
+// The decoder's state at the start of an MCU, beside the index of the stream word it begins in (ImageDesc::mcu_word):
+//   info bits 0..4   bit position inside that word
+//        bits 5..10  the reference reader's `left` there (1..63: what quirk Q1 depends on; kernels_body.h, "Fast mode")
+//        bit  11     kMcuDead: the reference's reader has run dry in an earlier data unit of the interval (quirk Q1):
+//                    it reads zeros from here on, whatever the position
+//   pred             the DC predictions (Y, Cb, Cr) up to here, i32 wrapping like the reference's
+struct alignas(16) McuState {
+    uint32_t info;
+    int32_t pred[3];
+};
+constexpr uint32_t kMcuDead = 1u << 11;
+
 // Everything the kernels need to know about one image.  Lives in device
 // memory (one array entry per image of a batch); all pointers are device
 // pointers.  Filled by the host from the reference-format Metadata block.
@@ -138,6 +150,16 @@ struct ImageDesc {
     // launch bookkeeping for batched grids
     uint32_t first_huff_block; // block index of this image's first huffman block
     uint32_t first_idct_block;
+    // The walk + lane-per-MCU route (kernels_body.h: walk_wave_422, decode_wave_fused_422<..., RECORDS>): the walk
+    // kernel writes, for every MCU, the stream word its first data unit begins in (mcu_word) and the rest of the
+    // decoder's state there (mcu_state); the decode kernel reads them through a second descriptor of the image in
+    // which an "interval" is one MCU -- starts = mcu_word, total_intervals = the image's MCUs, restart_interval = 1.
+    // mcu_ok: the image qualifies (4:2:2, direct tables for every component, no DC category above 15 in its tables:
+    // the reader's state at an MCU's start is then a position, or "run dry" -- quirk Q1 -- and nothing else).
+    uint32_t *mcu_word;
+    McuState *mcu_state;
+    uint32_t mcu_ok;
+    uint32_t total_mcus;
 };
 
 // How the huffman kernel's dynamic LDS is carved (bytes).

@@ -27,11 +27,12 @@ hipError_t launch_entropy(const ImageDesc *descs, uint32_t images, uint32_t max_
                           const HuffLdsPlan &plan, hipStream_t stream);
 // uniform: all images have max_intervals intervals and byte-identical LUTs (workgroups may then span images)
 // one_mcu_intervals: every image's restart interval is one MCU (the kernel whose rows leave wave-wide)
+// from_records: descs are the images' descriptors of MCUs (ImageDesc::mcu_word), max_intervals the most MCUs of any
 // queue: four bytes of device memory of the caller's (or null): the counter the resident waves of a uniform launch
 // draw their units from (zeroed here, in stream order)
 hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t max_intervals,
                             const HuffLdsPlan &plan, hipStream_t stream, bool uniform = false, bool one_mcu_intervals = false,
-                            uint32_t *queue = nullptr);
+                            uint32_t *queue = nullptr, bool from_records = false);
 // The batch kernel with the window in its streamed form (kernels_body.h: decode_wave_fused_422_stream), for launches
 // whose whole-interval windows would leave a CU fewer than its twelve waves.
 struct StreamPlan {
@@ -50,6 +51,18 @@ bool stream_plan_preferred(const HuffLdsPlan &plan, uint32_t max_intervals, uint
 // (hs, vs: the luma sampling all images of the launch share: 2x1, or an extension layout's -- paired kernels for 1x1 / 1x2)
 hipError_t launch_fused_stream(const ImageDesc *descs, uint32_t images, uint32_t max_intervals, const StreamPlan &plan,
                                    hipStream_t stream, uint32_t hs = 2, uint32_t vs = 1, uint32_t *queue = nullptr);
+// The first kernel of the walk + lane-per-MCU route (kernels_body.h): a lane per restart interval, entropy decode only,
+// every MCU's record into ImageDesc::mcu_word / mcu_state; the second one is launch_fused_422(..., from_records) over the
+// images' descriptors of MCUs.
+// walk_tables: every image has ImageDesc::walk (launch_walk_tables): two symbols a step
+struct WalkPlan {
+    uint32_t rows = 0, stage_below = 0, waves_per_block = 0, l2_entries_in_lds = 0, total_bytes = 0;
+    uint32_t waves_per_image = 0; // != 0: the flat grid (uniform launches)
+    bool walk_tables = false;
+};
+WalkPlan plan_walk(uint32_t max_intervals, uint32_t images, uint32_t max_l2, uint32_t mcu_words, bool uniform, bool walk_tables);
+hipError_t launch_walk_mcus(const ImageDesc *descs, uint32_t images, uint32_t max_intervals, const WalkPlan &plan, hipStream_t stream,
+                            uint32_t *queue = nullptr);
 // Extension layouts (luma hs x vs = 1x1, 1x2, 2x2), fused like the 4:2:2 kernel; plan with wave_cap = fused_layout_wave_cap.
 // pairs: (8-pixel MCUs) every image of the launch has an even restart interval -- a lane composites its MCUs two at a time
 uint32_t fused_layout_wave_cap(uint32_t hs, uint32_t vs, bool pairs);

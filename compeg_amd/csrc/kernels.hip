@@ -340,12 +340,12 @@ __device__ __forceinline__ void fused_kernel_body(const ImageDesc *__restrict__ 
 // units of one MCU a lane (DRI = 1) are drawn from the queue four at a time (launch_fused_422)
 constexpr uint32_t kMcuQueueGroup = 4;
 
-template <bool WIDE>
+template <bool WIDE, bool RECORDS = false>
 struct Wave422 {
     template <class AHEAD>
     static __device__ __forceinline__ void decode(const ImageDesc &d, const HuffShared &s, uint32_t interval, uint32_t lane, AHEAD &ahead)
     {
-        decode_wave_fused_422<AHEAD, WIDE>(d, s, interval, lane, ahead);
+        decode_wave_fused_422<AHEAD, WIDE, RECORDS>(d, s, interval, lane, ahead);
     }
 };
 #if !defined(CG_FUSED_BOUNDS) || !defined(COMPEG_LAB)
@@ -365,6 +365,14 @@ decode_fused_422_mcu_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_
                             uint32_t waves_per_image, uint32_t images, uint32_t *queue)
 {
     fused_kernel_body<Wave422<true>, kMcuQueueGroup>(descs, l2_in_lds, window_words, waves_per_image, images, queue);
+}
+// The second kernel of the walk + lane-per-MCU route (kernels_body.h): the kernel above over the images' descriptors of
+// MCUs -- every "interval" one MCU, begun from the record the walk wrote for it (walk_mcus_422_kernel below).
+__global__ void __launch_bounds__(768)
+decode_fused_422_mcu_rec_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words,
+                                uint32_t waves_per_image, uint32_t images, uint32_t *queue)
+{
+    fused_kernel_body<Wave422<true, true>, kMcuQueueGroup>(descs, l2_in_lds, window_words, waves_per_image, images, queue);
 }
 // Extension layouts: decode_wave_fused_layout behind the plain prologue -- grid (workgroups per image,
 // images), no resident waves: inside the larger body above these kernels spill (4:2:0: 356 registers), alone they
@@ -512,6 +520,89 @@ struct WaveLayoutStream {
         decode_wave_fused_layout<HS, VS, MC, true>(d, s, interval, lane, rows, stage_after, stage_below);
     }
 };
+// The first kernel of the walk + lane-per-MCU route (kernels_body.h): a lane per restart interval, entropy decode only,
+// the decoder's state at every MCU's start into ImageDesc::mcu_word / mcu_state.  The launch shapes of the streamed
+// batch kernel (fused_stream_kernel_body): a grid row per image, or the flat grid with resident waves and the units' queue.
+// LDS: [L1][L2 + direct tables][walk tables, if the images have them][80 bytes nobody reads][per wave: rows]
+__global__ void __launch_bounds__(768)
+walk_mcus_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t rows, uint32_t stage_below,
+                     uint32_t waves_per_image, uint32_t images, uint32_t *queue, uint32_t with_walk_tables)
+{
+    extern __shared__ __attribute__((aligned(32))) uint8_t smem[];
+    const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x / kWave))), lane = threadIdx.x % kWave;
+    uint32_t image = blockIdx.y, wave_first = (blockIdx.x * (blockDim.x / kWave) + wave) * kWave;
+    bool has_work = true;
+    if (waves_per_image) {
+        const uint32_t flat = blockIdx.x * (blockDim.x / kWave) + wave;
+        image = flat / waves_per_image;
+        wave_first = (flat % waves_per_image) * kWave;
+        has_work = image < images;
+        image = has_work ? image : images - 1u; // (it still helps staging the tables)
+    }
+    image = uint32_t(__builtin_amdgcn_readfirstlane(int(image)));
+    wave_first = uint32_t(__builtin_amdgcn_readfirstlane(int(wave_first)));
+    const ImageDesc &d = descs[image];
+    if (!waves_per_image && blockIdx.x * blockDim.x >= d.total_intervals)
+        return; // the whole workgroup
+    uint16_t *l1 = reinterpret_cast<uint16_t *>(smem);
+    uint16_t *l2 = l1 + kL1Entries;
+    // (as offsets from smem, see decode_coop_team_422_kernel: behind an integer round trip a pointer is no longer LDS)
+    const uint32_t walk_off = (align16((kL1Entries + l2_in_lds) * 2u) + 31u) & ~31u;
+    uint32_t *walk = reinterpret_cast<uint32_t *>(smem + walk_off);
+    const bool tables = with_walk_tables != 0u && d.walk != nullptr;
+    const uint32_t dump_off = walk_off + (with_walk_tables ? kWalkWords * 4u : 0u);
+    int16_t *dump = reinterpret_cast<int16_t *>(smem + dump_off);
+    // (a row more than is staged: a reader that has merged its last staged word asks for the one behind it -- never used)
+    const uint32_t wave_area = (rows + 1u) * kWave * 4u;
+    uint32_t *win = reinterpret_cast<uint32_t *>(smem + dump_off + 96u + wave * wave_area);
+    stage_luts(d, l1, l2, l2_in_lds, threadIdx.x, blockDim.x, 2u * kDcFastEntries);
+    if (tables)
+        copy_words_to_lds(walk, d.walk, kWalkWords, threadIdx.x, blockDim.x);
+    __syncthreads();
+    if (!has_work || wave_first >= d.total_intervals)
+        return; // the whole wave
+    HuffShared s;
+    s.l1 = l1;
+    s.l2 = l2;
+    s.l2_staged = umin(l2_in_lds, d.fast_off + 2u * kFastEntries + 2u * kDcFastEntries);
+    s.win = win;
+    s.win_base = 0u;
+    s.win_len = 0u; // (no whole-interval window: the reference reader's words come from global memory)
+    s.du_slots = nullptr;
+    WalkTabs tabs;
+    {
+        CoopTables t;
+        coop_tables(d, s, t);
+        tabs.walk = tables && t.walk_ok ? walk : nullptr;
+        tabs.dc_fast = t.dc_fast;
+        tabs.acsel = t.walk_acsel;
+        tabs.dcsel = t.walk_dcsel;
+        tabs.dcfsel = (d.dc_fast_table[0] & 1u) * 0x0101u | (d.dc_fast_table[1] & 1u) << 16 | (d.dc_fast_table[2] & 1u) << 24;
+        tabs.standard = d.standard_entropy != 0u;
+        for (uint32_t c = 0; c < 3u; c++) {
+            tabs.dc_off[c] = t.dc_off[c];
+            tabs.ac_off[c] = t.ac_off[c];
+        }
+    }
+    if (!waves_per_image) {
+        walk_wave_422_stream(d, s, tabs, dump, rows, stage_below, wave_first + lane, lane);
+        return;
+    }
+    // (the flat grid: resident waves that go on to further units of 64 intervals, drawn from the queue if there is one --
+    // the images of such a launch carry the same tables)
+    const uint32_t stride = gridDim.x * (blockDim.x / kWave), units = waves_per_image * images;
+    for (uint32_t flat = blockIdx.x * (blockDim.x / kWave) + wave;;) {
+        uint32_t drawn = 0u;
+        if (queue && lane == 0u)
+            drawn = atomicAdd(queue, 1u);
+        walk_wave_422_stream(descs[image], s, tabs, dump, rows, stage_below, wave_first + lane, lane);
+        flat = queue ? stride + uint32_t(__builtin_amdgcn_readfirstlane(int(drawn))) : flat + stride; // (wave-uniform)
+        if (flat >= units)
+            break;
+        image = uint32_t(__builtin_amdgcn_readfirstlane(int(flat / waves_per_image)));
+        wave_first = uint32_t(__builtin_amdgcn_readfirstlane(int((flat % waves_per_image) * kWave)));
+    }
+}
 __global__ void __launch_bounds__(768)
 decode_fused_422_stream_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t rows, uint32_t stage_after,
                                uint32_t stage_below, uint32_t waves_per_image, uint32_t images, uint32_t *queue)
@@ -836,7 +927,7 @@ hipError_t launch_fused_layout(const ImageDesc *descs, uint32_t images, uint32_t
 }
 
 hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t max_intervals,
-                            const HuffLdsPlan &plan, hipStream_t stream, bool uniform, bool one_mcu_intervals, uint32_t *queue)
+                            const HuffLdsPlan &plan, hipStream_t stream, bool uniform, bool one_mcu_intervals, uint32_t *queue, bool from_records)
 {
     if (images == 0 || max_intervals == 0)
         return hipSuccess;
@@ -844,7 +935,8 @@ hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t ma
         const char *e = lab_env("COMPEG_WIDE"); // experiment knob: 0 = the quad exchange for every restart interval, 2 = the wave-wide one
         return e ? atoi(e) : 1;
     }();
-    const auto kernel = (one_mcu_intervals && wide_knob != 0) || wide_knob == 2 ? decode_fused_422_mcu_kernel : decode_fused_422_kernel;
+    const auto kernel = from_records ? decode_fused_422_mcu_rec_kernel
+                        : (one_mcu_intervals && wide_knob != 0) || wide_knob == 2 ? decode_fused_422_mcu_kernel : decode_fused_422_kernel;
     const uint32_t wave_limit = kMaxWavesFused;
     const uint32_t threads = plan.waves_per_block * kWave;
     // uniform: every image has max_intervals intervals and the same LUT bytes -> workgroups may span images
@@ -881,7 +973,7 @@ hipError_t launch_fused_422(const ImageDesc *descs, uint32_t images, uint32_t ma
     // The units' queue: where the waves have more than one draw each.  Units of one MCU a lane (DRI = 1) are drawn four
     // at a time: one by one the draw and the later request for the starts cost more than the sharing brings (8 x 8K:
     // 0.426 against 0.397 ms without a queue; 256 x 4K DRI = 4 2.74 against 2.86, 300 x 720p 0.46 against 0.51).
-    const uint32_t group = kernel == decode_fused_422_mcu_kernel ? kMcuQueueGroup : 1u;
+    const uint32_t group = kernel == decode_fused_422_mcu_kernel || kernel == decode_fused_422_mcu_rec_kernel ? kMcuQueueGroup : 1u;
     uint32_t *q = flat && queue_allowed && queue && uint64_t(waves_per_image) * images > uint64_t(grid.x) * plan.waves_per_block * group
                       ? queue
                       : nullptr;
@@ -1026,6 +1118,69 @@ hipError_t launch_fused_stream(const ImageDesc *descs, uint32_t images, uint32_t
     return hipGetLastError();
 }
 
+// The walk kernel's shape: a CU's share of the launch's waves in one workgroup (at most twelve), and all the LDS the
+// tables leave for their rows -- the walk waits for every staging (no IDCT to land it under), so the fewer the better.
+WalkPlan plan_walk(uint32_t max_intervals, uint32_t images, uint32_t max_l2, uint32_t mcu_words, bool uniform, bool walk_tables)
+{
+    WalkPlan p;
+    const DeviceLimits lim = device_limits();
+    p.l2_entries_in_lds = (std::min(max_l2, 12288u) + 2u * kDcFastEntries + 1u) & ~1u;
+    p.walk_tables = walk_tables;
+    const uint32_t tables = (((((kL1Entries + p.l2_entries_in_lds) * 2u) + 15u) & ~15u) + 31u & ~31u) + (walk_tables ? kWalkWords * 4u : 0u) + 96u;
+    const uint32_t waves_per_image = (max_intervals + kWave - 1) / kWave;
+    const uint64_t total_waves = uint64_t(waves_per_image) * images;
+    uint32_t wpb = uint32_t(std::min<uint64_t>(std::max<uint64_t>((total_waves + lim.cus - 1) / lim.cus, 1u), kMaxWavesFused));
+    if (!uniform)
+        wpb = std::min(wpb, std::max(1u, waves_per_image));
+    if (const char *e = lab_env("COMPEG_WALK_WPB")) // experiment knob
+        wpb = uint32_t(std::max(1, std::min(12, atoi(e))));
+    uint32_t rows = (lim.lds_bytes - tables) / wpb / (kWave * 4u) - 1u; // (and a row nobody stages: walk_mcus_422_kernel)
+    rows = std::max(12u, std::min(rows, 160u));
+    if (const char *e = lab_env("COMPEG_WALK_ROWS")) // experiment knob
+        rows = uint32_t(std::max(4, std::min(256, atoi(e))));
+    p.rows = rows;
+    // staged anew when some lane has fewer words in front of it than three average MCUs (a lane that runs out inside
+    // an MCU decodes it once more through the reference's reader)
+    p.stage_below = std::min(rows / 2u, 3u * mcu_words + 4u);
+    if (const char *e = lab_env("COMPEG_WALK_BELOW")) // experiment knob
+        p.stage_below = uint32_t(std::max(0, atoi(e)));
+    p.waves_per_block = wpb;
+    p.total_bytes = tables + wpb * (rows + 1u) * kWave * 4u;
+    p.waves_per_image = uniform ? waves_per_image : 0u;
+    if (getenv("COMPEG_VERBOSE"))
+        fprintf(stderr, "[compeg] walk plan: images=%u intervals=%u waves/block=%u rows=%u below %u words lds=%u B%s%s\n", images, max_intervals, wpb,
+                rows, p.stage_below, p.total_bytes, uniform ? " flat" : "", walk_tables ? " walk tables" : "");
+    return p;
+}
+
+hipError_t launch_walk_mcus(const ImageDesc *descs, uint32_t images, uint32_t max_intervals, const WalkPlan &plan, hipStream_t stream, uint32_t *queue)
+{
+    if (images == 0 || max_intervals == 0)
+        return hipSuccess;
+    const uint32_t threads = plan.waves_per_block * kWave;
+    dim3 grid((max_intervals + threads - 1) / threads, images, 1);
+    const uint64_t flat_groups = (uint64_t(plan.waves_per_image) * images + plan.waves_per_block - 1) / plan.waves_per_block;
+    const bool flat = plan.waves_per_image != 0u && flat_groups <= 0x7fffffffu;
+    if (flat) {
+        const DeviceLimits lim = device_limits();
+        const uint32_t per_cu = std::max(1u, std::min(lim.lds_bytes / plan.total_bytes, kMaxWavesFused / plan.waves_per_block));
+        grid = dim3(uint32_t(std::min<uint64_t>(flat_groups, uint64_t(lim.cus) * per_cu)), 1, 1);
+    }
+    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(walk_mcus_422_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                int(device_limits().lds_bytes));
+    if (attr != hipSuccess)
+        return attr;
+    uint32_t *q = flat && queue && flat_groups > grid.x ? queue : nullptr;
+    if (q) {
+        const hipError_t z = hipMemsetAsync(q, 0, sizeof(uint32_t), stream);
+        if (z != hipSuccess)
+            return z;
+    }
+    hipLaunchKernelGGL(walk_mcus_422_kernel, grid, dim3(threads), plan.total_bytes, stream, descs, plan.l2_entries_in_lds, plan.rows, plan.stage_below,
+                       flat ? plan.waves_per_image : 0u, images, q, plan.walk_tables ? 1u : 0u);
+    return hipGetLastError();
+}
+
 hipError_t launch_pair_422(const ImageDesc *descs, uint32_t images, uint32_t max_intervals,
                            const HuffLdsPlan &plan, hipStream_t stream)
 {
@@ -1053,7 +1208,7 @@ constexpr uint32_t kCoopTeamWaves = 4;
 __global__ void __launch_bounds__(1024) walk_tables_kernel(const ImageDesc *__restrict__ descs)
 {
     const ImageDesc &d = descs[blockIdx.y];
-    if (!d.walk || !d.coop_ok)
+    if (!d.walk || !(d.coop_ok || d.mcu_ok))
         return;
     HuffShared h{};
     h.l2 = d.l2;

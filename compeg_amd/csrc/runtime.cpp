@@ -1854,6 +1854,29 @@ Status compeg_batch::upload_device_scan(size_t n, int threads, const FeedSource 
     return finish();
 }
 
+// The walk + lane-per-MCU route (kernels_body.h) for a batch whose launches are `step` images (the last one `smallest`)?
+// A lane per restart interval fills the chip with 3072 waves of 64 intervals; below that the route spreads the work
+// inside the intervals over the chip -- where the cooperative kernel (one or two frames per launch: latency) does not
+// take the launch.
+bool use_mcu_route(const compeg_batch &b, uint32_t step, uint32_t smallest)
+{
+    static const int forced = [] {
+        const char *e = lab_env("COMPEG_WALK"); // experiment knob: 0 / 1
+        return e ? atoi(e) : -1;
+    }();
+    if (forced >= 0)
+        return forced != 0;
+    if (b.one_mcu_intervals || b.min_restart_interval < 2u)
+        return false; // (a lane per interval is a lane per MCU already)
+    if (b.coop_r && use_coop_kernel(b.max_intervals, smallest, b.coop_r))
+        return false;
+    // Measured (walk_probe.py, ms per launch, this route / the streamed batch kernel): 256 x 960x720 with an interval per
+    // MCU row (360 waves of intervals) 0.97 / 1.25, 64 x DRI = 30 0.41 / 0.60, 16 x 4K with an interval per MCU row 2.9 / 4.5;
+    // 1024 x 960x720 (1440 waves) 1.84 / 1.51, 256 x DRI = 10 0.48 / 0.35.
+    const uint64_t waves = uint64_t((b.max_intervals + kWave - 1) / kWave) * step;
+    return b.min_restart_interval >= 24u && waves <= 640u;
+}
+
 // Uploads the descriptors; in front of that, gives every image its walk tables if the cooperative kernel may
 // decode this batch (uniform batches share one set), and makes them behind the upload.
 Status compeg_batch::make_walk_tables(hipStream_t stream, size_t n)
@@ -1862,8 +1885,13 @@ Status compeg_batch::make_walk_tables(hipStream_t stream, size_t n)
     // n % chunk -- the smallest of them decides, the kernel takes the small launches)
     const size_t step = chunk ? std::min<size_t>(chunk, n) : n;
     const size_t smallest = step && n % step ? n % step : step;
-    const bool want = n > 0 && coop_r != 0 && !generic_layout && use_fused_pipeline() &&
-                      use_coop_kernel(max_intervals, uint32_t(smallest), coop_r);
+    // The walk + lane-per-MCU route for this batch's launches?  (decided here, where the records' buffers are made)
+    mcu_route = n > 0 && !generic_layout && use_fused_pipeline() && use_mcu_route(*this, uint32_t(step), uint32_t(smallest));
+    for (size_t i = 0; i < n && mcu_route; i++)
+        mcu_route = descs[i].mcu_ok != 0;
+    // (the walk goes through the walk tables too)
+    const bool want = n > 0 && !generic_layout && use_fused_pipeline() &&
+                      (mcu_route || (coop_r != 0 && use_coop_kernel(max_intervals, uint32_t(smallest), coop_r))) && !lab_env("COMPEG_NO_WALK_TABLES");
     // one set for all: the same tables (uniform) used by the same components
     bool shared = uniform;
     for (size_t i = 1; i < n && shared; i++)
@@ -1876,9 +1904,56 @@ Status compeg_batch::make_walk_tables(hipStream_t stream, size_t n)
         descs[i].walk = want ? reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(walk_tables.ptr) +
                                                                   (shared ? 0 : i) * kWalkTableBytes)
                              : nullptr;
+    max_mcus = 0;
+    mcu_uniform = uniform;
+    for (size_t i = 0; i < n && mcu_route; i++) {
+        max_mcus = std::max(max_mcus, descs[i].total_mcus);
+        mcu_uniform = mcu_uniform && descs[i].total_mcus == descs[0].total_mcus;
+    }
+    std::vector<ImageDesc> views;
+    if (mcu_route) {
+        // per image: a word index per MCU (and 64 more: the window of an image's last wave asks for the entry behind
+        // its MCUs' -- never used) and a state per MCU
+        size_t words_total = 0, states_total = 0;
+        for (size_t i = 0; i < n; i++) {
+            words_total += align_up((size_t(descs[i].total_mcus) + kWave) * 4, 256);
+            states_total += align_up(size_t(descs[i].total_mcus) * sizeof(McuState), 256);
+        }
+        CG_TRY(mcu_words.reserve(words_total + 256));
+        CG_TRY(mcu_states.reserve(states_total + 256));
+        CG_TRY(mcu_descs.reserve(n * sizeof(ImageDesc) + 256));
+        views.resize(n);
+        size_t w_at = 0, s_at = 0;
+        for (size_t i = 0; i < n; i++) {
+            ImageDesc &d = descs[i];
+            d.mcu_word = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(mcu_words.ptr) + w_at);
+            d.mcu_state = reinterpret_cast<McuState *>(static_cast<uint8_t *>(mcu_states.ptr) + s_at);
+            w_at += align_up((size_t(d.total_mcus) + kWave) * 4, 256);
+            s_at += align_up(size_t(d.total_mcus) * sizeof(McuState), 256);
+            // the image as the second kernel sees it: every "interval" one MCU
+            ImageDesc &v = views[i];
+            v = d;
+            v.starts = d.mcu_word;
+            v.nstarts = d.total_mcus;
+            v.total_intervals = d.total_mcus;
+            v.restart_interval = 1;
+            v.walk = nullptr;
+            v.coop_ok = 0;
+        }
+        // Window of the second kernel: the words of 64 consecutive MCUs.  Known is the largest span of 64 consecutive
+        // *intervals* (max_span: 64 R MCUs): three times the average of its MCUs and a little, at most all of it.  (A lane
+        // whose words lie beyond its wave's window reads them from memory with the reference's reader: slower, the same
+        // result.)
+        const uint32_t r = std::max(1u, min_restart_interval);
+        const uint64_t avg64 = (uint64_t(max_span) + r - 1) / r;
+        mcu_span = uint32_t(std::min<uint64_t>(3 * avg64 + 64, max_span));
+        CG_HIP(hipMemcpyAsync(mcu_descs.ptr, views.data(), n * sizeof(ImageDesc), hipMemcpyHostToDevice, stream));
+    }
     CG_HIP(hipMemcpyAsync(dev_descs.ptr, descs.data(), n * sizeof(ImageDesc), hipMemcpyHostToDevice, stream));
     if (want)
         CG_HIP(launch_walk_tables(static_cast<const ImageDesc *>(dev_descs.ptr), uint32_t(shared ? 1 : n), stream));
+    if (mcu_route)
+        CG_HIP(hipStreamSynchronize(stream)); // (`views` is pageable memory of this call's)
     return Status{};
 }
 
@@ -1941,6 +2016,19 @@ Status compeg_batch::decode(hipStream_t stream)
             if (timing && at == 0)
                 CG_HIP(hipEventRecord(ev[1], stream));
             CG_HIP(launch_generic_composite(dd + at, m, max_out_w, max_out_h, stream));
+            continue;
+        }
+        if (fused && mcu_route) {
+            // the walk, a lane per restart interval (streamed windows: any interval length), then a lane per MCU
+            const ImageDesc *md = static_cast<const ImageDesc *>(mcu_descs.ptr);
+            CG_HIP(launch_walk_mcus(dd + at, m, max_intervals, plan_walk(max_intervals, m, max_l2, stream_mcu_words, uniform, descs[0].walk != nullptr),
+                                    stream, static_cast<uint32_t *>(unit_queue.ptr)));
+            if (timing && at == 0)
+                CG_HIP(hipEventRecord(ev[1], stream));
+            const HuffLdsPlan mcu_plan = plan_huffman(max_mcus, m, max_l2, mcu_span, true);
+            CG_HIP(launch_fused_422(md + at, m, max_mcus, mcu_plan, stream, mcu_uniform, true, static_cast<uint32_t *>(unit_queue.ptr), true));
+            if (at == 0)
+                last_kernel = COMPEG_KERNEL_WALK_MCU;
             continue;
         }
         if (fused) {

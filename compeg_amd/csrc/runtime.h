@@ -151,6 +151,13 @@ struct compeg_batch {
     // largest word span of a wave's group of intervals
     uint32_t coop_r = 0;
     compeg::CoopSpans coop_spans{};
+    // The walk + lane-per-MCU route (kernels_body.h): chosen at upload (make_walk_tables) for launches whose restart
+    // intervals are too few, or too long, to fill the chip with a lane each; the walk's records (a stream word index and
+    // a state per MCU) and the images' descriptors of MCUs
+    bool mcu_route = false;
+    compeg::DeviceBuffer mcu_words, mcu_states, mcu_descs;
+    uint32_t max_mcus = 0, mcu_span = 0;
+    bool mcu_uniform = false;
     uint32_t max_out_w = 0, max_out_h = 0;
     uint64_t algorithmic_bytes = 0, pixels = 0;
     uint32_t chunk = 0; // images per launch pair, 0 = all

@@ -178,6 +178,9 @@ int compeg_decoder_last_stage_times(const compeg_decoder *dec, compeg_stage_time
 #define COMPEG_KERNEL_FUSED_LAYOUT 6 /* decode_fused_444 / _440 / _420_kernel (one layout other than 4:2:2) */
 #define COMPEG_KERNEL_FUSED_STREAM 7 /* decode_fused_422 / _444 / _440 / _420_stream_kernel: the batch kernels with streamed
                                        windows (long restart intervals, dense streams) */
+#define COMPEG_KERNEL_WALK_MCU 8     /* walk_mcus_422_kernel + decode_fused_422_mcu_rec_kernel: a lane per restart interval
+                                       finds where the MCUs begin, then a lane per MCU decodes (batches of few or long
+                                       restart intervals) */
 int compeg_decoder_last_kernel(const compeg_decoder *dec);
 /* Extension: on != 0 moves the scan preprocessing of every following decode
  * from the host (the reference's data flow, default) to the device-side scan

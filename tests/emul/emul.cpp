@@ -182,6 +182,100 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
         return 0;
     }
 
+    // ---- mode 8: the walk + lane-per-MCU route: walk_mcus_422_kernel (walk_wave_422_stream played lane by lane, MCU by
+    // MCU), then decode_fused_422_mcu_rec_kernel -- the fused kernel over the image's descriptor of MCUs, every lane begun
+    // from its MCU's record.  window_words: the walk's rows (0: 16); EMUL_WALK_TABLES=0: nobody takes the walk tables.
+    bool from_records = false;
+    std::vector<uint32_t> mcu_word;
+    std::vector<McuState> mcu_state;
+    if (fused == 8) {
+        if (!d.mcu_ok) {
+            snprintf(err, errlen, "image does not qualify for the walk + lane-per-MCU route");
+            delete img;
+            return -5;
+        }
+        mcu_word.assign(size_t(d.total_mcus) + kWave, 0xdeadbeefu);
+        mcu_state.assign(d.total_mcus, McuState{0xffffffffu, {0x55555555, 0x55555555, 0x55555555}});
+        d.mcu_word = mcu_word.data();
+        d.mcu_state = mcu_state.data();
+        const uint32_t nrows = window_words ? window_words : 16u;
+        const uint32_t stage_below = getenv("EMUL_STREAM_BELOW") ? uint32_t(strtoul(getenv("EMUL_STREAM_BELOW"), nullptr, 0)) : nrows / 2u;
+        const bool with_tables = !(getenv("EMUL_WALK_TABLES") && atoi(getenv("EMUL_WALK_TABLES")) == 0);
+        const uint32_t l2n = (uint32_t(l2.size()) + 1u) & ~1u; // (everything staged: L2, direct AC and DC tables)
+        const uint32_t walk_off = (align16((kL1Entries + l2n) * 2u) + 31u) & ~31u;
+        const uint32_t lds_bytes = walk_off + kWalkWords * 4u + 96u + (nrows + 1u) * kWave * 4u; // (a row nobody stages, see walk_mcus_422_kernel)
+        for (uint32_t first = 0; first < d.total_intervals; first += kWave) {
+            uint8_t *smem = static_cast<uint8_t *>(aligned_alloc(32, (lds_bytes + 31u) & ~31u));
+            memset(smem, 0xa5, lds_bytes);
+            uint16_t *sl1 = reinterpret_cast<uint16_t *>(smem);
+            uint16_t *sl2 = sl1 + kL1Entries;
+            uint32_t *walk = reinterpret_cast<uint32_t *>(smem + walk_off);
+            int16_t *dump = reinterpret_cast<int16_t *>(smem + walk_off + kWalkWords * 4u);
+            uint32_t *win = reinterpret_cast<uint32_t *>(smem + walk_off + kWalkWords * 4u + 96u);
+            for (uint32_t tid = 0; tid < 128; tid++)
+                stage_luts(d, sl1, sl2, l2n, tid, 128, 2u * kDcFastEntries);
+            HuffShared sh{sl1, sl2, umin(l2n, d.fast_off + 2u * kFastEntries + 2u * kDcFastEntries), win, 0u, 0u, nullptr};
+            CoopTables ct;
+            coop_tables(d, sh, ct);
+            for (uint32_t i = 0; i < kWalkWords; i++)
+                walk[i] = ct.walk_ok ? coop_walk_word(ct.ac_fast, ct.dc_fast, ct.walk_ids, i) : 0u;
+            WalkTabs tabs;
+            tabs.walk = with_tables && ct.walk_ok ? walk : nullptr;
+            tabs.dc_fast = ct.dc_fast;
+            tabs.acsel = ct.walk_acsel;
+            tabs.dcsel = ct.walk_dcsel;
+            tabs.dcfsel = (d.dc_fast_table[0] & 1u) * 0x0101u | (d.dc_fast_table[1] & 1u) << 16 | (d.dc_fast_table[2] & 1u) << 24;
+            tabs.standard = d.standard_entropy != 0u;
+            for (uint32_t c = 0; c < 3u; c++) {
+                tabs.dc_off[c] = ct.dc_off[c];
+                tabs.ac_off[c] = ct.ac_off[c];
+            }
+            std::vector<EntropyState> es(kWave);
+            const uint32_t lanes = std::min<uint32_t>(kWave, d.total_intervals - first);
+            for (uint32_t lane = 0; lane < lanes; lane++)
+                stream_lane_init(es[lane], d, sh, nrows, first + lane, lane);
+            for (uint32_t i = 0; i < d.restart_interval; i++) {
+                for (uint32_t lane = 0; lane < lanes; lane++) {
+                    EntropyState &e = es[lane];
+                    mcu_record_write<true>(e, d, sh, lane, (first + lane) * d.restart_interval + i);
+                    bool done = false;
+                    if (tabs.walk != nullptr && e.fast) {
+                        const EntropyState saved = e;
+                        done = walk_mcu_fast(e, d, sh, tabs);
+                        g_walk_stats.fast_tried++;
+                        if (!done) {
+                            e = saved;
+                            g_walk_stats.fast_bailed++;
+                        }
+                    }
+                    if (!done) {
+                        g_walk_stats.slow_mcus++;
+                        for (uint32_t k = 0; k < 4u; k++)
+                            entropy_data_unit<true>(e, d, sh, k < 2u ? 0u : k - 1u, dump, lane);
+                    }
+                }
+                bool any = false;
+                for (uint32_t lane = 0; lane < lanes && i + 1u < d.restart_interval; lane++)
+                    any = any || stream_wants_rows(es[lane], d, sh, lane, stage_below);
+                for (uint32_t lane = 0; lane < lanes && any; lane++)
+                    stream_restage(es[lane], d, sh, nrows, lane);
+                g_walk_stats.restages += any ? 1 : 0;
+            }
+            free(smem);
+        }
+        if (getenv("EMUL_WALK_STATS"))
+            fprintf(stderr, "walk: fast tried %lu bailed %lu (escape %lu, dc %lu, rows %lu) slow MCUs %lu restages %lu\n", g_walk_stats.fast_tried, g_walk_stats.fast_bailed,
+                    g_walk_stats.bail_escape, g_walk_stats.bail_dc, g_walk_stats.bail_rows, g_walk_stats.slow_mcus, g_walk_stats.restages);
+        // the image as the second kernel sees it: every "interval" one MCU (runtime.cpp: make_walk_tables)
+        d.starts = mcu_word.data();
+        d.nstarts = d.total_mcus;
+        d.total_intervals = d.total_mcus;
+        d.restart_interval = 1;
+        from_records = true;
+        fused = 1;
+        window_words = getenv("EMUL_MCU_WINDOW") ? uint32_t(atoi(getenv("EMUL_MCU_WINDOW"))) : 512u;
+    }
+
     if (fused == 1 || fused == 2 || fused == 7) {
         // (7: decode_fused_422_stream_kernel -- `window_words` rows of every lane's stream instead of the wave's window)
         const bool stream = fused == 7;
@@ -223,6 +317,8 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
                 const bool active = first + lane < d.total_intervals;
                 if (active && stream)
                     stream_lane_init(es[lane], d, sh, nrows, first + lane, lane);
+                else if (active && from_records)
+                    entropy_init_from_record(es[lane], d, sh, first + lane);
                 else if (active)
                     entropy_init(es[lane], d, sh, first + lane);
                 pixel_init(ps[lane], d, active ? first + lane : 0u, active);

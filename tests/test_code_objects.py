@@ -12,7 +12,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "compeg_amd", "libcompeg_hip.so")
 LLVM = "/opt/rocm/lib/llvm/bin"
-KERNELS = ("decode_fused_422_kernel", "decode_fused_422_mcu_kernel", "decode_fused_422_stream_kernel", "decode_fused_444_stream_kernel", "decode_fused_440_stream_kernel", "decode_fused_420_stream_kernel", "decode_fused_444_kernel", "decode_fused_440_kernel", "decode_fused_420_kernel",
+KERNELS = ("decode_fused_422_kernel", "decode_fused_422_mcu_kernel", "decode_fused_422_mcu_rec_kernel", "walk_mcus_422_kernel", "decode_fused_422_stream_kernel", "decode_fused_444_stream_kernel", "decode_fused_440_stream_kernel", "decode_fused_420_stream_kernel", "decode_fused_444_kernel", "decode_fused_440_kernel", "decode_fused_420_kernel",
            "decode_fused_444_single_kernel", "decode_fused_440_single_kernel",
            "decode_pair_422_kernel", "decode_coop_team_422_kernel",
            "entropy_kernel", "idct_composite_kernel")
