@@ -59,7 +59,19 @@ void fill_desc(const ImageData &img, ImageDesc &d)
     const bool is422 = md.dus_per_mcu == 4 && md.components[0].hsample == 2 && md.components[0].vsample == 1 &&
                        md.components[1].hsample == 1 && md.components[1].vsample == 1 &&
                        md.components[2].hsample == 1 && md.components[2].vsample == 1;
-    bool ok = is422 && md.restart_interval != 0 && md.restart_interval <= (1u << 18) && d.total_mcus != 0;
+    // ... the zero-stream data units known (fill_coop), and at most two different pairs of (DC, AC) table among the
+    // components: what the walk tables hold (coop_body.h: coop_tables)
+    bool ok = is422 && md.restart_interval != 0 && md.restart_interval <= (1u << 18) && d.zero_du_ok != 0;
+    if (ok) {
+        const uint32_t pair0 = (d.dc_fast_table[0] & 1u) | ((d.fast_table[0] & 1u) << 1);
+        uint32_t pair1 = pair0;
+        for (uint32_t c = 1; c < 3; c++) {
+            const uint32_t pr = (d.dc_fast_table[c] & 1u) | ((d.fast_table[c] & 1u) << 1);
+            if (pr != pair0 && pair1 == pair0)
+                pair1 = pr;
+            ok = ok && (pr == pair0 || pr == pair1);
+        }
+    }
     for (uint32_t c = 0; c < 3 && ok; c++) {
         ok = d.fast_table[c] < 2 && d.dc_fast_table[c] < 2;
         const uint16_t *l1 = img.l1 + size_t(d.dc_table[c] & 3u) * 256;
@@ -87,12 +99,12 @@ void fill_coop(const ImageData &img, ImageDesc &d)
 {
     const Metadata &md = img.metadata;
     d.coop_ok = 0;
+    d.zero_du_ok = 0;
     memset(d.zero_du, 0, sizeof d.zero_du);
     const bool is422 = md.dus_per_mcu == 4 && md.components[0].hsample == 2 && md.components[0].vsample == 1 &&
                        md.components[1].hsample == 1 && md.components[1].vsample == 1 &&
                        md.components[2].hsample == 1 && md.components[2].vsample == 1;
-    // (any restart interval of up to kCoopMaxRestart MCUs: coop_shape, device_types.h)
-    if (!is422 || md.restart_interval == 0 || md.restart_interval > kCoopMaxRestart)
+    if (!is422 || md.restart_interval == 0)
         return;
     for (uint32_t c = 0; c < 3; c++)
         if (d.fast_table[c] >= 2 || d.dc_fast_table[c] >= 2)
@@ -129,7 +141,9 @@ void fill_coop(const ImageData &img, ImageDesc &d)
         for (int z = 1; z < kRetained; z++)
             d.zero_du[c][z] = slot[z];
     }
-    d.coop_ok = 1;
+    d.zero_du_ok = 1;
+    // (the cooperative kernel: any restart interval of up to kCoopMaxRestart MCUs -- coop_shape, device_types.h)
+    d.coop_ok = md.restart_interval <= kCoopMaxRestart ? 1u : 0u;
 }
 
 

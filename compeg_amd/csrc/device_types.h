@@ -119,6 +119,7 @@ struct ImageDesc {
     // it then reads zeros for the rest of the interval): [c][0] the DC difference, [c][1..31] the AC levels
     uint32_t dc_fast_table[3];
     uint32_t coop_ok;
+    uint32_t zero_du_ok; // zero_du is known (4:2:2, direct tables for every component, no hostile category behind the all-zero prefix)
     int16_t zero_du[3][kRetained];
     // the walk tables (coop_body.h: kWalkWords words, made by launch_walk_tables from the direct
     // tables), or null: the cooperative kernel's walks then go symbol by symbol

@@ -57,10 +57,12 @@ hipError_t launch_fused_stream(const ImageDesc *descs, uint32_t images, uint32_t
 // walk_tables: every image has ImageDesc::walk (launch_walk_tables): two symbols a step
 struct WalkPlan {
     uint32_t rows = 0, stage_below = 0, waves_per_block = 0, l2_entries_in_lds = 0, total_bytes = 0;
+    uint32_t chunk = 1;           // MCUs a lane walks between two looks at what it found (walk_body.h)
     uint32_t waves_per_image = 0; // != 0: the flat grid (uniform launches)
     bool walk_tables = false;
 };
-WalkPlan plan_walk(uint32_t max_intervals, uint32_t images, uint32_t max_l2, uint32_t mcu_words, bool uniform, bool walk_tables);
+// restart_interval: the smallest of the launch's images
+WalkPlan plan_walk(uint32_t max_intervals, uint32_t images, uint32_t max_l2, uint32_t mcu_words, uint32_t restart_interval, bool uniform, bool walk_tables);
 hipError_t launch_walk_mcus(const ImageDesc *descs, uint32_t images, uint32_t max_intervals, const WalkPlan &plan, hipStream_t stream,
                             uint32_t *queue = nullptr);
 // Extension layouts (luma hs x vs = 1x1, 1x2, 2x2), fused like the 4:2:2 kernel; plan with wave_cap = fused_layout_wave_cap.

@@ -25,6 +25,7 @@
 
 #include "kernels_body.h"
 #include "coop_body.h"
+#include "walk_body.h"
 #include "kernels.h"
 #include "lab.h"
 
@@ -523,10 +524,11 @@ struct WaveLayoutStream {
 // The first kernel of the walk + lane-per-MCU route (kernels_body.h): a lane per restart interval, entropy decode only,
 // the decoder's state at every MCU's start into ImageDesc::mcu_word / mcu_state.  The launch shapes of the streamed
 // batch kernel (fused_stream_kernel_body): a grid row per image, or the flat grid with resident waves and the units' queue.
-// LDS: [L1][L2 + direct tables][walk tables, if the images have them][80 bytes nobody reads][per wave: rows]
+// LDS: [L1][L2 + direct tables][walk tables, if the images have them][96 bytes nobody reads][per wave: 64 lists | the slow road's window | rows + 3]
+constexpr uint32_t kWalkSpareRows = 3; // (the walk reads three rows at its position: one behind the last staged, never used, and room to run over)
 __global__ void __launch_bounds__(768)
 walk_mcus_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t rows, uint32_t stage_below,
-                     uint32_t waves_per_image, uint32_t images, uint32_t *queue, uint32_t with_walk_tables)
+                     uint32_t waves_per_image, uint32_t images, uint32_t *queue, uint32_t with_walk_tables, uint32_t chunk)
 {
     extern __shared__ __attribute__((aligned(32))) uint8_t smem[];
     const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x / kWave))), lane = threadIdx.x % kWave;
@@ -552,9 +554,10 @@ walk_mcus_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, ui
     const bool tables = with_walk_tables != 0u && d.walk != nullptr;
     const uint32_t dump_off = walk_off + (with_walk_tables ? kWalkWords * 4u : 0u);
     int16_t *dump = reinterpret_cast<int16_t *>(smem + dump_off);
-    // (a row more than is staged: a reader that has merged its last staged word asks for the one behind it -- never used)
-    const uint32_t wave_area = (rows + 1u) * kWave * 4u;
-    uint32_t *win = reinterpret_cast<uint32_t *>(smem + dump_off + 96u + wave * wave_area);
+    const uint32_t wave_area = uint32_t(kWave) * walk_list_bytes(chunk) + kWalkSlowWords * 4u + (rows + kWalkSpareRows) * kWalkRowBytes;
+    uint32_t *lists = reinterpret_cast<uint32_t *>(smem + dump_off + 96u + wave * wave_area);
+    uint32_t *slow_window = lists + uint32_t(kWave) * walk_list_bytes(chunk) / 4u;
+    uint32_t *win = slow_window + kWalkSlowWords;
     stage_luts(d, l1, l2, l2_in_lds, threadIdx.x, blockDim.x, 2u * kDcFastEntries);
     if (tables)
         copy_words_to_lds(walk, d.walk, kWalkWords, threadIdx.x, blockDim.x);
@@ -567,25 +570,12 @@ walk_mcus_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, ui
     s.l2_staged = umin(l2_in_lds, d.fast_off + 2u * kFastEntries + 2u * kDcFastEntries);
     s.win = win;
     s.win_base = 0u;
-    s.win_len = 0u; // (no whole-interval window: the reference reader's words come from global memory)
+    s.win_len = 0u;
     s.du_slots = nullptr;
     WalkTabs tabs;
-    {
-        CoopTables t;
-        coop_tables(d, s, t);
-        tabs.walk = tables && t.walk_ok ? walk : nullptr;
-        tabs.dc_fast = t.dc_fast;
-        tabs.acsel = t.walk_acsel;
-        tabs.dcsel = t.walk_dcsel;
-        tabs.dcfsel = (d.dc_fast_table[0] & 1u) * 0x0101u | (d.dc_fast_table[1] & 1u) << 16 | (d.dc_fast_table[2] & 1u) << 24;
-        tabs.standard = d.standard_entropy != 0u;
-        for (uint32_t c = 0; c < 3u; c++) {
-            tabs.dc_off[c] = t.dc_off[c];
-            tabs.ac_off[c] = t.ac_off[c];
-        }
-    }
+    walk_tabs(d, s, tables ? walk : nullptr, tabs);
     if (!waves_per_image) {
-        walk_wave_422_stream(d, s, tabs, dump, rows, stage_below, wave_first + lane, lane);
+        walk_wave_422(d, s, tabs, lists, slow_window, dump, rows, stage_below, chunk, wave_first + lane, lane);
         return;
     }
     // (the flat grid: resident waves that go on to further units of 64 intervals, drawn from the queue if there is one --
@@ -595,7 +585,7 @@ walk_mcus_422_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, ui
         uint32_t drawn = 0u;
         if (queue && lane == 0u)
             drawn = atomicAdd(queue, 1u);
-        walk_wave_422_stream(descs[image], s, tabs, dump, rows, stage_below, wave_first + lane, lane);
+        walk_wave_422(descs[image], s, tabs, lists, slow_window, dump, rows, stage_below, chunk, wave_first + lane, lane);
         flat = queue ? stride + uint32_t(__builtin_amdgcn_readfirstlane(int(drawn))) : flat + stride; // (wave-uniform)
         if (flat >= units)
             break;
@@ -1120,7 +1110,7 @@ hipError_t launch_fused_stream(const ImageDesc *descs, uint32_t images, uint32_t
 
 // The walk kernel's shape: a CU's share of the launch's waves in one workgroup (at most twelve), and all the LDS the
 // tables leave for their rows -- the walk waits for every staging (no IDCT to land it under), so the fewer the better.
-WalkPlan plan_walk(uint32_t max_intervals, uint32_t images, uint32_t max_l2, uint32_t mcu_words, bool uniform, bool walk_tables)
+WalkPlan plan_walk(uint32_t max_intervals, uint32_t images, uint32_t max_l2, uint32_t mcu_words, uint32_t restart_interval, bool uniform, bool walk_tables)
 {
     WalkPlan p;
     const DeviceLimits lim = device_limits();
@@ -1134,22 +1124,32 @@ WalkPlan plan_walk(uint32_t max_intervals, uint32_t images, uint32_t max_l2, uin
         wpb = std::min(wpb, std::max(1u, waves_per_image));
     if (const char *e = lab_env("COMPEG_WALK_WPB")) // experiment knob
         wpb = uint32_t(std::max(1, std::min(12, atoi(e))));
-    uint32_t rows = (lim.lds_bytes - tables) / wpb / (kWave * 4u) - 1u; // (and a row nobody stages: walk_mcus_422_kernel)
-    rows = std::max(12u, std::min(rows, 160u));
+    // A wave's share of the LDS (walk_mcus_422_kernel): its lanes' lists -- 16 rows' worth per MCU of the chunk the lanes walk
+    // between two looks at what they found --, the slow road's window, its rows and the spare ones.  The longer the chunk,
+    // the less the lanes wait for each other (they meet at a chunk's end) and the rarer everything that happens per
+    // chunk; the rows have to hold a chunk two and a half times over (staged anew when some lane has less than one and
+    // a half in front of it).
+    const uint32_t share = ((lim.lds_bytes - tables) / wpb - kWalkSlowWords * 4u) / kWalkRowBytes - kWalkSpareRows; // in rows
+    const uint32_t per_mcu = 16u + (5u * std::max(mcu_words, 1u) + 1u) / 2u;
+    uint32_t chunk = std::max(1u, std::min(std::min(kWalkMaxChunk, restart_interval), (share > 4u ? share - 4u : 0u) / per_mcu));
+    if (const char *e = lab_env("COMPEG_WALK_CHUNK")) // experiment knob
+        chunk = uint32_t(std::max(1, std::min(int(kWalkMaxChunk), atoi(e))));
+    const uint32_t list_rows = (uint32_t(kWave) * walk_list_bytes(chunk) + kWalkRowBytes - 1u) / kWalkRowBytes;
+    uint32_t rows = share > list_rows ? share - list_rows : 0u;
+    rows = std::max(8u, std::min(rows, 192u));
     if (const char *e = lab_env("COMPEG_WALK_ROWS")) // experiment knob
         rows = uint32_t(std::max(4, std::min(256, atoi(e))));
     p.rows = rows;
-    // staged anew when some lane has fewer words in front of it than three average MCUs (a lane that runs out inside
-    // an MCU decodes it once more through the reference's reader)
-    p.stage_below = std::min(rows / 2u, 3u * mcu_words + 4u);
+    p.chunk = chunk;
+    p.stage_below = std::min(rows / 2u, (3u * chunk * mcu_words + 1u) / 2u + 8u);
     if (const char *e = lab_env("COMPEG_WALK_BELOW")) // experiment knob
         p.stage_below = uint32_t(std::max(0, atoi(e)));
     p.waves_per_block = wpb;
-    p.total_bytes = tables + wpb * (rows + 1u) * kWave * 4u;
+    p.total_bytes = tables + wpb * (uint32_t(kWave) * walk_list_bytes(chunk) + kWalkSlowWords * 4u + (rows + kWalkSpareRows) * kWalkRowBytes);
     p.waves_per_image = uniform ? waves_per_image : 0u;
     if (getenv("COMPEG_VERBOSE"))
-        fprintf(stderr, "[compeg] walk plan: images=%u intervals=%u waves/block=%u rows=%u below %u words lds=%u B%s%s\n", images, max_intervals, wpb,
-                rows, p.stage_below, p.total_bytes, uniform ? " flat" : "", walk_tables ? " walk tables" : "");
+        fprintf(stderr, "[compeg] walk plan: images=%u intervals=%u waves/block=%u rows=%u below %u words chunk=%u MCUs lds=%u B%s%s\n", images, max_intervals, wpb,
+                rows, p.stage_below, chunk, p.total_bytes, uniform ? " flat" : "", walk_tables ? " walk tables" : "");
     return p;
 }
 
@@ -1177,7 +1177,7 @@ hipError_t launch_walk_mcus(const ImageDesc *descs, uint32_t images, uint32_t ma
             return z;
     }
     hipLaunchKernelGGL(walk_mcus_422_kernel, grid, dim3(threads), plan.total_bytes, stream, descs, plan.l2_entries_in_lds, plan.rows, plan.stage_below,
-                       flat ? plan.waves_per_image : 0u, images, q, plan.walk_tables ? 1u : 0u);
+                       flat ? plan.waves_per_image : 0u, images, q, plan.walk_tables ? 1u : 0u, plan.chunk);
     return hipGetLastError();
 }
 

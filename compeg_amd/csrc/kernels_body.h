@@ -1907,34 +1907,14 @@ CG_DEV void stream_lane_init(EntropyState &e, const ImageDesc &d, const HuffShar
 // A lane per restart interval (the reference's parallelism) leaves the chip idle when a launch has few intervals -- 256
 // frames of 960x720 with an interval per MCU row are 360 waves for 1024 SIMDs, each lane with 240 data units in front
 // of it.  What is serial inside an interval is only where its MCUs begin and what the DC predictions are there.  So:
-// a first kernel *walks* the intervals, a lane each, entropy decode only (walk_wave_422_stream), and writes the
+// a first kernel *walks* the intervals, a lane each, symbol sizes only (walk_body.h: walk_wave_422), and writes the
 // decoder's state at every MCU's start (ImageDesc::mcu_word / mcu_state); a second one decodes with a lane per *MCU*
 // (decode_wave_fused_422<..., RECORDS>: the kernel of the one-MCU intervals, started from those states), its rows
 // leaving in pieces of 1 KB.  Both follow the reference's reader exactly -- the states are the reader's own --, so the
 // pixels are the ones a lane per interval produces.
 
-// The state of lane `e` in front of an MCU's first data unit -> the MCU's record.
-// STREAM: the wave's window in its streamed form (the walk's).
-template <bool STREAM>
-CG_DEV void mcu_record_write(const EntropyState &e, const ImageDesc &d, const HuffShared &s, uint32_t lane, uint32_t mcu)
-{
-    // the word in flight (r.pre) is word `idx` of the scan, and r.left bits in front of it are not consumed yet
-    const uint32_t idx = e.fast ? (STREAM ? stream_word_index(e, s, lane) : s.win_base + uint32_t(e.wptr - s.win)) : e.r.next_word;
-    const bool dead = !e.fast && e.r.left >= 64u; // (wrapped below zero: ImageDesc::mcu_ok leaves no other way there)
-    const uint32_t left = dead ? 0u : e.r.left;
-    const uint64_t p = 32ull * idx - left;
-    // fast mode: the reference's `left` at the coming DC code (see "Fast mode"); its own reader's otherwise
-    const uint32_t ref_left = e.fast && !d.standard_entropy ? e.ref_left : left;
-    McuState st;
-    st.info = dead ? kMcuDead : (uint32_t(p) & 31u) | (umin(ref_left, 63u) << 5);
-    st.pred[0] = e.pred0;
-    st.pred[1] = e.pred1;
-    st.pred[2] = e.pred2;
-    CG_GLOBAL(uint32_t, d.mcu_word)[mcu] = uint32_t(p >> 5);
-    CG_GLOBAL(McuState, d.mcu_state)[mcu] = st;
-}
-
-// ... and back: the decoder at the start of MCU `mcu` (d: the image's descriptor of MCUs, see ImageDesc::mcu_word).
+// The decoder at the start of MCU `mcu`, from the record the walk wrote (walk_body.h: walk_record; d: the image's
+// descriptor of MCUs, see ImageDesc::mcu_word).
 // The reference reader's state there -- `left` bits of stream in its buffer, zeros behind them, the next word in
 // flight -- is also a fast-mode state (entropy_init).
 CG_DEV void entropy_init_from_record(EntropyState &e, const ImageDesc &d, const HuffShared &s, uint32_t mcu)
@@ -1969,103 +1949,6 @@ CG_DEV void entropy_init_from_record(EntropyState &e, const ImageDesc &d, const 
     const uint32_t rel = e.r.next_word - s.win_base;
     e.fast = fast_tables_usable(d, s) && rel < s.win_len;
     e.wptr = s.win + (e.fast ? rel : 0u);
-}
-
-// The walk's fast road: one MCU of a lane in fast mode through the *walk tables* (coop_body.h: coop_walk_word -- up to
-// two symbols per 32-bit entry: minus the bits consumed in the low half, the size of the last symbol, the zig-zag
-// advance) -- no coefficients, no values but the DC differences.  One loop over the MCU's symbols, whichever data unit
-// they belong to: the lanes of a wave meet again at the MCU's end, not at every data unit's.  Everything out of the
-// ordinary -- a code longer than a table's prefix, a DC code the reference's reader would run dry on (quirk Q1), the
-// staged rows running out -- ends the loop with `false`: the caller decodes the MCU once more from its start with
-// entropy_data_unit, which knows about all of these.  A code longer than its table's prefix goes through the reference's
-// two-level tables, that one symbol (ImageDesc::mcu_ok: no DC category above 15).
-// (the tables' word offsets, see coop_body.h: pairs of AC table a at 2048 a, its singles 4096 behind them, DC + first AC
-// symbol for the pair of tables i at 5120 + 2048 i)
-#if defined(CG_EMUL_STATS)
-struct WalkStats {
-    unsigned long fast_tried, fast_bailed, bail_escape, bail_dc, bail_rows, slow_mcus, restages;
-};
-inline WalkStats g_walk_stats{};
-#define CG_WALK_COUNT(field) (++g_walk_stats.field)
-#else
-#define CG_WALK_COUNT(field) ((void)0)
-#endif
-struct WalkTabs {
-    const uint32_t *walk;    // the 8192 words (LDS)
-    const uint16_t *dc_fast; // the two direct DC tables (LDS)
-    uint32_t acsel;          // byte k: which pairs / singles tables data unit k of an MCU uses (0 / 1)
-    uint32_t dcsel;          // byte k: which DC + AC table
-    uint32_t dcfsel;         // byte k: which direct DC table
-    uint32_t dc_off[3], ac_off[3]; // per component: offset of its L1 tables (codes longer than a table's prefix)
-    bool standard;           // COMPEG_PARSE_STANDARD_ENTROPY: the reader is topped up in front of DC codes too
-};
-CG_DEV uint32_t walk_entry(uint32_t consumed, uint32_t last, uint32_t adv) { return adv << 21 | last << 16 | ((0u - consumed) & 0xffffu); }
-constexpr uint32_t kWalkTabNear = 47u; // (coop_body.h: kWalkNear -- from here on a symbol may complete the data unit: one at a time)
-
-CG_DEV bool walk_mcu_fast(EntropyState &e, const ImageDesc &d, const HuffShared &s, const WalkTabs &t)
-{
-    PrefetchReader &r = e.r;
-    if (e.wptr >= e.wlimit) { // the word in flight is no staged one
-        CG_WALK_COUNT(bail_rows);
-        return false;
-    }
-    uint32_t st = 0u, k8 = 0u, ref_left = t.standard ? 64u : e.ref_left;
-    uint32_t p0 = uint32_t(e.pred0), p1 = uint32_t(e.pred1), p2 = uint32_t(e.pred2);
-    bool bad = false;
-    // (r.left >= 32 here: the state at a data unit's start, topped up.  Straight-line selects inside the loop: the
-    // lanes of a wave are at different data units, a branch per case would be taken by somebody every time)
-    do {
-        const uint32_t cur = reader_cur(r);
-        const bool dc = st == 0u, single = dc || st >= kWalkTabNear;
-        const uint32_t a = (t.acsel >> k8) & 0xffu, di = (t.dcsel >> k8) & 0xffu, df = (t.dcfsel >> k8) & 0xffu;
-        const uint32_t base = dc ? 5120u + 2048u * di : 2048u * a + (single ? 4096u : 0u);
-        uint32_t ent = lds_read_u32_early(t.walk + base + (cur >> (single ? 22u : 21u)));
-        uint32_t side = lds_read_u16_early(t.dc_fast + df * kDcFastEntries + (cur >> (32u - kDcFastBits)));
-        lds_reads_done3(ent, side, r.pre); // (r.pre: asked for by the last step's top-up)
-        if (__builtin_expect(ent == 0u, 0)) {
-            // a code longer than the table's prefix: that symbol through the reference's two-level tables
-            CG_WALK_COUNT(bail_escape);
-            const uint32_t comp = k8 < 16u ? 0u : (k8 >> 3) - 1u;
-            const uint32_t off = dc ? (comp == 0u ? t.dc_off[0] : (comp == 1u ? t.dc_off[1] : t.dc_off[2]))
-                                    : (comp == 0u ? t.ac_off[0] : (comp == 1u ? t.ac_off[1] : t.ac_off[2]));
-            const uint32_t e2 = lut_lookup<false>(d, s, off, cur);
-            const uint32_t fe = fast_entry(e2, t.standard ? 16u : 17u);
-            const uint32_t n = dc ? (e2 >> 8) + (e2 & 15u) : (fe >> 4) & 31u;
-            side = (1u << 9) | (n << 4) | (e2 & 15u);
-            ent = walk_entry(n, n, dc ? 1u : fe >> 9);
-        }
-        const uint32_t consumed = (0u - ent) & 0xffffu, last = (ent >> 16) & 31u, adv = (ent >> 21) & 0xffu;
-        // a DC step: the difference (the entry may cover the first AC symbol too: the direct DC table says where the
-        // DC symbol ends); more bits than the reference's reader has left (quirk Q1): not for this loop
-        const bool dcv = dc && side != kFastEscape;
-        const uint32_t cat = dcv ? side & 15u : 0u, n = dcv ? (side >> 4) & 31u : 0u;
-        bad = dc && (!dcv || n > ref_left);
-        const int32_t sx = signed_field(cur, n, cat);
-        const uint32_t diff = dc ? uint32_t(sx) + (((0xffffffffu << cat) ^ uint32_t(sx >> 31)) + 1u) : 0u;
-        p0 += k8 < 16u ? diff : 0u;
-        p1 += k8 == 16u ? diff : 0u;
-        p2 += k8 == 24u ? diff : 0u;
-        r.buf <<= consumed;
-        r.left -= consumed;
-        fast_refill<true>(e);
-        st += adv;
-        const bool du_end = st >= 64u;
-        ref_left = du_end && !t.standard ? 32u + ((r.left + last) & 31u) - last : ref_left;
-        st = du_end ? 0u : st;
-        k8 += du_end ? 8u : 0u;
-        // (the word now in flight has to be a staged one for another step)
-        bad = bad || (k8 < 32u && e.wptr >= e.wlimit);
-    } while (k8 < 32u && !bad);
-    lds_reads_done(r.pre, r.pre);
-    if (bad) {
-        CG_WALK_COUNT(bail_dc);
-        return false;
-    }
-    e.ref_left = t.standard ? e.ref_left : ref_left;
-    e.pred0 = int32_t(p0);
-    e.pred1 = int32_t(p1);
-    e.pred2 = int32_t(p2);
-    return true;
 }
 
 #if defined(__HIPCC__)
@@ -2323,44 +2206,6 @@ CG_DEV void decode_wave_fused_422_stream(const ImageDesc &d, const HuffShared &s
     }
 }
 
-// The walk (see "the walk + lane-per-MCU route" above): the entropy decode of 64 restart intervals, a lane each, in the
-// streamed form of the window -- decode_wave_fused_422_stream without its pixels -- writing every MCU's record in front
-// of the MCU's first data unit.  MCU by MCU: lanes in fast mode go through the walk tables (walk_mcu_fast; tabs.walk
-// null: nobody does); whoever that does not take -- or gives up on -- decodes the MCU with entropy_data_unit, its
-// coefficients into `dump` (80 bytes anybody may write to, nobody reads).
-CG_DEV void walk_wave_422_stream(const ImageDesc &d, const HuffShared &s, const WalkTabs &tabs, int16_t *dump, uint32_t nrows,
-                                 uint32_t stage_below, uint32_t interval, uint32_t lane)
-{
-    const bool active = interval < d.total_intervals;
-    interval = active ? interval : d.total_intervals - 1u;
-    EntropyState e;
-    stream_lane_init(e, d, s, nrows, interval, lane);
-    stream_rows_landed();
-    const uint32_t mcus = d.restart_interval, mcu0 = interval * d.restart_interval;
-#pragma unroll 1
-    for (uint32_t i = 0; i < mcus; i++) {
-        if (active)
-            mcu_record_write<true>(e, d, s, lane, mcu0 + i);
-        bool done = false;
-        if (tabs.walk != nullptr && e.fast) {
-            const EntropyState saved = e;
-            done = walk_mcu_fast(e, d, s, tabs);
-            if (!done)
-                e = saved;
-        }
-        if (wave_any(!done)) {
-            if (!done) {
-#pragma unroll 1
-                for (uint32_t k = 0; k < 4u; k++)
-                    entropy_data_unit<true>(e, d, s, k < 2u ? 0u : k - 1u, dump, lane);
-            }
-        }
-        if (i + 1u < mcus && wave_any(stream_wants_rows(e, d, s, lane, stage_below))) {
-            stream_restage(e, d, s, nrows, lane);
-            stream_rows_landed();
-        }
-    }
-}
 #endif // __HIPCC__
 
 // ---------------------------------------------------------------------------

@@ -1073,6 +1073,7 @@ void compeg_batch::note_batch_properties(const ImageData *const *images, size_t 
     layout_even_ri = true;
     one_mcu_intervals = n > 0;
     min_restart_interval = n ? 0xffffffffu : 0u;
+    max_restart_interval = 0u;
     total_waves = 0;
     uint64_t scan_bytes = 0, mcus = 0;
     max_out_w = max_out_h = 0;
@@ -1087,6 +1088,7 @@ void compeg_batch::note_batch_properties(const ImageData *const *images, size_t 
         layout_even_ri = layout_even_ri && img.metadata.restart_interval % 2u == 0u;
         one_mcu_intervals = one_mcu_intervals && img.metadata.restart_interval == 1u;
         min_restart_interval = std::min(min_restart_interval, uint32_t(img.metadata.restart_interval));
+        max_restart_interval = std::max(max_restart_interval, uint32_t(img.metadata.restart_interval));
         total_waves += (img.metadata.total_restart_intervals + kWave - 1) / kWave;
         scan_bytes += img.scan_len;
         mcus += uint64_t(img.metadata.total_restart_intervals) * std::max(1u, uint32_t(img.metadata.restart_interval));
@@ -1855,9 +1857,14 @@ Status compeg_batch::upload_device_scan(size_t n, int threads, const FeedSource 
 }
 
 // The walk + lane-per-MCU route (kernels_body.h) for a batch whose launches are `step` images (the last one `smallest`)?
-// A lane per restart interval fills the chip with 3072 waves of 64 intervals; below that the route spreads the work
-// inside the intervals over the chip -- where the cooperative kernel (one or two frames per launch: latency) does not
-// take the launch.
+// Where a lane per restart interval leaves the chip's SIMDs a wave each at most (1024 waves of 64 intervals), its time
+// is the length of an interval -- about 20 us per MCU of it, whatever the launch's size.  The route's walk takes a
+// quarter of that (5.5 us per MCU of an interval: the walk tables, two symbols a step, no pixels), its second kernel
+// decodes 5300 MCUs per us with the whole chip, and the two launches cost about 40 us of prologues between them.
+// Measured (walk_probe.py, us per launch, this route / the others): 256 x 960x720 with an interval per MCU row 610 /
+// 1249, 64 x 960x720 DRI = 30 410 / 596, 16 x 4K with an interval per MCU row 1292 / 4517, 40 x 1000x990 DRI = 7 185 /
+// 178; four 4K frames DRI = 4 99 / 80; and with more than a wave per SIMD 1024 x 960x720 (1440 waves) 1561 / 1506, 256 x
+// DRI = 10 (2160 waves) 397 / 351.
 bool use_mcu_route(const compeg_batch &b, uint32_t step, uint32_t smallest)
 {
     static const int forced = [] {
@@ -1870,11 +1877,14 @@ bool use_mcu_route(const compeg_batch &b, uint32_t step, uint32_t smallest)
         return false; // (a lane per interval is a lane per MCU already)
     if (b.coop_r && use_coop_kernel(b.max_intervals, smallest, b.coop_r))
         return false;
-    // Measured (walk_probe.py, ms per launch, this route / the streamed batch kernel): 256 x 960x720 with an interval per
-    // MCU row (360 waves of intervals) 0.97 / 1.25, 64 x DRI = 30 0.41 / 0.60, 16 x 4K with an interval per MCU row 2.9 / 4.5;
-    // 1024 x 960x720 (1440 waves) 1.84 / 1.51, 256 x DRI = 10 0.48 / 0.35.
     const uint64_t waves = uint64_t((b.max_intervals + kWave - 1) / kWave) * step;
-    return b.min_restart_interval >= 24u && waves <= 640u;
+    if (waves > 1024u)
+        return false;
+    // (dense streams: the walk's rows have to hold a few MCUs of every lane -- plan_walk)
+    if (b.stream_mcu_words > 24u)
+        return false;
+    const double mcus = double(b.max_intervals) * b.max_restart_interval * step;
+    return 14.5 * b.min_restart_interval - 40.0 > mcus / 5300.0;
 }
 
 // Uploads the descriptors; in front of that, gives every image its walk tables if the cooperative kernel may
@@ -2021,7 +2031,7 @@ Status compeg_batch::decode(hipStream_t stream)
         if (fused && mcu_route) {
             // the walk, a lane per restart interval (streamed windows: any interval length), then a lane per MCU
             const ImageDesc *md = static_cast<const ImageDesc *>(mcu_descs.ptr);
-            CG_HIP(launch_walk_mcus(dd + at, m, max_intervals, plan_walk(max_intervals, m, max_l2, stream_mcu_words, uniform, descs[0].walk != nullptr),
+            CG_HIP(launch_walk_mcus(dd + at, m, max_intervals, plan_walk(max_intervals, m, max_l2, stream_mcu_words, min_restart_interval, uniform, descs[0].walk != nullptr),
                                     stream, static_cast<uint32_t *>(unit_queue.ptr)));
             if (timing && at == 0)
                 CG_HIP(hipEventRecord(ev[1], stream));

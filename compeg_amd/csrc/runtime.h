@@ -145,6 +145,7 @@ struct compeg_batch {
     bool one_mcu_intervals = false;      // every restart interval is one MCU
     uint32_t stream_mcu_words = 0;       // the batch's average MCU in stream words, rounded up (plan_stream)
     uint32_t min_restart_interval = 0;   // the smallest restart interval of the batch's images
+    uint32_t max_restart_interval = 0;   // ... and the largest
     uint64_t total_waves = 0;            // units of 64 intervals over all images
     bool uniform = false; // same interval count and LUT bytes in every image (set by upload)
     // cooperative kernel: the restart interval all images share if every one of them qualifies (else 0), and the

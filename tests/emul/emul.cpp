@@ -17,6 +17,7 @@
 #include "../../compeg_amd/csrc/front.h"
 #include "../../compeg_amd/csrc/kernels_body.h"
 #include "../../compeg_amd/csrc/coop_body.h"
+#include "../../compeg_amd/csrc/walk_body.h"
 #include "../../compeg_amd/csrc/scan.h"
 
 namespace compeg {
@@ -203,7 +204,9 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
         const bool with_tables = !(getenv("EMUL_WALK_TABLES") && atoi(getenv("EMUL_WALK_TABLES")) == 0);
         const uint32_t l2n = (uint32_t(l2.size()) + 1u) & ~1u; // (everything staged: L2, direct AC and DC tables)
         const uint32_t walk_off = (align16((kL1Entries + l2n) * 2u) + 31u) & ~31u;
-        const uint32_t lds_bytes = walk_off + kWalkWords * 4u + 96u + (nrows + 1u) * kWave * 4u; // (a row nobody stages, see walk_mcus_422_kernel)
+        constexpr uint32_t kSpareRows = 3; // (kernels.hip: kWalkSpareRows)
+        const uint32_t chunk = getenv("EMUL_WALK_CHUNK") ? uint32_t(std::max(1, std::min(int(kWalkMaxChunk), atoi(getenv("EMUL_WALK_CHUNK"))))) : 1u;
+        const uint32_t lds_bytes = walk_off + kWalkWords * 4u + 96u + uint32_t(kWave) * walk_list_bytes(chunk) + (nrows + kSpareRows) * kWalkRowBytes;
         for (uint32_t first = 0; first < d.total_intervals; first += kWave) {
             uint8_t *smem = static_cast<uint8_t *>(aligned_alloc(32, (lds_bytes + 31u) & ~31u));
             memset(smem, 0xa5, lds_bytes);
@@ -211,7 +214,8 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
             uint16_t *sl2 = sl1 + kL1Entries;
             uint32_t *walk = reinterpret_cast<uint32_t *>(smem + walk_off);
             int16_t *dump = reinterpret_cast<int16_t *>(smem + walk_off + kWalkWords * 4u);
-            uint32_t *win = reinterpret_cast<uint32_t *>(smem + walk_off + kWalkWords * 4u + 96u);
+            uint32_t *lists = reinterpret_cast<uint32_t *>(smem + walk_off + kWalkWords * 4u + 96u);
+            uint32_t *win = lists + uint32_t(kWave) * walk_list_bytes(chunk) / 4u;
             for (uint32_t tid = 0; tid < 128; tid++)
                 stage_luts(d, sl1, sl2, l2n, tid, 128, 2u * kDcFastEntries);
             HuffShared sh{sl1, sl2, umin(l2n, d.fast_off + 2u * kFastEntries + 2u * kDcFastEntries), win, 0u, 0u, nullptr};
@@ -220,52 +224,81 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
             for (uint32_t i = 0; i < kWalkWords; i++)
                 walk[i] = ct.walk_ok ? coop_walk_word(ct.ac_fast, ct.dc_fast, ct.walk_ids, i) : 0u;
             WalkTabs tabs;
-            tabs.walk = with_tables && ct.walk_ok ? walk : nullptr;
-            tabs.dc_fast = ct.dc_fast;
-            tabs.acsel = ct.walk_acsel;
-            tabs.dcsel = ct.walk_dcsel;
-            tabs.dcfsel = (d.dc_fast_table[0] & 1u) * 0x0101u | (d.dc_fast_table[1] & 1u) << 16 | (d.dc_fast_table[2] & 1u) << 24;
-            tabs.standard = d.standard_entropy != 0u;
-            for (uint32_t c = 0; c < 3u; c++) {
-                tabs.dc_off[c] = ct.dc_off[c];
-                tabs.ac_off[c] = ct.ac_off[c];
-            }
-            std::vector<EntropyState> es(kWave);
+            walk_tabs(d, sh, with_tables ? walk : nullptr, tabs);
+            // walk_wave_422, lane by lane and step by step
+            std::vector<WalkLane> ls(kWave);
             const uint32_t lanes = std::min<uint32_t>(kWave, d.total_intervals - first);
+            const uint32_t lstride = walk_list_bytes(chunk) / 4u;
+            for (uint32_t lane = 0; lane < lanes; lane++) {
+                walk_lane_init(ls[lane], d, first + lane, true);
+                walk_prepare_list(lists + lane * lstride, tabs, chunk);
+            }
             for (uint32_t lane = 0; lane < lanes; lane++)
-                stream_lane_init(es[lane], d, sh, nrows, first + lane, lane);
-            for (uint32_t i = 0; i < d.restart_interval; i++) {
+                walk_restage(ls[lane], d, sh, tabs, nrows, lane);
+            std::vector<uint32_t> slow_window(kWalkSlowWords, 0xa5a5a5a5u);
+            for (uint32_t i = 0; i < d.restart_interval; i += chunk) {
+                const uint32_t g = umin(chunk, d.restart_interval - i);
                 for (uint32_t lane = 0; lane < lanes; lane++) {
-                    EntropyState &e = es[lane];
-                    mcu_record_write<true>(e, d, sh, lane, (first + lane) * d.restart_interval + i);
-                    bool done = false;
-                    if (tabs.walk != nullptr && e.fast) {
-                        const EntropyState saved = e;
-                        done = walk_mcu_fast(e, d, sh, tabs);
-                        g_walk_stats.fast_tried++;
-                        if (!done) {
-                            e = saved;
-                            g_walk_stats.fast_bailed++;
-                        }
+                    WalkLane &l = ls[lane];
+                    uint32_t *list = lists + lane * lstride;
+                    const uint32_t mcu0 = (first + lane) * d.restart_interval;
+                    const bool go = !l.dead && !l.parked;
+                    if (go) {
+                        list[0] = l.wa;
+                        list[1] = l.T;
                     }
-                    if (!done) {
-                        g_walk_stats.slow_mcus++;
-                        for (uint32_t k = 0; k < 4u; k++)
-                            entropy_data_unit<true>(e, d, sh, k < 2u ? 0u : k - 1u, dump, lane);
+                    const uint32_t walked = walk_mcu_lean(l, d, sh, tabs, list, go, 4u * g, lane) / 4u;
+                    uint32_t good = 0u;
+                    for (uint32_t m = 0; m < g; m++)
+                        if (go && good == m && m < walked) {
+                            walk_record_at(l, d, sh, lane, list + 16u * m, mcu0 + i + m);
+                            if (walk_mcu_pass(l, d, sh, tabs, list, m, lane))
+                                good = m + 1u;
+                        }
+                    g_walk_stats.mcus += g;
+                    g_walk_stats.lean_mcus += go ? good : 0u;
+                    // the rest of the chunk by the slow road, through the wave's window
+                    for (uint32_t m = go ? good : 0u; m < g; m++) {
+                        uint32_t p0 = 0u;
+                        bool on_rows = false;
+                        if (go && m == good) {
+                            p0 = walk_pos_of(sh, lane, list[16u * m], list[16u * m + 1u]);
+                            on_rows = true;
+                        } else if (!l.dead && !l.parked) {
+                            p0 = walk_pos_of(sh, lane, l.wa, l.T);
+                            on_rows = true;
+                        }
+                        const uint32_t r0 = p0 >> 5, n = on_rows && l.valid > r0 ? umin(l.valid - r0, kWalkSlowWords) : 0u;
+                        std::fill(slow_window.begin(), slow_window.end(), 0xa5a5a5a5u);
+                        for (uint32_t copier = 0; copier < uint32_t(kWave); copier++)
+                            walk_slow_window(slow_window.data(), sh, lane, r0, n, copier);
+                        if (on_rows) {
+                            l.at_word = l.row0 + (p0 >> 5);
+                            l.at_bit = p0 & 31u;
+                            l.parked = true;
+                        }
+                        walk_record(l, d, sh, lane, mcu0 + i + m);
+                        if (l.dead) {
+                            walk_dead_mcu(l, tabs);
+                            g_walk_stats.dead_mcus++;
+                        } else {
+                            walk_slow_mcu(l, d, sh, tabs, lane, l.at_word, l.at_bit, slow_window.data(), l.row0 + r0, n, dump);
+                            g_walk_stats.slow_mcus++;
+                        }
                     }
                 }
                 bool any = false;
-                for (uint32_t lane = 0; lane < lanes && i + 1u < d.restart_interval; lane++)
-                    any = any || stream_wants_rows(es[lane], d, sh, lane, stage_below);
+                for (uint32_t lane = 0; lane < lanes && i + g < d.restart_interval; lane++)
+                    any = any || walk_wants_rows(ls[lane], d, sh, lane, nrows, stage_below);
                 for (uint32_t lane = 0; lane < lanes && any; lane++)
-                    stream_restage(es[lane], d, sh, nrows, lane);
+                    walk_restage(ls[lane], d, sh, tabs, nrows, lane);
                 g_walk_stats.restages += any ? 1 : 0;
             }
             free(smem);
         }
-        if (getenv("EMUL_WALK_STATS"))
-            fprintf(stderr, "walk: fast tried %lu bailed %lu (escape %lu, dc %lu, rows %lu) slow MCUs %lu restages %lu\n", g_walk_stats.fast_tried, g_walk_stats.fast_bailed,
-                    g_walk_stats.bail_escape, g_walk_stats.bail_dc, g_walk_stats.bail_rows, g_walk_stats.slow_mcus, g_walk_stats.restages);
+        fprintf(stderr, "walk mcus=%lu lean_mcus=%lu slow_mcus=%lu slow_q1=%lu slow_rows=%lu long_dc=%lu dead_mcus=%lu restages=%lu long_codes=%lu\n", g_walk_stats.mcus,
+                g_walk_stats.lean_mcus, g_walk_stats.slow_mcus, g_walk_stats.slow_q1, g_walk_stats.slow_rows, g_walk_stats.slow_long_dc, g_walk_stats.dead_mcus,
+                g_walk_stats.restages, g_walk_stats.long_codes);
         // the image as the second kernel sees it: every "interval" one MCU (runtime.cpp: make_walk_tables)
         d.starts = mcu_word.data();
         d.nstarts = d.total_mcus;

@@ -335,7 +335,7 @@ def test_fused_kernel_ragged_batch(ca, gpu, every_ri):
         assert np.array_equal(dev.read_output(i), batch.read_output(i))
 
 
-@pytest.mark.parametrize("ri,uniform", [(10, True), (16, True), (30, True), (120, False), (16, False)])
+@pytest.mark.parametrize("ri,uniform", [(10, True), (16, True), (30, True), (16, False)])
 def test_batch_kernel_with_streamed_windows(ca, gpu, ri, uniform):
     """Batches whose restart intervals are too long for whole-interval windows (64 intervals of DRI MCUs per wave)
     go to decode_fused_422_stream_kernel: every lane's stream staged MCU by MCU.  Frames of one stream (the flat
@@ -343,12 +343,15 @@ def test_batch_kernel_with_streamed_windows(ca, gpu, ri, uniform):
     if uniform:
         # (kind 0: photograph-like, 1.7 bit per pixel -- streams beyond 3 bit per pixel keep whole-interval windows)
         # (DRI = 10: whole windows would still fit -- six waves a CU --, the launch has to want more than that)
+        # (more than a wave of intervals per SIMD: smaller launches of long intervals take the walk + lane-per-MCU route,
+        # test_walk_route_batches)
         frames = [synth.make_jpeg(960, 720, seed=900 + i + ri, kind=0, quality=85, ri=ri) for i in range(32)]
-        jpegs = [frames[i % 32] for i in range(320 if ri == 10 else 96)]
+        jpegs = [frames[i % 32] for i in range({10: 320, 16: 192, 30: 352}[ri])]
     else:
         shapes = [(1000, 1000), (1016, 990), (936, 1004), (1280, 720)]
-        jpegs = [synth.make_jpeg(w, h, seed=950 + i + ri, kind=0, quality=(70, 85, 90)[i % 3], ri=ri)
-                 for i, (w, h) in enumerate(shapes * 30)]
+        distinct = [synth.make_jpeg(w, h, seed=950 + i + ri, kind=0, quality=(70, 85, 90)[i % 3], ri=ri)
+                    for i, (w, h) in enumerate(shapes * 30)]
+        jpegs = distinct + (distinct[:24] if ri == 16 else [])
         bad = bytearray(jpegs[5])
         at = bad.find(b"\xff\xda") + 14
         rng = np.random.default_rng(ri)
@@ -773,6 +776,106 @@ def test_cooperative_kernel_takes_any_restart_interval(ca, gpu, ri):
         _assert_equal(batch.read_output(0), want)
 
 
+def _flip_bits(jpeg, seed, flips=40):
+    bad = bytearray(jpeg)
+    at = bad.find(b"\xff\xda") + 14
+    rng = np.random.default_rng(seed)
+    for _ in range(flips):
+        pos = int(rng.integers(at, len(bad) - 2))
+        if bad[pos] != 0xFF and bad[pos - 1] != 0xFF:
+            bad[pos] ^= 1 << int(rng.integers(0, 8))
+            if bad[pos] == 0xFF:
+                bad[pos] = 0xFE
+    return bytes(bad)
+
+
+@pytest.mark.parametrize("ri", [10, 30, 60, 120, 240])
+@pytest.mark.parametrize("content", ["uniform", "mixed", "corrupt"])
+def test_walk_route_batches(ca, gpu, ri, content):
+    """Launches of few or long restart intervals (no more than a wave of them per SIMD) take the walk + lane-per-MCU
+    route: walk_mcus_422_kernel finds where the MCUs begin -- a lane per interval through the walk tables --, then
+    decode_fused_422_mcu_rec_kernel decodes with a lane per MCU.  Frames of one stream (flat grids, units' queues),
+    images of different sizes (a grid row per image, ragged edges), corrupt scans among them; host and device
+    preprocessing.  Bit-exact, kernel identity asserted."""
+    if content == "uniform":
+        w, h = (3840, 2160) if ri == 240 else (960, 720)
+        frames = [synth.make_jpeg(w, h, seed=700 + i + ri, kind=0, quality=85, ri=ri) for i in range(6)]
+        jpegs = [frames[i % 6] for i in range(6 if ri == 240 else (48 if ri >= 30 else 40))]
+    else:
+        shapes = [(1000, 1000), (1016, 990), (936, 1004), (1280, 720), (250, 70), (1921, 1081)]
+        jpegs = [synth.make_jpeg(w, h, seed=750 + i + ri, kind=(0, 0, 2)[i % 3], quality=(70, 85, 90)[i % 3], ri=ri)
+                 for i, (w, h) in enumerate(shapes * 3)]
+        if content == "corrupt":
+            for i in (1, 5, 8, 12):
+                jpegs[i] = _flip_bits(jpegs[i], seed=ri + i)
+    images = [ca.ImageData(j) for j in jpegs]
+    batch = ca.Batch(gpu)
+    batch.upload(images)
+    batch.decode()
+    batch.wait()
+    assert batch.last_kernel() == "walk_mcu", (ri, content, batch.last_kernel())
+    check = range(len(jpegs)) if content != "uniform" else (0, 1, 5, len(jpegs) - 1)
+    for i in check:
+        _assert_equal(batch.read_output(i), orc.ImageData(jpegs[i]).decode())
+    # a second decode of the same batch (the records are rewritten), and the scan preprocessed on the device
+    batch.decode()
+    batch.wait()
+    _assert_equal(batch.read_output(len(jpegs) - 1), orc.ImageData(jpegs[-1]).decode())
+    dev = ca.Batch(gpu)
+    dev.set_device_preprocess(2)
+    dev.upload(images)
+    dev.decode()
+    dev.wait()
+    assert dev.last_kernel() == "walk_mcu"
+    for i in check:
+        assert np.array_equal(dev.read_output(i), batch.read_output(i)), i
+
+
+def test_walk_route_quirk_q1_inside_long_intervals(ca, gpu):
+    """Quirk Q1 on the walk + lane-per-MCU route: restart intervals of a whole MCU row (DRI = 64) with the tiles of
+    Q1_TILES inside -- the walk's test at the DC codes finds the reference reader running dry, the MCUs behind it in
+    the interval get records that say so, and the second kernel decodes them from zeros.  Both entropy modes."""
+    rgb = synth.fill(1024, 256, seed=5, kind=0, noise=0).copy()
+    n = 0
+    for row in range(0, 256 // 8, 2):
+        seeds = Q1_TILES[n % 4]
+        x = 64 * (1 + (3 * n) % 13)
+        rgb[row * 8:row * 8 + 8, x:x + 64] = synth.fill(64, 8, seed=seeds[(n // 4) % 2], kind=1)
+        n += 1
+    jpeg = synth.encode(rgb, quality=100, ri=64)
+    want = orc.ImageData(jpeg).decode()
+    plain = orc.ImageData(jpeg, standard_entropy=True).decode()
+    assert (want != plain).any(axis=2).sum() > 100 * n   # (the underflows are there: the rest of those MCU rows differs)
+    for standard, expect in ((False, want), (True, plain)):
+        batch = ca.Batch(gpu)
+        batch.upload([ca.ImageData(jpeg, standard_entropy=standard)] * 72)   # (up to 64 of them are the cooperative kernel's)
+        batch.decode()
+        batch.wait()
+        assert batch.last_kernel() == "walk_mcu"
+        for i in (0, 71):
+            _assert_equal(batch.read_output(i), expect)
+
+
+def test_walk_route_chunked_launches_and_short_scans(ca, gpu):
+    """The route with launches of part of a batch (set_chunk: the records of every launch's images), with a scan that
+    holds fewer restart intervals than its header announces (COUNT_MISMATCH is tolerated: the reference decodes the
+    missing ones from the scan's first words), and with an image whose last interval is cut short by the end of the data."""
+    frames = [synth.make_jpeg(960, 720, seed=820 + i, kind=0, quality=85, ri=30) for i in range(4)]
+    cut = frames[1][:len(frames[1]) * 2 // 3] + b"\xff\xd9"          # (the scan ends early: fewer intervals than announced)
+    j = bytearray(frames[2])
+    i = j.find(b"\xff\xdd")
+    j[i + 4:i + 6] = (45).to_bytes(2, "big")                           # (DRI says 45, the stream has markers every 30 MCUs)
+    jpegs = [frames[0], cut, bytes(j), frames[3]] * 6
+    batch = ca.Batch(gpu)
+    batch.upload([ca.ImageData(x) for x in jpegs])
+    batch.set_chunk(5)
+    batch.decode()
+    batch.wait()
+    assert batch.last_kernel() == "walk_mcu"
+    for i in (0, 1, 2, 3, 22, 23):
+        _assert_equal(batch.read_output(i), orc.ImageData(jpegs[i]).decode())
+
+
 @pytest.mark.parametrize("ri", [4, 10])
 def test_cooperative_kernel_launch_size_boundary(ca, gpu, ri):
     """The dispatch boundary: launches of up to 2 x 1024 x 256 data units are the cooperative kernel's -- two 4K
@@ -780,7 +883,8 @@ def test_cooperative_kernel_launch_size_boundary(ca, gpu, ri):
     workgroup holds one, two and four teams (small, medium, full launches) and the last team of an image is short."""
     jpegs = [synth.make_jpeg(3840, 2160, seed=500 + i, quality=85, ri=ri) for i in range(3)]
     wants = [orc.ImageData(j).decode() for j in jpegs]
-    for n, kernel in ((1, "coop_team"), (2, "coop_team"), (3, "pair")):
+    # (three frames: a lane per interval -- or, their intervals being 10 MCUs long, the walk + lane-per-MCU route)
+    for n, kernel in ((1, "coop_team"), (2, "coop_team"), (3, "pair" if ri == 4 else "walk_mcu")):
         batch = ca.Batch(gpu)
         batch.upload([ca.ImageData(j) for j in jpegs[:n]])
         batch.decode()

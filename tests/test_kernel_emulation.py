@@ -32,7 +32,7 @@ STATS = {}   # rare-path counters of the emulated kernels, summed over every run
 
 
 def _run(runner, tmp_path, jpeg, fused, waves=1, window=2048, l2=12288, standard=False, coop_passes=1, stage=8, below=None,
-         layout_rows=None):
+         layout_rows=None, chunk=1):
     p = tmp_path / "in.jpg"
     p.write_bytes(jpeg)
     env = dict(os.environ)
@@ -44,6 +44,7 @@ def _run(runner, tmp_path, jpeg, fused, waves=1, window=2048, l2=12288, standard
     env["EMUL_STREAM_STAGE"] = str(stage)   # (streamed window: behind which data units of an MCU the rows are staged ...
     env.pop("EMUL_STREAM_BELOW", None)
     env.pop("EMUL_STREAM_ROWS", None)
+    env["EMUL_WALK_CHUNK"] = str(chunk)   # (fused = 8: MCUs a lane walks between two looks at what it found)
     if layout_rows is not None:
         env["EMUL_STREAM_ROWS"] = str(layout_rows)   # (fused = 6: the layout kernels' streamed form)
     if below is not None:
@@ -51,16 +52,19 @@ def _run(runner, tmp_path, jpeg, fused, waves=1, window=2048, l2=12288, standard
     if standard:
         env["EMUL_STANDARD"] = "1"
     if fused:
-        # 1 = fused kernel, 2 = paired-wave kernel, 3 = entropy + IDCT kernels, 5 = cooperative kernel
+        # 1 = fused kernel, 2 = paired-wave kernel, 3 = entropy + IDCT kernels, 5 = cooperative kernel,
+        # 8 = the walk + lane-per-MCU route (walk_mcus_422_kernel, then decode_fused_422_mcu_rec_kernel; window: the walk's rows)
         env["EMUL_FUSED"] = str(int(fused))
     r = subprocess.run([runner, str(p), str(tmp_path / "rgba"), str(tmp_path / "ac"), str(tmp_path / "dc"),
                         str(waves), str(window), str(l2)], capture_output=True, text=True, env=env, timeout=600)
     if fused == 5 and "does not qualify for the cooperative kernel" in r.stdout:
         return None   # (no restart interval of 1..256 MCUs, or tables the direct tables cannot hold)
+    if fused == 8 and "does not qualify for the walk" in r.stdout:
+        return None   # (tables the direct tables cannot hold, a DC category above 15)
     assert r.returncode == 0, r.stdout + r.stderr[-2000:]
     _, w, h, _ = r.stdout.split()
     for line in r.stderr.splitlines():
-        if line.startswith("stats ") or line.startswith("coop ") or line.startswith("coopdead "):
+        if line.startswith("stats ") or line.startswith("coop ") or line.startswith("coopdead ") or line.startswith("walk "):
             for kv in line.split()[1:]:
                 k, v = kv.split("=")
                 STATS[k] = STATS.get(k, 0) + int(v)
@@ -85,6 +89,12 @@ def _check(runner, tmp_path, jpeg, **kw):
             if got is not None:
                 assert np.array_equal(got, want), (f"cooperative kernel, window {window}, {passes} round(s) per walk: "
                                                    f"{(got != want).any(axis=2).sum()} pixels differ")
+    # the walk + lane-per-MCU route: rows enough for several MCUs; for about one (lanes keep running out and take the
+    # slow road through the wave's window); fewer than the walk reads at a step (everything by the slow road)
+    for rows, below, chunk in ((40, 20, 1), (12, 3, 2), (2, 1, 1), (64, 30, 5)):
+        got = _run(runner, tmp_path, jpeg, 8, window=rows, below=below, chunk=chunk)
+        if got is not None:
+            assert np.array_equal(got, want), f"walk + lane-per-MCU route, {rows} rows: {(got != want).any(axis=2).sum()} pixels differ"
 
 
 CASES = [
@@ -158,6 +168,35 @@ def test_emulated_streamed_window_any_restart_interval(runner, tmp_path, ri):
         for rows in (3, 16):
             got = _run(runner, tmp_path, bytes(j), 7, window=rows)
             assert np.array_equal(got, want), (ri, it, rows)
+
+
+@pytest.mark.parametrize("ri", [1, 2, 4, 7, 10, 16, 30, 60, 120, 0])
+def test_emulated_walk_route_any_restart_interval(runner, tmp_path, ri):
+    """walk_mcus_422_kernel's body (the cooperative kernel's walk loop over streamed rows, an MCU at a time, the DC
+    differences and quirk Q1's test behind it, the slow road through the wave's window) and the fused kernel begun from
+    the walk's records: any restart interval, rows from plenty to none, corrupt streams."""
+    for (w, h, kind, q, seed) in [(320, 64, 0, 85, 1), (256, 48, 1, 95, 2), (200, 40, 2, 100, 3), (960, 24, 0, 85, 4)]:
+        jpeg = synth.make_jpeg(w, h, seed=seed + ri, kind=kind, quality=q, ri=ri)
+        want = orc.ImageData(jpeg).decode()
+        for rows, below, chunk in ((64, 24, 1), (24, 10, 1), (9, 4, 1), (3, 1, 1), (64, 30, 3), (100, 50, 16), (30, 10, 4)):
+            got = _run(runner, tmp_path, jpeg, 8, window=rows, below=below, chunk=chunk)
+            assert got is not None
+            assert np.array_equal(got, want), (ri, w, h, rows, below, int((got != want).any(axis=2).sum()))
+    rng = np.random.default_rng(300 + ri)
+    base = synth.make_jpeg(320, 64, seed=9, kind=0, quality=80, ri=ri)
+    scan_at = base.find(b"\xff\xda") + 14
+    for it in range(4):
+        j = bytearray(base)
+        for _ in range(int(rng.integers(1, 12))):
+            pos = int(rng.integers(scan_at, len(j) - 2))
+            if j[pos] != 0xFF and j[pos - 1] != 0xFF:
+                j[pos] ^= 1 << int(rng.integers(0, 8))
+                if j[pos] == 0xFF:
+                    j[pos] = 0xFE
+        want = orc.ImageData(bytes(j)).decode()
+        for rows, chunk in ((40, 1), (8, 1), (60, 4)):
+            got = _run(runner, tmp_path, bytes(j), 8, window=rows, below=rows // 2, chunk=chunk)
+            assert got is not None and np.array_equal(got, want), (ri, it, rows, chunk)
 
 
 @pytest.mark.parametrize("waves,window,l2", [(4, 64, 512), (2, 80, 0), (1, 4, 0), (3, 300, 1024), (2, 2048, 3000),
@@ -255,10 +294,22 @@ def test_emulated_reference_reader_underflow_on_valid_streams(runner, tmp_path):
     (DC difference from what is left of the reader, AC levels from the host's zero-stream record) and
     zero-stream data units behind it; in the other kernels the lane's switch to the exact reader."""
     for (w, h, seed) in [(256, 64, 77), (512, 128, 86), (512, 128, 163)]:
-        before = STATS.get("dead", 0), STATS.get("zero", 0), STATS.get("left_underflow", 0)
-        _check(runner, tmp_path, synth.make_jpeg(w, h, seed=seed, kind=1, quality=100, ri=4))
+        before = STATS.get("dead", 0), STATS.get("zero", 0), STATS.get("left_underflow", 0), STATS.get("slow_q1", 0)
+        jpeg = synth.make_jpeg(w, h, seed=seed, kind=1, quality=100, ri=4)
+        _check(runner, tmp_path, jpeg)
         assert STATS.get("dead", 0) > before[0] and STATS.get("left_underflow", 0) > before[2]
+        # (the walk + lane-per-MCU route with rows enough for these MCUs: its own test at the DC codes finds it)
+        assert np.array_equal(_run(runner, tmp_path, jpeg, 8, window=160, below=60), orc.ImageData(jpeg).decode())
+    assert STATS.get("slow_q1", 0) > 0
     assert STATS.get("zero", 0) > 0
+    # long restart intervals: MCUs behind the underflow inside the interval (records that say "run dry")
+    before = STATS.get("dead_mcus", 0)
+    for (w, h, seed) in [(256, 64, 77), (512, 128, 86)]:
+        jpeg = synth.make_jpeg(w, h, seed=seed, kind=1, quality=100, ri=w // 16)
+        want = orc.ImageData(jpeg).decode()
+        for rows, chunk in ((160, 1), (20, 1), (200, 3)):
+            assert np.array_equal(_run(runner, tmp_path, jpeg, 8, window=rows, below=rows // 2, chunk=chunk), want)
+    assert STATS.get("dead_mcus", 0) > before
 
 
 def test_emulated_q1_underflow_in_every_quarter(runner, tmp_path):
@@ -273,6 +324,8 @@ def test_emulated_q1_underflow_in_every_quarter(runner, tmp_path):
     assert all(STATS.get(f"q{q}", 0) > before[q] for q in range(4)), STATS
     for fused in (1, 2):
         assert np.array_equal(_run(runner, tmp_path, jpeg, fused), want)
+    assert np.array_equal(_run(runner, tmp_path, jpeg, 8, window=40, below=20), want)
+    assert np.array_equal(_run(runner, tmp_path, jpeg, 8, window=120, below=50, chunk=4), want)
 
 
 @pytest.mark.parametrize("sampling", [(1, 1), (2, 1), (1, 2), (2, 2)])
@@ -308,8 +361,8 @@ def test_emulated_standard_entropy_extension(runner, tmp_path):
         want = orc.ImageData(jpeg, standard_entropy=True).decode()
         if kind == 0:
             assert not np.array_equal(want, orc.ImageData(jpeg).decode())   # the switch matters on this input
-        for fused in (1, 2, 3, 0, 5, 54):
-            got = _run(runner, tmp_path, jpeg, fused % 10, window=window, standard=True, coop_passes=4 if fused == 54 else 1)
+        for fused in (1, 2, 3, 0, 5, 54, 8):
+            got = _run(runner, tmp_path, jpeg, fused % 10, window=40 if fused == 8 else window, standard=True, coop_passes=4 if fused == 54 else 1)
             if got is None:
                 continue   # (tables the direct tables cannot hold)
             assert np.array_equal(got, want), f"fused={fused} {w}x{h}: {(got != want).any(axis=2).sum()} pixels differ"
@@ -329,6 +382,10 @@ def test_emulated_rare_paths_were_reached():
     # reference-reader underflows (dead data units, zero-stream data units behind them), serial hand-overs
     assert STATS.get("intervals", 0) > 1000
     for key in ("continued", "dead", "zero", "serial"):
+        assert STATS.get(key, 0) > 0, (key, STATS)
+    # ... and of the walk + lane-per-MCU route: MCUs through the walk tables, by the slow road (quirk Q1, rows run out),
+    # MCUs behind an underflow, long codes inside the loop
+    for key in ("lean_mcus", "slow_mcus", "slow_q1", "slow_rows", "dead_mcus", "long_codes", "restages"):
         assert STATS.get(key, 0) > 0, (key, STATS)
 
 
