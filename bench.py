@@ -62,6 +62,7 @@ def parse_args():
     p.add_argument("--cpu-seconds", type=float, default=12.0,
                    help="budget for the CPU-oracle baseline sample (0 disables it)")
     p.add_argument("--no-verify", action="store_true")
+    p.add_argument("--sweep-only", action="store_true", help="print the launch-size sweep (other_configs.launch_size_sweep) and leave")
     p.add_argument("--e2e-reps", type=int, default=5,
                    help="batches per arm (x2) of the host-fed pipeline measurement `end_to_end` (0 disables it)")
     p.add_argument("--no-extra-configs", action="store_true",
@@ -299,6 +300,63 @@ def bench_config(compeg_amd, gpu, width, height, ri, quality, batch, steps, warm
             "kernel": b.last_kernel(), "verified_bit_exact_vs_oracle": ok, "verified_slots": slots}
 
 
+def bench_launch_size_sweep(compeg_amd, gpu, quality, threads):
+    """Where the dispatch changes kernels: launches of 1 .. 256 4K frames (DRI = 4) and of 1 .. 1024 frames of the MJPEG
+    stream (960x720, DRI = 10) -- us per frame by the batch's HIP events, the kernel chosen, the fraction of the HBM
+    roofline -- and the single-frame latency of the other BASELINE sizes (8K DRI = 1: configs[4] as written; 1080p)."""
+    import numpy as np
+    from tools import synth
+
+    def frames_of(w, h, ri, distinct):
+        with ThreadPoolExecutor(threads) as ex:
+            jpegs = list(ex.map(lambda i: synth.make_jpeg(w, h, seed=0xBEEF + i, kind=0, quality=quality, ri=ri), range(distinct)))
+        return jpegs, [compeg_amd.ImageData(j, copy=False) for j in jpegs]
+
+    def point(images, n, reps=12):
+        b = compeg_amd.Batch(gpu)
+        b.upload([images[i % len(images)] for i in range(n)], host_threads=threads)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.03:   # (launches out of idle run long: bench_config)
+            b.decode()
+            b.wait()
+        b.timing(reset=True)
+        ts = []
+        for _ in range(reps):
+            b.decode()
+            b.wait()
+            _, total, _, _ = b.timing(reset=True)
+            ts.append(total * 1e3)
+        us = float(np.median(ts))
+        return {"frames": n, "kernel": b.last_kernel(), "us_per_launch": round(us, 1), "us_per_frame": round(us / n, 2),
+                "frac": round(b.algorithmic_bytes() / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+
+    out = {}
+    for name, (w, h, ri, sizes) in {"4K DRI=4": (3840, 2160, 4, (1, 2, 3, 4, 6, 8, 12, 16, 32, 64, 128, 256)),
+                                   "960x720 DRI=10": (960, 720, 10, (1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024))}.items():
+        jpegs, images = frames_of(w, h, ri, 8)
+        pts = [point(images, n) for n in sizes]
+        worst = max(pts[i]["us_per_frame"] / min(pts[i - 1]["us_per_frame"] if i else 1e9, pts[i + 1]["us_per_frame"] if i + 1 < len(pts) else 1e9)
+                    for i in range(len(pts)))
+        out[name] = {"points": pts, "worst_step_vs_better_neighbour": round(worst, 2)}
+    single = {}
+    for name, (w, h, ri) in {"8K DRI=1 (configs[4])": (7680, 4320, 1), "1080p DRI=4": (1920, 1080, 4)}.items():
+        jpegs, images = frames_of(w, h, ri, 1)
+        pt = point(images, 1, reps=20)
+        dec = compeg_amd.Decoder(gpu)
+        for _ in range(3):
+            dec.decode_blocking(images[0])
+        ts = []
+        for _ in range(15):
+            t = time.perf_counter()
+            dec.decode_blocking(images[0])
+            ts.append(time.perf_counter() - t)
+        pt["blocking_decode_ms"] = round(sorted(ts)[len(ts) // 2] * 1e3, 3)
+        pt["decoder_kernel"] = dec.last_kernel()
+        single[name] = pt
+    out["single_frame_latency"] = single
+    return out
+
+
 def host_feed_child(spec, args):
     """One rank of `host_feed_scaling` (no device, no torch): rank/world/start-time/seconds in `spec`."""
     rank, world, t_start, seconds = spec.split(",")
@@ -508,6 +566,13 @@ def main():
     if args.rehearse_on_one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    if args.sweep_only:
+        sweep = bench_launch_size_sweep(compeg_amd, compeg_amd.Gpu.open(local_rank), args.quality, 16)
+        print(json.dumps(sweep))
+        for name, rec in sweep.items():
+            for pt in rec.get("points", rec.values() if name == "single_frame_latency" else []):
+                print("#", name, pt, file=sys.stderr)
+        return
     if world > 1 and args.rehearse_on_one_gpu:
         dist.init_process_group("gloo")
     elif world > 1:
@@ -688,6 +753,7 @@ def main():
             compeg_amd, gpu, 7680, 4320, 1, args.quality, 8, args.steps, args.warmup, threads, 4,
             "8 x 7680x4320 YUV 4:2:2 baseline JPEG, DRI=1 per step (BASELINE configs[4] frame), 4 distinct frames")
         extra["mjpeg stream 960x720 DRI=10"] = bench_mjpeg_stream(compeg_amd, gpu, args.quality, args.steps, args.warmup, threads)
+        extra["launch_size_sweep"] = bench_launch_size_sweep(compeg_amd, gpu, args.quality, threads)
         # the extension layouts (opt-in, not what the reference accepts), fused kernels
         for name, smp in (("4:4:4", (1, 1)), ("4:2:0", (2, 2))):
             extra[f"extension {name}, 64 x 4K"] = bench_config(

@@ -417,6 +417,10 @@ class Batch:
         """Diagnostics: the decode kernel the first launch of the last decode went to (KERNEL_NAMES)."""
         return KERNEL_NAMES[lib.compeg_batch_last_kernel(self._h)]
 
+    def set_timing(self, on=True):
+        """compeg_batch_set_timing: off = decodes record no timing events (they run closer together)."""
+        check(lib.compeg_batch_set_timing(self._h, 1 if on else 0))
+
     def timing(self, reset=True):
         """(decodes, total_ms, huffman_ms, idct_composite_ms) summed over the decodes since the
         last upload/reset, from HIP events recorded on the stream the kernels ran on."""

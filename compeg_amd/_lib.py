@@ -90,6 +90,7 @@ def _load():
         "compeg_batch_algorithmic_bytes": (C.c_uint64, [vp]),
         "compeg_batch_pixels": (C.c_uint64, [vp]),
         "compeg_batch_timing": (i, [vp, i, pu32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "compeg_batch_set_timing": (i, [vp, i]),
         "compeg_batch_last_kernel": (i, [vp]),
         "compeg_host_feed_work": (i, [vp, vp, C.c_size_t, i, C.c_uint, i, i, C.POINTER(C.c_double)]),
         "compeg_host_alloc": (i, [C.c_size_t, C.POINTER(C.c_void_p)]),

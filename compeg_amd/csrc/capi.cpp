@@ -374,22 +374,18 @@ int compeg_decoder_decode_blocking(compeg_decoder *dec, const compeg_image *img,
         hipError_t e = hipStreamSynchronize(dec->gpu->stream);
         if (e != hipSuccess)
             return fail(hip_status(e, "hipStreamSynchronize"));
+        // (the stream is drained: nothing of this decode is pending -- enqueue recorded no events for a blocking decode)
+        dec->upload_pending = dec->decode_pending = false;
         const compeg_stage_times first = dec->stage_times; // (a re-decode through the host path would reset them)
         s = dec->finish_deferred(*img->data, dec->gpu->stream);
         if (!s.ok())
             return fail(s);
         dec->stage_times = first;
         dec->stage_times.poll_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_poll).count();
+        // (an operation that is complete already: no event to wait for)
         compeg_op *o = new compeg_op();
         o->device = dec->gpu->device;
         o->texture_changed = changed;
-        e = hipEventCreateWithFlags(&o->done, hipEventDisableTiming);
-        if (e == hipSuccess)
-            e = hipEventRecord(o->done, dec->gpu->stream);
-        if (e != hipSuccess) {
-            compeg_op_free(o);
-            return fail(hip_status(e, "hipEventRecord"));
-        }
         *op = o;
         return ok();
     });
@@ -432,6 +428,8 @@ int compeg_op_wait(compeg_op *op)
 {
     if (!op)
         return fail(COMPEG_E_INVALID_ARG, "op is NULL");
+    if (!op->done)
+        return ok(); // (a blocking decode's: complete when it was made)
     hipError_t e = hipEventSynchronize(op->done);
     return e == hipSuccess ? ok() : fail(hip_status(e, "hipEventSynchronize"));
 }
@@ -855,6 +853,14 @@ uint64_t compeg_batch_pixels(const compeg_batch *batch)
     return batch ? batch->pixels : 0;
 }
 
+int compeg_batch_set_timing(compeg_batch *batch, int on)
+{
+    if (!batch)
+        return fail(COMPEG_E_INVALID_ARG, "batch is NULL");
+    batch->timing_on = on != 0;
+    return ok();
+}
+
 int compeg_batch_timing(compeg_batch *batch, int reset, uint32_t *decodes, double *total_ms,
                         double stage_ms[2])
 {
@@ -870,10 +876,13 @@ int compeg_batch_timing(compeg_batch *batch, int reset, uint32_t *decodes, doubl
             float x = 0, y = 0, z = 0;
             if (e == hipSuccess)
                 e = hipEventElapsedTime(&x, ev[0], ev[2]);
-            if (e == hipSuccess && split) {
+            const bool staged = i < batch->has_stage_event.size() && batch->has_stage_event[i];
+            if (e == hipSuccess && split && staged) {
                 e = hipEventElapsedTime(&y, ev[0], ev[1]);
                 if (e == hipSuccess)
                     e = hipEventElapsedTime(&z, ev[1], ev[2]);
+            } else if (e == hipSuccess && split) {
+                y = x; // (one kernel does the whole path)
             }
             if (e != hipSuccess)
                 return fail(hip_status(e, "hipEventElapsedTime"));

@@ -741,8 +741,12 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
         if (n_words)
             CG_HIP(hipMemcpyAsync(words.ptr, scan.words(), n_words * 4, hipMemcpyHostToDevice, stream));
     }
-    CG_HIP(hipEventRecord(upload_done, stream));
-    upload_pending = true;
+    // (a blocking decode waits for the stream itself: a marker between the uploads and the decode kernel would only
+    // keep the kernel waiting for it -- 3 us of the 6 between the last pull's end and the kernel's start)
+    if (!may_defer) {
+        CG_HIP(hipEventRecord(upload_done, stream));
+        upload_pending = true;
+    }
     last_stream = stream;
     last_md = md;
     last_desc_dev = db;
@@ -752,8 +756,10 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     if (total_dus == 0) {
         if (deferred_check)
             CG_HIP(hipMemcpyAsync(scan_result.ptr, scan_result_dev, 16, hipMemcpyDeviceToHost, stream));
-        CG_HIP(hipEventRecord(decode_done, stream));
-        decode_pending = true;
+        if (!may_defer) {
+            CG_HIP(hipEventRecord(decode_done, stream));
+            decode_pending = true;
+        }
         return Status{};
     }
     const uint32_t span = on_device ? dev_span
@@ -840,8 +846,10 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     }
     if (deferred_check) // behind the decode kernel: no copy engine between the scan kernels and it
         CG_HIP(hipMemcpyAsync(scan_result.ptr, scan_result_dev, 16, hipMemcpyDeviceToHost, stream));
-    CG_HIP(hipEventRecord(decode_done, stream));
-    decode_pending = true;
+    if (!may_defer) {
+        CG_HIP(hipEventRecord(decode_done, stream));
+        decode_pending = true;
+    }
     trace.mark("launch");
     return Status{};
 }
@@ -1875,8 +1883,15 @@ bool use_mcu_route(const compeg_batch &b, uint32_t step, uint32_t smallest)
         return forced != 0;
     if (b.one_mcu_intervals || b.min_restart_interval < 2u)
         return false; // (a lane per interval is a lane per MCU already)
-    if (b.coop_r && use_coop_kernel(b.max_intervals, smallest, b.coop_r))
-        return false;
+    // The cooperative kernel's launches: its first round of teams (1024 x 256 data units) is the fastest thing there is;
+    // a second round is not, where its teams walk a lane per interval (960x720 DRI = 10, us per launch, cooperative /
+    // this route: 8 frames 60 / 91, 12 frames 105 / 90, 16 108 / 95, 24 154 / 102) -- with DRI = 4 the second round
+    // still wins (two 4K frames 63 / 70), and so do its speculative walks of long intervals (16 x 960x720 DRI = 60: 263 / 322).
+    if (b.coop_r && use_coop_kernel(b.max_intervals, smallest, b.coop_r)) {
+        const uint64_t data_units = uint64_t(b.max_intervals) * step * 4u * b.coop_r;
+        if (!(data_units > 1024ull * 256u && b.coop_r >= 8u && b.coop_r <= 16u && step == smallest))
+            return false;
+    }
     const uint64_t waves = uint64_t((b.max_intervals + kWave - 1) / kWave) * step;
     if (waves > 1024u)
         return false;
@@ -1974,7 +1989,7 @@ Status compeg_batch::decode(hipStream_t stream)
         return Status{};
     CG_HIP(hipSetDevice(gpu->device));
     constexpr size_t kMaxTimed = 4096;
-    const bool timing = decodes_timed < kMaxTimed;
+    const bool timing = timing_on && decodes_timed < kMaxTimed;
     hipEvent_t *ev = nullptr;
     if (timing) {
         while (events.size() < (decodes_timed + 1) * 3) {
@@ -1987,13 +2002,19 @@ Status compeg_batch::decode(hipStream_t stream)
     CG_TRY(unit_queue.reserve(256));
     // One batch, one set of device buffers and one units' queue: a decode recorded on another stream than the
     // previous one waits for that one (two launches drawing from one queue would each decode part of the units).
-    if (!decode_done)
-        CG_HIP(hipEventCreateWithFlags(&decode_done, hipEventDisableTiming));
-    if (decode_recorded && stream != last_stream)
+    // (the event is recorded only now, behind everything the earlier decodes put on their stream: every event a decode
+    // records is a packet the card works through between two kernels -- four of them were 18 us between two
+    // single-frame decodes of 32 us)
+    if (decode_recorded && stream != last_stream) {
+        if (!decode_done)
+            CG_HIP(hipEventCreateWithFlags(&decode_done, hipEventDisableTiming));
+        CG_HIP(hipEventRecord(decode_done, last_stream));
         CG_HIP(hipStreamWaitEvent(stream, decode_done, 0));
+    }
     const ImageDesc *dd = static_cast<const ImageDesc *>(dev_descs.ptr);
     const uint32_t n = uint32_t(count);
     const uint32_t step = chunk ? std::min(chunk, n) : n;
+    bool ev1_recorded = false;
     if (timing)
         CG_HIP(hipEventRecord(ev[0], stream));
     if (preprocess_mode == 2 && host_fallbacks == 0)
@@ -2016,15 +2037,15 @@ Status compeg_batch::decode(hipStream_t stream)
                                                stream, layout_h, layout_v, static_cast<uint32_t *>(unit_queue.ptr)));
             else
                 CG_HIP(launch_fused_layout(dd + at, m, max_intervals, plan, layout_h, layout_v, mcu_pairs, stream));
-            if (timing && at == 0)
-                CG_HIP(hipEventRecord(ev[1], stream));
             continue;
         }
         if (generic_layout) {
             last_kernel = at ? last_kernel : COMPEG_KERNEL_GENERIC;
             CG_HIP(launch_entropy_samples(dd + at, m, max_intervals, plan, stream));
-            if (timing && at == 0)
+            if (timing && at == 0) {
                 CG_HIP(hipEventRecord(ev[1], stream));
+                ev1_recorded = true;
+            }
             CG_HIP(launch_generic_composite(dd + at, m, max_out_w, max_out_h, stream));
             continue;
         }
@@ -2033,8 +2054,10 @@ Status compeg_batch::decode(hipStream_t stream)
             const ImageDesc *md = static_cast<const ImageDesc *>(mcu_descs.ptr);
             CG_HIP(launch_walk_mcus(dd + at, m, max_intervals, plan_walk(max_intervals, m, max_l2, stream_mcu_words, min_restart_interval, uniform, descs[0].walk != nullptr),
                                     stream, static_cast<uint32_t *>(unit_queue.ptr)));
-            if (timing && at == 0)
+            if (timing && at == 0) {
                 CG_HIP(hipEventRecord(ev[1], stream));
+                ev1_recorded = true;
+            }
             const HuffLdsPlan mcu_plan = plan_huffman(max_mcus, m, max_l2, mcu_span, true);
             CG_HIP(launch_fused_422(md + at, m, max_mcus, mcu_plan, stream, mcu_uniform, true, static_cast<uint32_t *>(unit_queue.ptr), true));
             if (at == 0)
@@ -2065,21 +2088,23 @@ Status compeg_batch::decode(hipStream_t stream)
                 last_kernel = coop.usable ? COMPEG_KERNEL_COOP_TEAM
                               : streamed  ? COMPEG_KERNEL_FUSED_STREAM
                                           : (use_pair_kernel(max_intervals, m) ? COMPEG_KERNEL_PAIR : COMPEG_KERNEL_FUSED);
-            if (timing && at == 0)
-                CG_HIP(hipEventRecord(ev[1], stream));
             continue;
         }
         last_kernel = at ? last_kernel : COMPEG_KERNEL_SPLIT;
         CG_HIP(launch_entropy(dd + at, m, max_intervals, plan, stream));
-        if (timing && at == 0)
+        if (timing && at == 0) {
             CG_HIP(hipEventRecord(ev[1], stream)); // stage split is exact for unchunked decodes
+            ev1_recorded = true;
+        }
         CG_HIP(launch_idct_composite(dd + at, m, max_dus, stream));
     }
     if (timing) {
         CG_HIP(hipEventRecord(ev[2], stream));
+        if (has_stage_event.size() <= decodes_timed)
+            has_stage_event.resize(decodes_timed + 1);
+        has_stage_event[decodes_timed] = ev1_recorded; // (one-kernel decodes: no event in the middle)
         decodes_timed++;
     }
-    CG_HIP(hipEventRecord(decode_done, stream));
     decode_recorded = true;
     last_stream = stream;
     return Status{};

@@ -165,6 +165,8 @@ struct compeg_batch {
     // one event triple per decode since the last upload / timing reset:
     // [start, after huffman, end], recorded on the decode's own stream
     std::vector<hipEvent_t> events;
+    std::vector<bool> has_stage_event; // per timed decode: the middle event was recorded (two-kernel routes)
+    bool timing_on = true;             // compeg_batch_set_timing: off = a decode records no events at all
     size_t decodes_timed = 0;
     hipStream_t last_stream = nullptr;
     int last_kernel = 0; // COMPEG_KERNEL_*: where the first launch of the last decode went

@@ -336,8 +336,12 @@ bool ScanBuffer::process_with_team(const uint8_t *scan, size_t len, uint32_t exp
     (void)expected;
     const size_t mask = slots - 1;
     size_t interval = 0, start_word = 0, bytes = 0; // the output's cursor: open interval, its start word, bytes in it
+    // (two rounds: the first a little longer than the second -- 9/16 of the segment.  The decoder ships a round's output
+    // while the next round is scanned; the second round's launch has to be made, and to reach the card, before the first
+    // round's transfer ends: with equal halves of a 4K frame's scan the card idled 4 us between the two)
+    auto round_start = [&](size_t r) { return rounds == 2 ? (r == 0 ? size_t(0) : (r == 1 ? len / 16 * 9 : len)) : len / rounds * r; };
     for (size_t r = 0; r < rounds; r++) {
-        const size_t lo = len / rounds * r, hi = r + 1 == rounds ? len : len / rounds * (r + 1);
+        const size_t lo = round_start(r), hi = r + 1 == rounds ? len : round_start(r + 1);
         const size_t shares = own + 4 * (n - 1); // (in quarters of a helper's piece)
         for (size_t k = 0; k <= n; k++) {
             const size_t at = cut(k == n ? hi : lo + (hi - lo) / shares * (k ? own + 4 * (k - 1) : 0));

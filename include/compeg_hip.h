@@ -305,6 +305,10 @@ uint64_t compeg_batch_pixels(const compeg_batch *batch);
  * then starts a new measurement. */
 int compeg_batch_timing(compeg_batch *batch, int reset, uint32_t *decodes, double *total_ms,
                         double stage_ms[2]);
+/* on == 0: decodes record no timing events (compeg_batch_timing then reports none).  Every event is a packet the card
+ * works through between two kernels: back-to-back decodes of a single frame run closer together without them.
+ * Default: on. */
+int compeg_batch_set_timing(compeg_batch *batch, int on);
 int compeg_batch_last_kernel(const compeg_batch *batch); /* COMPEG_KERNEL_* */
 
 #if defined(__GNUC__)

@@ -121,6 +121,7 @@ extern "C" {
     pub fn compeg_batch_read_output(batch: *mut compeg_batch, index: usize, host_rgba: *mut u8) -> c_int;
     pub fn compeg_batch_algorithmic_bytes(batch: *const compeg_batch) -> u64;
     pub fn compeg_batch_pixels(batch: *const compeg_batch) -> u64;
+    pub fn compeg_batch_set_timing(batch: *mut compeg_batch, on: c_int) -> c_int;
     pub fn compeg_batch_timing(batch: *mut compeg_batch, reset: c_int, decodes: *mut u32, total_ms: *mut c_double,
                                stage_ms: *mut c_double) -> c_int;
     pub fn compeg_batch_last_kernel(batch: *const compeg_batch) -> c_int;

@@ -215,7 +215,7 @@ def test_batch_matches_single_decodes(ca, gpu):
     for i, j in enumerate(jpegs):
         _assert_equal(batch.read_output(i), orc.ImageData(j).decode())
     n, total, huff, idct = batch.timing()
-    assert n == 1 and total > 0 and huff > 0 and idct > 0
+    assert n == 1 and total > 0 and huff > 0 and idct >= 0   # (one kernel does the whole path: no event in the middle)
     # chunked launches give the same pixels
     batch.set_chunk(2)
     batch.decode()
