@@ -63,6 +63,7 @@ def parse_args():
                    help="budget for the CPU-oracle baseline sample (0 disables it)")
     p.add_argument("--no-verify", action="store_true")
     p.add_argument("--sweep-only", action="store_true", help="print the launch-size sweep (other_configs.launch_size_sweep) and leave")
+    p.add_argument("--host-feed-only", action="store_true", help="print end_to_end.host_feed_scaling (no device touched) and leave")
     p.add_argument("--e2e-reps", type=int, default=5,
                    help="batches per arm (x2) of the host-fed pipeline measurement `end_to_end` (0 disables it)")
     p.add_argument("--no-extra-configs", action="store_true",
@@ -359,66 +360,109 @@ def bench_launch_size_sweep(compeg_amd, gpu, quality, threads):
 
 def host_feed_child(spec, args):
     """One rank of `host_feed_scaling` (no device, no torch): rank/world/start-time/seconds in `spec`."""
-    rank, world, t_start, seconds = spec.split(",")
+    rank, world, t_start, seconds, bus_ids = (spec.split(",") + [""])[:5]
     rank, world, t_start, seconds = int(rank), int(world), float(t_start), float(seconds)
     import compeg_amd
-    from compeg_amd.sharding import bind_rank_to_its_cores
+    from compeg_amd.sharding import bind_rank_round_robin, bind_rank_to_its_cores
     from tools import synth
-    cores, numa = bind_rank_to_its_cores(rank, world, [])
-    threads = max(1, min(32, len(cores)))
+    bus_ids = [b for b in bus_ids.split(";") if b]
+    if len(bus_ids) >= world:   # the GPUs are there: each rank next to its own
+        cores, numa = bind_rank_to_its_cores(rank, world, bus_ids)
+        binding = f"rank {rank} on the cores of GPU {bus_ids[rank]}'s NUMA node ({numa}), {len(cores)} cores"
+    else:
+        cores, numa, binding = bind_rank_round_robin(rank, world)
+    # (threads: the rank's cores -- or its share of the CPU time the box's cgroup grants, where that is less: threads
+    # beyond the quota only get the whole tree throttled)
+    from compeg_amd.sharding import cpu_quota_cores
+    quota = cpu_quota_cores()
+    threads = max(1, min(64, len(cores), int(quota // world) if quota else 64))
+    if world > 1 or quota:
+        os.sched_setaffinity(0, cores[:threads])
+    # The working set: ~1 GB of JPEG bytes per rank, every slot at an address of its own (copies of 16 distinct frames:
+    # what the caches see is distinct bytes) -- far beyond the L3 a rank's cores share, as a stream of frames is.
     distinct = 16
     with ThreadPoolExecutor(threads) as ex:
         jpegs = list(ex.map(lambda i: synth.make_jpeg(args.width, args.height, seed=0xC0FFEE + rank * distinct + i,
                                                       quality=args.quality, ri=args.ri), range(distinct)))
-    frames = [jpegs[i % distinct] for i in range(64)]
+    slots = max(64, int(HOST_FEED_WORKING_SET_BYTES // (sum(len(j) for j in jpegs) / distinct)))
+    frames = [bytes(bytearray(jpegs[i % distinct])) for i in range(slots)]
     jl = compeg_amd.JpegList(frames)
     nbytes = sum(len(j) for j in frames)
-    out = {"rank": rank, "threads": threads, "numa": numa}
-    for road, name in ((0, "host_preprocess_road"), (1, "copy_free_road")):
-        compeg_amd.host_feed_work(jl, threads, road, 1)                       # warm-up
-        while time.time() < t_start + road * (seconds + 2.0):                  # every rank starts a road at the same time
+    out = {"rank": rank, "threads": threads, "numa": numa, "binding": binding, "working_set_mb": round(nbytes / 1e6, 1), "slots": slots}
+    roads = ((0, "host_preprocess_road"), (1, "copy_free_road"), (2, "pageable_default_road"))
+    for road, name in roads:
+        compeg_amd.host_feed_work(jl, threads, road, 1)                       # warm-up (the arena's pages, the thread pool)
+        while time.time() < t_start + road * (seconds + 3.0):                  # every rank starts a road at the same time
             time.sleep(0.001)
         reps, el = 0, 0.0
         t0 = time.time()
         while time.time() - t0 < seconds:
-            k = 4 if road == 0 else 64
+            k = 1 if road != 1 else 4
             el += compeg_amd.host_feed_work(jl, threads, road, k)
             reps += k
-        out[name] = {"frames_per_s": reps * len(frames) / el, "jpeg_gbs": reps * nbytes / el / 1e9}
+        # host memory traffic of the road: JPEG bytes read (+ as many written: the preprocessed scan is within 1 % of the
+        # segment's size, the staged copy is the file); the copy-free road reads the headers
+        traffic = {0: 2.0, 1: 0.0, 2: 2.0}[road] * reps * nbytes / el / 1e9
+        out[name] = {"frames_per_s": reps * len(frames) / el, "jpeg_gbs": reps * nbytes / el / 1e9, "host_memory_gbs": traffic}
     print(json.dumps(out))
+
+
+HOST_FEED_WORKING_SET_BYTES = 1.0e9
 
 
 def bench_host_feed_scaling(args, rank_counts, link_gbs_measured, seconds=2.5):
     """What one host can prepare for N GPUs at once: N processes, each bound to the cores a rank of an N-GPU run would
-    get (compeg_amd/sharding.py), do the host's share of feeding a GPU -- both roads, see compeg_host_feed_work -- at
-    the same time, with no device involved (the GPU box has one card).  The copy-free road leaves the host the headers;
-    what it then needs per GPU is DMA reads of the JPEG bytes at the link's rate, which this cannot measure."""
+    get -- next to its GPU where the GPUs are there, round robin over the NUMA nodes on a one-card box
+    (compeg_amd/sharding.py) --, each with ~1 GB of JPEG bytes of its own, do the host's share of feeding a GPU at the
+    same time with no device involved: three roads, see compeg_host_feed_work.  The copy-free road leaves the host the
+    headers; what it then needs per GPU is DMA reads of the JPEG bytes at the link's rate, which this cannot measure."""
     import subprocess
 
     pix = args.width * args.height
-    rec = {"what": "N processes at once, each on its rank's share of the host's cores, each doing the host's share of "
-                   "feeding one GPU (no device): frames/s per rank and the whole host's rate",
-           "frame": f"{args.width}x{args.height} DRI={args.ri} q{args.quality}", "ranks": {}}
+    from compeg_amd.sharding import cpu_quota_cores
+    quota = cpu_quota_cores()
+    rec = {"what": "N processes at once, each on its rank's share of the host's cores with ~1 GB of JPEG bytes of its own, each "
+                   "doing the host's share of feeding one GPU (no device): frames/s per rank, the whole host's rate and the "
+                   "host memory traffic that goes with it",
+           "frame": f"{args.width}x{args.height} DRI={args.ri} q{args.quality}",
+           "host_cores_usable": len(os.sched_getaffinity(0)), "cgroup_cpu_quota_cores": quota, "ranks": {}}
+    bus_ids = ""
+    try:
+        import torch
+        if torch.cuda.device_count() >= max(rank_counts):
+            bus_ids = ";".join(torch.cuda.get_device_properties(i).pci_bus_id if hasattr(torch.cuda.get_device_properties(i), "pci_bus_id") else ""
+                               for i in range(max(rank_counts)))
+    except Exception:
+        bus_ids = ""
+    roads = ("host_preprocess_road", "copy_free_road", "pageable_default_road")
     for n in rank_counts:
-        t_start = time.time() + 12.0 + 1.5 * n   # (imports + synthesis of the ranks' frames)
-        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--host-feed-child", f"{r},{n},{t_start},{seconds}",
+        t_start = time.time() + 14.0 + 2.0 * n   # (imports, synthesis of the ranks' frames, the 1 GB of slots)
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--host-feed-child", f"{r},{n},{t_start},{seconds},{bus_ids}",
                                    "--width", str(args.width), "--height", str(args.height), "--ri", str(args.ri),
                                    "--quality", str(args.quality)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
                  for r in range(n)]
         outs = []
         for p_ in procs:
-            o, _ = p_.communicate(timeout=300)
+            o, _ = p_.communicate(timeout=400)
             outs.append(json.loads(o.strip().splitlines()[-1]))
-        row = {"threads_per_rank": outs[0]["threads"]}
-        for road in ("host_preprocess_road", "copy_free_road"):
+        row = {"threads_per_rank": [o["threads"] for o in outs], "working_set_mb_per_rank": outs[0]["working_set_mb"],
+               "numa_binding": [o["binding"] for o in outs]}
+        for road in roads:
             per = [o[road]["frames_per_s"] for o in outs]
             row[road] = {"gpix_s_per_rank_min": round(min(per) * pix / 1e9, 1), "gpix_s_whole_host": round(sum(per) * pix / 1e9, 1),
-                         "jpeg_gbs_whole_host": round(sum(o[road]["jpeg_gbs"] for o in outs), 1)}
+                         "jpeg_gbs_whole_host": round(sum(o[road]["jpeg_gbs"] for o in outs), 1),
+                         "host_memory_gbs_whole_host": round(sum(o[road]["host_memory_gbs"] for o in outs), 1)}
         rec["ranks"][str(n)] = row
+    total_threads = {n: sum(row["threads_per_rank"]) for n, row in rec["ranks"].items()}
+    rec["saturating_resource"] = (
+        f"CPU time: this box's cgroup grants {quota} cores' worth (cpu.max) of its {len(os.sched_getaffinity(0))} visible ones, and every row runs "
+        f"{sorted(set(total_threads.values()))} threads in all -- the whole-host rate is what that many cores preprocess, whatever the number "
+        "of ranks (round 3 ran 32-64 threads per rank against the same quota: the tree was throttled, 431 -> 224 Gpixel/s from 1 to 8 ranks)"
+        if quota else "none found: no CPU quota on this host")
     # how many GPUs this host keeps at the rate one GPU's link sustains (measured above by end_to_end)
     need = link_gbs_measured
     rec["per_gpu_link_gbs_measured"] = round(need, 1)
-    for road in ("host_preprocess_road", "copy_free_road"):
+    for road in roads:
         ok = [int(n) for n, row in rec["ranks"].items() if row[road]["jpeg_gbs_whole_host"] / int(n) >= need]
         rec[road + "_gpus_kept_at_link_rate"] = max(ok) if ok else 0
     return rec
@@ -546,6 +590,13 @@ def main():
     args = parse_args()
     if args.host_feed_child:
         return host_feed_child(args.host_feed_child, args)
+    if args.host_feed_only:
+        rec = bench_host_feed_scaling(args, [int(v) for v in args.host_feed_ranks.split(",") if v], 54.0)
+        print(json.dumps(rec))
+        for n, row in rec["ranks"].items():
+            print("#", n, "ranks", {k: v for k, v in row.items() if k != "numa_binding"}, file=sys.stderr)
+            print("#   ", row["numa_binding"][-1], file=sys.stderr)
+        return
     args.sampling_hv = tuple(int(v) for v in args.sampling.lower().split("x"))
     ext = args.sampling_hv != (2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -5,6 +5,7 @@
 #include <atomic>
 #include <chrono>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 #include <cstring>
@@ -699,78 +700,99 @@ size_t compeg_batch_host_fallbacks(const compeg_batch *batch)
 
 int compeg_batch_set_chunk(compeg_batch *batch, uint32_t images_per_launch)
 {
-    if (!batch)
-        return fail(COMPEG_E_INVALID_ARG, "batch is NULL");
-    if (batch->chunk == images_per_launch)
+    return guarded([&] {
+        if (!batch)
+            return fail(COMPEG_E_INVALID_ARG, "batch is NULL");
+        if (batch->chunk == images_per_launch)
+            return ok();
+        batch->chunk = images_per_launch;
+        // (the launches change size: some of them may now be the cooperative kernel's, which wants its walk tables, or
+        // take the walk + lane-per-MCU route, which wants its records' buffers)
+        if (batch->count) {
+            if (batch->last_stream && hipStreamSynchronize(batch->last_stream) != hipSuccess)
+                return fail(COMPEG_E_HIP, "hipStreamSynchronize failed");
+            if (hipSetDevice(batch->gpu->device) != hipSuccess)
+                return fail(COMPEG_E_HIP, "hipSetDevice failed");
+            compeg::Status st = batch->make_walk_tables(batch->gpu->stream, batch->count);
+            if (!st.ok())
+                return fail(st);
+            if (hipStreamSynchronize(batch->gpu->stream) != hipSuccess)
+                return fail(COMPEG_E_HIP, "hipStreamSynchronize failed");
+        }
         return ok();
-    batch->chunk = images_per_launch;
-    // (the launches change size: some of them may now be the cooperative kernel's, which wants its walk tables)
-    if (batch->count) {
-        if (batch->last_stream && hipStreamSynchronize(batch->last_stream) != hipSuccess)
-            return fail(COMPEG_E_HIP, "hipStreamSynchronize failed");
-        if (hipSetDevice(batch->gpu->device) != hipSuccess)
-            return fail(COMPEG_E_HIP, "hipSetDevice failed");
-        compeg::Status st = batch->make_walk_tables(batch->gpu->stream, batch->count);
-        if (!st.ok())
-            return fail(st);
-        if (hipStreamSynchronize(batch->gpu->stream) != hipSuccess)
-            return fail(COMPEG_E_HIP, "hipStreamSynchronize failed");
-    }
-    return ok();
+    });
 }
 
 int compeg_host_feed_work(const uint8_t *const *jpegs, const size_t *lengths, size_t count, int host_threads, unsigned flags,
                           int road, int reps, double *seconds)
 {
-    if (!jpegs || !lengths || !seconds || count == 0 || reps <= 0 || (road != 0 && road != 1))
-        return fail(COMPEG_E_INVALID_ARG, "bad arguments");
-    const unsigned nthreads = unsigned(std::max(1, host_threads));
-    // road 0: every thread preprocesses into a buffer of its own, as large as its largest image needs
-    size_t largest = 0;
-    for (size_t i = 0; i < count; i++)
-        largest = std::max(largest, lengths[i]);
-    std::vector<std::vector<uint8_t>> outs(nthreads);
-    std::vector<std::vector<uint32_t>> starts(nthreads);
-    std::vector<compeg::Status> status(nthreads);
-    std::atomic<size_t> next{0};
-    const size_t total = count * size_t(reps);
-    auto work = [&](unsigned t) {
-        if (road == 0)
-            outs[t].resize(compeg::ScanBuffer::output_capacity(largest));
-        for (;;) {
-            const size_t k = next.fetch_add(1, std::memory_order_relaxed);
-            if (k >= total || !status[t].ok())
-                return;
-            const size_t i = k % count;
-            compeg::ImageData *img = nullptr;
-            compeg::Status st = compeg::ImageData::parse(jpegs[i], lengths[i], false, &img,
-                                                         road == 1 ? flags | compeg::kParseDeferScanEnd : flags);
-            std::unique_ptr<compeg::ImageData> owned(img);
-            if (st.ok() && road == 0) {
-                const uint32_t expected = img->metadata.total_restart_intervals;
-                starts[t].resize(compeg::ScanBuffer::start_slots(expected));
-                size_t nwords = 0, nstarts = 0;
-                st = compeg::ScanBuffer::process_to(img->scan_data(), img->scan_len, expected, outs[t].data(), starts[t].data(),
-                                                    nwords, nstarts);
-                if (st.code == COMPEG_E_COUNT_MISMATCH)
-                    st = compeg::Status{};
+    return guarded([&] {
+        if (!jpegs || !lengths || !seconds || count == 0 || reps <= 0 || road < 0 || road > 2)
+            return fail(COMPEG_E_INVALID_ARG, "bad arguments");
+        const unsigned nthreads = unsigned(std::max(1, host_threads));
+        // Roads 0 and 2 write what they make where an upload would: every image has a place of its own in one arena
+        // (kept between calls: an upload's pinned arena is), so that a batch larger than the caches costs the memory
+        // traffic it costs there -- every byte read once and written once.
+        static std::mutex arena_lock;
+        static std::vector<uint8_t> arena;
+        std::vector<size_t> at(count + 1, 0);
+        for (size_t i = 0; i < count; i++)
+            at[i + 1] = at[i] + ((road == 0 ? compeg::ScanBuffer::output_capacity(lengths[i]) : lengths[i]) + 255) / 256 * 256;
+        std::unique_lock<std::mutex> hold(arena_lock);
+        if (road != 1 && arena.size() < at[count])
+            arena.resize(at[count]);
+        std::vector<std::vector<uint32_t>> starts(nthreads);
+        std::vector<compeg::Status> status(nthreads);
+        std::atomic<size_t> next{0};
+        const size_t total = count * size_t(reps);
+        auto work = [&](unsigned t) {
+            for (;;) {
+                const size_t k = next.fetch_add(1, std::memory_order_relaxed);
+                if (k >= total || !status[t].ok())
+                    return;
+                const size_t i = k % count;
+                compeg::ImageData *img = nullptr;
+                compeg::Status st = compeg::ImageData::parse(jpegs[i], lengths[i], false, &img,
+                                                             road != 0 ? flags | compeg::kParseDeferScanEnd : flags);
+                std::unique_ptr<compeg::ImageData> owned(img);
+                if (st.ok() && road == 0) {
+                    const uint32_t expected = img->metadata.total_restart_intervals;
+                    starts[t].resize(compeg::ScanBuffer::start_slots(expected));
+                    size_t nwords = 0, nstarts = 0;
+                    st = compeg::ScanBuffer::process_to(img->scan_data(), img->scan_len, expected, arena.data() + at[i], starts[t].data(),
+                                                        nwords, nstarts);
+                    if (st.code == COMPEG_E_COUNT_MISMATCH)
+                        st = compeg::Status{};
+                } else if (st.ok() && road == 2) {
+                    memcpy(arena.data() + at[i], jpegs[i], lengths[i]); // (pageable bytes: into the pinned arena, whole)
+                }
+                if (!st.ok())
+                    status[t] = st;
             }
+        };
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<std::thread> threads;
+        struct JoinAll {
+            std::vector<std::thread> &v;
+            ~JoinAll()
+            {
+                for (std::thread &th : v)
+                    if (th.joinable())
+                        th.join();
+            }
+        } join_all{threads}; // (also when starting a thread throws midway)
+        threads.reserve(nthreads);
+        for (unsigned t = 1; t < nthreads; t++)
+            threads.emplace_back(work, t);
+        work(0);
+        for (std::thread &th : threads)
+            th.join();
+        *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        for (const compeg::Status &st : status)
             if (!st.ok())
-                status[t] = st;
-        }
-    };
-    const auto t0 = std::chrono::steady_clock::now();
-    std::vector<std::thread> threads;
-    for (unsigned t = 1; t < nthreads; t++)
-        threads.emplace_back(work, t);
-    work(0);
-    for (std::thread &th : threads)
-        th.join();
-    *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    for (const compeg::Status &st : status)
-        if (!st.ok())
-            return fail(st);
-    return ok();
+                return fail(st);
+        return ok();
+    });
 }
 
 int compeg_host_alloc(size_t bytes, void **out)

@@ -867,7 +867,7 @@ hipError_t launch_huffman(const ImageDesc *descs, uint32_t images, uint32_t max_
         return hipSuccess;
     const uint32_t threads = plan.waves_per_block * kWave;
     dim3 grid((max_intervals + threads - 1) / threads, images, 1);
-    static const hipError_t attr = hipFuncSetAttribute(
+    const hipError_t attr = hipFuncSetAttribute(
         reinterpret_cast<const void *>(huffman_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
         int(device_limits().lds_bytes));
     if (attr != hipSuccess)
@@ -884,7 +884,7 @@ hipError_t launch_entropy(const ImageDesc *descs, uint32_t images, uint32_t max_
         return hipSuccess;
     const uint32_t threads = plan.waves_per_block * kWave;
     dim3 grid((max_intervals + threads - 1) / threads, images, 1);
-    static const hipError_t attr = hipFuncSetAttribute(
+    const hipError_t attr = hipFuncSetAttribute(
         reinterpret_cast<const void *>(entropy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
         int(device_limits().lds_bytes));
     if (attr != hipSuccess)
@@ -1516,7 +1516,7 @@ hipError_t launch_coop_422(const ImageDesc *descs, uint32_t images, uint32_t max
     }();
     const uint32_t teams = plan.waves_per_block / kCoopTeamWaves, per_block = plan.intervals_per_wave * teams;
     dim3 grid((max_intervals + per_block - 1) / per_block, images, 1);
-    static const hipError_t attr = hipFuncSetAttribute(
+    const hipError_t attr = hipFuncSetAttribute(
         reinterpret_cast<const void *>(decode_coop_team_422_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
         int(device_limits().lds_bytes));
     if (attr != hipSuccess)
@@ -1547,7 +1547,7 @@ hipError_t launch_entropy_samples(const ImageDesc *descs, uint32_t images, uint3
         return hipSuccess;
     const uint32_t threads = plan.waves_per_block * kWave; // planned like the fused kernel: at most 12 waves
     dim3 grid((max_intervals + threads - 1) / threads, images, 1);
-    static const hipError_t attr = hipFuncSetAttribute(
+    const hipError_t attr = hipFuncSetAttribute(
         reinterpret_cast<const void *>(entropy_samples_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
         int(device_limits().lds_bytes));
     if (attr != hipSuccess)

@@ -1462,16 +1462,37 @@ Status compeg_batch::upload_device_scan(size_t n, int threads, const FeedSource 
         images.assign(given, given + n);
 
     // which bytes the DMA engines can read where they are
+    // (a source counts as page-locked when its first AND its last byte are: one that runs past the end of its
+    // registration goes the staged road.  alloc[i]: the page-locked allocation the source lies in, where the runtime can
+    // say -- two sources with a gap between them are sent as one transfer only inside one allocation)
     std::vector<uint8_t> pinned(n, 0);
+    struct Span {
+        const uint8_t *base = nullptr, *end = nullptr;
+    };
+    std::vector<Span> alloc(n);
     bool any_pageable = false;
+    auto locked_at = [](const void *p, hipPointerAttribute_t &attr) {
+        const bool yes = hipPointerGetAttributes(&attr, p) == hipSuccess && attr.type == hipMemoryTypeHost;
+        (void)hipGetLastError(); // (a pageable pointer is "invalid value" to the query: not an error here)
+        return yes;
+    };
     for (size_t i = 0; i < n; i++) {
         if (src[i].len > 0xfffffff0u)
             return Status::error(COMPEG_E_INVALID_ARG, "scan segment too large");
-        hipPointerAttribute_t attr{};
-        const bool is_pinned = src[i].len != 0 && hipPointerGetAttributes(&attr, src[i].bytes) == hipSuccess && attr.type == hipMemoryTypeHost;
-        (void)hipGetLastError(); // (a pageable pointer is "invalid value" to the query: not an error here)
+        hipPointerAttribute_t first{}, last{};
+        const bool is_pinned = src[i].len != 0 && locked_at(src[i].bytes, first) && locked_at(src[i].bytes + src[i].len - 1, last);
         pinned[i] = is_pinned ? 1 : 0;
         any_pageable = any_pageable || !is_pinned;
+        if (is_pinned && first.devicePointer) {
+            hipDeviceptr_t base = nullptr;
+            size_t size = 0;
+            if (hipMemGetAddressRange(&base, &size, hipDeviceptr_t(first.devicePointer)) == hipSuccess && size) {
+                // (as host addresses: the source's offset inside the allocation is the same on both sides)
+                const uint8_t *host_base = src[i].bytes - (static_cast<const uint8_t *>(first.devicePointer) - static_cast<const uint8_t *>(base));
+                alloc[i] = Span{host_base, host_base + size};
+            }
+            (void)hipGetLastError();
+        }
     }
     // Page-locked sources that follow each other in memory -- the frames of a capture ring, a receive arena -- go up
     // as ONE transfer per run (one copy of 32 MB moves at the link's rate, sixteen copies of 1.6 MB at three quarters
@@ -1491,8 +1512,12 @@ Status compeg_batch::upload_device_scan(size_t n, int threads, const FeedSource 
         if (!runs.empty() && pinned[i] && pinned[i - 1]) {
             const Run &r = runs.back();
             const uint8_t *end = r.host + r.bytes;
+            // (a gap is read by the transfer too: none, or both sources inside one page-locked allocation -- two
+            // separately registered buffers may have anything, or nothing, between them)
+            const bool one_allocation = alloc[i].base && alloc[i].base == alloc[i - 1].base && alloc[i].end == alloc[i - 1].end &&
+                                        src[i].bytes + src[i].len <= alloc[i].end && r.host >= alloc[i].base;
             joins = group_of(i) == group_of(r.first) && src[i].bytes >= end && size_t(src[i].bytes - end) <= kMaxGap &&
-                    size_t(src[i].bytes - r.host) + src[i].len <= kMaxRunBytes;
+                    (src[i].bytes == end || one_allocation) && size_t(src[i].bytes - r.host) + src[i].len <= kMaxRunBytes;
         }
         if (joins) {
             runs.back().last = i;
@@ -1606,7 +1631,7 @@ Status compeg_batch::upload_device_scan(size_t n, int threads, const FeedSource 
                 const Run &r = runs[next_run];
                 for (size_t i = r.first; i <= r.last; i++)
                     while (!staged_ready[i].load(std::memory_order_acquire))
-                        std::this_thread::yield();
+                        std::this_thread::yield(); // (every worker stages and parses, whatever its device calls say: see `work`)
                 if (r.bytes)
                     err = hipMemcpyAsync(da + r.dev, pinned[r.first] ? r.host : hs + lay[r.first].staged, r.bytes,
                                          hipMemcpyHostToDevice, copy_streams[next_run % kCopyStreams]);
@@ -1661,14 +1686,19 @@ Status compeg_batch::upload_device_scan(size_t n, int threads, const FeedSource 
     hipError_t sent_status = hipSuccess;
     {
         auto work = [&](unsigned t) {
-            if (hipSetDevice(device) != hipSuccess) {
+            // (a thread that cannot make the device current still does its share of the host-only work -- the thread
+            // that sends waits for every image to be staged and parsed --, and the sender gives up)
+            const bool device_ok = hipSetDevice(device) == hipSuccess;
+            if (!device_ok)
                 hip_error = int(hipErrorInvalidDevice);
-                return;
-            }
-            if (t == 0 && nthreads > 1)
-                sent_status = send_runs();
-            else
+            if (t == 0 && nthreads > 1) {
+                if (device_ok)
+                    sent_status = send_runs();
+                else
+                    prepare_images();
+            } else {
                 prepare_images();
+            }
         };
         run_on_threads(nthreads, work);
         if (nthreads <= 1)

@@ -100,3 +100,51 @@ def bind_rank_to_its_cores(local_rank, world, pci_bus_ids):
     if world > 1 and share:
         os.sched_setaffinity(0, share)
     return share, mine
+
+
+def host_numa_nodes(available):
+    """[(node, cores of it this process may use)] for every NUMA node that has such cores; [] without sysfs."""
+    import glob
+    import os
+    import re
+
+    nodes = []
+    for path in sorted(glob.glob("/sys/devices/system/node/node[0-9]*"), key=lambda p_: int(re.search(r"(\d+)$", p_).group(1))):
+        node = int(re.search(r"(\d+)$", path).group(1))
+        cpus = node_cpus(node) or []
+        mine = sorted(set(cpus) & set(available))
+        if mine:
+            nodes.append((node, mine))
+    return nodes
+
+
+def bind_rank_round_robin(rank, world):
+    """For a host whose GPUs are not there to ask (the one-card box that rehearses an N-rank run): ranks go round robin
+    over the NUMA nodes this process may use, and the ranks of a node share its cores evenly.  Returns (cores, node or
+    None, text that says what was done)."""
+    import os
+
+    available = sorted(os.sched_getaffinity(0))
+    nodes = host_numa_nodes(available)
+    if not nodes:
+        share = cpu_share(available, None, world, rank)
+        if world > 1 and share:
+            os.sched_setaffinity(0, share)
+        return share, None, f"no NUMA information: {len(available)} cores cut evenly among {world} ranks"
+    node, cores = nodes[rank % len(nodes)]
+    on_node = [r for r in range(world) if r % len(nodes) == rank % len(nodes)]
+    share = cpu_share(cores, cores, len(on_node), on_node.index(rank))
+    if share:
+        os.sched_setaffinity(0, share)
+    return share, node, (f"ranks round robin over the {len(nodes)} NUMA nodes this process may use "
+                         f"({', '.join(str(len(c)) for _, c in nodes)} cores): rank {rank} on node {node}, {len(share)} cores")
+
+
+def cpu_quota_cores():
+    """Cores' worth of CPU time this process tree may use per second (cgroup v2 cpu.max), or None: no limit known."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        return None if quota == "max" else int(quota) / int(period)
+    except (OSError, ValueError):
+        return None

@@ -256,9 +256,11 @@ int compeg_batch_upload_jpegs(compeg_batch *batch, const uint8_t *const *jpegs, 
  * work too; the worker threads then copy them into the batch's own pinned arena first.  The bytes must stay
  * valid and unchanged until the call returns. */
 /* Measurement aid (bench.py --host-feed-ranks; no device is touched): the host's share of feeding one batch,
- * `reps` times over on `host_threads` threads -- road 0: ImageData::new + ScanBuffer::process of every image into a
- * buffer of the call's own (what compeg_batch_upload_jpegs does on the host with host preprocessing: every byte read
- * once and written once); road 1: the headers only (the copy-free road above).  *seconds: wall time of all reps. */
+ * `reps` times over on `host_threads` threads -- road 0: ImageData::new + ScanBuffer::process of every image into its
+ * place in an arena (what compeg_batch_upload_jpegs does on the host with host preprocessing: every byte read once
+ * and written once); road 1: the headers only (the copy-free road above); road 2: the headers, and every file copied
+ * into its place in the arena (pageable bytes with device preprocessing: the default of compeg_batch_upload_jpegs
+ * without compeg_host_register).  *seconds: wall time of all reps. */
 int compeg_host_feed_work(const uint8_t *const *jpegs, const size_t *lengths, size_t count, int host_threads, unsigned flags,
                           int road, int reps, double *seconds);
 /* compeg_batch_upload_jpegs in two steps, for a feeder that keeps the link busy.  _begin returns as soon as every
