@@ -124,7 +124,11 @@ def cpu_baseline_all_cores(jpegs, budget_s, pixels_per_image):
     with the whole host."""
     from oracle import oracle as orc
 
-    cores = os.cpu_count() or 1
+    # (every core this process may use -- or as many as the box's cgroup grants CPU time for, where that is fewer: 256
+    # threads on a quota of 16 cores spend their time being throttled)
+    from compeg_amd.sharding import cpu_quota_cores
+    quota = cpu_quota_cores()
+    cores = max(1, min(len(os.sched_getaffinity(0)), int(quota) if quota else 1 << 30))
     deadline = time.perf_counter() + budget_s
 
     def work(t):
@@ -139,6 +143,7 @@ def cpu_baseline_all_cores(jpegs, budget_s, pixels_per_image):
         done = sum(ex.map(work, range(cores)))
     el = time.perf_counter() - t0
     return {"value": round(done * pixels_per_image / el / 1e6, 3), "unit": "Mpixels/s", "cores": cores,
+            "host_cores_visible": os.cpu_count(), "cgroup_cpu_quota_cores": quota,
             "sample": f"{done} frames on {cores} threads, {el:.1f} s"}
 
 

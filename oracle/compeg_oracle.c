@@ -1221,6 +1221,24 @@ void orc_huffman_pass_ext(const uint8_t *md, const uint8_t *l1, const uint8_t *l
 
     memset(coef, 0, ncoef * sizeof(int32_t));
 
+    /* The uniform block's words the loops below use, read once (the shader reads them from the
+     * uniform buffer wherever it needs them: the same values every time): the components'
+     * fields and the quantisation tables.  A table index beyond the four tables reads words
+     * behind them, as the shader's indexing would (md_get inside the loops did the same). */
+    uint32_t c_vs[3], c_hs[3], c_qt[3], c_dct[3], c_act[3];
+    for (uint32_t comp = 0; comp < 3; comp++) {
+        const size_t o = MD_COMP + (size_t)comp * 20;
+        c_vs[comp] = md_get(md, o + 0);
+        c_hs[comp] = md_get(md, o + 4);
+        c_qt[comp] = md_get(md, o + 8);
+        c_dct[comp] = md_get(md, o + 12);
+        c_act[comp] = md_get(md, o + 16);
+    }
+    uint32_t quant[3][64];
+    for (uint32_t comp = 0; comp < 3; comp++)
+        for (uint32_t pos = 0; pos < 64; pos++)
+            quant[comp][pos] = md_get(md, ((size_t)c_qt[comp] * 64 + pos) * 4);
+
     for (uint32_t id = 0; id < count; id++) {
         orc_bits b;
         orc_bits_init(&b, words, nwords, id < nstarts ? starts[id] : 0u);
@@ -1229,10 +1247,8 @@ void orc_huffman_pass_ext(const uint8_t *md, const uint8_t *l1, const uint8_t *l
             uint32_t mcu_index = id * ri + i;
             uint32_t du_index = mcu_index * dus_per_mcu;
             for (uint32_t comp = 0; comp < 3; comp++) {
-                const size_t o = MD_COMP + (size_t)comp * 20;
-                uint32_t vs = md_get(md, o + 0), hs = md_get(md, o + 4);
-                uint32_t qt = md_get(md, o + 8);
-                uint32_t dct = md_get(md, o + 12), act = md_get(md, o + 16);
+                uint32_t vs = c_vs[comp], hs = c_hs[comp];
+                uint32_t dct = c_dct[comp], act = c_act[comp];
                 for (uint32_t v = 0; v < vs; v++) {
                     for (uint32_t h = 0; h < hs; h++) {
                         uint32_t start = du_index * retained;
@@ -1245,8 +1261,7 @@ void orc_huffman_pass_ext(const uint8_t *md, const uint8_t *l1, const uint8_t *l
                         diff = dccat == 0 ? 0 : orc_huff_extend(diff, dccat);
                         dcpred[comp] = (int32_t)((uint32_t)dcpred[comp] + (uint32_t)diff);
                         if ((size_t)start < ncoef)
-                            coef[start] = (int32_t)((uint32_t)dcpred[comp] *
-                                                    md_get(md, ((size_t)qt * 64 + 0) * 4));
+                            coef[start] = (int32_t)((uint32_t)dcpred[comp] * quant[comp][0]);
                         for (uint32_t pos = 1; pos < 64; pos++) {
                             orc_bits_refill(&b);
                             uint32_t rs = huffdecode(&b, &c, act);
@@ -1264,9 +1279,7 @@ void orc_huffman_pass_ext(const uint8_t *md, const uint8_t *l1, const uint8_t *l
                             if (pos < retained) { /* quirk Q3 */
                                 size_t idx = (size_t)start + pos;
                                 if (idx < ncoef)
-                                    coef[idx] =
-                                        (int32_t)((uint32_t)cf *
-                                                  md_get(md, ((size_t)qt * 64 + pos) * 4));
+                                    coef[idx] = (int32_t)((uint32_t)cf * quant[comp][pos]);
                             }
                         }
                         du_index++;
@@ -1422,6 +1435,34 @@ void orc_finalize_pass(const uint8_t *md, const int32_t *coef, size_t ncoef, uin
      * max_v == 1 the loops below are that shader, statement by statement.  For the 16-row MCUs
      * of 4:4:0 / 4:2:0 (extension) the same formulas are continued to rows 8..15: a component's
      * data unit is picked by block row as well as block column, its sample by row / yscale. */
+    uint32_t c_vs[3], c_hs[3]; /* (the components' sampling factors: read once, see orc_huffman_pass_ext) */
+    for (uint32_t comp = 0; comp < 3; comp++) {
+        c_vs[comp] = md_get(md, MD_COMP + (size_t)comp * 20 + 0);
+        c_hs[comp] = md_get(md, MD_COMP + (size_t)comp * 20 + 4);
+    }
+    /* Which data unit, row, word and byte of it a pixel (row, col) of an MCU takes its component
+     * from: the shader's index arithmetic, statement by statement, done once per (row, col) of
+     * the MCU instead of once per pixel of the image -- the same indices every MCU. */
+    if (total_mcus == 0)
+        return;
+    struct pick {
+        uint8_t du, y, word, shift;
+    } picks[3][16][16];
+    for (uint32_t row = 0; row < msy && row < 16; row++)
+        for (uint32_t col = 0; col < msx && col < 16; col++) {
+            uint32_t du_offset = 0;
+            for (uint32_t comp = 0; comp < 3; comp++) {
+                uint32_t vs = c_vs[comp], hs = c_hs[comp];
+                uint32_t du = du_offset + (row * vs / msy) * hs + col * hs / msx;
+                uint32_t xscale = max_h / hs, yscale = max_v / vs;
+                uint32_t x = col / xscale, y = row / yscale;
+                picks[comp][row][col].du = (uint8_t)(du < 6 ? du : 0);
+                picks[comp][row][col].y = (uint8_t)(y & 7);
+                picks[comp][row][col].word = (uint8_t)((x & 7u) > 3u);
+                picks[comp][row][col].shift = (uint8_t)((x & 7u) * 8u);
+                du_offset += hs * vs;
+            }
+        }
     for (uint32_t mcu = 0; mcu < total_mcus; mcu++) {
         uint32_t rows[6][8][2]; /* databuf[local_mcu].du[i].rows[row] */
         memset(rows, 0, sizeof rows);
@@ -1436,17 +1477,10 @@ void orc_finalize_pass(const uint8_t *md, const int32_t *coef, size_t ncoef, uin
         for (uint32_t row = 0; row < msy; row++) { /* reference: one thread per MCU row, 8 rows */
             for (uint32_t col = 0; col < msx; col++) {
                 uint32_t cx = mx * msx + col, cy = my * msy + row;
-                uint32_t du_offset = 0, comp_val[3];
+                uint32_t comp_val[3];
                 for (uint32_t comp = 0; comp < 3; comp++) {
-                    const size_t o = MD_COMP + (size_t)comp * 20;
-                    uint32_t vs = md_get(md, o + 0), hs = md_get(md, o + 4);
-                    uint32_t du = du_offset + (row * vs / msy) * hs + col * hs / msx;
-                    uint32_t xscale = max_h / hs, yscale = max_v / vs;
-                    uint32_t x = col / xscale, y = row / yscale;
-                    uint32_t word = (x & 7u) > 3u;
-                    uint32_t shift = (x & 7u) * 8u;
-                    comp_val[comp] = SHR(rows[du < 6 ? du : 0][y & 7][word], shift);
-                    du_offset += hs * vs;
+                    const struct pick k = picks[comp][row][col];
+                    comp_val[comp] = SHR(rows[k.du][k.y][k.word], k.shift);
                 }
                 int32_t yy = (int32_t)(comp_val[0] & 0xffu);
                 int32_t cb = (int32_t)(comp_val[1] & 0xffu) - 128;
@@ -1478,10 +1512,20 @@ int orc_image_decode(const orc_image *img, const uint8_t *jpeg, uint8_t *rgba, u
     uint32_t total_dus = total * md_get(img->md, MD_RI) * md_get(img->md, MD_DUS);
     size_t ncoef = (size_t)total_dus * md_get(img->md, MD_RET);
 
+    /* (the coefficient buffer is kept from frame to frame, one per thread -- the reference's
+     * Decoder keeps its DynamicBuffer the same way, src/lib.rs:302-370; orc_huffman_pass_ext
+     * clears it like the reference's clear_buffer does.  The scan buffer is a fresh one every
+     * time: its output is defined on a fresh buffer) */
+    static __thread int32_t *coef = NULL;
+    static __thread size_t coef_cap = 0;
     orc_scanbuf *sb = orc_scanbuf_new();
     int rc = orc_scanbuf_process(sb, jpeg + img->scan_off, img->scan_len, total, err);
 
-    int32_t *coef = (int32_t *)malloc((ncoef ? ncoef : 1) * sizeof(int32_t));
+    if (coef_cap < (ncoef ? ncoef : 1)) {
+        free(coef);
+        coef_cap = ncoef ? ncoef : 1;
+        coef = (int32_t *)malloc(coef_cap * sizeof(int32_t));
+    }
     orc_huffman_pass_ext(img->md, (const uint8_t *)img->l1, (const uint8_t *)img->l2,
                          img->l2_len * 2, sb->words, sb->words_len, sb->starts, sb->starts_len, coef,
                          ncoef, img->flags);
@@ -1489,8 +1533,6 @@ int orc_image_decode(const orc_image *img, const uint8_t *jpeg, uint8_t *rgba, u
         memcpy(coef_out, coef, ncoef * sizeof(int32_t));
     orc_dct_pass(img->md, coef, ncoef);
     orc_finalize_pass(img->md, coef, ncoef, rgba, tex_w, tex_h);
-
-    free(coef);
     orc_scanbuf_free(sb);
     return rc;
 }

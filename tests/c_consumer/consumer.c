@@ -1,8 +1,11 @@
 /* A plain C99 consumer of include/compeg_hip.h (test infrastructure): what a non-Python FFI user of the
  * boundary sees.  Compiled with gcc -std=c99 -Wall -Wextra -Werror and linked against libcompeg_hip.so by
- * tests/test_host_parity.py on every run of the CPU suite; it makes no GPU call.
- *   consumer file.jpg   prints what ImageData::new reports for the file, then exercises error strings and the
- *                       ScanBuffer known-answer vector of the reference (src/scan.rs:151-159). */
+ * tests/test_host_parity.py on every run of the CPU suite (no GPU call there) and by tests/test_gpu_parity.py.
+ *   consumer file.jpg            prints what ImageData::new reports for the file, then exercises error strings and
+ *                                the ScanBuffer known-answer vector of the reference (src/scan.rs:151-159).
+ *   consumer --decode file.jpg   the reference's own test flow (src/tests.rs:41-72: open the GPU, parse, decode
+ *                                blocking, read the texture back tightly packed) through the C ABI, on the GPU:
+ *                                prints the FNV-1a hash of the RGBA bytes. */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -15,11 +18,54 @@ static int fail(const char *what)
     return 1;
 }
 
+/* Gpu::open -> ImageData::new -> Decoder::decode_blocking -> texture read-back (src/tests.rs:41-72) */
+static int decode_on_gpu(const unsigned char *bytes, size_t n)
+{
+    compeg_gpu *gpu = NULL;
+    compeg_image *img = NULL;
+    compeg_decoder *dec = NULL;
+    compeg_op *op = NULL;
+    if (compeg_gpu_open(-1, &gpu) != COMPEG_OK)
+        return fail("compeg_gpu_open");
+    if (compeg_image_parse(bytes, n, 0, &img) != COMPEG_OK)
+        return fail("compeg_image_parse");
+    if (compeg_decoder_new(gpu, &dec) != COMPEG_OK)
+        return fail("compeg_decoder_new");
+    if (compeg_decoder_decode_blocking(dec, img, &op) != COMPEG_OK)
+        return fail("compeg_decoder_decode_blocking");
+    const uint32_t w = compeg_image_width(img), h = compeg_image_height(img);
+    printf("changed %d kernel %d\n", compeg_op_texture_changed(op), compeg_decoder_last_kernel(dec));
+    unsigned char *rgba = (unsigned char *)malloc((size_t)w * h * 4);
+    if (!rgba || compeg_decoder_read_output(dec, rgba, w, h) != COMPEG_OK)
+        return fail("compeg_decoder_read_output");
+    unsigned long long hash = 14695981039346656037ull; /* FNV-1a, 64 bit */
+    for (size_t i = 0; i < (size_t)w * h * 4; i++) {
+        hash ^= rgba[i];
+        hash *= 1099511628211ull;
+    }
+    printf("decoded %u %u fnv1a %016llx\n", w, h, hash);
+    /* a second decode into the same texture: not reallocated (lib.rs:564-573) */
+    compeg_op_free(op);
+    op = NULL;
+    if (compeg_decoder_decode_blocking(dec, img, &op) != COMPEG_OK)
+        return fail("compeg_decoder_decode_blocking (second)");
+    printf("changed_again %d\n", compeg_op_texture_changed(op));
+    free(rgba);
+    compeg_op_free(op);
+    compeg_decoder_free(dec);
+    compeg_image_free(img);
+    compeg_gpu_release(gpu);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 2)
         return 2;
-    FILE *f = fopen(argv[1], "rb");
+    const int decode = strcmp(argv[1], "--decode") == 0;
+    if (decode && argc < 3)
+        return 2;
+    FILE *f = fopen(argv[decode ? 2 : 1], "rb");
     if (!f)
         return 2;
     fseek(f, 0, SEEK_END);
@@ -29,6 +75,11 @@ int main(int argc, char **argv)
     if (!bytes || fread(bytes, 1, (size_t)n, f) != (size_t)n)
         return 2;
     fclose(f);
+    if (decode) {
+        const int rc_decode = decode_on_gpu(bytes, (size_t)n);
+        free(bytes);
+        return rc_decode;
+    }
 
     printf("version %s\n", compeg_version());
 

@@ -39,6 +39,23 @@ def _assert_equal(got, want):
                              f"got {got[ys[0], xs[0]]} want {want[ys[0], xs[0]]}")
 
 
+def _fnv1a_fast(flat):
+    """64-bit FNV-1a of a uint8 array without a Python loop per byte: the hash is h -> (h ^ b) * P mod 2^64, which a small
+    C routine does in a moment -- compiled on the fly with gcc (test infrastructure only)."""
+    import ctypes
+    import subprocess
+    import tempfile
+    src = "unsigned long long f(const unsigned char*p,unsigned long long n){unsigned long long h=14695981039346656037ull;for(unsigned long long i=0;i<n;i++){h^=p[i];h*=1099511628211ull;}return h;}"
+    d = tempfile.mkdtemp()
+    open(os.path.join(d, "f.c"), "w").write(src)
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", os.path.join(d, "f.c"), "-o", os.path.join(d, "f.so")])
+    lib = ctypes.CDLL(os.path.join(d, "f.so"))
+    lib.f.restype = ctypes.c_ulonglong
+    lib.f.argtypes = [ctypes.c_void_p, ctypes.c_ulonglong]
+    buf = np.ascontiguousarray(flat)
+    return int(lib.f(buf.ctypes.data, buf.size))
+
+
 def test_native_library_is_loaded(ca, gpu):
     assert "gfx950" in gpu.name()
     maps = open("/proc/self/maps").read()
@@ -765,8 +782,11 @@ def test_cooperative_kernel_takes_any_restart_interval(ca, gpu, ri):
             dec.set_device_preprocess(device)
             data = ca.ImageData(jpeg)
             dec.decode_blocking(data)
-            # (the busy frame's window from the device path's estimate may exceed what a team can have: other kernels then)
-            assert dec.last_kernel() == "coop_team" or (kind == 1 and device), (ri, w, h, device, dec.last_kernel())
+            # (the busy 640x360 frame with an interval of 240 or 256 MCUs, preprocessed on the device: the window the
+            # device path estimates for a team's interval -- twice the average -- exceeds what a team can have (32 KB), and
+            # the frame takes the streamed batch kernel; every other case is the cooperative kernel's)
+            expect = "fused_stream" if (kind == 1 and device and ri in (240, 256)) else "coop_team"
+            assert dec.last_kernel() == expect, (ri, w, h, device, dec.last_kernel())
             _assert_equal(dec.read_texture(w, h), want)
         batch = ca.Batch(gpu)
         batch.upload([ca.ImageData(jpeg)])
@@ -1134,3 +1154,59 @@ def test_bench_multi_rank_path_rehearsed_on_one_gpu(tmp_path):
     e2e = j["end_to_end"]
     assert e2e["verified_bit_exact_vs_oracle"] is True and e2e["from_jpeg_bytes_parse_included"]["whole_job_mpix_s"] > 0
     assert j["config"]["images_per_gpu"] == 6
+
+
+def test_c_consumer_decodes_on_the_gpu(ca, gpu, tmp_path):
+    """The boundary without Python: tests/c_consumer/consumer.c --decode is the reference's own test flow
+    (src/tests.rs:41-72: Gpu::open, ImageData::new, Decoder::decode_blocking, texture read-back) as a plain C99 program
+    linked against libcompeg_hip.so.  Its FNV-1a hash of the RGBA bytes equals the hash of the oracle's pixels, for the
+    reference's MJPEG fixture (DRI = 10, no DHT) and for a 4K frame."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "consumer")
+    libdir = os.path.dirname(ca.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c_consumer", "consumer.c"), "-o", exe,
+                           "-L", libdir, "-l:libcompeg_hip.so", "-Wl,-rpath," + libdir])
+
+    big = tmp_path / "frame4k.jpg"
+    big.write_bytes(synth.make_jpeg(3840, 2160, seed=0xC0FFEE, kind=0, quality=85, ri=4))
+    for path in (os.path.join(root, "tests", "golden", "parser", "mjpeg.jpg"), str(big)):
+        r = subprocess.run([exe, "--decode", path], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        lines = dict(l.split(" ", 1) for l in r.stdout.splitlines())
+        want = orc.ImageData(open(path, "rb").read()).decode()
+        h, w = want.shape[:2]
+        acc = _fnv1a_fast(want.reshape(-1))   # (the same hash of the oracle's pixels)
+        assert lines["decoded"] == f"{w} {h} fnv1a {acc:016x}", (path, lines)
+        assert lines["changed"].startswith("1 ") and lines["changed_again"] == "0"
+
+
+@pytest.mark.parametrize("sampling,single,paired", [((1, 1), "decode_fused_444_single_kernel", "decode_fused_444_kernel"),
+                                                     ((1, 2), "decode_fused_440_single_kernel", "decode_fused_440_kernel")])
+def test_extension_layouts_with_odd_restart_intervals(ca, gpu, sampling, single, paired):
+    """4:4:4 and 4:4:0 with odd restart intervals: the MCUs of an interval cannot be composited in pairs, every lane
+    stores its 8-pixel MCU alone (decode_fused_444_single_kernel / decode_fused_440_single_kernel: 32-byte rows).  The
+    batch reports "fused_layout" for both forms; which of the two kernels ran is told by their timing -- the single form
+    takes longer per frame than the paired one on the same frames with the interval one MCU longer -- and both are
+    bit-exact against the oracle's extension."""
+    times = {}
+    for ri in (3, 4, 5):
+        jpegs = [synth.make_jpeg(1280, 720, seed=60 + i, kind=0, quality=85, ri=ri, sampling=sampling) for i in range(4)]
+        images = [ca.ImageData(j, allow_sampling=True) for j in jpegs]
+        batch = ca.Batch(gpu)
+        batch.upload([images[i % 4] for i in range(64)])
+        for _ in range(3):
+            batch.decode()
+        batch.wait()
+        assert batch.last_kernel() == "fused_layout"
+        batch.timing(reset=True)
+        for _ in range(5):
+            batch.decode()
+        batch.wait()
+        n, total, _, _ = batch.timing(reset=True)
+        times[ri] = total / n
+        for i in (0, 3, 63):
+            _assert_equal(batch.read_output(i), orc.ImageData(jpegs[i % 4], allow_sampling=True).decode())
+    # (odd intervals: the single kernels; even: the paired ones -- two to three times faster per frame)
+    assert times[3] > 1.3 * times[4] and times[5] > 1.3 * times[4], (single, paired, times)
