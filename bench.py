@@ -752,6 +752,17 @@ def main():
         one.wait()
         dev_wall = (time.perf_counter() - t1) / reps * 1e3
         n1, tot1, h1, i1 = one.timing(reset=True)
+        # (the same without timing events: every event is a packet the card works through between two kernels)
+        one.set_timing(False)
+        for _ in range(5):
+            one.decode()
+        one.wait()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            one.decode()
+        one.wait()
+        dev_wall_untimed = (time.perf_counter() - t1) / reps * 1e3
+        one.set_timing(True)
         def blocking_ms(dec, reps=20):
             for _ in range(3):
                 dec.decode_blocking(images[0])
@@ -776,9 +787,10 @@ def main():
         for _ in range(20):
             compeg_amd.ImageData(jpegs[0], copy=False, allow_sampling=ext)
         t_parse = (time.perf_counter() - t_parse) / 20 * 1e3
-        single = {"frames": 1, "kernel": one.last_kernel(), "device_ms_per_frame": round(dev_wall, 4),
+        single = {"frames": 1, "kernel": one.last_kernel(), "device_ms_per_frame": round(dev_wall_untimed, 4),
+                  "device_ms_per_frame_with_timing_events": round(dev_wall, 4),
                   "kernel_ms": round(tot1 / n1, 4),
-                  "device_mpix_s": round(one.pixels() / dev_wall / 1e3, 1),
+                  "device_mpix_s": round(one.pixels() / dev_wall_untimed / 1e3, 1),
                   "host_end_to_end_ms": round(e2e, 3),
                   "host_end_to_end_mpix_s": round(one.pixels() / e2e / 1e3, 1),
                   "host_end_to_end_one_thread_ms": round(e2e_1t, 3),
@@ -815,6 +827,10 @@ def main():
             extra[f"extension {name}, 64 x 4K"] = bench_config(
                 compeg_amd, gpu, 3840, 2160, 4, args.quality, 64, args.steps, args.warmup, threads, 16,
                 f"64 x 3840x2160 YUV {name} baseline JPEG, DRI=4, 16 distinct frames (extension layout)", sampling=smp)
+        # (odd restart intervals: an interval's 8-pixel MCUs cannot be composited in pairs -- decode_fused_444_single_kernel)
+        extra["extension 4:4:4 odd DRI, 64 x 4K"] = bench_config(
+            compeg_amd, gpu, 3840, 2160, 3, args.quality, 64, max(3, args.steps // 2), args.warmup, threads, 16,
+            "64 x 3840x2160 YUV 4:4:4 baseline JPEG, DRI=3, 16 distinct frames (extension layout, MCUs composited singly)", sampling=(1, 1))
 
     feed_scaling = None
     if rank == 0 and world == 1 and args.host_feed_ranks and end_to_end is not None and not ext:
@@ -834,6 +850,7 @@ def main():
                     "fused_stream": {(1, 1): "decode_fused_444_stream_kernel", (1, 2): "decode_fused_440_stream_kernel",
                                      (2, 2): "decode_fused_420_stream_kernel"}.get(args.sampling_hv, "decode_fused_422_stream_kernel"),
                     "pair": "decode_pair_422_kernel", "coop_team": "decode_coop_team_422_kernel",
+                    "walk_mcu": "walk_mcus_422_kernel + decode_fused_422_mcu_rec_kernel",
                     "fused_layout": {(1, 1): "decode_fused_444_kernel", (1, 2): "decode_fused_440_kernel",
                                      (2, 2): "decode_fused_420_kernel"}.get(args.sampling_hv, "decode_fused_layout_kernel")}[which]
             kernels_ms = {name: round(ev_total_ms / max(n_timed, 1), 4)}
@@ -887,6 +904,9 @@ def main():
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
+                "traffic_source": ("profiles/traffic.json: FETCH_SIZE (doubled, MI355X_MICROARCH.md) + WRITE_SIZE of this kernel on this "
+                                   "workload from committed rocprofv3 --pmc passes, per image x the batch -- a look-up, not a "
+                                   "measurement of this run") if traffic is not None else None,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms": round(dominant[1], 4),
                 "kernels_ms": kernels_ms,
