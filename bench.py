@@ -62,6 +62,7 @@ def parse_args():
     p.add_argument("--cpu-seconds", type=float, default=12.0,
                    help="budget for the CPU-oracle baseline sample (0 disables it)")
     p.add_argument("--no-verify", action="store_true")
+    p.add_argument("--no-sweep", action="store_true", help="leave other_configs.launch_size_sweep out (profiling runs: its launches share grids with the headline's)")
     p.add_argument("--sweep-only", action="store_true", help="print the launch-size sweep (other_configs.launch_size_sweep) and leave")
     p.add_argument("--host-feed-only", action="store_true", help="print end_to_end.host_feed_scaling (no device touched) and leave")
     p.add_argument("--e2e-reps", type=int, default=5,
@@ -821,7 +822,8 @@ def main():
             compeg_amd, gpu, 7680, 4320, 1, args.quality, 8, args.steps, args.warmup, threads, 4,
             "8 x 7680x4320 YUV 4:2:2 baseline JPEG, DRI=1 per step (BASELINE configs[4] frame), 4 distinct frames")
         extra["mjpeg stream 960x720 DRI=10"] = bench_mjpeg_stream(compeg_amd, gpu, args.quality, args.steps, args.warmup, threads)
-        extra["launch_size_sweep"] = bench_launch_size_sweep(compeg_amd, gpu, args.quality, threads)
+        if not args.no_sweep:
+            extra["launch_size_sweep"] = bench_launch_size_sweep(compeg_amd, gpu, args.quality, threads)
         # the extension layouts (opt-in, not what the reference accepts), fused kernels
         for name, smp in (("4:4:4", (1, 1)), ("4:2:0", (2, 2))):
             extra[f"extension {name}, 64 x 4K"] = bench_config(

@@ -11,7 +11,7 @@ OUT=gpurun_out/prof_round
 rm -rf $OUT && mkdir -p $OUT
 # (the stats pass: 24 timed launches of the headline kernel -- its average has to reproduce the bench line's
 # kernel_ms -- and the sub-records, so that the single-frame and MJPEG-stream launches are in the trace too)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 24 --warmup 3 --cpu-seconds 0 --no-verify --e2e-reps 0 --host-feed-ranks "" > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 24 --warmup 3 --cpu-seconds 0 --no-verify --e2e-reps 0 --no-sweep --host-feed-ranks "" > $OUT/stats.log 2>&1
 B="python3 bench.py --steps 5 --warmup 2 --cpu-seconds 0 --no-verify --no-extra-configs --e2e-reps 0"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $B > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $B > $OUT/write.log 2>&1

@@ -29,7 +29,7 @@ def main():
         by.setdefault(key, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1000)
     print("## trace:", trace)
     for k, v in sorted(by.items()):
-        if k[0].startswith("decode"):
+        if k[0].startswith("decode") or k[0].startswith("walk_"):
             print("%-34s grid %8d x %4d launches %4d avg %8.1f min %8.1f max %8.1f us  first %s last %s" % (
                 k[0], k[1] // k[2], k[2], len(v), sum(v) / len(v), min(v), max(v), [round(x) for x in v[:4]], [round(x) for x in v[-3:]]))
     under = last_json_line(os.path.join(root, "bench_under_profiler.json"))
