@@ -1834,9 +1834,57 @@ CG_DEV bool wave_any(bool v)
 // that way); in dense streams the GPU fuzz found a few images in a thousand wrong with it, other ones on every run,
 // and none with this -- with M0 held still per sixteen rows, the in-flight count under its six bits and a stand-alone
 // stress of the staging clean, the cause was not found (profiles/r03/NOTES.md).
+#if defined(COMPEG_LAB) && defined(CG_STREAM_LDSDMA) && defined(__HIP_DEVICE_COMPILE__)
+// Laboratory builds only (-DCOMPEG_LAB -DCG_STREAM_LDSDMA; tools/repro_ldsdma.sh): the LDS-DMA staging of round 3, as it
+// was when the GPU fuzz found a few images in a thousand wrong with it in dense streams (seed 9902, batch 235) -- kept so
+// that the finding can be reproduced.  One global_load_lds_dword a row (per-lane source, the wave's 64 words to M0 +
+// offset + 4 lane); sixteen rows to one M0, told apart by the instruction's offset, a full wait in front of every
+// further sixteen; the count of vector memory operations in flight kept under its six bits.
+#define CG_GLDS_ROW(J) \
+    "global_load_lds_dword %[voff], %[base] offset:" #J "*256\n\t" \
+    "s_cmp_eq_u32 %[n], " #J "+1\n\t" \
+    "s_cbranch_scc1 9f\n\t" \
+    "v_add_u32 %[voff], 0xffffff04, %[voff]\n\t"
+#endif
+
 CG_DEV void stream_stage_rows(const ImageDesc &d, uint32_t *rows, uint32_t nrows, uint32_t first, uint32_t lane)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(COMPEG_LAB) && defined(CG_STREAM_LDSDMA) && defined(__HIP_DEVICE_COMPILE__)
+    (void)lane;
+    // CG_LDSDMA_TRY (a bit mask, tools/repro_ldsdma.sh): what was tried against the defect, one change a bit
+#if defined(CG_LDSDMA_TRY) && (CG_LDSDMA_TRY & 4)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (no store in flight beside the rows' loads)
+#else
+    asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+#endif
+#if defined(CG_LDSDMA_TRY) && (CG_LDSDMA_TRY & 8)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (no LDS read in flight when the first row is issued)
+#endif
+#if defined(CG_LDSDMA_TRY) && (CG_LDSDMA_TRY & 2)
+    uint32_t keep_m0;
+    asm volatile("s_mov_b32 %0, m0" : "=s"(keep_m0)::"memory"); // (M0 as the compiler left it, put back below)
+#endif
+    const uint8_t *base = reinterpret_cast<const uint8_t *>(d.words) - 4096;
+    uint32_t m0 = uint32_t(reinterpret_cast<uintptr_t>(rows));
+#pragma unroll 1
+    for (uint32_t j = 0; j < nrows; j += 16u) {
+        uint32_t voff = (first + j) * 4u + 4096u, n = umin(16u, nrows - j);
+        if (j)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the loads that still need the old M0)
+        asm volatile("s_mov_b32 m0, %[m0]\n\t"
+                     "s_nop 0\n\t" //
+                     CG_GLDS_ROW(0) CG_GLDS_ROW(1) CG_GLDS_ROW(2) CG_GLDS_ROW(3) CG_GLDS_ROW(4) CG_GLDS_ROW(5) CG_GLDS_ROW(6)
+                         CG_GLDS_ROW(7) CG_GLDS_ROW(8) CG_GLDS_ROW(9) CG_GLDS_ROW(10) CG_GLDS_ROW(11) CG_GLDS_ROW(12)
+                             CG_GLDS_ROW(13) CG_GLDS_ROW(14) CG_GLDS_ROW(15) "9:"
+                     : [voff] "+v"(voff)
+                     : [m0] "s"(m0), [base] "s"(base), [n] "s"(n)
+                     : "memory", "scc");
+        m0 += 16u * uint32_t(kWave) * 4u;
+    }
+#if defined(CG_LDSDMA_TRY) && (CG_LDSDMA_TRY & 2)
+    asm volatile("s_mov_b32 m0, %0" ::"s"(keep_m0) : "memory");
+#endif
+#elif defined(__HIP_DEVICE_COMPILE__)
     auto *words = CG_GLOBAL(const uint32_t, d.words);
 #pragma unroll 8
     for (uint32_t j = 0; j < nrows; j++)
@@ -1847,8 +1895,16 @@ CG_DEV void stream_stage_rows(const ImageDesc &d, uint32_t *rows, uint32_t nrows
 #endif
 }
 
-// (the LDS-DMA form waited here for its rows; kept as the place where a staging is complete)
-CG_DEV void stream_rows_landed() {}
+// (the LDS-DMA form waits here for its rows; the place where a staging is complete)
+CG_DEV void stream_rows_landed()
+{
+#if defined(COMPEG_LAB) && defined(CG_STREAM_LDSDMA) && defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if defined(CG_LDSDMA_TRY) && (CG_LDSDMA_TRY & 1)
+    asm volatile("s_sleep 8\n\ts_nop 7" ::: "memory"); // (some 500 cycles between the wait and the first read of a row)
+#endif
+#endif
+}
 
 // The lane's rows anew from the word it has in flight; lanes in fast mode go on in it, lanes that left it for want
 // of rows come back (at a data unit's boundary the reference reader's state is a fast-mode state), lanes whose reader
