@@ -1847,6 +1847,12 @@ CG_DEV bool wave_any(bool v)
     "v_add_u32 %[voff], 0xffffff04, %[voff]\n\t"
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// four stream words of a lane in one load (they need not lie on a 16-byte boundary)
+typedef uint32_t QuadWordsAligned __attribute__((ext_vector_type(4)));
+typedef QuadWordsAligned QuadWords __attribute__((aligned(4)));
+#endif
+
 CG_DEV void stream_stage_rows(const ImageDesc &d, uint32_t *rows, uint32_t nrows, uint32_t first, uint32_t lane)
 {
 #if defined(COMPEG_LAB) && defined(CG_STREAM_LDSDMA) && defined(__HIP_DEVICE_COMPILE__)
@@ -1884,6 +1890,21 @@ CG_DEV void stream_stage_rows(const ImageDesc &d, uint32_t *rows, uint32_t nrows
 #if defined(CG_LDSDMA_TRY) && (CG_LDSDMA_TRY & 2)
     asm volatile("s_mov_b32 m0, %0" ::"s"(keep_m0) : "memory");
 #endif
+#elif defined(__HIP_DEVICE_COMPILE__) && !defined(CG_STAGE_DWORDS)
+    // Four rows an instruction: a lane's words lie one behind the other in memory, every lane's in a line of its own -- the
+    // texture path takes a line a cycle whatever is asked of it, 16 bytes of a line cost what 4 do.
+    auto *words = CG_GLOBAL(const uint32_t, d.words);
+    const uint32_t whole = nrows & ~3u;
+#pragma unroll 4
+    for (uint32_t j = 0; j < whole; j += 4u) {
+        const QuadWords q = *reinterpret_cast<const __attribute__((address_space(1))) QuadWords *>(words + first + j);
+        CG_LDS(uint32_t, rows)[(j + 0u) * uint32_t(kWave) + lane] = q.x;
+        CG_LDS(uint32_t, rows)[(j + 1u) * uint32_t(kWave) + lane] = q.y;
+        CG_LDS(uint32_t, rows)[(j + 2u) * uint32_t(kWave) + lane] = q.z;
+        CG_LDS(uint32_t, rows)[(j + 3u) * uint32_t(kWave) + lane] = q.w;
+    }
+    for (uint32_t j = whole; j < nrows; j++)
+        CG_LDS(uint32_t, rows)[j * uint32_t(kWave) + lane] = words[first + j];
 #elif defined(__HIP_DEVICE_COMPILE__)
     auto *words = CG_GLOBAL(const uint32_t, d.words);
 #pragma unroll 8

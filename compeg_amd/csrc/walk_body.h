@@ -163,8 +163,16 @@ CG_DEV void walk_restage(WalkLane &l, const ImageDesc &d, const HuffShared &s, c
     uint32_t *rows = const_cast<uint32_t *>(s.win);
 #if defined(__HIP_DEVICE_COMPILE__)
     auto *words = CG_GLOBAL(const uint32_t, d.words);
-#pragma unroll 32
-    for (uint32_t j = 0; j < nrows; j++)
+    const uint32_t whole = nrows & ~3u; // (four rows a load: stream_stage_rows)
+#pragma unroll 8
+    for (uint32_t j = 0; j < whole; j += 4u) {
+        const QuadWords q = *reinterpret_cast<const __attribute__((address_space(1))) QuadWords *>(words + first + j);
+        CG_LDS(uint32_t, rows)[(j + 0u) * uint32_t(kWave) + lane] = bswap32(q.x);
+        CG_LDS(uint32_t, rows)[(j + 1u) * uint32_t(kWave) + lane] = bswap32(q.y);
+        CG_LDS(uint32_t, rows)[(j + 2u) * uint32_t(kWave) + lane] = bswap32(q.z);
+        CG_LDS(uint32_t, rows)[(j + 3u) * uint32_t(kWave) + lane] = bswap32(q.w);
+    }
+    for (uint32_t j = whole; j < nrows; j++)
         CG_LDS(uint32_t, rows)[j * uint32_t(kWave) + lane] = bswap32(words[first + j]);
 #else
     for (uint32_t j = 0; j < nrows; j++)
