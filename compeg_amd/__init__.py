@@ -129,7 +129,7 @@ class Gpu:
         return lib.compeg_gpu_name(self._h).decode()
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:  # (lib is None once the interpreter is shutting down)
             lib.compeg_gpu_release(self._h)
             self._h = None
 
@@ -183,7 +183,7 @@ class ImageData:
         return o.value, n.value
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:  # (lib is None once the interpreter is shutting down)
             lib.compeg_image_free(self._h)
             self._h = None
 
@@ -220,7 +220,7 @@ class ScanBuffer:
         return self._get(lib.compeg_scanbuffer_start_positions)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:  # (lib is None once the interpreter is shutting down)
             lib.compeg_scanbuffer_free(self._h)
             self._h = None
 
@@ -239,7 +239,7 @@ class Texture:
                 "strides": (self.pitch, 4, 1), "version": 3}
 
     def __del__(self):
-        if getattr(self, "_owned", False) and self.ptr:
+        if getattr(self, "_owned", False) and self.ptr and lib is not None:
             lib.compeg_device_free(C.c_void_p(self.ptr))
             self.ptr = None
 
@@ -260,7 +260,7 @@ class DecodeOp:
         return bool(lib.compeg_op_texture_changed(self._h))
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:  # (lib is None once the interpreter is shutting down)
             lib.compeg_op_free(self._h)
             self._h = None
 
@@ -337,7 +337,7 @@ class Decoder:
         return out
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:  # (lib is None once the interpreter is shutting down)
             lib.compeg_decoder_free(self._h)
             self._h = None
 
@@ -430,6 +430,6 @@ class Batch:
         return n.value, total.value, stages[0], stages[1]
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:  # (lib is None once the interpreter is shutting down)
             lib.compeg_batch_free(self._h)
             self._h = None
