@@ -278,24 +278,31 @@ CG_DEV uint32_t walk_mcu_lean(WalkLane &l, const ImageDesc &d, const HuffShared 
             "v_mov_b32 v51, %[T]\n\t"
             "ds_read2st64_b32 v[42:43], v50 offset1:1\n\t"        // A, B (a row apart)
             "ds_read_b32 v44, v50 offset:512\n\t"                 // C
-            "ds_read_b64 v[48:49], %[lp] offset:8\n"               // this data unit's AC pair table, the next one's DC table
-            "1:\n\t"
+            "ds_read_b32 v56, v50 offset:768\n\t"                 // D: what C becomes when the position leaves A
+            "ds_read_b64 v[48:49], %[lp] offset:8\n\t"            // this data unit's AC pair table, the next one's DC table
+            "ds_read_b64 v[58:59], %[lp] offset:24\n\t"           // ... and the next data unit's two
             "s_waitcnt lgkmcnt(0)\n\t"
+            "v_add_u32 v57, %[singles], v48\n"
+            // A step waits for one LDS read only, the table entry's: the stream words and the table names it needs were
+            // asked for a step ahead (D, the next entry's names) and move up through registers.  In flight at the top, in
+            // issue order: the entry's write, the table read, D, the names -- the first two are waited for there, the
+            // last two in the shadow of the next table read.
+            "1:\n\t"
+            "s_waitcnt lgkmcnt(2)\n\t"
             "v_pk_add_u16 v51, v51, %[ent]\n\t"                   // bits off the shift, advance onto the zig-zag state
-            "ds_write_b64 %[lp], v[50:51]\n\t"                    // (final when the data unit ends here)
-            "v_cmp_eq_u32 s[76:77], 0, %[ent]\n\t"                // lanes that met a long code
             "v_alignbit_b32 v41, v42, v43, v51\n\t"               // (the shift is taken modulo 32)
             "v_alignbit_b32 v45, v43, v44, v51\n\t"
             "v_cmp_gt_i16 vcc, 0, v51\n\t"                        // the position has left A
             "v_cmp_lt_u32 s[72:73], %[endabove], v51\n\t"         // the data unit is complete: a DC code comes next
             "v_cmp_lt_u32 s[82:83], %[nearabove], v51\n\t"        // the next symbol could complete it: one at a time
-            "v_add_u32 v47, %[singles], v48\n\t"
             "v_cndmask_b32 v41, v41, v45, vcc\n\t"                // the next 32 stream bits
-            "v_cndmask_b32_e64 v46, v48, v47, s[82:83]\n\t"
+            "v_cndmask_b32_e64 v46, v48, v57, s[82:83]\n\t"       // (v57: the singles table beside v48's pairs)
             "v_cndmask_b32_e64 v46, v46, v49, s[72:73]\n\t"       // the table's name: address, shift in the low bits
             "v_bfe_u32 v45, v41, v46, 11\n\t"
             "v_and_b32 v52, 0xffffffe0, v46\n\t"
             "v_lshl_add_u32 v52, v45, 2, v52\n\t"
+            "v_cmp_eq_u32 s[76:77], 0, %[ent]\n\t"                // lanes that met a long code
+            "ds_write_b64 %[lp], v[50:51]\n\t"                    // (final when the data unit ends here)
             "ds_read_b32 %[ent], v52\n\t"
             // ---- under that read: move on in the stream, in the list; who goes on
             "v_cndmask_b32_e64 v40, 0, %[rowstep], vcc\n\t"
@@ -304,9 +311,15 @@ CG_DEV uint32_t walk_mcu_lean(WalkLane &l, const ImageDesc &d, const HuffShared 
             "v_and_b32 v51, v51, v40\n\t"
             "v_cndmask_b32_e64 v40, 0, 16, s[72:73]\n\t"
             "v_add_u32 %[lp], %[lp], v40\n\t"
-            "ds_read2st64_b32 v[42:43], v50 offset1:1\n\t"
-            "ds_read_b32 v44, v50 offset:512\n\t"
-            "ds_read_b64 v[48:49], %[lp] offset:8\n\t"
+            "s_waitcnt lgkmcnt(2)\n\t"                            // D and the names of the step before are there
+            "v_cndmask_b32 v42, v42, v43, vcc\n\t"                // A B C <- B C D
+            "v_cndmask_b32 v43, v43, v44, vcc\n\t"
+            "v_cndmask_b32 v44, v44, v56, vcc\n\t"
+            "v_cndmask_b32_e64 v48, v48, v58, s[72:73]\n\t"       // the names <- the next entry's
+            "v_cndmask_b32_e64 v49, v49, v59, s[72:73]\n\t"
+            "ds_read_b32 v56, v50 offset:768\n\t"
+            "ds_read_b64 v[58:59], %[lp] offset:24\n\t"
+            "v_add_u32 v57, %[singles], v48\n\t"
             "v_cmp_ge_u32 s[78:79], %[lp], %[lpmax]\n\t"          // the MCU's four data units are complete
             "s_andn2_b64 exec, exec, s[78:79]\n\t"
             "s_and_b64 s[76:77], s[76:77], exec\n\t"              // (sets SCC: some walking lane met a long code)
@@ -394,8 +407,8 @@ CG_DEV uint32_t walk_mcu_lean(WalkLane &l, const ImageDesc &d, const HuffShared 
               [l1base] "s"(uint32_t(reinterpret_cast<uintptr_t>(s.l1))), [l2base] "s"(uint32_t(reinterpret_cast<uintptr_t>(s.l2))),
               [l2n] "s"(d.l2_entries), [zrl] "v"(t.zrl)
             : "memory", "vcc", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51",
-              "v52", "v53", "v54", "v55", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s82", "s83", "s86",
-              "s87", "s88", "s89");
+              "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s82",
+              "s83", "s86", "s87", "s88", "s89");
     }
     if (go) {
         l.wa = wa;
