@@ -1501,7 +1501,7 @@ CG_DEV void composite_row_from_quad(const ImageDesc &d, const uint8_t *wave_slot
 #pragma unroll
     for (uint32_t j = 0; j < 4; j++) {
         const SlotVec v = reinterpret_cast<const SlotVec *>(wave_slots + (quad + j) * kDuSlotBytes)[piece];
-#if CG_EXP == 9 && defined(__HIP_DEVICE_COMPILE__) // diagnostic build: everything but the global stores
+#if (CG_EXP == 9 || CG_EXP == 17 || CG_EXP == 18) && defined(__HIP_DEVICE_COMPILE__) // diagnostic build: everything but the global stores
         asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
         if (v.x == 0x12345678u && v.y == 0x9abcdef0u && bases[j] == nullptr)
 #else
@@ -1747,10 +1747,19 @@ CG_DEV void pixel_transform(PixelState &t, const ImageDesc &d, uint32_t comp, ui
 {
     uint32_t rec[kRetained / 2];
     take_slot(slot, rec);
-#if CG_EXP == 4 // diagnostic build: no IDCT (same data flow)
+#if CG_EXP == 4 || CG_EXP == 17 // diagnostic build: no IDCT (same data flow); 17: nor any global store
 #pragma unroll
     for (int w = 0; w < 16; w++)
         t.px[3][w] = rec[w] + uint32_t(dc);
+#elif CG_EXP == 16 || CG_EXP == 18 // diagnostic build: no IDCT for the chroma data units (more than a sparse chroma transform
+                                   // can save); 18: nor any global store
+    if (k >= 2u) {
+#pragma unroll
+        for (int w = 0; w < 16; w++)
+            t.px[3][w] = rec[w] + uint32_t(dc);
+    } else {
+        idct_data_unit(rec, dc, d.quant[comp], t.px[3]);
+    }
 #else
     idct_data_unit(rec, dc, d.quant[comp], t.px[3]);
 #endif
