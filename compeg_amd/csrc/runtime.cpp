@@ -1965,7 +1965,8 @@ Status compeg_batch::make_walk_tables(hipStream_t stream, size_t n)
         max_mcus = std::max(max_mcus, descs[i].total_mcus);
         mcu_uniform = mcu_uniform && descs[i].total_mcus == descs[0].total_mcus;
     }
-    std::vector<ImageDesc> views;
+    std::vector<ImageDesc> &views = mcu_views; // (a member: the asynchronous copy below reads it after this function has returned)
+    views.clear();
     if (mcu_route) {
         // per image: a word index per MCU (and 64 more: the window of an image's last wave asks for the entry behind
         // its MCUs' -- never used) and a state per MCU
@@ -2007,8 +2008,6 @@ Status compeg_batch::make_walk_tables(hipStream_t stream, size_t n)
     CG_HIP(hipMemcpyAsync(dev_descs.ptr, descs.data(), n * sizeof(ImageDesc), hipMemcpyHostToDevice, stream));
     if (want)
         CG_HIP(launch_walk_tables(static_cast<const ImageDesc *>(dev_descs.ptr), uint32_t(shared ? 1 : n), stream));
-    if (mcu_route)
-        CG_HIP(hipStreamSynchronize(stream)); // (`views` is pageable memory of this call's)
     return Status{};
 }
 

@@ -157,6 +157,7 @@ struct compeg_batch {
     // a state per MCU) and the images' descriptors of MCUs
     bool mcu_route = false;
     compeg::DeviceBuffer mcu_words, mcu_states, mcu_descs;
+    std::vector<compeg::ImageDesc> mcu_views; // host copy of mcu_descs
     uint32_t max_mcus = 0, mcu_span = 0;
     bool mcu_uniform = false;
     uint32_t max_out_w = 0, max_out_h = 0;
