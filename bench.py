@@ -346,7 +346,10 @@ def bench_launch_size_sweep(compeg_amd, gpu, quality, threads):
                     for i in range(len(pts)))
         out[name] = {"points": pts, "worst_step_vs_better_neighbour": round(worst, 2)}
     single = {}
-    for name, (w, h, ri) in {"8K DRI=1 (configs[4])": (7680, 4320, 1), "1080p DRI=4": (1920, 1080, 4)}.items():
+    # (4K frames with longer restart intervals: the decoder's dispatch between the cooperative kernel and the walk +
+    # lane-per-MCU route -- DRI = 16, and an interval per MCU row of 240 MCUs as many encoders write it)
+    for name, (w, h, ri) in {"8K DRI=1 (configs[4])": (7680, 4320, 1), "1080p DRI=4": (1920, 1080, 4),
+                             "4K DRI=16": (3840, 2160, 16), "4K DRI=240 (an interval per MCU row)": (3840, 2160, 240)}.items():
         jpegs, images = frames_of(w, h, ri, 1)
         pt = point(images, 1, reps=20)
         dec = compeg_amd.Decoder(gpu)

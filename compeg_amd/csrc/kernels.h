@@ -78,6 +78,8 @@ struct CoopPlan {
     bool usable;
     uint32_t group_waves; // 4, 2 or 1: a team takes coop_shape(restart_interval, group_waves).ipw whole intervals
     uint32_t intervals_per_wave, waves_per_block, window_words, l2_entries_in_lds, total_bytes, total_waves; // (intervals_per_wave: per team)
+    uint32_t fit_teams; // teams a CU's LDS holds at once with this window (1..4)
+    uint32_t places;    // ... and the chip: teams resident at once
 };
 // The kernel's teams of four waves take the whole restart intervals of 4 x 64 data units -- of 2 x 64 or 64 where
 // those do not fit the largest window (dense streams: bit positions inside a window are 16-bit).

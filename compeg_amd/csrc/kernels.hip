@@ -1493,6 +1493,8 @@ CoopPlan plan_coop(uint32_t max_intervals, uint32_t images, uint32_t restart_int
     // one workgroup per CU while that covers the launch (a small launch spreads over the CUs; the teams of a
     // workgroup share one copy of the tables and the sixteen waves that stage it)
     const uint32_t fit = teams;
+    p.fit_teams = fit;
+    p.places = cu_count * fit;
     teams = all_teams <= cu_count ? 1u : (all_teams <= 2ull * cu_count ? 2u : 4u);
     teams = teams < fit ? teams : fit;
     p.waves_per_block = teams * kCoopTeamWaves;

@@ -609,7 +609,16 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     const Metadata &md = img.metadata;
     deferred_check = false;
     const uint32_t total_dus = img.total_dus();
-    const size_t blob_bytes = align_up(sizeof(ImageDesc), 256) + table_blob_bytes(img);
+    // The walk + lane-per-MCU route may take this image (decided below, with the scan in hand): its records' place, and
+    // behind descriptor and tables the image's second descriptor, in which every MCU is an "interval" (kernels_body.h).
+    const uint64_t route_mcus = uint64_t(md.total_restart_intervals) * md.restart_interval;
+    const bool route_possible = is_422(img) && use_fused_pipeline() && md.restart_interval >= 8u && route_mcus < (1ull << 28);
+    const size_t view_off = align_up(sizeof(ImageDesc), 256) + align_up(table_blob_bytes(img), 256);
+    const size_t blob_bytes = route_possible ? view_off + align_up(sizeof(ImageDesc), 256) : align_up(sizeof(ImageDesc), 256) + table_blob_bytes(img);
+    if (route_possible) {
+        CG_TRY(mcu_words.reserve((size_t(route_mcus) + kWave) * 4 + 256));
+        CG_TRY(mcu_states.reserve(size_t(route_mcus) * sizeof(McuState) + 256));
+    }
     CG_TRY(host_blob.reserve(blob_bytes));
     CG_TRY(dev_blob.reserve(blob_bytes + 16));
     CG_TRY(ac.reserve(size_t(total_dus) * kRetained * 2 + 64));
@@ -619,7 +628,8 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     const size_t l1_off = align_up(sizeof(ImageDesc), 256), l2_off = l1_off + COMPEG_HUFFMAN_L1_BYTES;
 
     // the cooperative kernel may take this image: its walk tables' place
-    const bool want_walk = is_422(img) && use_fused_pipeline() && use_coop_kernel(md.total_restart_intervals, 1, md.restart_interval);
+    const bool want_walk = is_422(img) && use_fused_pipeline() &&
+                           (route_possible || use_coop_kernel(md.total_restart_intervals, 1, md.restart_interval));
     if (want_walk)
         CG_TRY(walk_tables.reserve(kWalkTableBytes));
 
@@ -627,7 +637,7 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     auto write_blob = [&](const void *words_ptr, const void *starts_ptr, size_t n_words, size_t n_starts) {
         ImageDesc &d = *reinterpret_cast<ImageDesc *>(hb);
         fill_desc(img, d);
-        d.walk = want_walk && d.coop_ok ? static_cast<const uint32_t *>(walk_tables.ptr) : nullptr;
+        d.walk = want_walk && (d.coop_ok || (route_possible && d.mcu_ok)) ? static_cast<const uint32_t *>(walk_tables.ptr) : nullptr;
         d.words = static_cast<const uint32_t *>(words_ptr);
         d.starts = static_cast<const uint32_t *>(starts_ptr);
         d.nwords = uint32_t(n_words);
@@ -641,6 +651,18 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
         d.out_h = out_h;
         d.out_pitch = uint32_t(out_pitch);
         write_tables(hb + l1_off, img);
+        if (route_possible) {
+            d.mcu_word = static_cast<uint32_t *>(mcu_words.ptr);
+            d.mcu_state = static_cast<McuState *>(mcu_states.ptr);
+            ImageDesc &v = *reinterpret_cast<ImageDesc *>(hb + view_off);
+            v = d;
+            v.starts = d.mcu_word;
+            v.nstarts = d.total_mcus;
+            v.total_intervals = d.total_mcus;
+            v.restart_interval = 1;
+            v.walk = nullptr;
+            v.coop_ok = 0;
+        }
     };
 
     uint32_t dev_nwords = 0, dev_nstarts = 0, dev_span = 0;
@@ -722,6 +744,8 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
         ImageDesc &d = *reinterpret_cast<ImageDesc *>(hb);
         d.nwords = uint32_t(n_words);
         d.nstarts = uint32_t(n_starts);
+        if (route_possible)
+            reinterpret_cast<ImageDesc *>(hb + view_off)->nwords = uint32_t(n_words);
     } else if (!blob_uploaded) {
         write_blob(on_device ? dev_words : words.ptr, on_device ? dev_starts : starts.ptr, n_words, n_starts);
     }
@@ -803,22 +827,47 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
                                                                  md.total_restart_intervals, md.restart_interval);
             coop = plan_coop(md.total_restart_intervals, 1, md.restart_interval, staged_lut_entries(img), spans);
         }
-        if (coop.usable) {
-            const ImageDesc &hd = *reinterpret_cast<const ImageDesc *>(hb);
-            if (hd.walk) {
-                // made from the direct tables and from which of them each component uses
-                const size_t tb = table_blob_bytes(img), extra = sizeof hd.fast_table + sizeof hd.dc_fast_table + sizeof hd.fast_off;
-                uint8_t ids[sizeof hd.fast_table + sizeof hd.dc_fast_table + sizeof hd.fast_off];
-                memcpy(ids, hd.fast_table, sizeof hd.fast_table);
-                memcpy(ids + sizeof hd.fast_table, hd.dc_fast_table, sizeof hd.dc_fast_table);
-                memcpy(ids + sizeof hd.fast_table + sizeof hd.dc_fast_table, &hd.fast_off, sizeof hd.fast_off);
-                if (walk_key.size() != tb + extra || memcmp(walk_key.data(), hb + l1_off, tb) != 0 ||
-                    memcmp(walk_key.data() + tb, ids, extra) != 0) {
-                    walk_key.assign(hb + l1_off, hb + l1_off + tb);
-                    walk_key.insert(walk_key.end(), ids, ids + extra);
-                    CG_HIP(launch_walk_tables(reinterpret_cast<const ImageDesc *>(db), 1, stream));
-                }
+        const ImageDesc &hd = *reinterpret_cast<const ImageDesc *>(hb);
+        // the walk tables: made from the direct tables and from which of them each component uses
+        auto ensure_walk_tables = [&]() -> Status {
+            if (!hd.walk)
+                return Status{};
+            const size_t tb = table_blob_bytes(img), extra = sizeof hd.fast_table + sizeof hd.dc_fast_table + sizeof hd.fast_off;
+            uint8_t ids[sizeof hd.fast_table + sizeof hd.dc_fast_table + sizeof hd.fast_off];
+            memcpy(ids, hd.fast_table, sizeof hd.fast_table);
+            memcpy(ids + sizeof hd.fast_table, hd.dc_fast_table, sizeof hd.dc_fast_table);
+            memcpy(ids + sizeof hd.fast_table + sizeof hd.dc_fast_table, &hd.fast_off, sizeof hd.fast_off);
+            if (walk_key.size() != tb + extra || memcmp(walk_key.data(), hb + l1_off, tb) != 0 ||
+                memcmp(walk_key.data() + tb, ids, extra) != 0) {
+                walk_key.assign(hb + l1_off, hb + l1_off + tb);
+                walk_key.insert(walk_key.end(), ids, ids + extra);
+                CG_HIP(launch_walk_tables(reinterpret_cast<const ImageDesc *>(db), 1, stream));
             }
+            return Status{};
+        };
+        // The walk + lane-per-MCU route (use_mcu_route: the same terms for one image): where the cooperative kernel is not
+        // the better of the two (coop_preferred) or cannot take the image, a lane per interval would leave the chip
+        // its SIMDs a wave each at most, and the walk's rows hold a few MCUs.  (Scans preprocessed on the host: the
+        // second descriptor's word count is known here.)
+        const uint64_t mcu_words_avg = (img.scan_len / 4u + std::max<uint64_t>(route_mcus, 1u) - 1u) / std::max<uint64_t>(route_mcus, 1u);
+        const bool route = route_possible && !on_device && hd.mcu_ok && hd.walk && !lab_env("COMPEG_NO_DECODER_ROUTE") &&
+                           !(coop.usable && coop_preferred(coop, md.total_restart_intervals, 1, md.restart_interval)) &&
+                           (md.total_restart_intervals + kWave - 1) / kWave <= 1024u && mcu_words_avg <= 24u &&
+                           14.5 * md.restart_interval - 40.0 > double(route_mcus) / 5300.0;
+        if (route) {
+            CG_TRY(ensure_walk_tables());
+            const uint32_t l2n = staged_lut_entries(img);
+            CG_HIP(launch_walk_mcus(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals,
+                                    plan_walk(md.total_restart_intervals, 1, l2n, uint32_t(mcu_words_avg), md.restart_interval, true, true), stream, nullptr));
+            // (the second kernel's window: the words of 64 consecutive MCUs -- three times the average of the largest
+            // span of 64 intervals' MCUs and a little, at most all of it: compeg_batch::make_walk_tables)
+            const uint64_t avg64 = (uint64_t(span) + md.restart_interval - 1) / md.restart_interval;
+            const uint32_t mcu_span = uint32_t(std::min<uint64_t>(3 * avg64 + 64, span));
+            const HuffLdsPlan mcu_plan = plan_huffman(hd.total_mcus, 1, l2n, mcu_span, true);
+            CG_HIP(launch_fused_422(reinterpret_cast<const ImageDesc *>(db + view_off), 1, hd.total_mcus, mcu_plan, stream, true, true, nullptr, true));
+            last_kernel = COMPEG_KERNEL_WALK_MCU;
+        } else if (coop.usable) {
+            CG_TRY(ensure_walk_tables());
             CG_HIP(launch_coop_422(reinterpret_cast<const ImageDesc *>(db), 1, md.total_restart_intervals, coop, stream));
             last_kernel = COMPEG_KERNEL_COOP_TEAM;
         } else if (use_stream_kernel(plan, md.total_restart_intervals, 1)) {
@@ -1894,6 +1943,34 @@ Status compeg_batch::upload_device_scan(size_t n, int threads, const FeedSource 
     return finish();
 }
 
+// A launch both the cooperative kernel and the walk + lane-per-MCU route can take: which?  Measured (tools/walk_probe.py
+// with COMPEG_WALK=0 / 1, profiles/r04/coop_vs_walk.txt; us per launch, cooperative / route):
+//  * up to 7 MCUs an interval the cooperative kernel, a second round of teams included (two 4K frames DRI = 4: 63 / 70);
+//  * up to 40 MCUs (its teams walk a lane per interval, like the route's walk): while all teams are resident at once
+//    -- as many to a CU as its LDS holds of their windows -- it is ahead (eight 960x720 DRI = 10 frames 60 / 91; one
+//    960x720 DRI = 30 90 / 177); with a team more than that the route is (one 4K frame DRI = 10, 1080 teams for 1024
+//    places: 98 / 86; DRI = 20 229 / 131; two 4K frames DRI = 16 183 / 124, DRI = 30 276 / 182);
+//  * 41 to 128 MCUs: its walks are speculative and twice as fast as a lane per interval (one 4K frame DRI = 90 199 /
+//    436, DRI = 128 298 / 610), but a second round of teams costs more than that brings (one 4K frame DRI = 60, 1080
+//    teams for 768 places: 540 / 309; eight 1080p frames DRI = 60 448 / 319), and a walk that has to be repeated a
+//    millisecond (eight distinct 1080p frames DRI = 120: 1205 / 589, six of them 392);
+//  * beyond 128 MCUs the route: the speculative walks' lists fill up (one 4K frame with an interval per MCU row --
+//    240 MCUs -- 1788 / 1100; DRI = 160 1177 / 744; 960x720 DRI = 240 1215 / 940).
+namespace compeg {
+bool coop_preferred(const CoopPlan &cp, uint32_t max_intervals, uint32_t images, uint32_t restart_interval)
+{
+    if (!cp.usable)
+        return false;
+    if (restart_interval < 8u)
+        return true;
+    if (restart_interval > 128u)
+        return false;
+    const uint64_t teams = uint64_t((max_intervals + cp.intervals_per_wave - 1) / cp.intervals_per_wave) * images;
+    const uint64_t places = std::max(1u, cp.places);
+    return restart_interval <= kCoopLeanMaxRestart ? teams <= places : teams * 10u <= places * 11u;
+}
+} // namespace compeg
+
 // The walk + lane-per-MCU route (kernels_body.h) for a batch whose launches are `step` images (the last one `smallest`)?
 // Where a lane per restart interval leaves the chip's SIMDs a wave each at most (1024 waves of 64 intervals), its time
 // is the length of an interval -- about 20 us per MCU of it, whatever the launch's size.  The route's walk takes a
@@ -1913,13 +1990,12 @@ bool use_mcu_route(const compeg_batch &b, uint32_t step, uint32_t smallest)
         return forced != 0;
     if (b.one_mcu_intervals || b.min_restart_interval < 2u)
         return false; // (a lane per interval is a lane per MCU already)
-    // The cooperative kernel's launches: its first round of teams (1024 x 256 data units) is the fastest thing there is;
-    // a second round is not, where its teams walk a lane per interval (960x720 DRI = 10, us per launch, cooperative /
-    // this route: 8 frames 60 / 91, 12 frames 105 / 90, 16 108 / 95, 24 154 / 102) -- with DRI = 4 the second round
-    // still wins (two 4K frames 63 / 70), and so do its speculative walks of long intervals (16 x 960x720 DRI = 60: 263 / 322).
+    // The cooperative kernel's launches: coop_preferred.  (Launches of different sizes -- a chunked decode with a smaller
+    // last launch -- keep the cooperative kernel: the records are planned for the whole batch.)
     if (b.coop_r && use_coop_kernel(b.max_intervals, smallest, b.coop_r)) {
-        const uint64_t data_units = uint64_t(b.max_intervals) * step * 4u * b.coop_r;
-        if (!(data_units > 1024ull * 256u && b.coop_r >= 8u && b.coop_r <= 16u && step == smallest))
+        if (step != smallest)
+            return false;
+        if (coop_preferred(plan_coop(b.max_intervals, step, b.coop_r, b.max_l2, b.coop_spans), b.max_intervals, step, b.coop_r))
             return false;
     }
     const uint64_t waves = uint64_t((b.max_intervals + kWave - 1) / kWave) * step;

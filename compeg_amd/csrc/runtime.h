@@ -25,6 +25,7 @@ Status hip_status(hipError_t e, const char *what);
 bool use_fused_pipeline();
 bool use_pair_kernel(uint32_t max_intervals, uint32_t images);
 bool use_coop_kernel(uint32_t max_intervals, uint32_t images, uint32_t restart_interval);
+bool coop_preferred(const CoopPlan &cp, uint32_t max_intervals, uint32_t images, uint32_t restart_interval);
 CoopSpans coop_spans_exact(const uint32_t *starts, size_t nstarts, size_t nwords, uint32_t intervals, uint32_t restart_interval);
 CoopSpans coop_spans_estimate(uint32_t span_of_64, uint32_t restart_interval, bool generous);
 void coop_spans_max(CoopSpans &into, const CoopSpans &other);
@@ -78,6 +79,8 @@ struct compeg_decoder {
     // stream carry the same tables, the walk tables are made again only when those change
     compeg::DeviceBuffer walk_tables;
     std::vector<uint8_t> walk_key;
+    // the walk + lane-per-MCU route's records (kernels_body.h): a stream word index and a state per MCU
+    compeg::DeviceBuffer mcu_words, mcu_states;
     uint32_t out_w = 0, out_h = 0;
     size_t out_pitch = 0;
     hipEvent_t upload_done = nullptr; // host staging may be rewritten after this

@@ -137,6 +137,35 @@ def test_no_dri_single_interval(ca, gpu):
     _assert_equal(got, orc.ImageData(jpeg).decode())
 
 
+def test_decoder_takes_the_walk_route_for_long_intervals(ca, gpu):
+    """compeg_decoder (the reference's Decoder: one image at a time) takes the walk + lane-per-MCU route where the
+    cooperative kernel cannot take the image or is the slower of the two (runtime.cpp: coop_preferred): no DRI at all
+    (the whole image one restart interval of 1800 MCUs, lib.rs:784: a single lane would decode it otherwise), an
+    interval of 160 MCUs, a scan with flipped bits (the walk's slow road), the same decoder used for all of them and
+    for an image of the cooperative kernel's in between; with the scan preprocessed on the device the decoder keeps the
+    other kernels.  Bit-exact either way."""
+    cases = [(synth.make_jpeg(640, 360, seed=61, quality=85, ri=0), "walk_mcu"),
+             (synth.make_jpeg(960, 720, seed=62, quality=85, ri=4), "coop_team"),
+             (synth.make_jpeg(1280, 720, seed=63, quality=85, ri=160), "walk_mcu"),
+             (_flip_bits(synth.make_jpeg(1280, 720, seed=64, quality=85, ri=160), 640, flips=12), "walk_mcu"),
+             (synth.make_jpeg(640, 360, seed=65, kind=1, quality=70, ri=0), None)]   # (dense: whichever kernel the terms name)
+    dec = ca.Decoder(gpu)
+    for jpeg, kernel in cases:
+        data = ca.ImageData(jpeg)
+        want = orc.ImageData(jpeg).decode()
+        dec.decode_blocking(data)
+        if kernel:
+            assert dec.last_kernel() == kernel, dec.last_kernel()
+        _assert_equal(dec.read_texture(data.width(), data.height()), want)
+    dev = ca.Decoder(gpu)
+    dev.set_device_preprocess(True)
+    for jpeg, _ in cases[:3]:
+        data = ca.ImageData(jpeg)
+        dev.decode_blocking(data)
+        assert dev.last_kernel() != "walk_mcu"
+        _assert_equal(dev.read_texture(data.width(), data.height()), orc.ImageData(jpeg).decode())
+
+
 def test_decoder_reuse_grows_and_reports_texture_changed(ca, gpu):
     """ref lib.rs:564-573 + dynamic.rs:214-248: first decode and every growth report true."""
     dec = ca.Decoder(gpu)
@@ -310,8 +339,9 @@ def test_full_size_8k_dri1_roundtrip_properties(ca, gpu):
 
 def test_single_large_frame_with_long_intervals_takes_the_streamed_windows(ca, gpu):
     """One 8K frame with DRI = 32: too many data units for the cooperative kernel, 64 intervals too long for a
-    whole-interval window -- the decoder's launch goes to decode_fused_422_stream_kernel, with the host's
-    preprocessing and with the device's (word counts patched into the descriptor behind the launch's planning)."""
+    whole-interval window -- with the device's preprocessing the decoder's launch goes to
+    decode_fused_422_stream_kernel (word counts patched into the descriptor behind the launch's planning); with the
+    host's, to the walk + lane-per-MCU route (127 waves of intervals for 1024 SIMDs: 149 against 471 us)."""
     jpeg = synth.make_jpeg(7680, 4320, seed=71, ri=32, quality=75, kind=0)
     want = orc.ImageData(jpeg).decode()
     data = ca.ImageData(jpeg)
@@ -319,7 +349,7 @@ def test_single_large_frame_with_long_intervals_takes_the_streamed_windows(ca, g
         dec = ca.Decoder(gpu)
         dec.set_device_preprocess(device)
         dec.decode_blocking(data)
-        assert dec.last_kernel() == "fused_stream"
+        assert dec.last_kernel() == ("fused_stream" if device else "walk_mcu")
         _assert_equal(dec.read_texture(7680, 4320), want)
 
 
@@ -785,14 +815,19 @@ def test_cooperative_kernel_takes_any_restart_interval(ca, gpu, ri):
             # (the busy 640x360 frame with an interval of 240 or 256 MCUs, preprocessed on the device: the window the
             # device path estimates for a team's interval -- twice the average -- exceeds what a team can have (32 KB), and
             # the frame takes the streamed batch kernel; every other case is the cooperative kernel's)
-            expect = "fused_stream" if (kind == 1 and device and ri in (240, 256)) else "coop_team"
+            # Beyond 128 MCUs an interval the walk + lane-per-MCU route is the faster of the two (the cooperative kernel's
+            # speculative walks run out of list: runtime.cpp, coop_preferred) and takes host-preprocessed scans; with the
+            # scan preprocessed on the device the decoder keeps the cooperative kernel.
+            long_interval = ri > 128
+            expect = ("fused_stream" if (kind == 1 and device and ri in (240, 256)) else
+                      "walk_mcu" if (long_interval and not device) else "coop_team")
             assert dec.last_kernel() == expect, (ri, w, h, device, dec.last_kernel())
             _assert_equal(dec.read_texture(w, h), want)
         batch = ca.Batch(gpu)
         batch.upload([ca.ImageData(jpeg)])
         batch.decode()
         batch.wait()
-        assert batch.last_kernel() == "coop_team"
+        assert batch.last_kernel() == ("walk_mcu" if ri > 128 else "coop_team"), (ri, w, h, batch.last_kernel())
         _assert_equal(batch.read_output(0), want)
 
 
@@ -903,9 +938,10 @@ def test_cooperative_kernel_launch_size_boundary(ca, gpu, ri):
     workgroup holds one, two and four teams (small, medium, full launches) and the last team of an image is short."""
     jpegs = [synth.make_jpeg(3840, 2160, seed=500 + i, quality=85, ri=ri) for i in range(3)]
     wants = [orc.ImageData(j).decode() for j in jpegs]
-    # (two frames are the cooperative kernel's second round of teams: with DRI = 10 -- teams that walk a lane per interval --
-    # the walk + lane-per-MCU route is faster, 93 against 145 us; three frames: a lane per interval, or that route)
-    for n, kernel in ((1, "coop_team"), (2, "coop_team" if ri == 4 else "walk_mcu"), (3, "pair" if ri == 4 else "walk_mcu")):
+    # (DRI = 10: one frame is 1080 teams for the chip's 1024 places -- a second round of teams that walk a lane per
+    # interval -- and the walk + lane-per-MCU route is faster, 86 against 98 us; two frames 93 against 145; with DRI = 4
+    # the cooperative kernel's second round still wins; three frames: a lane per interval, or that route)
+    for n, kernel in ((1, "coop_team" if ri == 4 else "walk_mcu"), (2, "coop_team" if ri == 4 else "walk_mcu"), (3, "pair" if ri == 4 else "walk_mcu")):
         batch = ca.Batch(gpu)
         batch.upload([ca.ImageData(j) for j in jpegs[:n]])
         batch.decode()
