@@ -847,10 +847,11 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
         };
         // The walk + lane-per-MCU route (use_mcu_route: the same terms for one image): where the cooperative kernel is not
         // the better of the two (coop_preferred) or cannot take the image, a lane per interval would leave the chip
-        // its SIMDs a wave each at most, and the walk's rows hold a few MCUs.  (Scans preprocessed on the host: the
-        // second descriptor's word count is known here.)
+        // its SIMDs a wave each at most, and the walk's rows hold a few MCUs.  (Not where the descriptors went up in front of
+        // the scan kernels -- a blocking decode with device preprocessing: the second descriptor's word count is theirs to
+        // fill in, and they know of one descriptor.)
         const uint64_t mcu_words_avg = (img.scan_len / 4u + std::max<uint64_t>(route_mcus, 1u) - 1u) / std::max<uint64_t>(route_mcus, 1u);
-        const bool route = route_possible && !on_device && hd.mcu_ok && hd.walk && !lab_env("COMPEG_NO_DECODER_ROUTE") &&
+        const bool route = route_possible && !blob_uploaded && hd.mcu_ok && hd.walk && !lab_env("COMPEG_NO_DECODER_ROUTE") &&
                            !(coop.usable && coop_preferred(coop, md.total_restart_intervals, 1, md.restart_interval)) &&
                            (md.total_restart_intervals + kWave - 1) / kWave <= 1024u && mcu_words_avg <= 24u &&
                            14.5 * md.restart_interval - 40.0 > double(route_mcus) / 5300.0;

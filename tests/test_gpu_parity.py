@@ -164,6 +164,13 @@ def test_decoder_takes_the_walk_route_for_long_intervals(ca, gpu):
         dev.decode_blocking(data)
         assert dev.last_kernel() != "walk_mcu"
         _assert_equal(dev.read_texture(data.width(), data.height()), orc.ImageData(jpeg).decode())
+    # (a non-blocking decode with device preprocessing has the scan kernels' counts in hand when it writes the
+    # descriptors -- one more read-back than the blocking one --, and takes the route)
+    jpeg = cases[2][0]
+    data = ca.ImageData(jpeg)
+    dev.start_decode(data).wait()
+    assert dev.last_kernel() == "walk_mcu"
+    _assert_equal(dev.read_texture(data.width(), data.height()), orc.ImageData(jpeg).decode())
 
 
 def test_decoder_reuse_grows_and_reports_texture_changed(ca, gpu):
