@@ -71,6 +71,12 @@ constexpr uint32_t kCoopTail = 3;          // trailing entries of a lane's own l
 constexpr uint32_t kCoopPosBits = 18;      // bit positions inside a walk's window
 constexpr uint32_t kCoopPosMask = (1u << kCoopPosBits) - 1u;
 constexpr uint32_t kCoopMaxWindow = (1u << (kCoopPosBits - 5u)) - 8u; // words (32 KB: what a team alone on its CU can have)
+// Words of the stream a team's window holds behind its intervals' end, beside the reader's slack: the reference's reader
+// stands up to three words beyond an interval's end when it begins that interval's last data units (quirk Q2, the words
+// it has in hand), and a walk may not begin a data unit kDuWordSlack words in front of the window's end -- with two words
+// of room (round 3) one frame in five with intervals of 60 to 128 MCUs had an interval whose walk stopped a data unit
+// or two short of the end and went to the serial decoder: a millisecond for a 250 us frame (profiles/r04/NOTES.md).
+constexpr uint32_t kCoopEndSlack = 16;
 constexpr uint32_t kCoopMaxRestart = 256;  // MCUs per interval (1024 data units: 16 rounds of 64)
 constexpr uint32_t kCoopMaxRounds = 16;    // rounds of 64 data units per walk
 constexpr uint32_t kCoopQuantStride = 36;  // floats between the components' quantiser rows in LDS
@@ -326,7 +332,7 @@ CG_DEV void coop_window_from(const ImageDesc &d, uint32_t first_word, uint32_t e
 {
     // (+ 2: the reader keeps up to two words in hand, so at the start of the last data units of the wave's last
     // interval its position is that far beyond the interval's end -- still inside the window with these)
-    const uint32_t end = umin(end_word, d.nwords) + kDuWordSlack + 2u;
+    const uint32_t end = umin(end_word, d.nwords) + kDuWordSlack + 2u + kCoopEndSlack;
     base = umin(first_word, d.nwords);
     len = end > base ? umin(end - base, window_words) : 0u;
 }
@@ -971,6 +977,11 @@ CG_DEV void coop_publish(const ChaseState &c, const CoopShared &cs, const CoopGe
 {
     const uint32_t anomaly = c.flags | ((c.used && c.p >= coop_hard_end(cs.h)) ? kStopAnomaly : 0u);
     const uint32_t n = uint32_t(c.lp - (cs.lists + lane * g.list_cap));
+#if defined(CG_EMUL_STATS)
+    if (getenv("EMUL_COOP_FAILS") && anomaly)
+        fprintf(stderr, "anomaly lane %u: flags %u used %d p %u hard end %u (window %u words) stop_p %u sub_end %u entries %u of %u\n", lane, c.flags, int(c.used), c.p,
+                coop_hard_end(cs.h), cs.h.win_len, c.stop_p, c.sub_end, n, uint32_t(c.lp_max - (cs.lists + lane * g.list_cap)));
+#endif
     cs.lane_n[lane] = n | (anomaly << 8) | (c.k0 << 16);
     cs.link[lane] = 0u;
 }
@@ -1077,6 +1088,10 @@ CG_DEV void coop_follow(const CoopShared &cs, const CoopGeom &g, uint32_t il, ui
 #endif
             // the chain ends with lane x: it walks on, unless it cannot
             v = ((stop & kStopAnomaly) || du == 0u) ? kVerdictSerial : (kVerdictContinue | (x << 8) | (du << 16));
+#if defined(CG_EMUL_STATS)
+            if (getenv("EMUL_COOP_FAILS") && v == kVerdictSerial)
+                fprintf(stderr, "serial il %u: chain ends with lane %u, stop flags %u, data units noted %u of %u\n", il, x, stop, du, g.dpi);
+#endif
             break;
         }
         x = (l >> 8) & 0xffu;
@@ -1546,8 +1561,13 @@ CG_DEV void coop_walk_422(const ImageDesc &d, const CoopShared &cs, const CoopTa
     // (an interval still waiting for a walk after the last round goes the same way as one given up on)
     CG_EACH_LANE
     {
-        if (L[li].tl == 0u && L[li].exists && (cs.verdict[L[li].il] & 0xffu) != kVerdictDone)
+        if (L[li].tl == 0u && L[li].exists && (cs.verdict[L[li].il] & 0xffu) != kVerdictDone) {
+#if defined(CG_EMUL_STATS)
+            if (getenv("EMUL_COOP_FAILS"))
+                fprintf(stderr, "serial il %u: still waiting for a walk after the last round (verdict %#x)\n", L[li].il, cs.verdict[L[li].il]);
+#endif
             cs.verdict[L[li].il] = kVerdictSerial;
+        }
     }
     CG_WAVE_SYNC();
 }

@@ -1452,11 +1452,11 @@ CoopPlan plan_coop(uint32_t max_intervals, uint32_t images, uint32_t restart_int
     // team: the other kernels do better.
     constexpr uint32_t kCoopCosyWindow = 2040;
     uint32_t k = 0;
-    while (k < 3u && spans.words[k] + kDuWordSlack + 4u > kCoopCosyWindow)
+    while (k < 3u && spans.words[k] + kDuWordSlack + 4u + kCoopEndSlack > kCoopCosyWindow)
         k++;
     if (k == 3u) {
         k = 2u;
-        if (spans.words[k] + kDuWordSlack + 4u > kCoopMaxWindow)
+        if (spans.words[k] + kDuWordSlack + 4u + kCoopEndSlack > kCoopMaxWindow)
             return p;
     }
     p.group_waves = kCoopTeamWaves >> k;
@@ -1466,7 +1466,7 @@ CoopPlan plan_coop(uint32_t max_intervals, uint32_t images, uint32_t restart_int
     const uint32_t lds_per_cu = lim.lds_bytes, cu_count = lim.cus;
     p.intervals_per_wave = sh.ipw;
     p.l2_entries_in_lds = (max_l2 + 2u * kDcFastEntries + 1u) & ~1u;
-    uint32_t w = max_group_words + kDuWordSlack + 4u;
+    uint32_t w = max_group_words + kDuWordSlack + 4u + kCoopEndSlack;
     w = std::max(w, 128u);
     w = std::min(w, kCoopMaxWindow);
     p.window_words = (w + 3u) & ~3u;

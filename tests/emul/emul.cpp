@@ -105,7 +105,7 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
         const CoopShape shape = coop_shape(d.restart_interval, waves >= 4 ? 4u : (waves >= 2 ? 2u : 1u));
         const uint32_t ipw = shape.ipw;
         if (window_words == 0) { // as the runtime plans it
-            window_words = max_wave_span(starts.data(), starts.size(), words.size(), d.total_intervals, ipw) + kDuWordSlack + 4u;
+            window_words = max_wave_span(starts.data(), starts.size(), words.size(), d.total_intervals, ipw) + kDuWordSlack + 4u + kCoopEndSlack;
             window_words = std::min(std::max(window_words, 128u), kCoopMaxWindow);
         }
         window_words = (window_words + 3u) & ~3u;
