@@ -1330,8 +1330,12 @@ CG_DEV void coop_lane(const ImageDesc &d, const HuffShared &s, const CoopGeom &g
     L.exists = L.il < g.intervals; // (the lanes behind the last interval's, where 64 is no multiple of lpi: none)
     const uint32_t interval = g.first_interval + (L.exists ? L.il : 0u);
     const uint32_t ws = interval < d.nstarts ? CG_GLOBAL(const uint32_t, d.starts)[interval] : 0u;
-    const uint32_t we = (interval + 1u < d.total_intervals && interval + 1u < d.nstarts)
-                            ? CG_GLOBAL(const uint32_t, d.starts)[interval + 1u] : d.nwords;
+    // (the image's last interval too ends where the next one begins, if the scan goes on behind it -- an image whose MCUs
+    // the restart interval does not divide: lib.rs:784 counts whole intervals, the scan's preprocessing notes every
+    // marker; up to the scan's end it would be that much longer, its subsequences laid over data that is not its own,
+    // three times the walk -- tools/coop_tail_stamps.py)
+    const uint32_t nx = interval + 1u < d.nstarts ? CG_GLOBAL(const uint32_t, d.starts)[interval + 1u] : d.nwords;
+    const uint32_t we = (interval + 1u < d.total_intervals || (nx > ws && nx <= d.nwords)) ? nx : d.nwords;
     L.start_rel = ws >= s.win_base ? umin(ws - s.win_base, 0x7fffffu) : 0x7fffffu; // (outside the window: no walk)
     L.len_words = we > ws ? umin(we - ws, kCoopMaxWindow) : 0u;
 }

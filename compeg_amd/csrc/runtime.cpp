@@ -852,7 +852,7 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
         // fill in, and they know of one descriptor.)
         const uint64_t mcu_words_avg = (img.scan_len / 4u + std::max<uint64_t>(route_mcus, 1u) - 1u) / std::max<uint64_t>(route_mcus, 1u);
         const bool route = route_possible && !blob_uploaded && hd.mcu_ok && hd.walk && !lab_env("COMPEG_NO_DECODER_ROUTE") &&
-                           !(coop.usable && coop_preferred(coop, md.total_restart_intervals, 1, md.restart_interval, truncated_tail_mcus(img))) &&
+                           !(coop.usable && coop_preferred(coop, md.total_restart_intervals, 1, md.restart_interval)) &&
                            (md.total_restart_intervals + kWave - 1) / kWave <= 1024u && mcu_words_avg <= 24u &&
                            14.5 * md.restart_interval - 40.0 > double(route_mcus) / 5300.0;
         if (route) {
@@ -1135,7 +1135,6 @@ void compeg_batch::note_batch_properties(const ImageData *const *images, size_t 
     total_waves = 0;
     uint64_t scan_bytes = 0, mcus = 0;
     max_out_w = max_out_h = 0;
-    max_tail_mcus = 0;
     // frames of one stream: the same number of restart intervals and byte-identical LUTs in every image
     // (the fused kernel's workgroups may then span image boundaries)
     uniform = n > 0;
@@ -1153,7 +1152,6 @@ void compeg_batch::note_batch_properties(const ImageData *const *images, size_t 
         mcus += uint64_t(img.metadata.total_restart_intervals) * std::max(1u, uint32_t(img.metadata.restart_interval));
         max_out_w = std::max(max_out_w, img.width);
         max_out_h = std::max(max_out_h, img.height);
-        max_tail_mcus = std::max(max_tail_mcus, truncated_tail_mcus(img));
         uniform = uniform && img.metadata.total_restart_intervals == first.metadata.total_restart_intervals &&
                   img.l2 == first.l2 && img.ac_fast == first.ac_fast && img.dc_fast == first.dc_fast &&
                   memcmp(img.l1, first.l1, sizeof img.l1) == 0;
@@ -1957,22 +1955,11 @@ Status compeg_batch::upload_device_scan(size_t n, int threads, const FeedSource 
 //    (one 4K frame DRI = 60 197 / 309, DRI = 128 298 / 610, an interval per MCU row -- 240 MCUs -- 528 / 1084; two of
 //    them 531 / 1102), and two or three rounds of teams are no worse than the route (eight 1080p frames DRI = 60 331 /
 //    319, DRI = 120 475 / 586; sixteen 960x720 frames DRI = 60 263 / 323);
-//  * ... except where the image's last interval is cut short by the image's end: the speculative walk of that one runs
-//    into the zeros behind the scan and the interval goes to the serial decoder, one lane for its MCUs (one 1080p frame
-//    DRI = 96, 72 MCUs in the last interval: 508 / 463; 960x720 DRI = 240, 120 MCUs: 1214 / 922; one 4K frame DRI = 256,
-//    32 MCUs: 623 / 1162) -- about 6 us per MCU of it against the 2.7 us per MCU of an interval the route loses.
+//    (Round 4 found two things that had made its long intervals look worse, both fixed in coop_body.h: a walk's room behind
+//    its interval's end -- kCoopEndSlack --, and the end of an image's last interval where the scan goes on behind it: one 4K
+//    frame with an interval per MCU row was 1788 us, one 960x720 frame with DRI = 240 1214 -- now 322 / 922.)
 namespace compeg {
-// MCUs of the image in its last restart interval where that one is cut short by the image's end (0: the intervals
-// divide the image evenly) -- lib.rs:784: ceil(MCUs / restart interval) intervals.
-uint32_t truncated_tail_mcus(const ImageData &img)
-{
-    const Metadata &md = img.metadata;
-    const uint32_t mcu_h = std::max(1u, uint32_t(md.max_vsample)) * 8u, r = md.restart_interval;
-    const uint64_t mcus = uint64_t(md.width_mcus) * ((img.height + mcu_h - 1u) / mcu_h);
-    return r ? uint32_t(mcus % r) : 0u;
-}
-
-bool coop_preferred(const CoopPlan &cp, uint32_t max_intervals, uint32_t images, uint32_t restart_interval, uint32_t tail_mcus)
+bool coop_preferred(const CoopPlan &cp, uint32_t max_intervals, uint32_t images, uint32_t restart_interval)
 {
     if (!cp.usable)
         return false;
@@ -1980,9 +1967,7 @@ bool coop_preferred(const CoopPlan &cp, uint32_t max_intervals, uint32_t images,
         return true;
     const uint64_t teams = uint64_t((max_intervals + cp.intervals_per_wave - 1) / cp.intervals_per_wave) * images;
     const uint64_t places = std::max(1u, cp.places);
-    if (restart_interval <= kCoopLeanMaxRestart)
-        return teams <= places;
-    return teams * 2u <= places * 5u && tail_mcus * 20u < 9u * restart_interval + 50u;
+    return restart_interval <= kCoopLeanMaxRestart ? teams <= places : teams * 2u <= places * 5u;
 }
 } // namespace compeg
 
@@ -2010,7 +1995,7 @@ bool use_mcu_route(const compeg_batch &b, uint32_t step, uint32_t smallest)
     if (b.coop_r && use_coop_kernel(b.max_intervals, smallest, b.coop_r)) {
         if (step != smallest)
             return false;
-        if (coop_preferred(plan_coop(b.max_intervals, step, b.coop_r, b.max_l2, b.coop_spans), b.max_intervals, step, b.coop_r, b.max_tail_mcus))
+        if (coop_preferred(plan_coop(b.max_intervals, step, b.coop_r, b.max_l2, b.coop_spans), b.max_intervals, step, b.coop_r))
             return false;
     }
     const uint64_t waves = uint64_t((b.max_intervals + kWave - 1) / kWave) * step;

@@ -25,8 +25,7 @@ Status hip_status(hipError_t e, const char *what);
 bool use_fused_pipeline();
 bool use_pair_kernel(uint32_t max_intervals, uint32_t images);
 bool use_coop_kernel(uint32_t max_intervals, uint32_t images, uint32_t restart_interval);
-bool coop_preferred(const CoopPlan &cp, uint32_t max_intervals, uint32_t images, uint32_t restart_interval, uint32_t tail_mcus);
-uint32_t truncated_tail_mcus(const ImageData &img);
+bool coop_preferred(const CoopPlan &cp, uint32_t max_intervals, uint32_t images, uint32_t restart_interval);
 CoopSpans coop_spans_exact(const uint32_t *starts, size_t nstarts, size_t nwords, uint32_t intervals, uint32_t restart_interval);
 CoopSpans coop_spans_estimate(uint32_t span_of_64, uint32_t restart_interval, bool generous);
 void coop_spans_max(CoopSpans &into, const CoopSpans &other);
@@ -150,7 +149,6 @@ struct compeg_batch {
     uint32_t stream_mcu_words = 0;       // the batch's average MCU in stream words, rounded up (plan_stream)
     uint32_t min_restart_interval = 0;   // the smallest restart interval of the batch's images
     uint32_t max_restart_interval = 0;   // ... and the largest
-    uint32_t max_tail_mcus = 0;          // the most MCUs any image has in a last restart interval its end cuts short
     uint64_t total_waves = 0;            // units of 64 intervals over all images
     bool uniform = false; // same interval count and LUT bytes in every image (set by upload)
     // cooperative kernel: the restart interval all images share if every one of them qualifies (else 0), and the
