@@ -17,6 +17,8 @@ out = []
 for sd in range(seeds):
     j = synth.make_jpeg(w, h, seed=4120 + sd, kind=0, quality=q, ri=ri)
     b = ca.Batch(gpu)
+    if os.environ.get("PROBE_DEVICE"):
+        b.set_device_preprocess(1)   # (the scan kernels preprocess the raw segment: windows planned from estimates)
     b.upload([ca.ImageData(j)])
     for _ in range(2):
         b.decode(); b.wait()
@@ -27,5 +29,5 @@ for sd in range(seeds):
         ts.append(b.timing(reset=True)[1] * 1000.0)
     out.append((4120 + sd, b.last_kernel(), float(np.median(ts))))
 ts = [t for _, _, t in out]
-print(f"{cfg[0]} DRI={ri} q{q}: kernel {out[0][1]}, us per frame over {seeds} seeds: median {np.median(ts):.0f}, min {min(ts):.0f}, max {max(ts):.0f}; "
+print(f"{cfg[0]} DRI={ri} q{q}{' device-preprocessed' if os.environ.get('PROBE_DEVICE') else ''}: kernel {out[0][1]}, us per frame over {seeds} seeds: median {np.median(ts):.0f}, min {min(ts):.0f}, max {max(ts):.0f}; "
       f"above 1.5 x the median: {[(s, round(t)) for s, _, t in out if t > 1.5 * np.median(ts)]}")
