@@ -54,7 +54,10 @@ constexpr uint32_t kDcFastEntries = 1u << kDcFastBits;
 // no speculation, nothing to validate); longer intervals are cut into subsequences walked side by side.  Measured on
 // one 960x720 frame (kernel time by HIP events, lane-per-interval / speculative): 5 MCUs 38 / 62 us, 10: 49 / 87,
 // 16: 64 / 106, 30: 92 / 101, 60: 164 / 154, 120: 314 / 217.
-constexpr uint32_t kCoopLeanMaxRestart = 40;
+#ifndef CG_COOP_LEAN_MAX
+#define CG_COOP_LEAN_MAX 40
+#endif
+constexpr uint32_t kCoopLeanMaxRestart = CG_COOP_LEAN_MAX;
 struct CoopShape {
     uint32_t dpi, ipw, rounds, lpi, count, list_cap;
 };
