@@ -271,6 +271,22 @@ def test_emulated_cooperative_kernel_on_the_gpu_suite_inputs(runner, tmp_path):
     assert checked >= 10
 
 
+def test_emulated_speculative_walks_need_no_serial_decoder(runner, tmp_path):
+    """Frames on which the cooperative kernel's speculative walks (more than 40 MCUs an interval) used to give an interval
+    up -- handed to the serial decoder: a millisecond on the GPU for a frame of 250 us -- now walk all of them: the last
+    walker of an interval stands up to 140 bits behind the interval's end when it begins its last data units (room for
+    that in the window: kCoopEndSlack), and an image's last counted interval ends where the next start position says
+    when the scan goes on behind it (an image whose MCUs the interval does not divide).  Counted by the emulator
+    (`coop ... serial=`), bit-exact as ever.  (profiles/r04/NOTES.md, tools/coop_cliff_probe.py)"""
+    for (w, h, ri, seed) in ((1920, 1080, 120, 4127), (1920, 1080, 60, 4121), (960, 720, 250, 4121)):
+        jpeg = synth.make_jpeg(w, h, seed=seed, kind=0, quality=85, ri=ri)
+        before = STATS.get("serial", 0), STATS.get("intervals", 0)
+        got = _run(runner, tmp_path, jpeg, 5, window=0, coop_passes=4)
+        assert got is not None and np.array_equal(got, orc.ImageData(jpeg).decode()), (w, h, ri, seed)
+        assert STATS.get("intervals", 0) > before[1]
+        assert STATS.get("serial", 0) == before[0], (w, h, ri, seed, "an interval went to the serial decoder")
+
+
 def test_emulated_count_mismatch_and_truncated_interval(runner, tmp_path):
     j = bytearray(synth.make_jpeg(128, 32, seed=40, ri=2))
     i = j.find(b"\xff\xdd")
