@@ -53,7 +53,8 @@ constexpr uint32_t kDcFastEntries = 1u << kDcFastBits;
 // Up to this many MCUs per interval one lane walks the whole interval through the walk tables (two symbols a step,
 // no speculation, nothing to validate); longer intervals are cut into subsequences walked side by side.  Measured on
 // one 960x720 frame (kernel time by HIP events, lane-per-interval / speculative): 5 MCUs 38 / 62 us, 10: 49 / 87,
-// 16: 64 / 106, 30: 92 / 101, 60: 164 / 154, 120: 314 / 217.
+// 16: 64 / 106, 30: 92 / 101, 60: 164 / 154, 120: 314 / 217 (round 3); with round 4's repairs of the speculative walks
+// (kCoopEndSlack, coop_lane's interval ends) 30: 91 / 108, 40: 113 / 112, 60: - / 131, 128: - / 216, 240: - / 322.
 #ifndef CG_COOP_LEAN_MAX
 #define CG_COOP_LEAN_MAX 40
 #endif
