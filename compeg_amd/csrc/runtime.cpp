@@ -672,7 +672,11 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     if (on_device) {
         bool fell_back = false;
         BlobWriter before_submit;
-        if (may_defer)
+        // (an image only the walk route decodes well -- intervals longer than the cooperative kernel takes, up to no DRI
+        // at all -- gets its scan's counts read back even in a blocking decode: the route's second descriptor needs them,
+        // and a lane per interval would take the whole image's time several times over)
+        const bool defer_scan = may_defer && !(route_possible && md.restart_interval > 256u);
+        if (defer_scan)
             before_submit = [&](uint8_t *host_at, uint8_t *dev_at, uint32_t **patch_nwords,
                                 uint32_t **patch_nstarts) -> Status {
                 // the blob rides in front of the raw segment; the scan kernels fill in the two counts
