@@ -296,9 +296,9 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
             }
             free(smem);
         }
-        fprintf(stderr, "walk mcus=%lu lean_mcus=%lu slow_mcus=%lu slow_q1=%lu slow_rows=%lu long_dc=%lu dead_mcus=%lu restages=%lu long_codes=%lu\n", g_walk_stats.mcus,
+        fprintf(stderr, "walk mcus=%lu lean_mcus=%lu slow_mcus=%lu slow_q1=%lu slow_rows=%lu long_dc=%lu dead_mcus=%lu restages=%lu long_codes=%lu slow_cut=%lu\n", g_walk_stats.mcus,
                 g_walk_stats.lean_mcus, g_walk_stats.slow_mcus, g_walk_stats.slow_q1, g_walk_stats.slow_rows, g_walk_stats.slow_long_dc, g_walk_stats.dead_mcus,
-                g_walk_stats.restages, g_walk_stats.long_codes);
+                g_walk_stats.restages, g_walk_stats.long_codes, g_walk_stats.slow_cut);
         // the image as the second kernel sees it: every "interval" one MCU (runtime.cpp: make_walk_tables)
         d.starts = mcu_word.data();
         d.nstarts = d.total_mcus;

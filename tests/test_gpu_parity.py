@@ -184,6 +184,26 @@ def test_decoder_takes_the_walk_route_for_long_intervals(ca, gpu):
     _assert_equal(dev.read_texture(data.width(), data.height()), orc.ImageData(jpeg).decode())
 
 
+def test_walk_route_dc_code_cut_by_the_readers_buffer(ca, gpu):
+    """tests/golden/route/cut_dc_code.jpg (see its README): the reference's reader, six bits left in front of a DC code,
+    reads a code the stream's own bits do not hold and runs dry -- the route's walk hands that MCU to its slow road.
+    Through the decoder and in a batch beside an ordinary frame."""
+    jpeg = read_golden("route", "cut_dc_code.jpg")
+    want = orc.ImageData(jpeg).decode()
+    dec, data, got = _decode(ca, gpu, jpeg)
+    assert dec.last_kernel() == "walk_mcu"
+    _assert_equal(got, want)
+    other = synth.make_jpeg(1016, 408, seed=91, quality=85, ri=0)
+    batch = ca.Batch(gpu)
+    batch.upload([ca.ImageData(jpeg), ca.ImageData(other), ca.ImageData(jpeg)])
+    batch.decode()
+    batch.wait()
+    assert batch.last_kernel() == "walk_mcu"
+    _assert_equal(batch.read_output(0), want)
+    _assert_equal(batch.read_output(1), orc.ImageData(other).decode())
+    _assert_equal(batch.read_output(2), want)
+
+
 def test_decoder_reuse_grows_and_reports_texture_changed(ca, gpu):
     """ref lib.rs:564-573 + dynamic.rs:214-248: first decode and every growth report true."""
     dec = ca.Decoder(gpu)

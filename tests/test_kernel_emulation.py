@@ -271,6 +271,21 @@ def test_emulated_cooperative_kernel_on_the_gpu_suite_inputs(runner, tmp_path):
     assert checked >= 10
 
 
+def test_emulated_walk_route_dc_code_cut_by_the_readers_buffer(runner, tmp_path):
+    """tests/golden/route/cut_dc_code.jpg: at one data unit's start the stream's bits are no DC code, the six bits the
+    reference's reader has left (zeros behind them: it is not topped up in front of DC codes) are -- of more bits than it
+    has: it runs dry (quirk Q1).  The route's walk has to notice that the two readings differ (`slow_cut`) and hand
+    the MCU to the slow road; rows enough for the lean walk to get there, and few (the slow road all the way)."""
+    jpeg = read_golden("route", "cut_dc_code.jpg")
+    want = orc.ImageData(jpeg).decode()
+    before = STATS.get("slow_cut", 0)
+    for rows, chunk in ((64, 6), (16, 1)):
+        got = _run(runner, tmp_path, jpeg, 8, window=rows, chunk=chunk)
+        assert got is not None and np.array_equal(got, want), (rows, chunk)
+    assert STATS.get("slow_cut", 0) > before
+    assert STATS.get("dead_mcus", 0) > 0
+
+
 def test_emulated_speculative_walks_need_no_serial_decoder(runner, tmp_path):
     """Frames on which the cooperative kernel's speculative walks (more than 40 MCUs an interval) used to give an interval
     up -- handed to the serial decoder: a millisecond on the GPU for a frame of 250 us -- now walk all of them: the last

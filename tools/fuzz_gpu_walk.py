@@ -59,16 +59,33 @@ def run(seed=4242, batches=60, log=print):
         order = [int(rng.integers(0, len(frames))) for _ in range(slots)]
         images = [ca.ImageData(frames[k][0], standard_entropy=std) for k in range(len(frames))]
         mode = int(rng.integers(0, 3))
+        only = os.environ.get("FUZZ_ONLY")   # (replay of one batch: the others only draw their random numbers)
+        if only is not None and int(only) != it:
+            if rng.integers(0, 5) == 0 and slots > 3:
+                rng.integers(2, slots)
+            for rep in range(2):
+                rng.integers(0, slots), rng.integers(0, slots)
+            continue
+        if only is not None:
+            log(f"batch {it}: {len(frames)} frames {[(orc.ImageData(j).width(), orc.ImageData(j).height(), len(j)) for j, _ in frames]} ri {ri0} slots {slots} mode {mode} std {std} same {same}")
+            if os.environ.get("FUZZ_DUMP"):
+                for k, (j, _) in enumerate(frames):
+                    open(os.path.join(os.environ["FUZZ_DUMP"], f"batch{it}_frame{k}.jpg"), "wb").write(j)
+                open(os.path.join(os.environ["FUZZ_DUMP"], f"batch{it}_order.txt"), "w").write(" ".join(map(str, order)))
         b = ca.Batch(gpu)
         b.set_device_preprocess(mode)
         b.upload([images[k] for k in order])
         if rng.integers(0, 5) == 0 and slots > 3:
-            b.set_chunk(int(rng.integers(2, slots)))
+            ch = int(rng.integers(2, slots))
+            b.set_chunk(ch)
+            if only is not None:
+                log(f"  chunk {ch}")
         for rep in range(2):
             b.decode()
             b.wait()
             kernels[b.last_kernel()] = kernels.get(b.last_kernel(), 0) + 1
-            for i in sorted({0, slots - 1, int(rng.integers(0, slots)), int(rng.integers(0, slots))}):
+            picks = sorted({0, slots - 1, int(rng.integers(0, slots)), int(rng.integers(0, slots))})
+            for i in (range(slots) if only is not None else picks):
                 n += 1
                 if not np.array_equal(b.read_output(i), frames[order[i]][1]):
                     bad += 1
