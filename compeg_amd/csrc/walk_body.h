@@ -496,27 +496,26 @@ CG_DEV bool walk_mcu_pass(WalkLane &l, const ImageDesc &d, const HuffShared &s, 
             ref_left = 32u + ((last - p) & 31u) - last;
         }
         const uint32_t cur = walk_bits_at(s, lane, p);
-        auto dc_code = [&](uint32_t bits) {
-            uint32_t side = t.dc_fast[t.dcf[k] * kDcFastEntries + (bits >> (32u - kDcFastBits))];
-            if (__builtin_expect(side == kFastEscape, 0)) {
-                // a DC code longer than the direct table's prefix
-                const uint32_t e2 = lut_lookup<false>(d, s, t.dc_off[comp], bits);
-                side = (1u << 9) | (((e2 >> 8) + (e2 & 15u)) << 4) | (e2 & 15u);
-                CG_WALK_COUNT(slow_long_dc);
-            }
-            return side;
-        };
-        const uint32_t side = dc_code(cur);
+        uint32_t side = t.dc_fast[t.dcf[k] * kDcFastEntries + (cur >> (32u - kDcFastBits))];
+        if (__builtin_expect(side == kFastEscape, 0)) {
+            // a DC code longer than the direct table's prefix
+            const uint32_t e2 = lut_lookup<false>(d, s, t.dc_off[comp], cur);
+            side = (1u << 9) | (((e2 >> 8) + (e2 & 15u)) << 4) | (e2 & 15u);
+            CG_WALK_COUNT(slow_long_dc);
+        }
         const uint32_t cat = side & 15u, n = (side >> 4) & 31u;
         fine = fine && (t.standard || n <= ref_left); // (more than the reference's reader has left: it runs dry here, quirk Q1)
         // The reference's reader is not topped up in front of a DC code: with fewer than 32 bits left it looks the code up
-        // in those bits and zeros behind them (kernels_body.h: fast_dc).  A code that fits the bits it has reads the
-        // same either way; where the stream's bits are no code at all (a corrupt scan) and the cut ones are -- or the
-        // other way round -- the reader's road parts from the walk's: the slow road.
-        if (!t.standard && ref_left < 32u && fine && dc_code(cur & ~(0xffffffffu >> ref_left)) != side) {
+        // in those bits and zeros behind them (kernels_body.h: fast_dc), not in the stream's.  A code that fits the bits
+        // it has reads the same either way, one that does not is caught above -- but bits that are no code at all (n = 0:
+        // a corrupt scan, an interval read on into its padding) may be one once zeros stand behind the first few of
+        // them (codes are handed out from the low end), of more bits than the reader has: the slow road finds out.
+#if !(defined(COMPEG_LAB) && defined(CG_NO_CUT_CHECK)) // (laboratory builds may leave the test out: what it costs)
+        if (__builtin_expect(n == 0u && ref_left < 32u && !t.standard, 0)) { // (32 bits or more left: the reader looks at the same bits)
             fine = false;
             CG_WALK_COUNT(slow_cut);
         }
+#endif
         const int32_t sx = signed_field(cur, n, cat);
         const uint32_t diff = uint32_t(sx) + (((0xffffffffu << cat) ^ uint32_t(sx >> 31)) + 1u);
         pred[comp] = int32_t(uint32_t(pred[comp]) + diff);
