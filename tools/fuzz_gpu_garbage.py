@@ -21,10 +21,13 @@ t0 = time.time()
 for it in range(frames):
     w, h = [(1016, 990), (640, 360), (960, 720), (1280, 720)][int(rng.integers(0, 4))]
     ri = int(rng.choice([0, 0, 0, 300, 120, 64, 30, 10]))
-    j = bytearray(synth.make_jpeg(w, h, seed=int(rng.integers(1, 1 << 30)), kind=int(rng.choice([1, 1, 0, 2])),
-                                  quality=int(rng.choice([70, 85, 95, 95, 100])), ri=ri))
+    quirky = os.environ.get("FUZZ_QUIRKS") is not None   # valid streams of the kind the reader's quirks live on: noise at q97-100
+    if quirky:
+        ri = int(rng.choice([0, 300, 240, 120, 60, 30, 16, 10, 7, 4, 2, 1]))
+    j = bytearray(synth.make_jpeg(w, h, seed=int(rng.integers(1, 1 << 30)), kind=int(rng.choice([1, 1, 0, 2])) if not quirky else 1,
+                                  quality=int(rng.choice([70, 85, 95, 95, 100])) if not quirky else int(rng.choice([97, 99, 100, 100])), ri=ri))
     at = j.find(b"\xff\xda") + 14
-    for _ in range(int(rng.integers(1, 12))):
+    for _ in range(int(rng.integers(1, 12)) if not quirky else 0):
         pos = int(rng.integers(at, at + max(16, (len(j) - at) // int(rng.choice([1, 4, 16])))))
         pos = min(pos, len(j) - 3)
         if j[pos] != 0xFF and j[pos - 1] != 0xFF:
