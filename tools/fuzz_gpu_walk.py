@@ -84,7 +84,8 @@ def run(seed=4242, batches=60, log=print):
             b.decode()
             b.wait()
             kernels[b.last_kernel()] = kernels.get(b.last_kernel(), 0) + 1
-            picks = sorted({0, slots - 1, int(rng.integers(0, slots)), int(rng.integers(0, slots))})
+            picks = sorted({0, slots - 1, int(rng.integers(0, slots)), int(rng.integers(0, slots))} |
+                           {order.index(k) for k in set(order)})   # (... and one slot of every distinct frame)
             for i in (range(slots) if only is not None else picks):
                 n += 1
                 if not np.array_equal(b.read_output(i), frames[order[i]][1]):
