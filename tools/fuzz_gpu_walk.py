@@ -44,6 +44,17 @@ def run(seed=4242, batches=60, log=print):
                         j[pos] ^= 1 << int(rng.integers(0, 8))
                         if j[pos] == 0xFF:
                             j[pos] = 0xFE
+            if os.environ.get("FUZZ_ONES") is not None and rng.integers(0, 3) == 0:
+                # runs of one bits (0xFF 0x00: eight of them): bits that are no Huffman code, at DC codes and AC codes alike
+                scan_at = j.find(b"\xff\xda") + 14
+                for _ in range(int(rng.integers(3, 40))):
+                    pos = int(rng.integers(scan_at, max(scan_at + 1, len(j) - 12)))
+                    if j[pos - 1] == 0xFF or j[pos] == 0xFF:
+                        continue
+                    run_ = bytes([0xFF, 0x00] * int(rng.integers(1, 3)) + [0xFE] * int(rng.integers(0, 2)))
+                    if 0xFF in j[pos + len(run_):pos + len(run_) + 1]:
+                        continue
+                    j[pos:pos + len(run_)] = run_
             j = bytes(j)
             try:
                 frames.append((j, orc.ImageData(j, standard_entropy=std).decode()))
