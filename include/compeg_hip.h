@@ -180,7 +180,8 @@ int compeg_decoder_last_stage_times(const compeg_decoder *dec, compeg_stage_time
                                        windows (long restart intervals, dense streams) */
 #define COMPEG_KERNEL_WALK_MCU 8     /* walk_mcus_422_kernel + decode_fused_422_mcu_rec_kernel: a lane per restart interval
                                        finds where the MCUs begin, then a lane per MCU decodes (batches of few or long
-                                       restart intervals) */
+                                       restart intervals; single images whose intervals the cooperative kernel does not
+                                       take or takes less well: beyond 256 MCUs, no DRI at all, a 4K frame's 1080 teams) */
 int compeg_decoder_last_kernel(const compeg_decoder *dec);
 /* Extension: on != 0 moves the scan preprocessing of every following decode
  * from the host (the reference's data flow, default) to the device-side scan
