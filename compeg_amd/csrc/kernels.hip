@@ -849,7 +849,7 @@ HuffLdsPlan plan_huffman(uint32_t max_intervals, uint32_t images, uint32_t max_l
     while (wpb < most && groups(wpb) > uint64_t(cu_count) * rounds * groups_per_cu(wpb))
         wpb++;
     if (const char *e = lab_env("COMPEG_WPB")) // experiment knob
-        wpb = uint32_t(atoi(e));
+        wpb = atoi(e) > 0 ? uint32_t(atoi(e)) : wpb;
     p.waves_per_block = wpb;
     p.total_bytes = tables + p.waves_per_block * wave_area;
     if (const char *e = lab_env("COMPEG_LDS_PAD")) // experiment knob: lowers occupancy
@@ -1049,8 +1049,15 @@ StreamPlan plan_stream(uint32_t max_intervals, uint32_t images, uint32_t max_l2,
     uint32_t best = uint32_t(std::min<uint64_t>(std::max<uint64_t>((total_waves + lim.cus - 1) / lim.cus, 1u), std::min(fit, group_waves)));
     if (!uniform)
         best = std::min(best, std::max(1u, waves_per_image));
+    // Thirteen to sixteen units a CU: two rounds of eight resident waves (two to a SIMD) rather than one of twelve and a
+    // nearly empty one -- a wave's unit takes a fifth longer three to a SIMD, and the second round's few units a whole
+    // unit's time again (256 x 1280x720, us per launch, twelve / eight waves a CU: DRI = 9 -- 3328 units -- 601 / 502,
+    // DRI = 8 -- 3840 -- 569 / 474; 4608 units, 18 a CU: 668 / 734, left at twelve).
+    const uint64_t units_per_cu = (total_waves + lim.cus - 1) / lim.cus;
+    if (uniform && cu_waves == kMaxWavesFused && group_waves == cu_waves && units_per_cu >= 13u && units_per_cu <= 16u && fit >= 8u)
+        best = 8u;
     if (const char *e = lab_env("COMPEG_WPB")) // experiment knob
-        best = uint32_t(atoi(e));
+        best = atoi(e) > 0 ? uint32_t(atoi(e)) : best;
     // With LDS to spare at that size, more rows: the stagings get rarer by as much as they get larger, and every
     // one of them waits for the stores in front of it (sparse streams, short MCU steps -- 256 x 1080p q50 DRI = 16:
     // 0.90 ms with 12 rows, 0.83 with the 27 that fit).
