@@ -1513,6 +1513,21 @@ CG_DEV void composite_row_from_quad(const ImageDesc &d, const uint8_t *wave_slot
     }
 }
 
+// The limits of four MCUs (byte j: target_limit of source j) as this lane needs them -- byte j: the rows of source j in
+// which the lane's piece lies inside the output, none if the piece does not.
+CG_DEV uint32_t cut_rows_for_piece(uint32_t limits, uint32_t piece)
+{
+    uint32_t rows = 0u;
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) {
+        const uint32_t lim = (limits >> (8u * j)) & 0xffu;
+        rows |= (piece < lim >> 5 ? lim & 31u : 0u) << (8u * j);
+    }
+    return rows;
+}
+// bit 8 j + 7: row `row` of source j is inside (bytes of at most 16 rows: no carry from byte to byte)
+CG_DEV uint32_t cut_row_inside(uint32_t rows, uint32_t row) { return (rows + 0x01010101u * (127u - row)) & 0x80808080u; }
+
 // The same for a restart interval of one MCU, where the wave's lanes hold 64 consecutive MCUs: store t of a row
 // takes the MCUs of lanes 16 t .. 16 t + 15, lane l piece l & 3 of the MCU of lane 16 t + (l >> 2) -- 1 KB in one
 // piece wherever those sixteen MCUs lie in one MCU row (64-byte segments 256 bytes apart are what every longer
@@ -1788,6 +1803,18 @@ struct McuTarget {
     uint8_t *base; // top-left byte
     bool whole;    // entirely inside the output, 16-byte aligned rows: stored through the quad
 };
+
+// What of an MCU (group) the output's right or bottom edge cuts still goes through the quad: rows | 16-byte pieces of a row
+// << 5 that lie inside (the cut at a piece's end, 16-byte aligned rows); 0: nothing -- an MCU outside, or the edge path's,
+// pixel by pixel.  (1920x1080 in 16-row MCUs: the last MCU row is such; a wave that holds one MCU of the edge path's
+// waits for it -- 256 x 1080p 4:2:0 1030 us against 786 for 1088 rows.)  Worked out where a wave has such an MCU only:
+// the common case keeps its registers.  (The layouts' kernels; the 4:2:2 kernels of 168 registers have none to spare for
+// it -- their MCUs are 8 rows high, what cuts them is rarer.)
+CG_DEV uint32_t target_limit(const ImageDesc &d, bool active, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h)
+{
+    const uint32_t px_in = x0 < d.out_w ? umin(w, d.out_w - x0) : 0u, rows_in = y0 < d.out_h ? umin(h, d.out_h - y0) : 0u;
+    return active && (d.out_pitch & 15u) == 0u && (px_in & 3u) == 0u && px_in && rows_in ? rows_in | (px_in >> 2) << 5 : 0u; // (rows <= 16, pieces <= 4: a byte)
+}
 
 CG_DEV McuTarget mcu_target(const PixelState &t, const ImageDesc &d)
 {
@@ -2360,9 +2387,25 @@ CG_DEV void layout_row_from_quad(const ImageDesc &d, const uint8_t *wave_slots, 
     }
 }
 
-// MCUs cut by the right / bottom edge of the output (stores outside it are dropped, like textureStore in the
-// reference), an unaligned pitch, or a pair whose second MCU begins the next MCU row: the owning lane stores them
-// pixel by pixel, each held MCU at its own place.
+// ... of MCU groups the output's edge cuts: `rows` = cut_rows_for_piece of the quad's four groups for this lane's piece.
+template <int PIECES>
+CG_DEV void layout_row_from_quad_cut(const ImageDesc &d, const uint8_t *wave_slots, uint32_t lane, uint32_t row,
+                                     uint8_t *const (&bases)[4], uint32_t rows)
+{
+    const uint32_t quad = lane & ~3u, liq = lane & 3u, inside = cut_row_inside(rows, row);
+#pragma unroll
+    for (uint32_t j = 0; j < uint32_t(PIECES); j++) {
+        const uint32_t src = PIECES == 4 ? j : 2u * j + (liq >> 1), piece = PIECES == 4 ? liq : (liq & 1u);
+        const SlotVec v = reinterpret_cast<const SlotVec *>(wave_slots + (quad + src) * kDuSlotBytes)[piece];
+        uint8_t *base = src == 0u ? bases[0] : (src == 1u ? bases[1] : (src == 2u ? bases[2] : bases[3]));
+        if (inside & (0x80u << (8u * src)))
+            store_pixels<true>(base + size_t(row) * d.out_pitch + piece * 16u, Vec4u{v.x, v.y, v.z, v.w});
+    }
+}
+
+// MCUs cut by the right / bottom edge of the output inside a 16-byte piece (stores outside it are dropped, like
+// textureStore in the reference), an unaligned pitch, or a pair whose second MCU begins the next MCU row: the owning lane
+// stores them pixel by pixel, each held MCU at its own place.
 template <int HS, int VS, int MC>
 CG_DEV void composite_layout_edge(const LayoutPixels<HS, VS, MC> &t, const ImageDesc &d)
 {
@@ -2460,6 +2503,12 @@ CG_DEV McuTarget layout_target(const LayoutPixels<HS, VS, MC> &t, const ImageDes
 }
 
 template <int HS, int VS, int MC>
+CG_DEV uint32_t layout_limit(const LayoutPixels<HS, VS, MC> &t, const ImageDesc &d)
+{
+    return target_limit(d, t.active && t.mx + uint32_t(MC) <= d.width_mcus, t.mx * (8u * HS), t.my * (8u * VS), 8u * HS * MC, 8u * VS);
+}
+
+template <int HS, int VS, int MC>
 CG_DEV void layout_next_group(LayoutPixels<HS, VS, MC> &t, const ImageDesc &d)
 {
     t.mx += uint32_t(MC);
@@ -2487,14 +2536,27 @@ CG_DEV void composite_layout_mcus(LayoutPixels<HS, VS, MC> &t, const ImageDesc &
     };
     const uint32_t whole_mask = quad_lane<0>(wh) | quad_lane<1>(wh) << 1 | quad_lane<2>(wh) << 2 | quad_lane<3>(wh) << 3;
     uint8_t *slot = wave_slots + lane * kDuSlotBytes;
+    if (__builtin_amdgcn_ballot_w64(whole_mask != 0xfu) == 0u) {
 #pragma unroll
-    for (int row = 0; row < 8 * VS; row++) {
-        layout_row_to_slot<HS, VS, MC>(t, row, slot);
-        layout_row_from_quad<2 * HS * MC>(d, wave_slots, lane, uint32_t(row), bases, whole_mask);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int row = 0; row < 8 * VS; row++) {
+            layout_row_to_slot<HS, VS, MC>(t, row, slot);
+            layout_row_from_quad<2 * HS * MC>(d, wave_slots, lane, uint32_t(row), bases, 0xfu);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        // (some group of the wave is cut by the output's edge, or outside: what lies inside in whole pieces the same way)
+        const uint32_t lim = layout_limit<HS, VS, MC>(t, d);
+        const uint32_t limits = cut_rows_for_piece(quad_lane<0>(lim) | quad_lane<1>(lim) << 8 | quad_lane<2>(lim) << 16 | quad_lane<3>(lim) << 24,
+                                                   2 * HS * MC == 4 ? lane & 3u : lane & 1u);
+#pragma unroll
+        for (int row = 0; row < 8 * VS; row++) {
+            layout_row_to_slot<HS, VS, MC>(t, row, slot);
+            layout_row_from_quad_cut<2 * HS * MC>(d, wave_slots, lane, uint32_t(row), bases, limits);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     zero_slot(slot);
-    if (t.active && !g.whole)
+    if (t.active && !g.whole && layout_limit<HS, VS, MC>(t, d) == 0u)
         composite_layout_edge<HS, VS, MC>(t, d);
     layout_next_group<HS, VS, MC>(t, d);
 }
