@@ -859,9 +859,11 @@ int compeg_batch_read_output(compeg_batch *batch, size_t index, uint8_t *host_rg
         if (rc != COMPEG_OK)
             return rc;
         const ImageDesc &d = batch->descs[index];
-        const size_t bytes = size_t(d.out_pitch) * d.out_h;
-        hipError_t e = bytes ? hipMemcpy(host_rgba, d.out, bytes, hipMemcpyDeviceToHost) : hipSuccess;
-        return e == hipSuccess ? ok() : fail(hip_status(e, "hipMemcpy"));
+        // (tightly packed on the host; the device rows are out_pitch apart)
+        hipError_t e = d.out_w && d.out_h ? hipMemcpy2D(host_rgba, size_t(d.out_w) * 4, d.out, d.out_pitch, size_t(d.out_w) * 4, d.out_h,
+                                                        hipMemcpyDeviceToHost)
+                                          : hipSuccess;
+        return e == hipSuccess ? ok() : fail(hip_status(e, "hipMemcpy2D"));
     });
 }
 

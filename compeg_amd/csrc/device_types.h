@@ -151,6 +151,10 @@ struct ImageDesc {
     // output
     uint8_t *out; // RGBA8
     uint32_t out_w, out_h;
+    // what lies behind the pointer: out_pitch / 4 pixels a row and this many rows -- the logical extent rounded up to
+    // whole MCUs (16 x 16 pixels), so that an MCU the extent's edge cuts is stored whole, its outside into padding nobody
+    // reads (0: as much as out_h)
+    uint32_t out_alloc_h;
     uint32_t out_pitch; // bytes
     // launch bookkeeping for batched grids
     uint32_t first_huff_block; // block index of this image's first huffman block

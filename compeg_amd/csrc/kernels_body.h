@@ -211,6 +211,7 @@ constexpr uint32_t kDuWordSlack = 66;
 
 CG_DEV uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
 CG_DEV uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+CG_DEV uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 
 // Four consecutive dwords from a dword-aligned global address.
 struct __attribute__((packed, aligned(4))) Dwords4 {
@@ -1830,7 +1831,9 @@ CG_DEV McuTarget mcu_target(const PixelState &t, const ImageDesc &d)
 #endif
     McuTarget g;
     g.base = d.out + size_t(y0) * d.out_pitch + size_t(x0) * 4u;
-    g.whole = t.active && x0 + 16u <= d.out_w && y0 + 8u <= d.out_h && (d.out_pitch & 15u) == 0u;
+    // (inside what is allocated: an MCU the output's edge cuts puts its outside into the rows' and the image's padding)
+    g.whole = t.active && x0 + 16u <= umax(d.out_w, d.out_pitch / 4u) && y0 + 8u <= umax(d.out_h, d.out_alloc_h) && (d.out_pitch & 15u) == 0u &&
+              x0 < d.out_w && y0 < d.out_h;
     return g;
 }
 
@@ -2497,8 +2500,9 @@ CG_DEV McuTarget layout_target(const LayoutPixels<HS, VS, MC> &t, const ImageDes
     McuTarget g;
     g.base = d.out + size_t(y0) * d.out_pitch + size_t(x0) * 4u;
     // (all held MCUs in one MCU row, inside the output)
-    g.whole = t.active && t.mx + uint32_t(MC) <= d.width_mcus && x0 + 8u * HS * MC <= d.out_w && y0 + 8u * VS <= d.out_h &&
-              (d.out_pitch & 15u) == 0u;
+    // (inside what is allocated: mcu_target)
+    g.whole = t.active && t.mx + uint32_t(MC) <= d.width_mcus && x0 + 8u * HS * MC <= umax(d.out_w, d.out_pitch / 4u) &&
+              y0 + 8u * VS <= umax(d.out_h, d.out_alloc_h) && (d.out_pitch & 15u) == 0u && x0 < d.out_w && y0 < d.out_h;
     return g;
 }
 
@@ -2545,7 +2549,8 @@ CG_DEV void composite_layout_mcus(LayoutPixels<HS, VS, MC> &t, const ImageDesc &
         }
     } else {
         // (some group of the wave is cut by the output's edge, or outside: what lies inside in whole pieces the same way)
-        const uint32_t lim = layout_limit<HS, VS, MC>(t, d);
+        // (a whole group -- inside what is allocated, if not inside the extent -- stores all of itself)
+        const uint32_t lim = g.whole ? uint32_t(8 * VS) | uint32_t(2 * HS * MC) << 5 : layout_limit<HS, VS, MC>(t, d);
         const uint32_t limits = cut_rows_for_piece(quad_lane<0>(lim) | quad_lane<1>(lim) << 8 | quad_lane<2>(lim) << 16 | quad_lane<3>(lim) << 24,
                                                    2 * HS * MC == 4 ? lane & 3u : lane & 1u);
 #pragma unroll

@@ -128,6 +128,12 @@ bool use_pair_kernel(uint32_t max_intervals, uint32_t images)
 // look at where a scan ends (up to 64 words beyond its last; never used).
 constexpr size_t kStreamSlackBytes = 1024;
 
+// A batch image's output: rows of whole MCUs (16 pixels each way) -- an MCU the image's edge cuts is stored whole, its
+// outside into padding; rows begin on 64-byte boundaries whatever the width (device_types.h: out_alloc_h).
+static uint32_t output_pitch(uint32_t width) { return (width + 15u) / 16u * 64u; }
+static uint32_t output_rows(uint32_t height) { return (height + 15u) / 16u * 16u; }
+static size_t output_bytes(uint32_t width, uint32_t height) { return size_t(output_pitch(width)) * output_rows(height); }
+
 bool use_stream_kernel(const HuffLdsPlan &plan, uint32_t max_intervals, uint32_t images, uint32_t cu_waves = 0, uint32_t group_waves = 0)
 {
     static const int forced = [] {
@@ -582,18 +588,22 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     // requested size when either dimension is too small.
     bool realloc_out = false;
     if (img.width > out_w || img.height > out_h || !out.ptr) {
-        const size_t pitch = align_up(size_t(img.width) * 4, 16);
+        // (rows of whole MCUs, 16 pixels each way: an MCU the extent's edge cuts is stored whole, rows begin on 64-byte
+        // boundaries whatever the width -- 256 x 1080x1920 portrait frames 1608 -> 8xx us, device_types.h: out_alloc_h)
+        const size_t pitch = align_up(size_t(img.width), 16) * 4;
+        const size_t alloc_rows = align_up(size_t(img.height), 16);
         // never shrink the allocation itself, only the logical extent
         bool fresh = false;
-        CG_TRY(out.reserve(std::max<size_t>(pitch * img.height, 256), &fresh));
+        CG_TRY(out.reserve(std::max<size_t>(pitch * alloc_rows, 256), &fresh));
         // wgpu zero-initialises new textures; texels no MCU covers (a truncated
         // last restart interval, lib.rs:785) therefore read as 0 in the reference --
         // also when the new logical texture lands in an allocation that is already there
         (void)fresh;
-        CG_HIP(hipMemsetAsync(out.ptr, 0, std::min(out.capacity, std::max<size_t>(pitch * img.height, 256)), stream));
+        CG_HIP(hipMemsetAsync(out.ptr, 0, std::min(out.capacity, std::max<size_t>(pitch * alloc_rows, 256)), stream));
         out_w = img.width;
         out_h = img.height;
         out_pitch = pitch;
+        out_alloc_h = uint32_t(alloc_rows);
         realloc_out = true;
     }
     if (changed)
@@ -650,6 +660,7 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
         d.out_w = out_w;
         d.out_h = out_h;
         d.out_pitch = uint32_t(out_pitch);
+        d.out_alloc_h = out_alloc_h;
         write_tables(hb + l1_off, img);
         if (route_possible) {
             d.mcu_word = static_cast<uint32_t *>(mcu_words.ptr);
@@ -1202,7 +1213,7 @@ Status compeg_batch::upload_host(size_t n, int threads, const void *items_, cons
         in_total += align_up(it.tables_cap + ScanBuffer::start_slots(it.intervals) * 4 +
                                  ScanBuffer::output_capacity(it.scan_cap) + 16, 256);
         out_offset[i] = out_total;
-        out_total += align_up(size_t(it.width) * 4 * it.height, 256);
+        out_total += align_up(output_bytes(it.width, it.height), 256);
         ac_total += size_t(it.total_dus) * kRetained * 2;
         dc_total += size_t(it.total_dus) * 4;
         any_generic = any_generic || !it.is422;
@@ -1303,7 +1314,8 @@ Status compeg_batch::upload_host(size_t n, int threads, const void *items_, cons
             d.out = static_cast<uint8_t *>(out.ptr) + out_offset[i];
             d.out_w = img.width;
             d.out_h = img.height;
-            d.out_pitch = img.width * 4;
+            d.out_pitch = output_pitch(img.width);
+            d.out_alloc_h = output_rows(img.height);
             spans[i] = max_wave_span(starts_at, nstarts, nwords, img.metadata.total_restart_intervals);
             if (d.coop_ok)
                 group_spans[i] = coop_spans_exact(starts_at, nstarts, nwords, img.metadata.total_restart_intervals,
@@ -1832,7 +1844,7 @@ Status compeg_batch::upload_device_scan(size_t n, int threads, const FeedSource 
         bool all_covered = true;
         for (size_t i = 0; i < n; i++) {
             const ImageData &img = *images[i];
-            out_total += align_up(size_t(img.width) * 4 * img.height, 256);
+            out_total += align_up(output_bytes(img.width, img.height), 256);
             max_tiles = std::max(max_tiles, sd[i].ntiles);
             max_intervals = std::max(max_intervals, img.metadata.total_restart_intervals);
             max_dus = std::max(max_dus, img.total_dus());
@@ -1909,10 +1921,11 @@ Status compeg_batch::upload_device_scan(size_t n, int threads, const FeedSource 
             dc_at += size_t(img.total_dus()) * 4;
             out_offset[i] = out_at;
             d.out = static_cast<uint8_t *>(out.ptr) + out_at;
-            out_at += align_up(size_t(img.width) * 4 * img.height, 256);
+            out_at += align_up(output_bytes(img.width, img.height), 256);
             d.out_w = img.width;
             d.out_h = img.height;
-            d.out_pitch = img.width * 4;
+            d.out_pitch = output_pitch(img.width);
+            d.out_alloc_h = output_rows(img.height);
             max_span = std::max(max_span, span);
             if (i == 0) {
                 coop_r = img.metadata.restart_interval;

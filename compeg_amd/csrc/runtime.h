@@ -83,6 +83,7 @@ struct compeg_decoder {
     compeg::DeviceBuffer mcu_words, mcu_states;
     uint32_t out_w = 0, out_h = 0;
     size_t out_pitch = 0;
+    uint32_t out_alloc_h = 0; // rows behind `out` (the extent rounded up to whole MCUs)
     hipEvent_t upload_done = nullptr; // host staging may be rewritten after this
     bool upload_pending = false;
     hipEvent_t decode_done = nullptr; // the device buffers may be rewritten after this (enqueue on another stream waits for it)

@@ -201,7 +201,10 @@ int compeg_op_texture_changed(const compeg_op *op);
 void compeg_op_free(compeg_op *op);
 
 /* `Decoder::texture()` (lib.rs:372-374): the device-resident RGBA8 output,
- * row-major, bytes R,G,B,255, `pitch` bytes per row.  Like the reference's
+ * row-major, bytes R,G,B,255, `pitch` bytes per row -- the width rounded up to
+ * 16 pixels (rows begin on 64-byte boundaries; the allocation has whole MCU rows
+ * too: what an MCU at the texture's edge holds beyond it lands in that padding,
+ * which nobody should read).  Like the reference's
  * texture it never shrinks, so width/height may exceed the last image; only
  * the image's own WxH corner is defined.  The pointer stays valid until the
  * next decode that reallocates (texture_changed) or the decoder is freed. */
@@ -228,8 +231,10 @@ int compeg_decoder_read_coefficients(compeg_decoder *dec, int32_t *host_coeffici
  * Decodes many independent images with one launch sequence: the images'
  * preprocessed scans and tables are made resident in HBM once
  * (compeg_batch_upload), after which every compeg_batch_decode is pure device
- * work.  Outputs are tightly packed RGBA8 images (pitch = 4*width) in one
- * device allocation. */
+ * work.  Outputs are RGBA8 images in one device allocation, each with rows
+ * `pitch` bytes apart (compeg_batch_output: 4 x the width rounded up to 16
+ * pixels -- rows on 64-byte boundaries; compeg_batch_read_output hands out a
+ * tightly packed copy). */
 int compeg_batch_new(compeg_gpu *gpu, compeg_batch **out);
 void compeg_batch_free(compeg_batch *batch);
 /* Host front-end for all images (preprocess or stage on `host_threads` threads,

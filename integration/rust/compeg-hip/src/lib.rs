@@ -419,7 +419,7 @@ pub enum Preprocess {
 
 /// Extension: many independent images decoded by one launch sequence.  The
 /// images' scans and tables are made resident in HBM once; every `decode` is
-/// pure device work.  Outputs are tightly packed RGBA8 images.
+/// pure device work.  Outputs are RGBA8 images, rows `pitch_bytes` apart (the width rounded up to 16 pixels).
 pub struct Batch {
     raw: NonNull<ffi::compeg_batch>,
     _gpu: Arc<Gpu>,

@@ -46,6 +46,10 @@ struct LayoutTag {
     static constexpr int hs = H, vs = V, mc = M;
 };
 
+// EMUL_PADDED=1: the output as the runtime allocates it -- rows of whole MCUs, 16 pixels each way (device_types.h:
+// out_alloc_h); 0 / unset: a tight buffer
+static uint32_t g_out_pitch = 0, g_out_alloc_h = 0;
+
 extern "C" __attribute__((visibility("default")))
 int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, uint32_t tex_h,
                 int16_t *ac_out, int32_t *dc_out, uint32_t waves_per_block, uint32_t window_words,
@@ -90,7 +94,8 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
     d.out = rgba;
     d.out_w = tex_w;
     d.out_h = tex_h;
-    d.out_pitch = tex_w * 4;
+    d.out_alloc_h = g_out_alloc_h ? g_out_alloc_h : tex_h; // (a tight buffer: nothing behind the extent)
+    d.out_pitch = g_out_pitch ? g_out_pitch : tex_w * 4;
 
     if (fused == 5) {
         // ---- decode_coop_422_kernel: coop_wave_422 plays a whole wave, lane after lane, phase by phase ----
@@ -521,7 +526,7 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
                                 uint32_t limits = 0;
                                 for (uint32_t j = 0; j < 4; j++) {
                                     bases[j] = tg[quad + j].base;
-                                    limits |= layout_limit<HS, VS, MC>(ps[quad + j], d) << (8u * j);
+                                    limits |= (tg[quad + j].whole ? uint32_t(8 * VS) | uint32_t(2 * HS * MC) << 5 : layout_limit<HS, VS, MC>(ps[quad + j], d)) << (8u * j);
                                 }
                                 bool all_whole = true; // (the kernel's ballot: every group of the wave whole)
                                 for (uint32_t l2 = 0; l2 < uint32_t(kWave); l2++)
@@ -665,10 +670,16 @@ int main(int argc, char **argv)
     const uint32_t dus = probe->total_dus();
     delete probe;
     std::vector<uint8_t> rgba(size_t(tex_w) * tex_h * 4, 0);
+    std::vector<uint8_t> padded;
+    if (getenv("EMUL_PADDED") && atoi(getenv("EMUL_PADDED"))) {
+        g_out_pitch = (tex_w + 15u) / 16u * 64u;
+        g_out_alloc_h = (tex_h + 15u) / 16u * 16u;
+        padded.assign(size_t(g_out_pitch) * g_out_alloc_h, 0);
+    }
     std::vector<int16_t> ac(size_t(dus) * kRetained);
     std::vector<int32_t> dc(dus);
     char err[256] = "";
-    int rc = emul_decode(exact, jpeg.size(), rgba.data(), tex_w, tex_h, ac.data(), dc.data(),
+    int rc = emul_decode(exact, jpeg.size(), padded.empty() ? rgba.data() : padded.data(), tex_w, tex_h, ac.data(), dc.data(),
                          uint32_t(atoi(argv[5])), uint32_t(atoi(argv[6])), uint32_t(atoi(argv[7])),
                          err, sizeof err, mode);
     free(exact);
@@ -684,6 +695,8 @@ int main(int argc, char **argv)
             fclose(o);
         }
     };
+    for (uint32_t y = 0; !padded.empty() && y < tex_h; y++)
+        memcpy(rgba.data() + size_t(y) * tex_w * 4, padded.data() + size_t(y) * g_out_pitch, size_t(tex_w) * 4);
     dump(argv[2], rgba.data(), rgba.size());
     dump(argv[3], ac.data(), ac.size() * 2);
     dump(argv[4], dc.data(), dc.size() * 4);

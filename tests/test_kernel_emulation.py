@@ -32,7 +32,7 @@ STATS = {}   # rare-path counters of the emulated kernels, summed over every run
 
 
 def _run(runner, tmp_path, jpeg, fused, waves=1, window=2048, l2=12288, standard=False, coop_passes=1, stage=8, below=None,
-         layout_rows=None, chunk=1):
+         layout_rows=None, chunk=1, padded=False):
     p = tmp_path / "in.jpg"
     p.write_bytes(jpeg)
     env = dict(os.environ)
@@ -45,6 +45,7 @@ def _run(runner, tmp_path, jpeg, fused, waves=1, window=2048, l2=12288, standard
     env.pop("EMUL_STREAM_BELOW", None)
     env.pop("EMUL_STREAM_ROWS", None)
     env["EMUL_WALK_CHUNK"] = str(chunk)   # (fused = 8: MCUs a lane walks between two looks at what it found)
+    env["EMUL_PADDED"] = "1" if padded else "0"   # (the output as the runtime allocates it: rows of whole MCUs, 16 pixels each way)
     if layout_rows is not None:
         env["EMUL_STREAM_ROWS"] = str(layout_rows)   # (fused = 6: the layout kernels' streamed form)
     if below is not None:
@@ -269,6 +270,20 @@ def test_emulated_cooperative_kernel_on_the_gpu_suite_inputs(runner, tmp_path):
                 assert np.array_equal(got, want), f"{passes} round(s) per walk: {(got != want).any(axis=2).sum()} pixels differ"
                 checked += passes == 4
     assert checked >= 10
+
+
+@pytest.mark.parametrize("sampling", [(2, 1), (2, 2), (1, 1), (1, 2)])
+def test_emulated_outputs_of_whole_mcus(runner, tmp_path, sampling):
+    """The output as the runtime allocates it -- rows of whole MCUs, 16 pixels each way: an MCU (group) the image's edge
+    cuts is stored whole, its outside into the padding (and, in the layouts' kernels, one that is cut at a 16-byte
+    piece's end but not whole goes through the quad with its limits) -- ragged sizes, even and odd restart intervals,
+    tight buffers beside them; under ASan: nothing is written behind the allocation."""
+    for (w, h, ri) in ((250, 70, 3), (250, 70, 2), (33, 17, 1), (264, 120, 4), (1080 // 4, 104, 6)):
+        jpeg = synth.make_jpeg(w, h, seed=50 + w + ri, kind=1, quality=85, ri=ri, sampling=sampling)
+        want = orc.ImageData(jpeg, allow_sampling=True).decode()
+        for padded in (True, False):
+            got = _run(runner, tmp_path, jpeg, 1 if sampling == (2, 1) else 6, padded=padded)
+            assert got is not None and np.array_equal(got, want), (sampling, w, h, ri, padded)
 
 
 def test_emulated_walk_route_dc_code_cut_by_the_readers_buffer(runner, tmp_path):
