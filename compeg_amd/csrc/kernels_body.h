@@ -2371,11 +2371,24 @@ CG_DEV void layout_row_to_slot(const LayoutPixels<HS, VS, MC> &t, int row, uint8
     }
 }
 
+// A 16-byte piece of a row of an MCU group.  Where the groups' rows are whole 64-byte segments the stores are
+// non-temporal (store_pixels); where they are 32-byte halves of one -- single 8-pixel MCUs; pairs of them in an image
+// with an odd number of MCUs a row, where every second MCU row's pairs lie across two segments -- ordinary stores
+// (MERGE) have the L2 keep a half until the other has come: a non-temporal half goes to memory as a 32-byte write of
+// its own (TCC_EA0_WRREQ of 256 x 1920x1088 4:4:4: 33.6 M, all of 64 bytes, in pairs, 1.1 ms; 67.2 M of 32 as single
+// MCUs, 3.2 ms; 1912 across: 16.9 M of 64 + 38.7 M of 32, 1.7 ms -- profiles/r04/NOTES.md).  A template argument:
+// chosen per store by a wave-uniform branch, the aligned case lost 7 %; per row of a group it is one branch for four.
+template <bool MERGE>
+CG_DEV void layout_store(uint8_t *p, const Vec4u &v)
+{
+    store_pixels<!MERGE>(p, v);
+}
+
 // The lane's share of row `row` of its quad's four MCU groups (composite_row_from_quad's counterpart): with 64-byte rows
 // (PIECES = 4) lane i stores piece i of each of the four rows; with 32-byte rows (PIECES = 2) lanes 0, 1 store the two
 // pieces of one group's row and lanes 2, 3 those of the next, twice -- a wave-wide store then writes whole rows of
 // MCU groups instead of 64 separate 16-byte pieces.
-template <int PIECES>
+template <int PIECES, bool MERGE>
 CG_DEV void layout_row_from_quad(const ImageDesc &d, const uint8_t *wave_slots, uint32_t lane, uint32_t row,
                                  uint8_t *const (&bases)[4], uint32_t whole_mask)
 {
@@ -2386,7 +2399,7 @@ CG_DEV void layout_row_from_quad(const ImageDesc &d, const uint8_t *wave_slots, 
         const SlotVec v = reinterpret_cast<const SlotVec *>(wave_slots + (quad + src) * kDuSlotBytes)[piece];
         uint8_t *base = src == 0u ? bases[0] : (src == 1u ? bases[1] : (src == 2u ? bases[2] : bases[3]));
         if (whole_mask >> src & 1u)
-            store_pixels<true>(base + size_t(row) * d.out_pitch + piece * 16u, Vec4u{v.x, v.y, v.z, v.w});
+            layout_store<MERGE>(base + size_t(row) * d.out_pitch + piece * 16u, Vec4u{v.x, v.y, v.z, v.w});
     }
 }
 
@@ -2402,7 +2415,7 @@ CG_DEV void layout_row_from_quad_cut(const ImageDesc &d, const uint8_t *wave_slo
         const SlotVec v = reinterpret_cast<const SlotVec *>(wave_slots + (quad + src) * kDuSlotBytes)[piece];
         uint8_t *base = src == 0u ? bases[0] : (src == 1u ? bases[1] : (src == 2u ? bases[2] : bases[3]));
         if (inside & (0x80u << (8u * src)))
-            store_pixels<true>(base + size_t(row) * d.out_pitch + piece * 16u, Vec4u{v.x, v.y, v.z, v.w});
+            layout_store<true>(base + size_t(row) * d.out_pitch + piece * 16u, Vec4u{v.x, v.y, v.z, v.w}); // (cut groups are few: whatever their halves)
     }
 }
 
@@ -2512,6 +2525,73 @@ CG_DEV uint32_t layout_limit(const LayoutPixels<HS, VS, MC> &t, const ImageDesc 
     return target_limit(d, t.active && t.mx + uint32_t(MC) <= d.width_mcus, t.mx * (8u * HS), t.my * (8u * VS), 8u * HS * MC, 8u * VS);
 }
 
+// MCU pairs (MC = 2: 8-pixel MCUs, a 64-byte row of two halves of 32 bytes) in the cut branch of the composite: each
+// half with its own limit and the second with its own place, so that a pair whose second MCU begins the next MCU row --
+// one in every two MCU rows wherever a row holds an odd number of MCUs: 1080 pixels across, 360, 1912 -- goes through the
+// quad like any other (the edge path's pixel-by-pixel stores held its whole wave: 256 x 1912x1088 4:4:4 DRI = 4 ...).
+constexpr uint32_t kPairEdge = 1u << 16; // the group is the edge path's (cut inside a 16-byte piece, or an unaligned pitch)
+
+// One 8-pixel MCU at (x0, y0): rows | pieces << 5 of it that the quad stores; 0: it lies outside; kPairEdge: see above.
+template <int VS>
+CG_DEV uint32_t pair_half_limit(const ImageDesc &d, uint32_t x0, uint32_t y0)
+{
+    if (x0 >= d.out_w || y0 >= d.out_h)
+        return 0u;
+    if ((d.out_pitch & 15u) == 0u && x0 + 8u <= umax(d.out_w, d.out_pitch / 4u) && y0 + 8u * VS <= umax(d.out_h, d.out_alloc_h))
+        return uint32_t(8 * VS) | 2u << 5; // (inside what is allocated: mcu_target)
+    const uint32_t lim = target_limit(d, true, x0, y0, 8u, 8u * VS);
+    return lim ? lim : kPairEdge;
+}
+
+// bits 0-7: the limit of the pair's first MCU, 8-15: of its second (each rows | pieces << 5, pieces <= 2), or kPairEdge.
+template <int HS, int VS, int MC>
+CG_DEV uint32_t pair_limits(const LayoutPixels<HS, VS, MC> &t, const ImageDesc &d, bool whole)
+{
+    static_assert(HS == 1 && MC == 2, "pairs of 8-pixel MCUs");
+    const uint32_t full = uint32_t(8 * VS) | 2u << 5;
+    if (whole)
+        return full | full << 8;
+    if (!t.active)
+        return 0u;
+    if (t.mx + 2u <= d.width_mcus) {
+        const uint32_t lim = layout_limit<HS, VS, MC>(t, d);
+        if (!lim)
+            return kPairEdge;
+        const uint32_t rows = lim & 31u, pieces = lim >> 5;
+        return (rows | umin(pieces, 2u) << 5) | (pieces > 2u ? (rows | (pieces - 2u) << 5) << 8 : 0u);
+    }
+    const uint32_t a = pair_half_limit<VS>(d, t.mx * 8u, t.my * (8u * VS)), b = pair_half_limit<VS>(d, 0u, (t.my + 1u) * (8u * VS));
+    return (a | b) & kPairEdge ? kPairEdge : a | b << 8;
+}
+
+// How far behind its place in the pair's row the second MCU lies (bytes; 0 in one MCU row with the first)
+template <int HS, int VS, int MC>
+CG_DEV uint32_t pair_second_offset(const LayoutPixels<HS, VS, MC> &t, const ImageDesc &d)
+{
+    return t.active && t.mx + 2u > d.width_mcus ? uint32_t(8 * VS) * d.out_pitch - t.mx * 32u - 32u : 0u;
+}
+
+// The receiving lane's side: `limits` = pair_limits of its quad's four groups; its piece's rows of each (cut_row_inside)
+CG_DEV uint32_t pair_rows_for_lane(const uint32_t (&limits)[4], uint32_t liq)
+{
+    const uint32_t sh = (liq >> 1) * 8u;
+    return cut_rows_for_piece(((limits[0] >> sh) & 0xffu) | ((limits[1] >> sh) & 0xffu) << 8 | ((limits[2] >> sh) & 0xffu) << 16 |
+                                  ((limits[3] >> sh) & 0xffu) << 24,
+                              liq & 1u);
+}
+
+// The lane's group is the edge path's: nothing of it went through the quad.
+template <int HS, int VS, int MC>
+CG_DEV bool layout_is_edge(const LayoutPixels<HS, VS, MC> &t, const ImageDesc &d, bool whole)
+{
+    if (!t.active || whole)
+        return false;
+    if constexpr (MC == 2)
+        return pair_limits<HS, VS, MC>(t, d, false) == kPairEdge;
+    else
+        return layout_limit<HS, VS, MC>(t, d) == 0u;
+}
+
 template <int HS, int VS, int MC>
 CG_DEV void layout_next_group(LayoutPixels<HS, VS, MC> &t, const ImageDesc &d)
 {
@@ -2540,11 +2620,33 @@ CG_DEV void composite_layout_mcus(LayoutPixels<HS, VS, MC> &t, const ImageDesc &
     };
     const uint32_t whole_mask = quad_lane<0>(wh) | quad_lane<1>(wh) << 1 | quad_lane<2>(wh) << 2 | quad_lane<3>(wh) << 3;
     uint8_t *slot = wave_slots + lane * kDuSlotBytes;
+    // (pairs, an odd number of MCUs a row: every second MCU row's lie across two 64-byte segments -- layout_store; chosen
+    // row by row: two copies of the whole loop took the pairs' kernels beyond their registers)
+    const bool across = MC == 2 && (d.width_mcus & 1u) != 0u;
     if (__builtin_amdgcn_ballot_w64(whole_mask != 0xfu) == 0u) {
 #pragma unroll
         for (int row = 0; row < 8 * VS; row++) {
             layout_row_to_slot<HS, VS, MC>(t, row, slot);
-            layout_row_from_quad<2 * HS * MC>(d, wave_slots, lane, uint32_t(row), bases, 0xfu);
+            if (across)
+                layout_row_from_quad<2 * HS * MC, true>(d, wave_slots, lane, uint32_t(row), bases, 0xfu);
+            else
+                layout_row_from_quad<2 * HS * MC, 2 * HS * MC != 4>(d, wave_slots, lane, uint32_t(row), bases, 0xfu);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else if constexpr (MC == 2) {
+        // (pairs: some group is cut, outside, or has its second MCU at the next MCU row's beginning)
+        const uint32_t lim = pair_limits<HS, VS, MC>(t, d, g.whole), off = pair_second_offset<HS, VS, MC>(t, d);
+        const uint32_t lims[4] = {quad_lane<0>(lim), quad_lane<1>(lim), quad_lane<2>(lim), quad_lane<3>(lim)};
+        const uint32_t limits = pair_rows_for_lane(lims, lane & 3u);
+        // (the exchange by every lane, then masked: a select would let the compiler move the DPP read under the
+        // selecting lanes' EXEC, where the quad's first two lanes -- the ones read -- are off and read as 0)
+        const uint32_t second = 0u - ((lane >> 1) & 1u);
+        uint8_t *moved[4] = {bases[0] + (quad_lane<0>(off) & second), bases[1] + (quad_lane<1>(off) & second),
+                             bases[2] + (quad_lane<2>(off) & second), bases[3] + (quad_lane<3>(off) & second)};
+#pragma unroll
+        for (int row = 0; row < 8 * VS; row++) {
+            layout_row_to_slot<HS, VS, MC>(t, row, slot);
+            layout_row_from_quad_cut<2 * HS * MC>(d, wave_slots, lane, uint32_t(row), moved, limits);
             __builtin_amdgcn_sched_barrier(0);
         }
     } else {
@@ -2561,7 +2663,7 @@ CG_DEV void composite_layout_mcus(LayoutPixels<HS, VS, MC> &t, const ImageDesc &
         }
     }
     zero_slot(slot);
-    if (t.active && !g.whole && layout_limit<HS, VS, MC>(t, d) == 0u)
+    if (layout_is_edge<HS, VS, MC>(t, d, g.whole))
         composite_layout_edge<HS, VS, MC>(t, d);
     layout_next_group<HS, VS, MC>(t, d);
 }

@@ -523,24 +523,34 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
                             for (uint32_t lane = 0; lane < uint32_t(kWave); lane++) {
                                 const uint32_t quad = lane & ~3u;
                                 uint8_t *bases[4];
-                                uint32_t limits = 0;
+                                uint32_t limits = 0, pair_lims[4] = {0, 0, 0, 0};
                                 for (uint32_t j = 0; j < 4; j++) {
                                     bases[j] = tg[quad + j].base;
-                                    limits |= (tg[quad + j].whole ? uint32_t(8 * VS) | uint32_t(2 * HS * MC) << 5 : layout_limit<HS, VS, MC>(ps[quad + j], d)) << (8u * j);
+                                    if constexpr (MC == 2) {
+                                        pair_lims[j] = pair_limits<HS, VS, MC>(ps[quad + j], d, tg[quad + j].whole);
+                                    } else {
+                                        limits |= (tg[quad + j].whole ? uint32_t(8 * VS) | uint32_t(2 * HS * MC) << 5 : layout_limit<HS, VS, MC>(ps[quad + j], d)) << (8u * j);
+                                    }
                                 }
                                 bool all_whole = true; // (the kernel's ballot: every group of the wave whole)
                                 for (uint32_t l2 = 0; l2 < uint32_t(kWave); l2++)
                                     all_whole = all_whole && tg[l2].whole;
-                                if (all_whole)
-                                    layout_row_from_quad<2 * HS * MC>(d, slots, lane, uint32_t(row), bases, 0xfu);
-                                else
+                                if (all_whole) {
+                                    layout_row_from_quad<2 * HS * MC, false>(d, slots, lane, uint32_t(row), bases, 0xfu);
+                                } else if constexpr (MC == 2) {
+                                    // (pairs: each half its own limit, the second its own place)
+                                    for (uint32_t j = 0; j < 4 && (lane & 2u); j++)
+                                        bases[j] += pair_second_offset<HS, VS, MC>(ps[quad + j], d);
+                                    layout_row_from_quad_cut<2 * HS * MC>(d, slots, lane, uint32_t(row), bases, pair_rows_for_lane(pair_lims, lane & 3u));
+                                } else {
                                     layout_row_from_quad_cut<2 * HS * MC>(d, slots, lane, uint32_t(row), bases,
                                                                           cut_rows_for_piece(limits, 2 * HS * MC == 4 ? lane & 3u : lane & 1u));
+                                }
                             }
                         }
                         for (uint32_t lane = 0; lane < uint32_t(kWave); lane++) {
                             zero_slot(slots + lane * kDuSlotBytes);
-                            if (ps[lane].active && !tg[lane].whole && layout_limit<HS, VS, MC>(ps[lane], d) == 0u)
+                            if (layout_is_edge<HS, VS, MC>(ps[lane], d, tg[lane].whole))
                                 composite_layout_edge<HS, VS, MC>(ps[lane], d);
                             layout_next_group<HS, VS, MC>(ps[lane], d);
                         }

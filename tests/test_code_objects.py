@@ -50,6 +50,25 @@ def test_decode_kernels_use_lds_instructions_and_no_scratch(tmp_path):
     assert seen == set(KERNELS), f"kernels not found in the code objects: {set(KERNELS) - seen}"
 
 
+def test_no_lane_exchange_under_a_narrowed_exec_mask(tmp_path):
+    """`cond ? quad_lane<j>(v) : 0` -- the compiler is free to run the DPP move under the EXEC mask of the lanes where
+    `cond` holds; the lanes it reads from, off there, read as 0 (round 4: the pairs' second halves, selected by
+    lane & 2, lost every offset that came from their quad's lanes 0 and 1 -- on the GPU only, the emulator has no EXEC).
+    The kernels exchange in every lane and mask the value; here: no DPP instruction between a saveexec and the
+    instruction that restores EXEC, in any kernel of the library."""
+    for co in _code_objects(tmp_path):
+        asm = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co], check=True, capture_output=True, text=True).stdout
+        narrowed, found = None, []
+        for line in asm.splitlines():
+            if "saveexec" in line:
+                narrowed = line.strip()
+            elif re.search(r"s_or_b64 exec, exec|s_mov_b64 exec|s_endpgm|^[0-9a-f]+ <\S+>:", line):
+                narrowed = None
+            elif narrowed and re.search(r"_dpp\b|ds_swizzle|ds_bpermute|ds_permute|v_permlane", line):
+                found.append(line.strip())
+        assert not found, f"lane exchanges under a narrowed EXEC mask: {found[:4]}"
+
+
 def test_shipped_library_has_no_laboratory_switches():
     """The experiment knobs (compeg_amd/csrc/lab.h) exist in the laboratory build only: the shipped library's
     strings name no environment variable but the four it documents, and the knock-out arms of the kernel bodies

@@ -1260,9 +1260,9 @@ def test_c_consumer_decodes_on_the_gpu(ca, gpu, tmp_path):
 def test_extension_layouts_with_odd_restart_intervals(ca, gpu, sampling, single, paired):
     """4:4:4 and 4:4:0 with odd restart intervals: the MCUs of an interval cannot be composited in pairs, every lane
     stores its 8-pixel MCU alone (decode_fused_444_single_kernel / decode_fused_440_single_kernel: 32-byte rows).  The
-    batch reports "fused_layout" for both forms; which of the two kernels ran is told by their timing -- the single form
-    takes longer per frame than the paired one on the same frames with the interval one MCU longer -- and both are
-    bit-exact against the oracle's extension."""
+    batch reports "fused_layout" for both forms; both are bit-exact against the oracle's extension.  The single form
+    was two to three times slower per frame than the paired one while its 32-byte rows were non-temporal stores -- each
+    a write of its own at the memory; as ordinary stores they cost it no such factor (kernels_body.h, layout_store)."""
     times = {}
     for ri in (3, 4, 5):
         jpegs = [synth.make_jpeg(1280, 720, seed=60 + i, kind=0, quality=85, ri=ri, sampling=sampling) for i in range(4)]
@@ -1281,5 +1281,5 @@ def test_extension_layouts_with_odd_restart_intervals(ca, gpu, sampling, single,
         times[ri] = total / n
         for i in (0, 3, 63):
             _assert_equal(batch.read_output(i), orc.ImageData(jpegs[i % 4], allow_sampling=True).decode())
-    # (odd intervals: the single kernels; even: the paired ones -- two to three times faster per frame)
-    assert times[3] > 1.3 * times[4] and times[5] > 1.3 * times[4], (single, paired, times)
+    # (odd intervals: the single kernels; even: the paired ones)
+    assert times[3] < 1.9 * times[4] and times[5] < 1.9 * times[4], (single, paired, times)
