@@ -1255,6 +1255,28 @@ def test_c_consumer_decodes_on_the_gpu(ca, gpu, tmp_path):
         assert lines["changed"].startswith("1 ") and lines["changed_again"] == "0"
 
 
+@pytest.mark.parametrize("sampling", [(1, 1), (1, 2)])
+def test_mcu_pairs_across_mcu_rows(ca, gpu, sampling):
+    """4:4:4 / 4:4:0 with an even restart interval (MCUs composited in pairs) and an odd number of MCUs a row -- 1000,
+    360, 1080 pixels across: every second MCU row begins with the second MCU of a pair.  That pair's halves go to two
+    places (`pair_limits`, `pair_second_offset`); the pairs of such rows lie across two 64-byte segments (ordinary
+    stores, `layout_store`).  On the GPU a select around the lane exchange once sent the second halves of half the
+    quads' pairs to the wrong place (tests/test_code_objects.py has the scan for it): batches and single frames,
+    ragged heights, bit-exact."""
+    for (w, h, ri) in ((1000, 600, 4), (360, 642, 2), (1080, 250, 8), (1001, 97, 4)):
+        jpegs = [synth.make_jpeg(w, h, seed=90 + i, kind=0, quality=85, ri=ri, sampling=sampling) for i in range(3)]
+        batch = ca.Batch(gpu)
+        batch.upload([ca.ImageData(jpegs[i % 3], allow_sampling=True) for i in range(24)])
+        batch.decode()
+        batch.wait()
+        assert batch.last_kernel() in ("fused_layout", "fused_stream")
+        for i in (0, 1, 23):
+            _assert_equal(batch.read_output(i), orc.ImageData(jpegs[i % 3], allow_sampling=True).decode())
+        dec = ca.Decoder(gpu)
+        dec.decode_blocking(ca.ImageData(jpegs[2], allow_sampling=True))
+        _assert_equal(dec.read_texture(w, h), orc.ImageData(jpegs[2], allow_sampling=True).decode())
+
+
 @pytest.mark.parametrize("sampling,single,paired", [((1, 1), "decode_fused_444_single_kernel", "decode_fused_444_kernel"),
                                                      ((1, 2), "decode_fused_440_single_kernel", "decode_fused_440_kernel")])
 def test_extension_layouts_with_odd_restart_intervals(ca, gpu, sampling, single, paired):
