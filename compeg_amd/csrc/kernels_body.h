@@ -2420,8 +2420,9 @@ CG_DEV void layout_row_from_quad_cut(const ImageDesc &d, const uint8_t *wave_slo
 }
 
 // MCUs cut by the right / bottom edge of the output inside a 16-byte piece (stores outside it are dropped, like
-// textureStore in the reference), an unaligned pitch, or a pair whose second MCU begins the next MCU row: the owning lane
-// stores them pixel by pixel, each held MCU at its own place.
+// textureStore in the reference) or an unaligned pitch -- neither arises with outputs the runtime allocates (whole MCUs,
+// 16 pixels each way) --: the owning lane stores them pixel by pixel, each held MCU at its own place (a pair's second MCU
+// at the next MCU row's beginning where the first ends its row).
 template <int HS, int VS, int MC>
 CG_DEV void composite_layout_edge(const LayoutPixels<HS, VS, MC> &t, const ImageDesc &d)
 {
@@ -2528,7 +2529,8 @@ CG_DEV uint32_t layout_limit(const LayoutPixels<HS, VS, MC> &t, const ImageDesc 
 // MCU pairs (MC = 2: 8-pixel MCUs, a 64-byte row of two halves of 32 bytes) in the cut branch of the composite: each
 // half with its own limit and the second with its own place, so that a pair whose second MCU begins the next MCU row --
 // one in every two MCU rows wherever a row holds an odd number of MCUs: 1080 pixels across, 360, 1912 -- goes through the
-// quad like any other (the edge path's pixel-by-pixel stores held its whole wave: 256 x 1912x1088 4:4:4 DRI = 4 ...).
+// quad like any other (it was the edge path's, pixel by pixel, its wave waiting; what such images cost beyond that is
+// their pairs' place in the 64-byte segments: layout_store).
 constexpr uint32_t kPairEdge = 1u << 16; // the group is the edge path's (cut inside a 16-byte piece, or an unaligned pitch)
 
 // One 8-pixel MCU at (x0, y0): rows | pieces << 5 of it that the quad stores; 0: it lies outside; kPairEdge: see above.
