@@ -66,7 +66,7 @@ WalkPlan plan_walk(uint32_t max_intervals, uint32_t images, uint32_t max_l2, uin
 hipError_t launch_walk_mcus(const ImageDesc *descs, uint32_t images, uint32_t max_intervals, const WalkPlan &plan, hipStream_t stream,
                             uint32_t *queue = nullptr);
 // Extension layouts (luma hs x vs = 1x1, 1x2, 2x2), fused like the 4:2:2 kernel; plan with wave_cap = fused_layout_wave_cap.
-// pairs: (8-pixel MCUs) every image of the launch has an even restart interval -- a lane composites its MCUs two at a time
+// pairs: (8-pixel MCUs) every image of the launch has restart intervals of two MCUs or more -- a lane composites its MCUs two at a time (an odd interval's last alone)
 uint32_t fused_layout_wave_cap(uint32_t hs, uint32_t vs, bool pairs);
 hipError_t launch_fused_layout(const ImageDesc *descs, uint32_t images, uint32_t max_intervals, const HuffLdsPlan &plan,
                                uint32_t hs, uint32_t vs, bool pairs, hipStream_t stream);

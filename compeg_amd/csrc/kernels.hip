@@ -411,7 +411,7 @@ __device__ __forceinline__ void fused_layout_kernel_body(const ImageDesc *__rest
     decode_wave_fused_layout<HS, VS, MC>(d, s, wave_first + lane, lane);
 }
 
-// (4:4:4 and 4:4:0: MCUs in pairs -- rows of 64 bytes -- where the restart interval is even: two waves to a SIMD;
+// (4:4:4 and 4:4:0: MCUs in pairs -- rows of 64 bytes; the last MCU of an odd restart interval alone -- from two MCUs an interval on: two waves to a SIMD;
 // singly otherwise)
 __global__ void __launch_bounds__(512)
 decode_fused_444_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t window_words)
@@ -599,7 +599,7 @@ decode_fused_422_stream_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_
 {
     fused_stream_kernel_body<Wave422Stream>(descs, l2_in_lds, rows, stage_after, stage_below, waves_per_image, images, queue);
 }
-// ... and of the extension layouts' kernels (4:4:4 / 4:4:0 in pairs -- even restart intervals --, 4:2:0)
+// ... and of the extension layouts' kernels (4:4:4 / 4:4:0 in pairs -- restart intervals of two MCUs or more --, 4:2:0)
 __global__ void __launch_bounds__(512)
 decode_fused_444_stream_kernel(const ImageDesc *__restrict__ descs, uint32_t l2_in_lds, uint32_t rows, uint32_t stage_after,
                                uint32_t stage_below, uint32_t waves_per_image, uint32_t images, uint32_t *queue)

@@ -2335,8 +2335,8 @@ CG_DEV void decode_wave_fused_422_stream(const ImageDesc &d, const HuffShared &s
 // its block, chroma nearest neighbour.  It replaces the two-kernel route (entropy_samples_kernel +
 // composite_generic_kernel) and its round trip of sample records.
 // MC: MCUs a lane holds before it composites them -- 1, or 2 for the layouts with 8-pixel MCUs (their rows are 32
-// bytes; two neighbours of an interval make the 64-byte segments the write path takes twice as well; even restart
-// intervals only, so that a pair never straddles two intervals).
+// bytes; two neighbours of an interval make the 64-byte segments the write path takes twice as well; a pair never
+// straddles two intervals: the last MCU of an odd one is composited alone).
 template <int HS, int VS, int MC>
 struct LayoutPixels {
     static constexpr int kDus = HS * VS + 2;
@@ -2424,13 +2424,13 @@ CG_DEV void layout_row_from_quad_cut(const ImageDesc &d, const uint8_t *wave_slo
 // 16 pixels each way) --: the owning lane stores them pixel by pixel, each held MCU at its own place (a pair's second MCU
 // at the next MCU row's beginning where the first ends its row).
 template <int HS, int VS, int MC>
-CG_DEV void composite_layout_edge(const LayoutPixels<HS, VS, MC> &t, const ImageDesc &d)
+CG_DEV void composite_layout_edge(const LayoutPixels<HS, VS, MC> &t, const ImageDesc &d, uint32_t held = uint32_t(MC))
 {
     constexpr int kDus = HS * VS + 2;
     // (rolled loops, the words selected without dynamic register indexing: unrolled, the 64 conversions of a 16 x 16
     // MCU are hoisted over their stores' guards and the kernel spills)
 #pragma unroll 1
-    for (uint32_t m = 0; m < uint32_t(MC); m++) {
+    for (uint32_t m = 0; m < held; m++) {
         uint32_t mx = t.mx + m, my = t.my;
         if (mx >= d.width_mcus) {
             mx -= d.width_mcus;
@@ -2546,11 +2546,14 @@ CG_DEV uint32_t pair_half_limit(const ImageDesc &d, uint32_t x0, uint32_t y0)
 }
 
 // bits 0-7: the limit of the pair's first MCU, 8-15: of its second (each rows | pieces << 5, pieces <= 2), or kPairEdge.
+// alone: the pair's first MCU is all there is -- the last MCU of an odd restart interval.
 template <int HS, int VS, int MC>
-CG_DEV uint32_t pair_limits(const LayoutPixels<HS, VS, MC> &t, const ImageDesc &d, bool whole)
+CG_DEV uint32_t pair_limits(const LayoutPixels<HS, VS, MC> &t, const ImageDesc &d, bool whole, bool alone = false)
 {
     static_assert(HS == 1 && MC == 2, "pairs of 8-pixel MCUs");
     const uint32_t full = uint32_t(8 * VS) | 2u << 5;
+    if (alone)
+        return t.active ? pair_half_limit<VS>(d, t.mx * 8u, t.my * (8u * VS)) : 0u;
     if (whole)
         return full | full << 8;
     if (!t.active)
@@ -2584,12 +2587,12 @@ CG_DEV uint32_t pair_rows_for_lane(const uint32_t (&limits)[4], uint32_t liq)
 
 // The lane's group is the edge path's: nothing of it went through the quad.
 template <int HS, int VS, int MC>
-CG_DEV bool layout_is_edge(const LayoutPixels<HS, VS, MC> &t, const ImageDesc &d, bool whole)
+CG_DEV bool layout_is_edge(const LayoutPixels<HS, VS, MC> &t, const ImageDesc &d, bool whole, bool alone = false)
 {
-    if (!t.active || whole)
+    if (!t.active || (whole && !alone))
         return false;
     if constexpr (MC == 2)
-        return pair_limits<HS, VS, MC>(t, d, false) == kPairEdge;
+        return pair_limits<HS, VS, MC>(t, d, false, alone) == kPairEdge;
     else
         return layout_limit<HS, VS, MC>(t, d) == 0u;
 }
@@ -2608,8 +2611,9 @@ CG_DEV uint32_t layout_comp_of(uint32_t k, uint32_t luma_dus) { return k < luma_
 
 #if defined(__HIPCC__)
 // The composite of the wave's 64 current MCU groups through the lanes' quads (composite_mcus_422's counterpart).
+// alone (wave-uniform; pairs): the groups' first MCUs are all there is -- the last MCU of an odd restart interval.
 template <int HS, int VS, int MC>
-CG_DEV void composite_layout_mcus(LayoutPixels<HS, VS, MC> &t, const ImageDesc &d, uint8_t *wave_slots, uint32_t lane)
+CG_DEV void composite_layout_mcus(LayoutPixels<HS, VS, MC> &t, const ImageDesc &d, uint8_t *wave_slots, uint32_t lane, bool alone = false)
 {
     const McuTarget g = layout_target<HS, VS, MC>(t, d);
     const uint64_t addr = reinterpret_cast<uint64_t>(g.base);
@@ -2622,10 +2626,11 @@ CG_DEV void composite_layout_mcus(LayoutPixels<HS, VS, MC> &t, const ImageDesc &
     };
     const uint32_t whole_mask = quad_lane<0>(wh) | quad_lane<1>(wh) << 1 | quad_lane<2>(wh) << 2 | quad_lane<3>(wh) << 3;
     uint8_t *slot = wave_slots + lane * kDuSlotBytes;
-    // (pairs, an odd number of MCUs a row: every second MCU row's lie across two 64-byte segments -- layout_store; chosen
-    // row by row: two copies of the whole loop took the pairs' kernels beyond their registers)
-    const bool across = MC == 2 && (d.width_mcus & 1u) != 0u;
-    if (__builtin_amdgcn_ballot_w64(whole_mask != 0xfu) == 0u) {
+    // (pairs, an odd number of MCUs a row or an interval: every second MCU row's, or every second interval's, lie across
+    // two 64-byte segments -- layout_store; chosen row by row: two copies of the whole loop took the pairs' kernels beyond
+    // their registers)
+    const bool across = MC == 2 && ((d.width_mcus | d.restart_interval) & 1u) != 0u;
+    if (!alone && __builtin_amdgcn_ballot_w64(whole_mask != 0xfu) == 0u) {
 #pragma unroll
         for (int row = 0; row < 8 * VS; row++) {
             layout_row_to_slot<HS, VS, MC>(t, row, slot);
@@ -2637,7 +2642,8 @@ CG_DEV void composite_layout_mcus(LayoutPixels<HS, VS, MC> &t, const ImageDesc &
         }
     } else if constexpr (MC == 2) {
         // (pairs: some group is cut, outside, or has its second MCU at the next MCU row's beginning)
-        const uint32_t lim = pair_limits<HS, VS, MC>(t, d, g.whole), off = pair_second_offset<HS, VS, MC>(t, d);
+        // (... or the groups are single MCUs: second halves without a limit store nothing)
+        const uint32_t lim = pair_limits<HS, VS, MC>(t, d, g.whole, alone), off = pair_second_offset<HS, VS, MC>(t, d);
         const uint32_t lims[4] = {quad_lane<0>(lim), quad_lane<1>(lim), quad_lane<2>(lim), quad_lane<3>(lim)};
         const uint32_t limits = pair_rows_for_lane(lims, lane & 3u);
         // (the exchange by every lane, then masked: a select would let the compiler move the DPP read under the
@@ -2665,14 +2671,15 @@ CG_DEV void composite_layout_mcus(LayoutPixels<HS, VS, MC> &t, const ImageDesc &
         }
     }
     zero_slot(slot);
-    if (layout_is_edge<HS, VS, MC>(t, d, g.whole))
-        composite_layout_edge<HS, VS, MC>(t, d);
+    if (layout_is_edge<HS, VS, MC>(t, d, g.whole, alone))
+        composite_layout_edge<HS, VS, MC>(t, d, alone ? 1u : uint32_t(MC));
     layout_next_group<HS, VS, MC>(t, d);
 }
 
 // The whole path for 64 restart intervals, one per lane (decode_wave_fused_422's counterpart; tests/emul drives the
 // same steps lane by lane).  Lanes past the image's last interval decode that last interval once more and never
-// store an MCU of their own: they stay for their quad's exchange.  MC = 2: the restart interval is even.
+// store an MCU of their own: they stay for their quad's exchange.  MC = 2: pairs by the MCU's place in its interval;
+// the last MCU of an odd interval is composited alone (the second halves store nothing).
 // STREAM: the window in its streamed form (decode_wave_fused_422_stream): nrows words of every lane's stream, staged
 // anew behind an MCU's last data unit -- stage_after other than 8: behind every data unit -- when a lane has fewer than
 // stage_below in front of it.
@@ -2712,9 +2719,11 @@ CG_DEV void decode_wave_fused_layout(const ImageDesc &d, const HuffShared &s, ui
         if (stage)
             stream_rows_landed(); // (in front of the composite's stores)
         k = k == kDus - 1u ? 0u : k + 1u;
-        if (place == kBlocks - 1u) {
+        // (pairs, an odd restart interval: its last MCU alone)
+        const bool alone = MC == 2 && du + 1u == du_total && place != kBlocks - 1u;
+        if (place == kBlocks - 1u || alone) {
             __builtin_amdgcn_s_setprio(CG_PRIO_COMPOSITE);
-            composite_layout_mcus<HS, VS, MC>(t, d, s.du_slots, lane);
+            composite_layout_mcus<HS, VS, MC>(t, d, s.du_slots, lane, alone);
             place = 0;
         } else {
             place++;

@@ -144,7 +144,7 @@ bool use_stream_kernel(const HuffLdsPlan &plan, uint32_t max_intervals, uint32_t
 }
 
 // The extension layouts' kernels: waves a CU holds (their registers: two to a SIMD) and the most a workgroup has
-// (fused_layout_wave_cap); a streamed form exists for 4:2:0 and for 4:4:4 / 4:4:0 with even restart intervals.
+// (fused_layout_wave_cap); a streamed form exists for 4:2:0 and for 4:4:4 / 4:4:0 with restart intervals of two MCUs or more.
 constexpr uint32_t kLayoutCuWaves = 8;
 bool layout_has_stream_kernel(uint32_t hs, uint32_t vs, bool pairs) { return (hs == 2 && vs == 2) || (hs == 1 && pairs); }
 
@@ -807,7 +807,8 @@ Status compeg_decoder::enqueue(const ImageData &img, hipStream_t stream, bool *c
     const bool fused = use_fused_pipeline() && is_422(img);
     // (the extension pipeline's first kernel carries the IDCT: planned like the fused kernel)
     const uint32_t luma_h = md.components[0].hsample, luma_v = md.components[0].vsample;
-    const bool mcu_pairs = luma_h == 1 && md.restart_interval % 2u == 0u;
+    // (8-pixel MCUs in pairs: rows of 64 bytes; of an odd interval the last MCU alone.  Intervals of one MCU: the single form)
+    const bool mcu_pairs = luma_h == 1 && md.restart_interval >= 2u;
     const HuffLdsPlan plan = plan_huffman(md.total_restart_intervals, 1, staged_lut_entries(img), span,
                                           fused || !is_422(img), is_422(img) ? 0u : fused_layout_wave_cap(luma_h, luma_v, mcu_pairs));
     last_span = span;
@@ -1143,7 +1144,7 @@ void compeg_batch::note_batch_properties(const ImageData *const *images, size_t 
     generic_layout = false;
     layout_h = n ? images[0]->metadata.components[0].hsample : 0;
     layout_v = n ? images[0]->metadata.components[0].vsample : 0;
-    layout_even_ri = true;
+    layout_pairs = true;
     one_mcu_intervals = n > 0;
     min_restart_interval = n ? 0xffffffffu : 0u;
     max_restart_interval = 0u;
@@ -1158,7 +1159,7 @@ void compeg_batch::note_batch_properties(const ImageData *const *images, size_t 
         generic_layout = generic_layout || !is_422(img);
         if (img.metadata.components[0].hsample != layout_h || img.metadata.components[0].vsample != layout_v)
             layout_h = layout_v = 0; // (mixed samplings in one batch)
-        layout_even_ri = layout_even_ri && img.metadata.restart_interval % 2u == 0u;
+        layout_pairs = layout_pairs && img.metadata.restart_interval >= 2u;
         one_mcu_intervals = one_mcu_intervals && img.metadata.restart_interval == 1u;
         min_restart_interval = std::min(min_restart_interval, uint32_t(img.metadata.restart_interval));
         max_restart_interval = std::max(max_restart_interval, uint32_t(img.metadata.restart_interval));
@@ -2145,7 +2146,7 @@ Status compeg_batch::decode(hipStream_t stream)
         const uint32_t m = std::min(step, n - at);
         const bool fused = use_fused_pipeline() && !generic_layout;
         const bool one_layout = generic_layout && layout_h != 0 && use_fused_pipeline();
-        const bool mcu_pairs = layout_h == 1 && layout_even_ri;
+        const bool mcu_pairs = layout_h == 1 && layout_pairs;
         const HuffLdsPlan plan = plan_huffman(max_intervals, m, max_l2, max_span, fused || generic_layout,
                                               one_layout ? fused_layout_wave_cap(layout_h, layout_v, mcu_pairs) : 0u);
         if (one_layout) {

@@ -145,7 +145,7 @@ struct compeg_batch {
     // some image is not 4:2:2 (extension): the whole batch takes the three-kernel pipeline
     bool generic_layout = false;
     uint32_t layout_h = 0, layout_v = 0; // luma sampling all images share (0: they differ)
-    bool layout_even_ri = false;         // ... and every restart interval is even
+    bool layout_pairs = false;           // ... and every restart interval holds two MCUs or more (8-pixel MCUs in pairs)
     bool one_mcu_intervals = false;      // every restart interval is one MCU
     uint32_t stream_mcu_words = 0;       // the batch's average MCU in stream words, rounded up (plan_stream)
     uint32_t min_restart_interval = 0;   // the smallest restart interval of the batch's images

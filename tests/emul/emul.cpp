@@ -510,7 +510,8 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
                         for (uint32_t lane = 0; lane < uint32_t(kWave); lane++)
                             layout_transform<HS, VS, MC>(ps[lane], d, comp, place, slots + lane * kDuSlotBytes, dcs[lane]);
                         k = k == kDus - 1u ? 0u : k + 1u;
-                        if (place != kBlocks - 1u) {
+                        const bool alone = MC == 2 && du + 1u == du_total && place != kBlocks - 1u; // (decode_wave_fused_layout)
+                        if (place != kBlocks - 1u && !alone) {
                             place++;
                             continue;
                         }
@@ -527,12 +528,12 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
                                 for (uint32_t j = 0; j < 4; j++) {
                                     bases[j] = tg[quad + j].base;
                                     if constexpr (MC == 2) {
-                                        pair_lims[j] = pair_limits<HS, VS, MC>(ps[quad + j], d, tg[quad + j].whole);
+                                        pair_lims[j] = pair_limits<HS, VS, MC>(ps[quad + j], d, tg[quad + j].whole, alone);
                                     } else {
                                         limits |= (tg[quad + j].whole ? uint32_t(8 * VS) | uint32_t(2 * HS * MC) << 5 : layout_limit<HS, VS, MC>(ps[quad + j], d)) << (8u * j);
                                     }
                                 }
-                                bool all_whole = true; // (the kernel's ballot: every group of the wave whole)
+                                bool all_whole = !alone; // (the kernel's ballot: every group of the wave whole)
                                 for (uint32_t l2 = 0; l2 < uint32_t(kWave); l2++)
                                     all_whole = all_whole && tg[l2].whole;
                                 if (all_whole) {
@@ -550,13 +551,14 @@ int emul_decode(const uint8_t *jpeg, size_t len, uint8_t *rgba, uint32_t tex_w, 
                         }
                         for (uint32_t lane = 0; lane < uint32_t(kWave); lane++) {
                             zero_slot(slots + lane * kDuSlotBytes);
-                            if (layout_is_edge<HS, VS, MC>(ps[lane], d, tg[lane].whole))
-                                composite_layout_edge<HS, VS, MC>(ps[lane], d);
+                            if (layout_is_edge<HS, VS, MC>(ps[lane], d, tg[lane].whole, alone))
+                                composite_layout_edge<HS, VS, MC>(ps[lane], d, alone ? 1u : uint32_t(MC));
                             layout_next_group<HS, VS, MC>(ps[lane], d);
                         }
                     }
                 };
-                const bool pairs = hs == 1 && d.restart_interval % 2u == 0u; // (as the runtime dispatches)
+                // (as the runtime dispatches: pairs from two MCUs an interval on; EMUL_SINGLES: the single form for every odd interval)
+                const bool pairs = hs == 1 && (getenv("EMUL_SINGLES") ? d.restart_interval % 2u == 0u : d.restart_interval >= 2u);
                 if (hs == 1 && vs == 1 && pairs)
                     run(LayoutTag<1, 1, 2>{});
                 else if (hs == 1 && vs == 1)

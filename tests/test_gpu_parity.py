@@ -1280,13 +1280,15 @@ def test_mcu_pairs_across_mcu_rows(ca, gpu, sampling):
 @pytest.mark.parametrize("sampling,single,paired", [((1, 1), "decode_fused_444_single_kernel", "decode_fused_444_kernel"),
                                                      ((1, 2), "decode_fused_440_single_kernel", "decode_fused_440_kernel")])
 def test_extension_layouts_with_odd_restart_intervals(ca, gpu, sampling, single, paired):
-    """4:4:4 and 4:4:0 with odd restart intervals: the MCUs of an interval cannot be composited in pairs, every lane
-    stores its 8-pixel MCU alone (decode_fused_444_single_kernel / decode_fused_440_single_kernel: 32-byte rows).  The
-    batch reports "fused_layout" for both forms; both are bit-exact against the oracle's extension.  The single form
-    was two to three times slower per frame than the paired one while its 32-byte rows were non-temporal stores -- each
-    a write of its own at the memory; as ordinary stores they cost it no such factor (kernels_body.h, layout_store)."""
+    """4:4:4 and 4:4:0 with odd restart intervals: the paired kernels composite an interval's MCUs two at a time and its
+    last one alone (the second halves store nothing); intervals of one MCU take the single form
+    (decode_fused_444_single_kernel / decode_fused_440_single_kernel: 32-byte rows).  The batch reports "fused_layout"
+    for all of them; all are bit-exact against the oracle's extension.  Odd intervals were two to three times slower per
+    frame than even ones while their 32-byte rows were non-temporal stores -- each a write of its own at the memory; as
+    ordinary stores they cost no such factor (kernels_body.h, layout_store; every second interval's pairs lie across two
+    64-byte segments)."""
     times = {}
-    for ri in (3, 4, 5):
+    for ri in (1, 3, 4, 5):
         jpegs = [synth.make_jpeg(1280, 720, seed=60 + i, kind=0, quality=85, ri=ri, sampling=sampling) for i in range(4)]
         images = [ca.ImageData(j, allow_sampling=True) for j in jpegs]
         batch = ca.Batch(gpu)
@@ -1303,5 +1305,4 @@ def test_extension_layouts_with_odd_restart_intervals(ca, gpu, sampling, single,
         times[ri] = total / n
         for i in (0, 3, 63):
             _assert_equal(batch.read_output(i), orc.ImageData(jpegs[i % 4], allow_sampling=True).decode())
-    # (odd intervals: the single kernels; even: the paired ones)
     assert times[3] < 1.9 * times[4] and times[5] < 1.9 * times[4], (single, paired, times)

@@ -32,7 +32,7 @@ STATS = {}   # rare-path counters of the emulated kernels, summed over every run
 
 
 def _run(runner, tmp_path, jpeg, fused, waves=1, window=2048, l2=12288, standard=False, coop_passes=1, stage=8, below=None,
-         layout_rows=None, chunk=1, padded=False):
+         layout_rows=None, chunk=1, padded=False, singles=False):
     p = tmp_path / "in.jpg"
     p.write_bytes(jpeg)
     env = dict(os.environ)
@@ -45,6 +45,9 @@ def _run(runner, tmp_path, jpeg, fused, waves=1, window=2048, l2=12288, standard
     env.pop("EMUL_STREAM_BELOW", None)
     env.pop("EMUL_STREAM_ROWS", None)
     env["EMUL_WALK_CHUNK"] = str(chunk)   # (fused = 8: MCUs a lane walks between two looks at what it found)
+    env.pop("EMUL_SINGLES", None)
+    if singles:
+        env["EMUL_SINGLES"] = "1"   # (fused = 6, 8-pixel MCUs: every odd restart interval through the single-MCU form -- the library's for intervals of one MCU)
     env["EMUL_PADDED"] = "1" if padded else "0"   # (the output as the runtime allocates it: rows of whole MCUs, 16 pixels each way)
     if layout_rows is not None:
         env["EMUL_STREAM_ROWS"] = str(layout_rows)   # (fused = 6: the layout kernels' streamed form)
@@ -280,7 +283,7 @@ def test_emulated_outputs_of_whole_mcus(runner, tmp_path, sampling):
     tight buffers beside them; under ASan: nothing is written behind the allocation."""
     # (264, 200, 195 pixels across: an odd number of 8-pixel MCUs a row -- with an even restart interval the pairs of the
     # 4:4:4 / 4:4:0 kernels have their second MCU at the next MCU row's beginning once in two rows: each half its own place)
-    for (w, h, ri) in ((250, 70, 3), (250, 70, 2), (33, 17, 1), (264, 120, 4), (1080 // 4, 104, 6), (200, 64, 2), (195, 50, 4), (264, 41, 2)):
+    for (w, h, ri) in ((250, 70, 3), (250, 70, 2), (33, 17, 1), (264, 120, 4), (1080 // 4, 104, 6), (200, 64, 2), (195, 50, 4), (264, 41, 2), (200, 64, 3), (195, 50, 5), (264, 41, 7)):
         jpeg = synth.make_jpeg(w, h, seed=50 + w + ri, kind=1, quality=85, ri=ri, sampling=sampling)
         want = orc.ImageData(jpeg, allow_sampling=True).decode()
         for padded in (True, False):
@@ -380,8 +383,8 @@ def test_emulated_q1_underflow_in_every_quarter(runner, tmp_path):
 def test_emulated_extension_layouts(runner, tmp_path, sampling):
     """4:4:4, 4:2:2, 4:4:0, 4:2:0 through the extension pipeline (entropy records, IDCT in place,
     generic composite) against the oracle with the same extension switched on."""
-    # (even restart intervals: 8-pixel MCUs in pairs, also across the end of an MCU row -- 250 and 33 pixels are 32 and 5
-    # MCUs -- and odd ones: singly)
+    # (8-pixel MCUs in pairs, also across the end of an MCU row -- 250 and 33 pixels are 32 and 5 MCUs --, the last MCU of
+    # an odd restart interval alone; intervals of one MCU singly)
     for (w, h, kind, q, ri, seed) in [(96, 48, 0, 90, 2, 91), (250, 70, 1, 75, 3, 92), (33, 17, 2, 85, 1, 93), (250, 70, 0, 85, 4, 94),
                                       (33, 17, 1, 90, 2, 95), (40, 24, 0, 85, 6, 96)]:
         jpeg = synth.make_jpeg(w, h, seed=seed, kind=kind, quality=q, ri=ri, sampling=sampling)
@@ -391,6 +394,9 @@ def test_emulated_extension_layouts(runner, tmp_path, sampling):
         if sampling != (2, 1):   # the fused kernels of the extension layouts (decode_fused_444 / _440 / _420_kernel)
             got = _run(runner, tmp_path, jpeg, 6, waves=3, window=300)
             assert np.array_equal(got, want), f"fused {sampling} {w}x{h}: {(got != want).any(axis=2).sum()} pixels differ"
+            if ri % 2:   # (pairs with the interval's last MCU alone above; here the single-MCU form)
+                got = _run(runner, tmp_path, jpeg, 6, waves=3, window=300, singles=True)
+                assert np.array_equal(got, want), f"fused, single MCUs {sampling} {w}x{h}: {(got != want).any(axis=2).sum()} pixels differ"
             # ... and their streamed form (the odd restart intervals too: the body is the same, only the GPU library
             # has no kernel of it for them): rows enough; too few; staged behind every data unit
             for rows, stage, below in ((24, 8, 24), (3, 8, 2), (6, 0xf, 3)):
