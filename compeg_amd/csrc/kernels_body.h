@@ -2601,9 +2601,12 @@ template <int HS, int VS, int MC>
 CG_DEV void layout_next_group(LayoutPixels<HS, VS, MC> &t, const ImageDesc &d)
 {
     t.mx += uint32_t(MC);
-    if (t.mx >= d.width_mcus) {
-        t.mx -= d.width_mcus;
-        t.my++;
+#pragma unroll
+    for (int m = 0; m < MC; m++) { // (an image one MCU across: a pair is two MCU rows)
+        if (t.mx >= d.width_mcus) {
+            t.mx -= d.width_mcus;
+            t.my++;
+        }
     }
 }
 

@@ -1263,7 +1263,7 @@ def test_mcu_pairs_across_mcu_rows(ca, gpu, sampling):
     stores, `layout_store`).  On the GPU a select around the lane exchange once sent the second halves of half the
     quads' pairs to the wrong place (tests/test_code_objects.py has the scan for it): batches and single frames,
     ragged heights, bit-exact."""
-    for (w, h, ri) in ((1000, 600, 4), (360, 642, 2), (1080, 250, 8), (1001, 97, 4)):
+    for (w, h, ri) in ((1000, 600, 4), (360, 642, 2), (1080, 250, 8), (1001, 97, 4), (8, 93, 4), (8, 90, 3)):   # (... and one MCU across)
         jpegs = [synth.make_jpeg(w, h, seed=90 + i, kind=0, quality=85, ri=ri, sampling=sampling) for i in range(3)]
         batch = ca.Batch(gpu)
         batch.upload([ca.ImageData(jpegs[i % 3], allow_sampling=True) for i in range(24)])

@@ -283,7 +283,8 @@ def test_emulated_outputs_of_whole_mcus(runner, tmp_path, sampling):
     tight buffers beside them; under ASan: nothing is written behind the allocation."""
     # (264, 200, 195 pixels across: an odd number of 8-pixel MCUs a row -- with an even restart interval the pairs of the
     # 4:4:4 / 4:4:0 kernels have their second MCU at the next MCU row's beginning once in two rows: each half its own place)
-    for (w, h, ri) in ((250, 70, 3), (250, 70, 2), (33, 17, 1), (264, 120, 4), (1080 // 4, 104, 6), (200, 64, 2), (195, 50, 4), (264, 41, 2), (200, 64, 3), (195, 50, 5), (264, 41, 7)):
+    for (w, h, ri) in ((250, 70, 3), (250, 70, 2), (33, 17, 1), (264, 120, 4), (1080 // 4, 104, 6), (200, 64, 2), (195, 50, 4), (264, 41, 2), (200, 64, 3), (195, 50, 5), (264, 41, 7),
+                       (8, 93, 4), (8, 40, 3), (16, 30, 2)):   # (one MCU across: a pair is two MCU rows -- the emulation fuzz's find)
         jpeg = synth.make_jpeg(w, h, seed=50 + w + ri, kind=1, quality=85, ri=ri, sampling=sampling)
         want = orc.ImageData(jpeg, allow_sampling=True).decode()
         for padded in (True, False):
