@@ -23,6 +23,8 @@ for it in range(int(sys.argv[2]) if len(sys.argv)>2 else 150):
     w=int(rng.integers(16,300)); h=int(rng.integers(8,120)); kind=int(rng.integers(0,3)); q=int(rng.choice([30,60,85,95,100])); ri=int(rng.integers(0,9))
     if it%4==3:   # long restart intervals that seldom divide the image: the cooperative kernel's speculative walks, the last interval's end
         w=int(rng.integers(200,700)); h=int(rng.integers(64,260)); ri=int(rng.choice([10,17,30,45,60,100,130]))
+    if os.environ.get('FUZZ_NARROW'):   # (one to three MCUs across)
+        w=int(rng.integers(8,50))
     base=synth.make_jpeg(w,h,seed=int(rng.integers(1,1<<30)),kind=kind,quality=q,ri=ri)
     j=bytearray(base)
     if it%3!=0:
