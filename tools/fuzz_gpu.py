@@ -35,6 +35,8 @@ def run(seed=4321, iters=200, budget_s=None, log=print):
         big = it % 10 == 0                      # now and then a scan large enough for the threaded host path
         w = int(rng.integers(600, 2600)) if big else int(rng.integers(16, 420))
         h = int(rng.integers(300, 1300)) if big else int(rng.integers(8, 200))
+        if os.environ.get('FUZZ_NARROW'):   # (one to three MCUs across, many MCU rows)
+            w = int(rng.integers(1, 50)); h = int(rng.integers(8, 900))
         kind = int(rng.integers(0, 3))
         q = int(rng.choice([30, 60, 85, 95, 100]))
         ri = int(rng.integers(0, 9))
