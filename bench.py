@@ -832,10 +832,11 @@ def main():
             extra[f"extension {name}, 64 x 4K"] = bench_config(
                 compeg_amd, gpu, 3840, 2160, 4, args.quality, 64, args.steps, args.warmup, threads, 16,
                 f"64 x 3840x2160 YUV {name} baseline JPEG, DRI=4, 16 distinct frames (extension layout)", sampling=smp)
-        # (odd restart intervals: an interval's 8-pixel MCUs cannot be composited in pairs -- decode_fused_444_single_kernel)
+        # (odd restart intervals: an interval's 8-pixel MCUs in pairs, its last one alone; every second interval's pairs across two
+        # 64-byte segments -- decode_fused_444_kernel's cut branch and ordinary stores)
         extra["extension 4:4:4 odd DRI, 64 x 4K"] = bench_config(
             compeg_amd, gpu, 3840, 2160, 3, args.quality, 64, max(3, args.steps // 2), args.warmup, threads, 16,
-            "64 x 3840x2160 YUV 4:4:4 baseline JPEG, DRI=3, 16 distinct frames (extension layout, MCUs composited singly)", sampling=(1, 1))
+            "64 x 3840x2160 YUV 4:4:4 baseline JPEG, DRI=3, 16 distinct frames (extension layout, MCUs in pairs, an interval's last one alone)", sampling=(1, 1))
 
     feed_scaling = None
     if rank == 0 and world == 1 and args.host_feed_ranks and end_to_end is not None and not ext:
